@@ -1,0 +1,58 @@
+"""Deterministic, name-keyed parameter fill shared by the golden generator, the oracle and the
+tests, so that every side starts from bit-identical weights without shipping 14 MB state dicts.
+Oracle / test infrastructure only."""
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(tag, seed):
+    return np.random.default_rng([int(seed), zlib.crc32(tag.encode())])
+
+
+def fill_value(tag, shape, seed):
+    """float32 array for the parameter called ``tag`` (e.g. 'critic/linear1.weight')."""
+    r = _rng(tag, seed)
+    shape = tuple(int(s) for s in shape)
+    leaf = tag.rsplit(".", 1)[-1]
+    if len(shape) >= 2:                      # conv / linear weight
+        fan_in = int(np.prod(shape[1:]))
+        a = 1.4 * np.sqrt(3.0 / fan_in)
+        v = r.uniform(-a, a, size=shape)
+    elif leaf == "weight":                   # BatchNorm gamma: mostly positive, ~10 % negative
+        v = r.uniform(0.6, 1.4, size=shape) * np.where(r.random(shape) < 0.1, -1.0, 1.0)
+    else:                                    # biases / BatchNorm beta
+        v = r.uniform(-0.2, 0.2, size=shape)
+    return v.astype(np.float32)
+
+
+def fill_module_(module, prefix, seed):
+    """Overwrite every parameter of ``module`` in place (buffers keep their defaults)."""
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            p.copy_(torch.from_numpy(fill_value(prefix + "/" + name, p.shape, seed)).to(p.device))
+    return module
+
+
+SAMPLES = 24
+
+
+def summarize(t):
+    """Compact fingerprint of a tensor: [sum, abs-sum, l2, abs-max] + SAMPLES strided entries
+    (the full tensor when it has <= 4096 entries)."""
+    a = np.asarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float64).ravel()
+    stats = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a * a).sum()), np.abs(a).max() if a.size else 0.0])
+    if a.size <= 4096:
+        return stats, a.astype(np.float32)
+    pos = np.linspace(0, a.size - 1, SAMPLES).astype(np.int64)
+    return stats, a[pos].astype(np.float32)
+
+
+def summarize_named(named, out, key_prefix):
+    for name, t in named:
+        if t is None:
+            continue
+        s, v = summarize(t)
+        out[key_prefix + name + "#stats"] = s
+        out[key_prefix + name + "#vals"] = v

@@ -1,0 +1,172 @@
+/*
+ * oracle/pn2_ref.c -- TEST INFRASTRUCTURE ONLY (the CPU oracle).  Never imported, linked or
+ * executed by the product path (ga-ddpg_amd/); only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may use it, and only as the checker.
+ *
+ * Plain-C restatement of the index-producing PointNet++ operators that GA-DDPG calls through
+ * the un-vendored `pointnet2_ops` extension (reference call sites: core/networks.py:10,66-81,
+ * core/utils.py:32,795-797).  The extension's source is NOT under /root/reference (README.md:23
+ * is a bare link to github.com/liruiw/Pointnet2_PyTorch, no pinned commit), so this file
+ * restates the published algorithm of erikwijmans/Pointnet2_PyTorch pointnet2_ops_lib v3.x
+ * (`_ext-src/src/sampling_gpu.cu`, `ball_query_gpu.cu`, `group_points_gpu.cu`) as recorded in
+ * SURVEY.md section 2b / 8c.  PARITY UNPINNED at this boundary: the reference holds no test or
+ * golden vector for these operators; they are pinned instead by the hand-computed known-answer
+ * tests in tests/test_oracle_ops.py and by brute-force numpy restatements there.
+ *
+ * Floating-point evaluation order is pinned (this file is compiled with -ffp-contract=off):
+ *   d2 = ((dx*dx) + (dy*dy)) + (dz*dz), every product and sum rounded to f32,
+ * and the HIP kernels in ga-ddpg_amd/csrc use the same order so indices are bit-reproducible
+ * between the oracle and the device.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float sqdist(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx;
+    float yy = dy * dy;
+    float zz = dz * dz;
+    float s = xx + yy;
+    return s + zz;
+}
+
+/* upstream opt_n_threads(): largest power of two <= n, clamped to [1, 512] */
+static int fps_block_size(int n) {
+    int p = 1;
+    while ((p << 1) <= n && (p << 1) <= 512) p <<= 1;
+    return p;
+}
+
+/*
+ * Furthest point sampling  (upstream furthest_point_sampling_kernel<block_size>):
+ *   idx[0] = 0; temp[k] = 1e10
+ *   each round: for every point k with |p_k|^2 > 1e-3:  temp[k] = min(temp[k], d2(p_k, p_old));
+ *   pick arg-max of temp.  Points with |p|^2 <= 1e-3 are never updated NOR considered.
+ * Tie rule (block-size dependent upstream): "thread" t = k mod bs scans k = t, t+bs, ... with a
+ * strict '>' (lowest k of a thread wins), threads are then merged by a pairwise tree with
+ * `v2 > v1 ? i2 : i1` (the lower thread id wins a tie).  A thread that saw no candidate holds
+ * (best=-1, besti=0).  We emulate exactly that.
+ *   xyz: (B,N,3) f32    idx: (B,M) i32
+ */
+void pn2ref_fps(const float* xyz, int B, int N, int M, int32_t* idx) {
+    const int bs = fps_block_size(N);
+    float* temp = (float*)malloc(sizeof(float) * (size_t)N);
+    float* tv = (float*)malloc(sizeof(float) * (size_t)bs);
+    int* ti = (int*)malloc(sizeof(int) * (size_t)bs);
+    for (int b = 0; b < B; ++b) {
+        const float* p = xyz + (size_t)b * N * 3;
+        int32_t* out = idx + (size_t)b * M;
+        for (int k = 0; k < N; ++k) temp[k] = 1e10f;
+        int old = 0;
+        if (M > 0) out[0] = 0;
+        for (int j = 1; j < M; ++j) {
+            const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+            for (int t = 0; t < bs; ++t) {
+                float best = -1.0f;
+                int besti = 0;
+                for (int k = t; k < N; k += bs) {
+                    const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+                    float m0 = x2 * x2;
+                    float m1 = y2 * y2;
+                    float m2 = z2 * z2;
+                    float mag = (m0 + m1) + m2;
+                    if (mag <= 1e-3f) continue;
+                    float d = sqdist(x2, y2, z2, x1, y1, z1);
+                    float d2 = d < temp[k] ? d : temp[k];
+                    temp[k] = d2;
+                    if (d2 > best) { best = d2; besti = k; }
+                }
+                tv[t] = best;
+                ti[t] = besti;
+            }
+            for (int s = bs >> 1; s >= 1; s >>= 1) {
+                for (int t = 0; t < s; ++t) {
+                    float v1 = tv[t], v2 = tv[t + s];
+                    int i1 = ti[t], i2 = ti[t + s];
+                    tv[t] = v1 > v2 ? v1 : v2;
+                    ti[t] = v2 > v1 ? i2 : i1;
+                }
+            }
+            old = ti[0];
+            out[j] = old;
+        }
+    }
+    free(temp); free(tv); free(ti);
+}
+
+/*
+ * Ball query (upstream query_ball_point_kernel): for every centre, the first `nsample` point
+ * indices k in ascending order with d2 < radius*radius (radius2 evaluated in f32, strict '<');
+ * on the first hit every slot is pre-filled with that index, so unfilled slots repeat the first
+ * hit; a centre with no hit keeps the zero-initialised output (all slots 0).
+ *   new_xyz: (B,M,3)  xyz: (B,N,3)  idx: (B,M,nsample) i32   cnt (optional): (B,M) hits kept
+ */
+void pn2ref_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
+                       int nsample, int32_t* idx, int32_t* cnt_out) {
+    const float r2 = radius * radius;
+    for (int b = 0; b < B; ++b) {
+        const float* p = xyz + (size_t)b * N * 3;
+        for (int m = 0; m < M; ++m) {
+            const float* c = new_xyz + ((size_t)b * M + m) * 3;
+            int32_t* o = idx + ((size_t)b * M + m) * nsample;
+            for (int l = 0; l < nsample; ++l) o[l] = 0;
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < nsample; ++k) {
+                float d2 = sqdist(c[0], c[1], c[2], p[k * 3 + 0], p[k * 3 + 1], p[k * 3 + 2]);
+                if (d2 < r2) {
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) o[l] = k;
+                    o[cnt] = k;
+                    ++cnt;
+                }
+            }
+            if (cnt_out) cnt_out[(size_t)b * M + m] = cnt;
+        }
+    }
+}
+
+/* group_points: out[b,c,m,s] = pts[b,c,idx[b,m,s]]   pts (B,C,N), idx (B,M,S), out (B,C,M,S) */
+void pn2ref_group_points(const float* pts, const int32_t* idx, int B, int C, int N, int M, int S,
+                         float* out) {
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float* src = pts + ((size_t)b * C + c) * N;
+            float* dst = out + ((size_t)b * C + c) * M * S;
+            const int32_t* ii = idx + (size_t)b * M * S;
+            for (int q = 0; q < M * S; ++q) dst[q] = src[ii[q]];
+        }
+}
+
+/* group_points_grad: grad_pts[b,c,idx[b,m,s]] += grad_out[b,c,m,s]  (sequential m,s order) */
+void pn2ref_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                              int S, float* grad_pts) {
+    memset(grad_pts, 0, sizeof(float) * (size_t)B * C * N);
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float* dst = grad_pts + ((size_t)b * C + c) * N;
+            const float* src = grad_out + ((size_t)b * C + c) * M * S;
+            const int32_t* ii = idx + (size_t)b * M * S;
+            for (int q = 0; q < M * S; ++q) dst[ii[q]] += src[q];
+        }
+}
+
+/* gather_points: out[b,c,m] = pts[b,c,idx[b,m]]   pts (B,C,N), idx (B,M) */
+void pn2ref_gather_points(const float* pts, const int32_t* idx, int B, int C, int N, int M,
+                          float* out) {
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int m = 0; m < M; ++m)
+                out[((size_t)b * C + c) * M + m] = pts[((size_t)b * C + c) * N + idx[(size_t)b * M + m]];
+}
+
+void pn2ref_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                               float* grad_pts) {
+    memset(grad_pts, 0, sizeof(float) * (size_t)B * C * N);
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int m = 0; m < M; ++m)
+                grad_pts[((size_t)b * C + c) * N + idx[(size_t)b * M + m]] +=
+                    grad_out[((size_t)b * C + c) * M + m];
+}

@@ -1,0 +1,45 @@
+"""Shared comparison helpers for the parity tests."""
+import numpy as np
+import torch
+
+from oracle.detfill import summarize
+
+
+def assert_close(a, b, rtol, atol, what=""):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    if not np.all(err <= tol):
+        i = int(np.argmax(err - tol))
+        raise AssertionError("%s: max violation at flat index %d: got %.9g expected %.9g (|err| %.3g > tol %.3g); "
+                             "max abs err %.3g" % (what, i, a.ravel()[i], b.ravel()[i], err.ravel()[i],
+                                                   tol.ravel()[i], err.max()))
+
+
+def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=()):
+    """Compare tensors against fingerprints written by oracle.detfill.summarize_named.
+    The tolerance on the aggregate stats is scaled by the tensor's abs-sum / l2."""
+    n = 0
+    for name, t in named_tensors:
+        if t is None or any(s in name for s in skip):
+            continue
+        ks, kv = prefix + name + "#stats", prefix + name + "#vals"
+        assert ks in golden, "missing golden entry " + ks
+        stats, vals = summarize(t)
+        g_stats, g_vals = golden[ks], golden[kv]
+        assert_close(vals, g_vals, rtol, atol, what=kv)
+        abs_sum = max(g_stats[1], 1e-30)
+        assert abs(stats[0] - g_stats[0]) <= rtol * abs_sum + atol * max(1.0, vals.size), ks + " sum"
+        assert abs(stats[1] - g_stats[1]) <= rtol * abs_sum + atol * max(1.0, vals.size), ks + " abs-sum"
+        assert abs(stats[2] - g_stats[2]) <= rtol * g_stats[2] + atol, ks + " l2"
+        assert abs(stats[3] - g_stats[3]) <= rtol * g_stats[3] + atol, ks + " abs-max"
+        n += 1
+    assert n > 0, "nothing compared under " + prefix
+    return n
+
+
+def golden_batch(golden, prefix):
+    p = prefix + "batch/"
+    return {k[len(p):]: golden[k] for k in golden.files if k.startswith(p)}
