@@ -1,0 +1,428 @@
+// PointNet++ geometry operators for gfx950: furthest point sampling, ball query, grouping (+grad),
+// gather (+grad), and the compaction of ball-query output into de-duplicated neighbourhood rows.
+// Replaces the CUDA kernels of the reference's external `pointnet2_ops._ext` (sampling_gpu.cu,
+// ball_query_gpu.cu, group_points_gpu.cu; reached from reference core/networks.py:66-81).
+// Design (MI355X-first, not a translation): wave64 ballot/prefix-popcount compaction for the ball
+// query (one wavefront per centroid instead of one thread), register-resident clouds with a
+// shuffle arg-max for FPS (one workgroup per cloud, no global scratch), 16-byte coalesced
+// streams for the materialising group kernels.
+#include "common.hpp"
+
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void gad_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* gad_last_error(void) { return g_err; }
+extern "C" int gad_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------
+// furthest point sampling
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool fps_better(float v, unsigned key, float bv, unsigned bkey) {
+    return v > bv || (v == bv && key < bkey);
+}
+
+// One workgroup (WAVES wavefronts) per cloud; thread t keeps points k = s*T + t (s < NPL) in
+// registers.  The cloud is also staged in LDS so the coordinates of the last pick are a broadcast
+// LDS read.  Tie rule: (value desc, k mod tie_bs asc, k asc) == the upstream block reduction.
+template <int NPL, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict__ xyz, int N, int M,
+                                                          int tie_bs, int32_t* __restrict__ idx,
+                                                          float* __restrict__ new_xyz) {
+    constexpr int T = 64 * WAVES;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* sp = lds;                                   // N*3 coordinates
+    float* red_v = lds + ((N * 3 + 3) & ~3);           // WAVES values
+    unsigned* red_k = (unsigned*)(red_v + WAVES);      // WAVES keys
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* p = xyz + (size_t)b * N * 3;
+    for (int i = tid; i < N * 3; i += T) sp[i] = p[i];
+    __syncthreads();
+
+    float px[NPL], py[NPL], pz[NPL], tmp[NPL];
+    unsigned key[NPL];
+    unsigned valid = 0;
+#pragma unroll
+    for (int s = 0; s < NPL; ++s) {
+        const int k = s * T + tid;
+        px[s] = py[s] = pz[s] = 0.f;
+        tmp[s] = 1e10f;
+        key[s] = 0;
+        if (k < N) {
+            px[s] = sp[k * 3 + 0];
+            py[s] = sp[k * 3 + 1];
+            pz[s] = sp[k * 3 + 2];
+            const float mag = __fadd_rn(__fadd_rn(__fmul_rn(px[s], px[s]), __fmul_rn(py[s], py[s])),
+                                        __fmul_rn(pz[s], pz[s]));
+            if (mag > 1e-3f) valid |= 1u << s;
+            key[s] = ((unsigned)(k % tie_bs) << 16) | (unsigned)k;
+        }
+    }
+    int old = 0;
+    if (tid == 0 && M > 0) {
+        idx[(size_t)b * M] = 0;
+        if (new_xyz) {
+            float* o = new_xyz + (size_t)b * M * 3;
+            o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
+        }
+    }
+    for (int j = 1; j < M; ++j) {
+        const float x1 = sp[old * 3 + 0], y1 = sp[old * 3 + 1], z1 = sp[old * 3 + 2];
+        float best = -1.f;
+        unsigned bkey = 0;
+#pragma unroll
+        for (int s = 0; s < NPL; ++s) {
+            if (valid & (1u << s)) {
+                const float d = gad_sqdist(px[s], py[s], pz[s], x1, y1, z1);
+                const float d2 = d < tmp[s] ? d : tmp[s];
+                tmp[s] = d2;
+                if (fps_better(d2, key[s], best, bkey)) { best = d2; bkey = key[s]; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const unsigned ok = __shfl_xor(bkey, o, 64);
+            if (fps_better(ov, ok, best, bkey)) { best = ov; bkey = ok; }
+        }
+        if (WAVES > 1) {
+            if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_k[tid >> 6] = bkey; }
+            __syncthreads();
+            best = red_v[0]; bkey = red_k[0];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w)
+                if (fps_better(red_v[w], red_k[w], best, bkey)) { best = red_v[w]; bkey = red_k[w]; }
+            __syncthreads();
+        }
+        old = (int)(bkey & 0xFFFFu);
+        if (tid == 0) {
+            idx[(size_t)b * M + j] = old;
+            if (new_xyz) {
+                float* o = new_xyz + ((size_t)b * M + j) * 3;
+                o[0] = sp[old * 3 + 0]; o[1] = sp[old * 3 + 1]; o[2] = sp[old * 3 + 2];
+            }
+        }
+    }
+}
+
+static int fps_tie_block(int n) {  // upstream opt_n_threads()
+    int p = 1;
+    while ((p << 1) <= n && (p << 1) <= 512) p <<= 1;
+    return p;
+}
+
+extern "C" int gad_furthest_point_sampling(const float* xyz, int B, int N, int M, int32_t* idx,
+                                           float* new_xyz, void* stream) {
+    GAD_REQUIRE(xyz && idx, GAD_ERR_NULL, "fps: null pointer");
+    GAD_REQUIRE(B >= 0 && N >= 1 && M >= 0 && N <= 16384, GAD_ERR_SHAPE, "fps: unsupported shape B=%d N=%d M=%d", B, N, M);
+    if (B == 0 || M == 0) return GAD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int tie = fps_tie_block(N);
+    const size_t lds = (size_t)(((N * 3 + 3) & ~3) + 64) * sizeof(float);
+    if (N <= 64) {
+        hipLaunchKernelGGL((fps_kernel<1, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
+    } else if (N <= 1024) {
+        hipLaunchKernelGGL((fps_kernel<4, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
+    } else if (N <= 4096) {
+        hipLaunchKernelGGL((fps_kernel<16, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
+    } else {
+        hipLaunchKernelGGL((fps_kernel<16, 16>), dim3(B), dim3(1024), lds, st, xyz, N, M, tie, idx, new_xyz);
+    }
+    GAD_CHECK_LAUNCH("fps");
+    return GAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ball query: one wavefront per centroid, ballot + prefix popcount keeps ascending index order
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_ball_query(const float* __restrict__ p, int N, float cx, float cy,
+                                               float cz, float r2, int nsample, int lane,
+                                               int32_t* __restrict__ out) {
+    int cnt = 0, first = 0;
+    for (int base = 0; base < N && cnt < nsample; base += 64) {
+        const int k = base + lane;
+        bool in = false;
+        if (k < N) {
+            const float d2 = gad_sqdist(cx, cy, cz, p[k * 3 + 0], p[k * 3 + 1], p[k * 3 + 2]);
+            in = d2 < r2;
+        }
+        const unsigned long long mask = __ballot(in);
+        if (mask) {
+            if (cnt == 0) first = base + __ffsll((long long)mask) - 1;
+            const int slot = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+            if (in && slot < nsample) out[slot] = k;
+            cnt += __popcll(mask);
+        }
+    }
+    cnt = cnt < nsample ? cnt : nsample;
+    for (int s = cnt + lane; s < nsample; s += 64) out[s] = first;   // pad with the first hit (0 if none)
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict__ new_xyz,
+                                                         const float* __restrict__ xyz, int G, int N,
+                                                         int M, float r2, int nsample,
+                                                         int32_t* __restrict__ idx,
+                                                         int32_t* __restrict__ cnt_out) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int lane = threadIdx.x & 63;
+    const int b = g / M;
+    const float* c = new_xyz + (size_t)g * 3;
+    const int cnt = wave_ball_query(xyz + (size_t)b * N * 3, N, c[0], c[1], c[2], r2, nsample, lane,
+                                    idx + (size_t)g * nsample);
+    if (lane == 0 && cnt_out) cnt_out[g] = cnt;
+}
+
+extern "C" int gad_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
+                              int nsample, int32_t* idx, int32_t* cnt, void* stream) {
+    GAD_REQUIRE(new_xyz && xyz && idx, GAD_ERR_NULL, "ball_query: null pointer");
+    GAD_REQUIRE(B >= 0 && N >= 1 && M >= 0 && nsample >= 1, GAD_ERR_SHAPE, "ball_query: bad shape");
+    const int G = B * M;
+    if (G == 0) return GAD_OK;
+    hipLaunchKernelGGL(ball_query_kernel, dim3(gad_cdiv(G, 4)), dim3(256), 0, (hipStream_t)stream, new_xyz,
+                       xyz, G, N, M, radius * radius, nsample, idx, cnt);
+    GAD_CHECK_LAUNCH("ball_query");
+    return GAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// materialising group / gather operators (reference-API layouts, channel-major)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ pts,
+                                                           const int32_t* __restrict__ idx, int C, int N,
+                                                           int MS, long long total,
+                                                           float* __restrict__ out) {
+    // 4 consecutive outputs per thread: one 16-B idx load, one 16-B store
+    const long long q4 = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q4 >= total) return;
+    const long long bc = q4 / MS;            // (b*C + c); MS % 4 == 0 is guaranteed by the host
+    const int ms = (int)(q4 - bc * MS);
+    const int b = (int)(bc / C);
+    const int4 ii = *reinterpret_cast<const int4*>(idx + (size_t)b * MS + ms);
+    const float* src = pts + (size_t)bc * N;
+    float4 v = make_float4(src[ii.x], src[ii.y], src[ii.z], src[ii.w]);
+    *reinterpret_cast<float4*>(out + q4) = v;
+}
+
+__global__ __launch_bounds__(256) void group_points_scalar_kernel(const float* __restrict__ pts,
+                                                                  const int32_t* __restrict__ idx, int C,
+                                                                  int N, int MS, long long total,
+                                                                  float* __restrict__ out) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const long long bc = q / MS;
+    const int ms = (int)(q - bc * MS);
+    const int b = (int)(bc / C);
+    out[q] = pts[(size_t)bc * N + idx[(size_t)b * MS + ms]];
+}
+
+extern "C" int gad_group_points(const float* points, const int32_t* idx, int B, int C, int N, int M, int S,
+                                float* out, void* stream) {
+    GAD_REQUIRE(points && idx && out, GAD_ERR_NULL, "group_points: null pointer");
+    const long long total = (long long)B * C * M * S;
+    if (total == 0) return GAD_OK;
+    const int MS = M * S;
+    if (MS % 4 == 0) {
+        hipLaunchKernelGGL(group_points_kernel, dim3(gad_cdiv(total / 4, 256)), dim3(256), 0,
+                           (hipStream_t)stream, points, idx, C, N, MS, total, out);
+    } else {
+        hipLaunchKernelGGL(group_points_scalar_kernel, dim3(gad_cdiv(total, 256)), dim3(256), 0,
+                           (hipStream_t)stream, points, idx, C, N, MS, total, out);
+    }
+    GAD_CHECK_LAUNCH("group_points");
+    return GAD_OK;
+}
+
+__global__ __launch_bounds__(256) void group_points_grad_kernel(const float* __restrict__ go,
+                                                                const int32_t* __restrict__ idx, int C,
+                                                                int N, int MS, long long total,
+                                                                float* __restrict__ gp) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const long long bc = q / MS;
+    const int ms = (int)(q - bc * MS);
+    const int b = (int)(bc / C);
+    atomic_add_f32(gp + (size_t)bc * N + idx[(size_t)b * MS + ms], go[q]);
+}
+
+extern "C" int gad_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                                     int S, float* grad_points, void* stream) {
+    GAD_REQUIRE(grad_out && idx && grad_points, GAD_ERR_NULL, "group_points_grad: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if ((long long)B * C * N > 0) { hipError_t me = hipMemsetAsync(grad_points, 0, sizeof(float) * (size_t)B * C * N, st); (void)me; }
+    const long long total = (long long)B * C * M * S;
+    if (total == 0) return GAD_OK;
+    hipLaunchKernelGGL(group_points_grad_kernel, dim3(gad_cdiv(total, 256)), dim3(256), 0, st, grad_out, idx,
+                       C, N, M * S, total, grad_points);
+    GAD_CHECK_LAUNCH("group_points_grad");
+    return GAD_OK;
+}
+
+extern "C" int gad_gather_points(const float* points, const int32_t* idx, int B, int C, int N, int M,
+                                 float* out, void* stream) {
+    // gather == group with S = 1
+    return gad_group_points(points, idx, B, C, N, M, 1, out, stream);
+}
+extern "C" int gad_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                                      float* grad_points, void* stream) {
+    return gad_group_points_grad(grad_out, idx, B, C, N, M, 1, grad_points, stream);
+}
+
+// QueryAndGroup(use_xyz=True) in one pass: a wavefront owns a centroid, keeps its idx row in LDS,
+// then streams the (3+C) grouped channels out as contiguous S-float runs.
+__global__ __launch_bounds__(256) void query_and_group_kernel(const float* __restrict__ new_xyz,
+                                                              const float* __restrict__ xyz,
+                                                              const float* __restrict__ feat, int G, int C,
+                                                              int N, int M, float r2, int S,
+                                                              int32_t* __restrict__ idx,
+                                                              float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) int32_t sidx[];   // 4 waves x S
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = blockIdx.x * 4 + w;
+    if (g >= G) return;
+    const int b = g / M, m = g - b * M;
+    const float* c = new_xyz + (size_t)g * 3;
+    const float cx = c[0], cy = c[1], cz = c[2];
+    const float* p = xyz + (size_t)b * N * 3;
+    int32_t* my = sidx + w * S;
+    wave_ball_query(p, N, cx, cy, cz, r2, S, lane, my);
+    // LDS writes of this wave are read back by the same wave only
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    int32_t* gi = idx + (size_t)g * S;
+    const size_t plane = (size_t)M * S;
+    float* o = out + ((size_t)b * (3 + C)) * plane + (size_t)m * S;
+    for (int s = lane; s < S; s += 64) {
+        const int k = my[s];
+        gi[s] = k;
+        o[0 * plane + s] = __fsub_rn(p[k * 3 + 0], cx);
+        o[1 * plane + s] = __fsub_rn(p[k * 3 + 1], cy);
+        o[2 * plane + s] = __fsub_rn(p[k * 3 + 2], cz);
+        const float* f = feat + (size_t)b * C * N + k;
+        for (int ch = 0; ch < C; ++ch) o[(3 + ch) * plane + s] = f[(size_t)ch * N];
+    }
+}
+
+extern "C" int gad_query_and_group(const float* new_xyz, const float* xyz, const float* features, int B,
+                                   int C, int N, int M, float radius, int nsample, int32_t* idx, float* out,
+                                   void* stream) {
+    GAD_REQUIRE(new_xyz && xyz && idx && out && (features || C == 0), GAD_ERR_NULL, "query_and_group: null pointer");
+    GAD_REQUIRE(nsample >= 1 && nsample <= 4096, GAD_ERR_SHAPE, "query_and_group: nsample out of range");
+    const int G = B * M;
+    if (G == 0) return GAD_OK;
+    hipLaunchKernelGGL(query_and_group_kernel, dim3(gad_cdiv(G, 4)), dim3(256), sizeof(int32_t) * 4 * nsample,
+                       (hipStream_t)stream, new_xyz, xyz, features, G, C, N, M, radius * radius, nsample, idx,
+                       out);
+    GAD_CHECK_LAUNCH("query_and_group");
+    return GAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused-path geometry: point layout conversion and row compaction
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void prep_points_kernel(const float* __restrict__ ps, int C4, int NP,
+                                                          int skip, int N, long long total,
+                                                          float* __restrict__ xyz, float* __restrict__ feat) {
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int b = (int)(q / N), j = (int)(q - (long long)b * N);
+    const float* src = ps + (size_t)b * C4 * NP + skip + j;
+    const float x = src[0], y = src[(size_t)NP], z = src[(size_t)2 * NP];
+    const float f = C4 > 3 ? src[(size_t)3 * NP] : 0.f;
+    xyz[q * 3 + 0] = x; xyz[q * 3 + 1] = y; xyz[q * 3 + 2] = z;
+    *reinterpret_cast<float4*>(feat + q * 4) = make_float4(x, y, z, f);
+}
+
+extern "C" int gad_prep_points(const float* point_state, int B, int C4, int NP, int skip, float* xyz,
+                               float* feat, void* stream) {
+    GAD_REQUIRE(point_state && xyz && feat, GAD_ERR_NULL, "prep_points: null pointer");
+    GAD_REQUIRE(C4 >= 3 && NP > skip && skip >= 0, GAD_ERR_SHAPE, "prep_points: bad shape");
+    const int N = NP - skip;
+    const long long total = (long long)B * N;
+    if (total == 0) return GAD_OK;
+    hipLaunchKernelGGL(prep_points_kernel, dim3(gad_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       point_state, C4, NP, skip, N, total, xyz, feat);
+    GAD_CHECK_LAUNCH("prep_points");
+    return GAD_OK;
+}
+
+// exclusive scan of max(cnt,1) over G groups by one 1024-thread workgroup
+__global__ __launch_bounds__(1024) void rows_scan_kernel(const int32_t* __restrict__ cnt, int G,
+                                                         int32_t* __restrict__ off,
+                                                         int32_t* __restrict__ n_rows) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (G + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, G);
+    int s = 0;
+    for (int g = lo; g < hi; ++g) s += max(cnt[g], 1);
+    part[tid] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                 // Hillis-Steele inclusive scan
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - s;
+    for (int g = lo; g < hi; ++g) { off[g] = run; run += max(cnt[g], 1); }
+    if (tid == 1023) { off[G] = part[1023]; *n_rows = part[1023]; }
+}
+
+__global__ __launch_bounds__(256) void rows_fill_kernel(const int32_t* __restrict__ idx,
+                                                        const int32_t* __restrict__ cnt,
+                                                        const int32_t* __restrict__ off, int G, int M, int Nsrc,
+                                                        int nsample, int32_t* __restrict__ row_pt,
+                                                        int32_t* __restrict__ row_grp,
+                                                        float* __restrict__ row_w) {
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= G) return;
+    const int lane = threadIdx.x & 63;
+    const int n = max(cnt[g], 1);
+    const int base = off[g];
+    const int b = g / M;
+    for (int s = lane; s < n; s += 64) {
+        row_pt[base + s] = b * Nsrc + idx[(size_t)g * nsample + s];
+        row_grp[base + s] = g;
+        row_w[base + s] = s == 0 ? (float)(nsample - n + 1) : 1.f;
+    }
+}
+
+extern "C" int gad_rows_from_ball_query(const int32_t* idx, const int32_t* cnt, int G, int M, int Nsrc,
+                                        int nsample, int32_t* grp_off, int32_t* row_pt, int32_t* row_grp,
+                                        float* row_w, int32_t* n_rows, void* stream) {
+    GAD_REQUIRE(idx && cnt && grp_off && row_pt && row_grp && row_w && n_rows, GAD_ERR_NULL, "rows: null pointer");
+    GAD_REQUIRE(G >= 1 && M >= 1, GAD_ERR_SHAPE, "rows: bad shape");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rows_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, G, grp_off, n_rows);
+    hipLaunchKernelGGL(rows_fill_kernel, dim3(gad_cdiv(G, 4)), dim3(256), 0, st, idx, cnt, grp_off, G, M, Nsrc,
+                       nsample, row_pt, row_grp, row_w);
+    GAD_CHECK_LAUNCH("rows_from_ball_query");
+    return GAD_OK;
+}
+
+__global__ __launch_bounds__(256) void rows_group_all_kernel(int G, int P, int32_t* __restrict__ off,
+                                                             int32_t* __restrict__ row_pt,
+                                                             int32_t* __restrict__ row_grp,
+                                                             float* __restrict__ row_w,
+                                                             int32_t* __restrict__ n_rows) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q < G * P) { row_pt[q] = q; row_grp[q] = q / P; row_w[q] = 1.f; }
+    if (q <= G) off[q] = q * P;
+    if (q == 0) *n_rows = G * P;
+}
+
+extern "C" int gad_rows_group_all(int G, int P, int32_t* grp_off, int32_t* row_pt, int32_t* row_grp,
+                                  float* row_w, int32_t* n_rows, void* stream) {
+    GAD_REQUIRE(grp_off && row_pt && row_grp && row_w && n_rows, GAD_ERR_NULL, "rows_group_all: null pointer");
+    hipLaunchKernelGGL(rows_group_all_kernel, dim3(gad_cdiv((long long)G * P + 1, 256)), dim3(256), 0,
+                       (hipStream_t)stream, G, P, grp_off, row_pt, row_grp, row_w, n_rows);
+    GAD_CHECK_LAUNCH("rows_group_all");
+    return GAD_OK;
+}

@@ -1,0 +1,155 @@
+// Optimiser / bookkeeping kernels over flat parameter buffers.
+// Reference arithmetic replaced: torch.optim.Adam.step x4 (core/utils.py:969-970,993-994,
+// 183-237), clip_grad_norm_ (core/ddpg.py:141), soft/half-soft/half-hard target updates
+// (core/utils.py:750-774), module_max_param / module_max_gradient (core/utils.py:92-108).
+// One launch per optimiser instead of ~10 small kernels per parameter tensor; the updated value is
+// also mirrored into the packed, padded compute layout the GEMMs read (no separate repack pass).
+#include "common.hpp"
+
+__global__ __launch_bounds__(256) void grad_from_arena_kernel(const double* __restrict__ gacc,
+                                                              const int32_t* __restrict__ m2p, int n,
+                                                              float* __restrict__ grad, int accumulate) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = m2p[i];
+    const float g = j >= 0 ? (float)gacc[j] : 0.f;
+    grad[i] = accumulate ? grad[i] + g : g;
+}
+
+extern "C" int gad_grad_from_arena(const double* gacc, const int32_t* m2p, int n, float* grad, int accumulate,
+                                   void* stream) {
+    GAD_REQUIRE(gacc && m2p && grad, GAD_ERR_NULL, "grad_from_arena: null pointer");
+    if (n <= 0) return GAD_OK;
+    hipLaunchKernelGGL(grad_from_arena_kernel, dim3(gad_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, gacc, m2p, n,
+                       grad, accumulate);
+    GAD_CHECK_LAUNCH("grad_from_arena");
+    return GAD_OK;
+}
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int n, double* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) { const double v = g[i]; s += v * v; }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f64(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int gad_sumsq(const float* grad, int n, double* out, void* stream) {
+    GAD_REQUIRE(grad && out, GAD_ERR_NULL, "sumsq: null pointer");
+    if (n <= 0) return GAD_OK;
+    int gx = gad_cdiv(n, 256 * 8);
+    if (gx > 512) gx = 512;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, grad, n, out);
+    GAD_CHECK_LAUNCH("sumsq");
+    return GAD_OK;
+}
+
+// out[s] = max |x| over segment s.  Non-negative floats order like their bit patterns.
+__global__ __launch_bounds__(256) void absmax_segments_kernel(const float* __restrict__ x,
+                                                              const int32_t* __restrict__ seg_off,
+                                                              float* __restrict__ out) {
+    const int s = blockIdx.y;
+    const int lo = seg_off[s], hi = seg_off[s + 1];
+    float m = 0.f;
+    for (int i = lo + blockIdx.x * 256 + threadIdx.x; i < hi; i += gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned int*>(out + s), __float_as_uint(m));
+}
+
+extern "C" int gad_absmax_segments(const float* x, const int32_t* seg_off, int n_seg, float* out, void* stream) {
+    GAD_REQUIRE(x && seg_off && out, GAD_ERR_NULL, "absmax_segments: null pointer");
+    if (n_seg <= 0) return GAD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * n_seg, st);
+    (void)e;
+    hipLaunchKernelGGL(absmax_segments_kernel, dim3(64, n_seg), dim3(256), 0, st, x, seg_off, out);
+    GAD_CHECK_LAUNCH("absmax_segments");
+    return GAD_OK;
+}
+
+// hyper: {lr, beta1, beta2, eps, weight_decay, 1-beta1^t, sqrt(1-beta2^t), grad_scale}
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ grad,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   const uint8_t* __restrict__ active,
+                                                   const int32_t* __restrict__ m2p, float* __restrict__ packed, int n,
+                                                   const float* __restrict__ hyper,
+                                                   const double* __restrict__ clip_sumsq, float clip_max) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (active && !active[i]) return;
+    const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5],
+                sbc2 = hyper[6];
+    float coef = hyper[7];
+    if (clip_sumsq) {
+        const float c = clip_max / ((float)sqrt(*clip_sumsq) + 1e-6f);     // torch clip_grad_norm_
+        coef *= c < 1.f ? c : 1.f;
+    }
+    float g = grad[i] * coef;
+    if (clip_sumsq) grad[i] = g;                                           // torch scales .grad in place
+    const float pv = p[i];
+    g = fmaf(wd, pv, g);
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sbc2 + eps;
+    const float np = pv - (lr / bc1) * (mi / denom);
+    p[i] = np;
+    if (packed) { const int j = m2p[i]; if (j >= 0) packed[j] = np; }
+}
+
+extern "C" int gad_adam_step(float* p, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* active,
+                             const int32_t* m2p, float* packed, int n, const float* hyper, const double* clip_sumsq,
+                             float clip_max, void* stream) {
+    GAD_REQUIRE(p && grad && exp_avg && exp_avg_sq && hyper, GAD_ERR_NULL, "adam_step: null pointer");
+    GAD_REQUIRE(!packed || m2p, GAD_ERR_NULL, "adam_step: packed mirror needs m2p");
+    if (n <= 0) return GAD_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(gad_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p,
+                       const_cast<float*>(grad), exp_avg, exp_avg_sq, active, m2p, packed, n, hyper, clip_sumsq,
+                       clip_max);
+    GAD_CHECK_LAUNCH("adam_step");
+    return GAD_OK;
+}
+
+__global__ __launch_bounds__(256) void polyak_kernel(float* __restrict__ t, const float* __restrict__ s,
+                                                     const uint8_t* __restrict__ sel, const int32_t* __restrict__ m2p,
+                                                     float* __restrict__ packed, int n, float tau, int hard_enable) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int k = sel ? sel[i] : 1;
+    float nv;
+    if (k == 1) nv = t[i] * (1.f - tau) + s[i] * tau;
+    else if (k == 2 && hard_enable) nv = s[i];
+    else return;
+    t[i] = nv;
+    if (packed) { const int j = m2p[i]; if (j >= 0) packed[j] = nv; }
+}
+
+extern "C" int gad_polyak(float* target, const float* source, const uint8_t* sel, const int32_t* m2p,
+                          float* target_packed, int n, float tau, int hard_enable, void* stream) {
+    GAD_REQUIRE(target && source, GAD_ERR_NULL, "polyak: null pointer");
+    GAD_REQUIRE(!target_packed || m2p, GAD_ERR_NULL, "polyak: packed mirror needs m2p");
+    if (n <= 0) return GAD_OK;
+    hipLaunchKernelGGL(polyak_kernel, dim3(gad_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, target, source, sel, m2p,
+                       target_packed, n, tau, hard_enable);
+    GAD_CHECK_LAUNCH("polyak");
+    return GAD_OK;
+}
+
+__global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ p, const int32_t* __restrict__ m2p,
+                                                          int n, float* __restrict__ packed) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int j = m2p[i];
+    if (j >= 0) packed[j] = p[i];
+}
+
+extern "C" int gad_pack_params(const float* p, const int32_t* m2p, int n, float* packed, void* stream) {
+    GAD_REQUIRE(p && m2p && packed, GAD_ERR_NULL, "pack_params: null pointer");
+    if (n <= 0) return GAD_OK;
+    hipLaunchKernelGGL(pack_params_kernel, dim3(gad_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, p, m2p, n, packed);
+    GAD_CHECK_LAUNCH("pack_params");
+    return GAD_OK;
+}

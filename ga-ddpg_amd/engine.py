@@ -1,0 +1,534 @@
+"""Host-side engine of the fused update-step path: flat parameter storage in the packed compute
+layout, per-pass activation workspaces, and the launch plans (sequences of C-ABI calls) for the
+PointNet++ encoder, the actor/critic heads and their backward passes.
+
+Nothing here computes: every arithmetic step is a libgaddpg kernel (ga-ddpg_amd/hip.py).  torch
+only owns device memory and the stream.  A *plan* is a list of pre-built calls over static buffers,
+so it can be replayed eagerly or captured once into a HIP graph (torch.cuda.CUDAGraph).
+
+Reference structure mirrored: core/networks.py:65-92 (base_network = SA1, SA2, SA3, FC head),
+:253-300 (QNetwork), :303-371 (GaussianPolicy); upstream PointnetSAModule.forward.
+"""
+import numpy as np
+import torch
+
+from . import hip
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def round8(k):
+    return (k + 7) // 8 * 8
+
+
+# ----------------------------------------------------------------------------------------------
+# flat parameter storage
+# ----------------------------------------------------------------------------------------------
+class MatSpec(object):
+    """One Conv2d-1x1 / Linear weight (n_out, k_in) [+ bias] and an optional BatchNorm after it."""
+
+    def __init__(self, weight, bias=None, bn=None):
+        self.weight, self.bias, self.bn = weight, bias, bn
+        self.n_out = weight.shape[0]
+        self.k_in = int(np.prod(weight.shape[1:]))
+        self.ones_col = self.k_in if bias is not None else -1
+        self.Kp = round8(self.k_in + (1 if bias is not None else 0))
+        self.w_off = self.g_off = self.b_off = -1          # packed offsets (filled by FlatNet)
+        self.bn_index = -1                                 # index into the per-pass BN vectors
+
+
+class FlatNet(object):
+    """Flat float32 master buffer holding every parameter of a network (the nn.Parameters become
+    views into it), a packed/padded compute copy for the GEMMs, flat .grad / Adam state, an f64
+    gradient-accumulation arena in the packed layout, and the master->packed index map."""
+
+    def __init__(self, named_params, mats, device, never_trained=()):
+        """named_params: ordered (name, nn.Parameter); mats: MatSpecs in PACKED order."""
+        self.device = device
+        self.names = [n for n, _ in named_params]
+        self.params = [p for _, p in named_params]
+        sizes = [p.numel() for p in self.params]
+        self.offsets = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+        self.n = int(self.offsets[-1])
+        self.mats = list(mats)
+        off_of = {id(p): int(o) for p, o in zip(self.params, self.offsets[:-1])}
+
+        m2p = np.full(self.n, -1, dtype=np.int32)
+        pk = 0
+        for m in self.mats:
+            m.w_off = pk
+            rows = np.arange(m.n_out, dtype=np.int64)[:, None]
+            cols = np.arange(m.k_in, dtype=np.int64)[None, :]
+            mo = off_of[id(m.weight)]
+            m2p[mo:mo + m.n_out * m.k_in] = (pk + rows * m.Kp + cols).reshape(-1)
+            if m.bias is not None:
+                mo = off_of[id(m.bias)]
+                m2p[mo:mo + m.n_out] = pk + np.arange(m.n_out) * m.Kp + m.k_in
+            pk += m.n_out * m.Kp
+        for m in self.mats:
+            if m.bn is not None:
+                c = m.n_out
+                m.g_off, m.b_off = pk, pk + c
+                mo = off_of[id(m.bn.weight)]
+                m2p[mo:mo + c] = pk + np.arange(c)
+                mo = off_of[id(m.bn.bias)]
+                m2p[mo:mo + c] = pk + c + np.arange(c)
+                pk += 2 * c
+        assert (m2p >= 0).all(), "every parameter must have a packed slot"
+        self.packed_n = pk
+
+        f32 = dict(dtype=torch.float32, device=device)
+        self.master = torch.zeros(self.n, **f32)
+        self.grad = torch.zeros(self.n, **f32)
+        self.exp_avg = torch.zeros(self.n, **f32)
+        self.exp_avg_sq = torch.zeros(self.n, **f32)
+        self.packed = torch.zeros(self.packed_n, **f32)
+        self.gacc = torch.zeros(self.packed_n, dtype=torch.float64, device=device)
+        self.m2p = torch.from_numpy(m2p).to(device)
+        active = np.ones(self.n, dtype=np.uint8)
+        for name, p in named_params:
+            if any(name.startswith(s) for s in never_trained):
+                o = off_of[id(p)]
+                active[o:o + p.numel()] = 0
+        self.active = torch.from_numpy(active).to(device)
+        self.hyper = torch.zeros(8, **f32)                 # {lr,b1,b2,eps,wd,bc1,sqrt(bc2),grad_scale}
+        self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if device.type == "cuda" \
+            else torch.zeros(8, dtype=torch.float32)
+        self.step_count = 0
+        # re-home the parameters into the flat buffers
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets[:-1]):
+                o = int(o)
+                self.master[o:o + p.numel()].copy_(p.detach().reshape(-1).to(device))
+                p.data = self.master[o:o + p.numel()].view(p.shape)
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        self.sync_packed()
+
+    def segment(self, prefix):
+        """(lo, hi) master range of the parameters whose name starts with prefix (must be contiguous)."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix)]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1))
+        return int(self.offsets[idx[0]]), int(self.offsets[idx[-1] + 1])
+
+    def sync_packed(self):
+        """master -> packed (after load_state_dict / external edits)."""
+        hip.call("gad_pack_params", self.master, self.m2p, self.n, self.packed)
+
+    def p_w(self, m):
+        return self.packed.data_ptr() + 4 * m.w_off
+
+    def p_gamma(self, m):
+        return self.packed.data_ptr() + 4 * m.g_off
+
+    def p_beta(self, m):
+        return self.packed.data_ptr() + 4 * m.b_off
+
+    def set_adam_hyper(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        self.step_count += 1
+        t = self.step_count
+        h = self.hyper_host
+        h[0], h[1], h[2], h[3], h[4] = lr, betas[0], betas[1], eps, weight_decay
+        h[5] = 1.0 - betas[0] ** t
+        h[6] = float(np.sqrt(1.0 - betas[1] ** t))
+        h[7] = grad_scale
+        self.hyper.copy_(h, non_blocking=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# geometry workspace (depends on the xyz of a cloud set only; shared by every pass over it)
+# ----------------------------------------------------------------------------------------------
+class SAConfig(object):
+    def __init__(self, npoint, radius, nsample):
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+
+
+class Geometry(object):
+    """FPS / ball-query / de-duplicated rows of SA1 and SA2 plus the static GroupAll rows of SA3."""
+
+    def __init__(self, B, N, sa1, sa2, device):
+        self.B, self.N, self.sa1, self.sa2 = B, N, sa1, sa2
+        i32 = dict(dtype=torch.int32, device=device)
+        f32 = dict(dtype=torch.float32, device=device)
+        M1, M2 = sa1.npoint, sa2.npoint
+        self.M1, self.M2 = M1, M2
+        self.xyz = torch.empty(B, N, 3, **f32)
+        self.feat0 = torch.empty(B * N, 4, **f32)
+        self.fps1 = torch.empty(B, M1, **i32)
+        self.new_xyz1 = torch.empty(B, M1, 3, **f32)
+        self.idx1 = torch.empty(B, M1, sa1.nsample, **i32)
+        self.cnt1 = torch.empty(B, M1, **i32)
+        self.fps2 = torch.empty(B, M2, **i32)
+        self.new_xyz2 = torch.empty(B, M2, 3, **f32)
+        self.idx2 = torch.empty(B, M2, sa2.nsample, **i32)
+        self.cnt2 = torch.empty(B, M2, **i32)
+        self.rows = []
+        for G, cap in ((B * M1, B * M1 * sa1.nsample), (B * M2, B * M2 * sa2.nsample), (B, B * M2)):
+            self.rows.append(dict(G=G, cap=cap, off=torch.zeros(G + 1, **i32), pt=torch.zeros(cap, **i32),
+                                  grp=torch.zeros(cap, **i32), w=torch.zeros(cap, **f32),
+                                  n=torch.zeros(1, **i32)))
+        r3 = self.rows[2]
+        hip.call("gad_rows_group_all", B, M2, r3["off"], r3["pt"], r3["grp"], r3["w"], r3["n"])
+        self.counts = (float(B * M1 * sa1.nsample), float(B * M2 * sa2.nsample), float(B * M2))
+
+    def run(self, point_state):
+        """point_state (B,4,NP) f32 device tensor in the replay layout (gripper points first)."""
+        B, N = self.B, self.N
+        NP = point_state.shape[2]
+        skip = NP - N
+        hip.call("gad_prep_points", point_state, B, point_state.shape[1], NP, skip, self.xyz, self.feat0)
+        hip.call("gad_furthest_point_sampling", self.xyz, B, N, self.M1, self.fps1, self.new_xyz1)
+        hip.call("gad_ball_query", self.new_xyz1, self.xyz, B, N, self.M1, float(self.sa1.radius),
+                 self.sa1.nsample, self.idx1, self.cnt1)
+        r = self.rows[0]
+        hip.call("gad_rows_from_ball_query", self.idx1, self.cnt1, B * self.M1, self.M1, N, self.sa1.nsample,
+                 r["off"], r["pt"], r["grp"], r["w"], r["n"])
+        hip.call("gad_furthest_point_sampling", self.new_xyz1, B, self.M1, self.M2, self.fps2, self.new_xyz2)
+        hip.call("gad_ball_query", self.new_xyz2, self.new_xyz1, B, self.M1, self.M2, float(self.sa2.radius),
+                 self.sa2.nsample, self.idx2, self.cnt2)
+        r = self.rows[1]
+        hip.call("gad_rows_from_ball_query", self.idx2, self.cnt2, B * self.M2, self.M2, self.M1,
+                 self.sa2.nsample, r["off"], r["pt"], r["grp"], r["w"], r["n"])
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder description and per-pass activation slot
+# ----------------------------------------------------------------------------------------------
+class EncoderNet(object):
+    """Packed view of one `base_network`: 3 SA stages of 3 (conv, BN) pairs + 2 (Linear, BN1d)."""
+
+    def __init__(self, module, device, prefix=""):
+        """module = nn.ModuleList([ModuleList(SA1,SA2,SA3), Sequential(fc)]) as core.networks builds."""
+        sa_mods, fc = module[0], module[1]
+        self.sa_mats = []
+        for sa in sa_mods:
+            seq = sa.mlps[0]
+            self.sa_mats.append([MatSpec(seq[0].weight, None, seq[1]), MatSpec(seq[3].weight, None, seq[4]),
+                                 MatSpec(seq[6].weight, None, seq[7])])
+        self.fc_mats = [MatSpec(fc[0].weight, fc[0].bias, fc[1]), MatSpec(fc[3].weight, fc[3].bias, fc[4])]
+        self.mats = [m for st in self.sa_mats for m in st] + self.fc_mats
+        for i, m in enumerate(self.mats):
+            m.bn_index = i
+        self.flat = FlatNet(list(module.named_parameters()), self.mats, device)
+        self.c_feat = self.sa_mats[0][0].k_in - 3              # 4 (policy) or 10 (critic: + 6 action channels)
+        self.act_c = self.c_feat - 4
+        # BatchNorm running statistics: one flat buffer per kind, module buffers become views
+        tot = sum(m.n_out for m in self.mats)
+        self.running_mean = torch.zeros(tot, dtype=torch.float32, device=device)
+        self.running_var = torch.ones(tot, dtype=torch.float32, device=device)
+        self.bn_off = []
+        o = 0
+        for m in self.mats:
+            self.bn_off.append(o)
+            with torch.no_grad():
+                self.running_mean[o:o + m.n_out].copy_(m.bn.running_mean.to(device))
+                self.running_var[o:o + m.n_out].copy_(m.bn.running_var.to(device))
+            m.bn.running_mean = self.running_mean[o:o + m.n_out]
+            m.bn.running_var = self.running_var[o:o + m.n_out]
+            m.bn.num_batches_tracked = m.bn.num_batches_tracked.to(device)
+            o += m.n_out
+        self.bn_total = tot
+
+    def bump_batches_tracked(self, k=1):
+        for m in self.mats:
+            m.bn.num_batches_tracked += k
+
+
+class EncoderSlot(object):
+    """Activations of one encoder pass (raw pre-BN layer outputs, pooled features, arg-max, the
+    per-layer BN vectors) + the scratch the backward pass needs.  Sized for the worst case
+    (every neighbourhood full)."""
+
+    def __init__(self, geo, enc, device, with_backward=True):
+        f32 = dict(dtype=torch.float32, device=device)
+        B = geo.B
+        self.geo, self.B = geo, B
+        caps = [geo.rows[0]["cap"], geo.rows[1]["cap"], geo.rows[2]["cap"]]
+        self.Z = []
+        for s, st in enumerate(enc.sa_mats):
+            self.Z.append([torch.empty(caps[s], m.n_out, **f32) for m in st])
+        self.F = [torch.empty(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, **f32) for s in range(3)]
+        self.argmax = [torch.empty(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, dtype=torch.int32, device=device)
+                       for s in range(3)]
+        self.Zfc = [torch.empty(B, m.n_out, **f32) for m in enc.fc_mats]
+        tot = enc.bn_total
+        self.stats = torch.zeros(2 * tot, dtype=torch.float64, device=device)      # fwd sums | sq sums
+        self.scale = torch.empty(tot, **f32)
+        self.shift = torch.empty(tot, **f32)
+        self.mean = torch.empty(tot, **f32)
+        self.istd = torch.empty(tot, **f32)
+        if with_backward:
+            self.bstats = torch.zeros(2 * tot, dtype=torch.float64, device=device)  # dbeta | dgamma
+            self.coef = torch.empty(3 * tot, **f32)                                  # P | Q | S
+            gmax = max(caps[s] * max(m.n_out for m in enc.sa_mats[s]) for s in range(3))
+            gmax = max(gmax, B * 1024)
+            self.G = [torch.empty(gmax, **f32), torch.empty(gmax, **f32)]
+            self.dF = [torch.zeros(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, **f32) for s in range(3)]
+            self.daction = torch.zeros(B, 6, **f32)
+        self.tot = tot
+
+
+def _ptr(t, off_elems=0, size=4):
+    return None if t is None else t.data_ptr() + size * off_elems
+
+
+def _fwd_args(**kw):
+    a = hip.GemmFwdArgs()
+    a.n_groups = 1
+    a.ones_col = -1
+    a.grp_per_sample = 1
+    for k, v in kw.items():
+        if k in ("zin_off", "w_off", "out_off", "n_out"):
+            arr = getattr(a, k)
+            for i, x in enumerate(v):
+                arr[i] = int(x)
+        else:
+            setattr(a, k, v)
+    return a
+
+
+def _dz(**kw):
+    d = hip.DzSrc()
+    for k, v in kw.items():
+        setattr(d, k, v)
+    return d
+
+
+class Plan(object):
+    """A recorded sequence of C-ABI calls over static buffers."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []       # keeps ctypes structs / tensors alive
+
+    def call(self, name, *a):
+        f = getattr(hip.lib(), name)
+        args = hip._args(*a)
+        self.keep.append(a)
+        self.calls.append((name, f, args, None))
+
+    def call_struct(self, name, s):
+        f = getattr(hip.lib(), name)
+        self.keep.append(s)
+        self.calls.append((name, f, None, s))
+
+    def zero(self, t):
+        self.keep.append(t)
+        self.calls.append(("zero", None, t, None))
+
+    def fn(self, f):
+        self.calls.append(("py", f, None, None))
+
+    def extend(self, other):
+        self.calls += other.calls
+        self.keep += other.keep
+
+    def run(self):
+        import ctypes as C
+        st = hip.stream()
+        for name, f, args, s in self.calls:
+            if name == "zero":
+                args.zero_()
+            elif name == "py":
+                f()
+            elif s is not None:
+                hip.check(f(C.byref(s), st), name)
+            else:
+                hip.check(f(*(args + [st])), name)
+
+
+# ----------------------------------------------------------------------------------------------
+# encoder forward / backward plans
+# ----------------------------------------------------------------------------------------------
+def _bn_vec(slot, enc, m, which):
+    return _ptr(getattr(slot, which), enc.bn_off[m.bn_index])
+
+
+def _finalize(plan, enc, slot, m, count, train=True):
+    o, tot = enc.bn_off[m.bn_index], slot.tot
+    plan.call("gad_bn_finalize", _ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), enc.flat.p_gamma(m),
+              enc.flat.p_beta(m), m.n_out, hip.Dbl(count), BN_EPS, BN_MOMENTUM,
+              _ptr(enc.running_mean, o) if train else None, _ptr(enc.running_var, o) if train else None,
+              _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "shift"), _bn_vec(slot, enc, m, "mean"),
+              _bn_vec(slot, enc, m, "istd"))
+
+
+def _gather_src(geo, slot, s, action):
+    """input description of SA stage s's first layer"""
+    r = geo.rows[s]
+    if s == 0:
+        return dict(src_xyz=_ptr(geo.xyz), ctr_xyz=_ptr(geo.new_xyz1), feat=_ptr(geo.feat0), feat_c=4,
+                    action=_ptr(action), act_c=6 if action is not None else 0, grp_per_sample=geo.M1,
+                    row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]))
+    if s == 1:
+        return dict(src_xyz=_ptr(geo.new_xyz1), ctr_xyz=_ptr(geo.new_xyz2), feat=_ptr(slot.F[0]),
+                    feat_c=slot.F[0].shape[1], action=None, act_c=0, grp_per_sample=geo.M2,
+                    row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]))
+    return dict(src_xyz=_ptr(geo.new_xyz2), ctr_xyz=None, feat=_ptr(slot.F[1]), feat_c=slot.F[1].shape[1],
+                action=None, act_c=0, grp_per_sample=1, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]))
+
+
+def _layer_input(enc, slot, geo, s, l, action):
+    """gad_gemm_fwd_args fields describing the INPUT of SA stage s layer l (s==3: FC layer l)."""
+    if s < 3:
+        r = geo.rows[s]
+        base = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], row_w=_ptr(r["w"]))
+        if l == 0:
+            base.update(mode=1, c_in=enc.sa_mats[s][0].k_in, **_gather_src(geo, slot, s, action))
+        else:
+            pm = enc.sa_mats[s][l - 1]
+            base.update(mode=0, zin=_ptr(slot.Z[s][l - 1]), zin_pitch=pm.n_out, c_in=pm.n_out,
+                        scale=_bn_vec(slot, enc, pm, "scale"), shift=_bn_vec(slot, enc, pm, "shift"), relu=1)
+        return base
+    B = slot.B
+    if l == 0:
+        return dict(n_rows=B, mode=0, zin=_ptr(slot.F[2]), zin_pitch=slot.F[2].shape[1], c_in=slot.F[2].shape[1],
+                    relu=0, ones_col=enc.fc_mats[0].ones_col)
+    pm = enc.fc_mats[0]
+    return dict(n_rows=B, mode=0, zin=_ptr(slot.Zfc[0]), zin_pitch=pm.n_out, c_in=pm.n_out,
+                scale=_bn_vec(slot, enc, pm, "scale"), shift=_bn_vec(slot, enc, pm, "shift"), relu=1,
+                ones_col=enc.fc_mats[1].ones_col)
+
+
+def plan_encoder_forward(enc, slot, action=None, train=True):
+    """SA1 -> SA2 -> SA3 -> FC.  The last BN+ReLU is left to the consumer (scale/shift of fc[1])."""
+    geo = slot.geo
+    plan = Plan()
+    plan.zero(slot.stats)
+    tot = slot.tot
+    for s in range(3):
+        r = geo.rows[s]
+        for l, m in enumerate(enc.sa_mats[s]):
+            o = enc.bn_off[m.bn_index]
+            a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(slot.Z[s][l]),
+                          zout_pitch=m.n_out, stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8),
+                          **_layer_input(enc, slot, geo, s, l, action))
+            plan.call_struct("gad_gemm_fwd", a)
+            _finalize(plan, enc, slot, m, geo.counts[s], train)
+        m = enc.sa_mats[s][2]
+        plan.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, _bn_vec(slot, enc, m, "scale"),
+                  _bn_vec(slot, enc, m, "shift"), r["off"], r["G"], slot.F[s], slot.argmax[s])
+    for l, m in enumerate(enc.fc_mats):
+        o = enc.bn_off[m.bn_index]
+        a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(slot.Zfc[l]), zout_pitch=m.n_out,
+                      stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8),
+                      **_layer_input(enc, slot, geo, 3, l, action))
+        plan.call_struct("gad_gemm_fwd", a)
+        _finalize(plan, enc, slot, m, float(slot.B), train)
+    return plan
+
+
+def _coef_ptrs(slot, enc, m):
+    o, tot = enc.bn_off[m.bn_index], slot.tot
+    return _ptr(slot.coef, o), _ptr(slot.coef, tot + o), _ptr(slot.coef, 2 * tot + o)
+
+
+def _bn_coef(plan, enc, slot, m, count, want_dw):
+    o, tot = enc.bn_off[m.bn_index], slot.tot
+    P, Q, S = _coef_ptrs(slot, enc, m)
+    gacc = enc.flat.gacc
+    plan.call("gad_bn_bwd_coef", _ptr(slot.bstats, o, 8), _ptr(slot.bstats, tot + o, 8),
+              _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "mean"), _bn_vec(slot, enc, m, "istd"),
+              m.n_out, hip.Dbl(count), P, Q, S, _ptr(gacc, m.g_off, 8) if want_dw else None,
+              _ptr(gacc, m.b_off, 8) if want_dw else None)
+
+
+def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False):
+    """Backward of plan_encoder_forward.  g_fc2 (B, 512) is dLoss/d(relu(bn(Zfc[1]))) as produced by
+    the consumer head's dX kernel, whose epilogue must also have filled this slot's bstats for fc[1].
+    Weight gradients accumulate (f64) into enc.flat.gacc when want_dw."""
+    geo = slot.geo
+    plan = Plan()
+    B = slot.B
+    tot = slot.tot
+    gbuf = slot.G
+
+    def prev_stats(pm, zprev):
+        o = enc.bn_off[pm.bn_index]
+        return dict(zprev=_ptr(zprev), zprev_pitch=pm.n_out, prev_scale=_bn_vec(slot, enc, pm, "scale"),
+                    prev_shift=_bn_vec(slot, enc, pm, "shift"), prev_mean=_bn_vec(slot, enc, pm, "mean"),
+                    prev_istd=_bn_vec(slot, enc, pm, "istd"), prev_dbeta=_ptr(slot.bstats, o, 8),
+                    prev_dgamma=_ptr(slot.bstats, tot + o, 8))
+
+    def bn_dz(m, z, G=None, pooled=None, row_w=None):
+        P, Q, S = _coef_ptrs(slot, enc, m)
+        d = dict(z=_ptr(z), z_pitch=m.n_out, scale=_bn_vec(slot, enc, m, "scale"),
+                 shift=_bn_vec(slot, enc, m, "shift"), relu=1, coefP=P, coefQ=Q, coefS=S, row_w=row_w, c=m.n_out)
+        if pooled is None:
+            d.update(gmode=0, G=_ptr(G), g_pitch=m.n_out)
+        else:
+            d.update(gmode=1, argmax=_ptr(pooled[0]), dout=_ptr(pooled[1]), row_grp=_ptr(pooled[2]))
+        return _dz(**d)
+
+    def dx(rows_kw, dz, m, k_valid, **epi):
+        a = hip.GemmDxArgs()
+        a.n_rows_dev = rows_kw.get("n_rows_dev")
+        a.n_rows = rows_kw["n_rows"]
+        a.dz = dz
+        a.n_groups = 1
+        a.n_out[0] = m.n_out
+        a.W = enc.flat.p_w(m)
+        a.Kp = m.Kp
+        a.k_valid = k_valid
+        a.grp_per_sample = 1
+        for k, v in epi.items():
+            setattr(a, k, v)
+        plan.call_struct("gad_gemm_dx", a)
+
+    def dw(s, l, dz, m, action):
+        if not want_dw:
+            return
+        a = hip.GemmDwArgs()
+        a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **_layer_input(enc, slot, geo, s, l, action))
+        a.dz = dz
+        a.gacc = _ptr(enc.flat.gacc)
+        plan.call_struct("gad_gemm_dw", a)
+
+    # ---- FC head ----
+    fc1, fc2 = enc.fc_mats
+    _bn_coef(plan, enc, slot, fc2, float(B), want_dw)
+    d = bn_dz(fc2, slot.Zfc[1], G=g_fc2)
+    dw(3, 1, d, fc2, action)
+    dx(dict(n_rows=B), d, fc2, fc1.n_out, epilogue=0, gout=_ptr(gbuf[0]), gout_pitch=fc1.n_out,
+       **prev_stats(fc1, slot.Zfc[0]))
+    _bn_coef(plan, enc, slot, fc1, float(B), want_dw)
+    d = bn_dz(fc1, slot.Zfc[0], G=gbuf[0])
+    dw(3, 0, d, fc1, action)
+    dx(dict(n_rows=B), d, fc1, slot.F[2].shape[1], epilogue=0, gout=_ptr(slot.dF[2]), gout_pitch=slot.F[2].shape[1])
+    # ---- SA3 -> SA1 ----
+    for s in (2, 1, 0):
+        r = geo.rows[s]
+        rows_kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"])
+        m1, m2, m3 = enc.sa_mats[s]
+        o3 = enc.bn_off[m3.bn_index]
+        plan.call("gad_pool_bwd_stats", slot.dF[s], slot.argmax[s], r["G"], m3.n_out, slot.Z[s][2], m3.n_out,
+                  _bn_vec(slot, enc, m3, "scale"), _bn_vec(slot, enc, m3, "shift"), _bn_vec(slot, enc, m3, "mean"),
+                  _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8))
+        _bn_coef(plan, enc, slot, m3, geo.counts[s], want_dw)
+        d = bn_dz(m3, slot.Z[s][2], pooled=(slot.argmax[s], slot.dF[s], r["grp"]), row_w=_ptr(r["w"]))
+        dw(s, 2, d, m3, action)
+        dx(rows_kw, d, m3, m2.n_out, epilogue=0, gout=_ptr(gbuf[0]), gout_pitch=m2.n_out, **prev_stats(m2, slot.Z[s][1]))
+        _bn_coef(plan, enc, slot, m2, geo.counts[s], want_dw)
+        d = bn_dz(m2, slot.Z[s][1], G=gbuf[0], row_w=_ptr(r["w"]))
+        dw(s, 1, d, m2, action)
+        dx(rows_kw, d, m2, m1.n_out, epilogue=0, gout=_ptr(gbuf[1]), gout_pitch=m1.n_out, **prev_stats(m1, slot.Z[s][0]))
+        _bn_coef(plan, enc, slot, m1, geo.counts[s], want_dw)
+        d = bn_dz(m1, slot.Z[s][0], G=gbuf[1], row_w=_ptr(r["w"]))
+        dw(s, 0, d, m1, action)
+        if s > 0:
+            fc = slot.F[s - 1].shape[1]
+            plan.zero(slot.dF[s - 1])
+            dx(rows_kw, d, m1, 3 + fc, epilogue=1, dfeat=_ptr(slot.dF[s - 1]), feat_c=fc, row_pt=_ptr(r["pt"]),
+               row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
+        elif want_daction and action is not None:
+            plan.zero(slot.daction)
+            dx(rows_kw, d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),
+               daction=_ptr(slot.daction), act_c=6, grp_per_sample=geo.M1)
+    return plan
+
+
+def plan_zero_backward(enc, slot):
+    """clear the backward statistics of a slot (call before the consumer head's dX fills fc[1]'s)."""
+    plan = Plan()
+    plan.zero(slot.bstats)
+    return plan

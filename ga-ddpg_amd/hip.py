@@ -1,0 +1,142 @@
+"""ctypes binding of libgaddpg.so (include/gaddpg.h).  There is NO CPU fallback: if the library is
+missing or an entry point fails, this module raises.  torch is used only to own device memory and
+to name the current stream."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgaddpg.so")
+MAX_GROUPS = 3
+
+_i32, _f32, _f64, _vp = C.c_int32, C.c_float, C.c_double, C.c_void_p
+
+
+class GemmFwdArgs(C.Structure):
+    _fields_ = [("n_rows_dev", _vp), ("n_rows", _i32), ("row_w", _vp), ("mode", _i32),
+                ("zin", _vp), ("zin_pitch", _i32), ("c_in", _i32), ("scale", _vp), ("shift", _vp),
+                ("relu", _i32), ("extra", _vp), ("ones_col", _i32),
+                ("src_xyz", _vp), ("ctr_xyz", _vp), ("feat", _vp), ("feat_c", _i32),
+                ("action", _vp), ("act_c", _i32), ("grp_per_sample", _i32),
+                ("row_pt", _vp), ("row_grp", _vp),
+                ("n_groups", _i32), ("zin_off", _i32 * MAX_GROUPS), ("w_off", _i32 * MAX_GROUPS),
+                ("out_off", _i32 * MAX_GROUPS), ("n_out", _i32 * MAX_GROUPS),
+                ("W", _vp), ("Kp", _i32), ("zout", _vp), ("zout_pitch", _i32),
+                ("stat_sum", _vp), ("stat_sq", _vp)]
+
+
+class DzSrc(C.Structure):
+    _fields_ = [("z", _vp), ("z_pitch", _i32), ("scale", _vp), ("shift", _vp), ("relu", _i32),
+                ("coefP", _vp), ("coefQ", _vp), ("coefS", _vp), ("row_w", _vp), ("gmode", _i32),
+                ("G", _vp), ("g_pitch", _i32), ("argmax", _vp), ("dout", _vp), ("row_grp", _vp),
+                ("c", _i32)]
+
+
+class GemmDxArgs(C.Structure):
+    _fields_ = [("n_rows_dev", _vp), ("n_rows", _i32), ("dz", DzSrc), ("n_groups", _i32),
+                ("dz_off", _i32 * MAX_GROUPS), ("w_off", _i32 * MAX_GROUPS), ("n_out", _i32 * MAX_GROUPS),
+                ("gout_off", _i32 * MAX_GROUPS), ("accumulate", _i32), ("W", _vp), ("Kp", _i32),
+                ("k_valid", _i32), ("epilogue", _i32), ("gout", _vp), ("gout_pitch", _i32),
+                ("zprev", _vp), ("zprev_pitch", _i32), ("prev_scale", _vp), ("prev_shift", _vp),
+                ("prev_mean", _vp), ("prev_istd", _vp), ("prev_dbeta", _vp), ("prev_dgamma", _vp),
+                ("dfeat", _vp), ("feat_c", _i32), ("row_pt", _vp), ("row_grp", _vp),
+                ("daction", _vp), ("act_c", _i32), ("grp_per_sample", _i32)]
+
+
+class GemmDwArgs(C.Structure):
+    _fields_ = [("inp", GemmFwdArgs), ("dz", DzSrc), ("dz_off", _i32 * MAX_GROUPS), ("gacc", _vp),
+                ("row_splits", _i32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libgaddpg.so (raises with the build hint if it is absent -- by design no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libgaddpg.so not found at %s -- build it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+                               "The update-step path has no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.gad_last_error.restype = C.c_char_p
+        L.gad_abi_version.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+EXPORTS = (
+    "gad_abi_version", "gad_last_error", "gad_furthest_point_sampling", "gad_gather_points",
+    "gad_gather_points_grad", "gad_ball_query", "gad_group_points", "gad_group_points_grad",
+    "gad_query_and_group", "gad_prep_points", "gad_rows_from_ball_query", "gad_rows_group_all",
+    "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_affine_act",
+    "gad_pool_bwd_stats", "gad_bn_bwd_coef", "gad_gemm_dx", "gad_gemm_dw", "gad_critic_loss",
+    "gad_policy_outputs", "gad_actor_loss", "gad_actor_critic_loss", "gad_target_noise",
+    "gad_grad_from_arena", "gad_sumsq", "gad_absmax_segments", "gad_adam_step", "gad_polyak",
+    "gad_pack_params")
+
+
+def ptr(t):
+    """device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError("%s failed (status %d): %s" % (what, status, lib().gad_last_error().decode()))
+
+
+def _args(*a):
+    out = []
+    for x in a:
+        if x is None:
+            out.append(C.c_void_p(None))
+        elif torch.is_tensor(x):
+            out.append(C.c_void_p(x.data_ptr()))
+        elif isinstance(x, float):
+            out.append(C.c_float(x))
+        elif isinstance(x, Dbl):
+            out.append(C.c_double(x.v))
+        elif isinstance(x, bool):
+            out.append(C.c_int(int(x)))
+        elif isinstance(x, int):
+            out.append(C.c_int(x))
+        else:
+            out.append(x)
+    return out
+
+
+class Dbl(object):
+    """marks a Python float that must cross the ABI as a C double"""
+    def __init__(self, v):
+        self.v = float(v)
+
+
+def call(name, *a):
+    """Call an entry point: tensors -> device pointers, ints -> int, floats -> float, Dbl -> double,
+    None -> NULL; the current torch stream is appended as the trailing `stream` argument."""
+    f = getattr(lib(), name)
+    check(f(*(_args(*a) + [stream()])), name)
+
+
+def call_struct(name, s):
+    f = getattr(lib(), name)
+    check(f(C.byref(s), stream()), name)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and (not t.is_cuda):
+            raise RuntimeError("CPU tensor passed to a libgaddpg operator (CPU not supported)")
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("libgaddpg operators need contiguous tensors")

@@ -1,0 +1,308 @@
+/*
+ * gaddpg.h -- C ABI of libgaddpg.so: the MI355X (gfx950) implementation of GA-DDPG's
+ * PointNet++-encoded actor-critic update step.
+ *
+ * Boundary rules (all entry points):
+ *   - extern "C", plain device pointers + sizes, no torch / C++ types.  Every pointer is a DEVICE
+ *     pointer unless named host_*.  `stream` is a hipStream_t passed as void* (NULL = default).
+ *   - outputs are caller-allocated; no hidden allocation, no host synchronisation, re-entrant,
+ *     ordered only by `stream` (same contract as the reference extension, which launches on
+ *     at::cuda::getCurrentCUDAStream() without syncing).
+ *   - return value: 0 = GAD_OK, <0 = gad_status error (no exceptions cross the ABI).  The Python
+ *     binding turns a non-zero status into RuntimeError, mirroring the TORCH_CHECK -> RuntimeError
+ *     behaviour of the reference extension's CHECK_* macros.
+ *
+ * Section A replaces the C++/CUDA extension `pointnet2_ops._ext` that reference core/networks.py:10
+ * and core/utils.py:32 reach through pointnet2_ops.pointnet2_utils (upstream bindings.cpp:
+ * furthest_point_sampling, gather_points[_grad], ball_query, group_points[_grad]).
+ * Sections B-E are the fused update-step path that sits behind core/networks.py:65-92,182-371,
+ * core/ddpg.py:119-185, core/agent.py:127-139,192-259, core/loss.py:17-31 and core/utils.py:750-774.
+ */
+#ifndef GADDPG_H
+#define GADDPG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    GAD_OK = 0,
+    GAD_ERR_NULL = -1,      /* required pointer is NULL                                   */
+    GAD_ERR_SHAPE = -2,     /* size / shape outside what the kernels support              */
+    GAD_ERR_LAUNCH = -3,    /* hipGetLastError() != hipSuccess after a launch             */
+    GAD_ERR_UNSUPPORTED = -4
+} gad_status;
+
+int gad_abi_version(void);                 /* bumped on any signature change            */
+const char* gad_last_error(void);          /* thread-local description of the last <0   */
+
+/* ---------------------------------------------------------------------------------------------
+ * A. pointnet2_ops._ext operator parity (materialising, reference API shapes)
+ * ------------------------------------------------------------------------------------------- */
+
+/* furthest_point_sampling(xyz (B,N,3) f32, npoint) -> idx (B,M) i32.  Start index 0, points with
+ * |p|^2 <= 1e-3 are never selected/updated, arg-max ties resolved as the upstream block reduction
+ * does.  new_xyz (B,M,3) is optional (fused gather_operation of the xyz rows).    */
+int gad_furthest_point_sampling(const float* xyz, int B, int N, int M, int32_t* idx,
+                                float* new_xyz /*nullable*/, void* stream);
+
+/* gather_points(points (B,C,N), idx (B,M)) -> out (B,C,M);  _grad scatters back (zero-fills).  */
+int gad_gather_points(const float* points, const int32_t* idx, int B, int C, int N, int M,
+                      float* out, void* stream);
+int gad_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                           float* grad_points, void* stream);
+
+/* ball_query(new_xyz (B,M,3), xyz (B,N,3), radius, nsample) -> idx (B,M,nsample) i32: first
+ * nsample indices with d2 < radius^2 in ascending order, padded with the first hit, zeros if none.
+ * cnt (B,M) (optional) receives the number of distinct hits kept (<= nsample).                  */
+int gad_ball_query(const float* new_xyz, const float* xyz, int B, int N, int M, float radius,
+                   int nsample, int32_t* idx, int32_t* cnt /*nullable*/, void* stream);
+
+/* group_points(points (B,C,N), idx (B,M,S)) -> out (B,C,M,S);  _grad: atomic scatter-add into
+ * grad_points (B,C,N), which the call zero-fills first (upstream torch::zeros + atomicAdd).      */
+int gad_group_points(const float* points, const int32_t* idx, int B, int C, int N, int M, int S,
+                     float* out, void* stream);
+int gad_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N, int M,
+                          int S, float* grad_points, void* stream);
+
+/* QueryAndGroup in one pass (ball_query + group xyz + recentre + group features + concat):
+ * out (B,3+C,M,S) exactly as pointnet2_utils.QueryAndGroup(use_xyz=True) returns it; idx as above.
+ * This is the HBM-bound "config 4a" kernel of BASELINE.md.                                       */
+int gad_query_and_group(const float* new_xyz, const float* xyz, const float* features /*(B,C,N)*/,
+                        int B, int C, int N, int M, float radius, int nsample, int32_t* idx,
+                        float* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * B. geometry for the fused set-abstraction path (de-duplicated neighbourhood rows)
+ * ------------------------------------------------------------------------------------------- */
+
+/* point_state (B,C4,NP) channel-major f32 (rows x,y,z,flag; reference replay layout) ->
+ * xyz (B,N,3) and point-major features feat (B*N,4) = [x,y,z,flag], N = NP - skip.              */
+int gad_prep_points(const float* point_state, int B, int C4, int NP, int skip, float* xyz,
+                    float* feat, void* stream);
+
+/* Compact ball-query output into unique (group, point) rows.  Group g = b*M+m keeps its
+ * max(cnt,1) distinct hits; the first hit carries weight nsample-cnt+1 (the padded duplicates).
+ * grp_off (G+1) exclusive offsets, row_pt global point index b*Nsrc+j, row_grp = g, row_w weight,
+ * n_rows device scalar = grp_off[G].  Deterministic order (g ascending, slot ascending).         */
+int gad_rows_from_ball_query(const int32_t* idx, const int32_t* cnt, int G, int M, int Nsrc,
+                             int nsample, int32_t* grp_off, int32_t* row_pt, int32_t* row_grp,
+                             float* row_w, int32_t* n_rows, void* stream);
+/* GroupAll: rows = all points, group = sample (pts_per_group points each), weight 1.            */
+int gad_rows_group_all(int G, int pts_per_group, int32_t* grp_off, int32_t* row_pt,
+                       int32_t* row_grp, float* row_w, int32_t* n_rows, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * C. layer kernels (FP32 MFMA GEMMs with fused producers / epilogues)
+ *
+ * Weights use the PACKED layout: W (n_out, Kp) row-major, Kp = K rounded up to 8, an optional bias
+ * stored as column `ones_col`, zero padding after it.  Activations are row-major (rows, channels).
+ * ------------------------------------------------------------------------------------------- */
+
+#define GAD_MAX_GROUPS 3
+
+typedef struct {
+    /* rows */
+    const int32_t* n_rows_dev; /* device scalar with the live row count, or NULL -> n_rows       */
+    int32_t n_rows;            /* static row count (upper bound when n_rows_dev is given)        */
+    const float* row_w;        /* (rows) multiplicity weights, NULL -> 1                         */
+    /* input mode: 0 = ACT (act(scale*z+shift) of a previous layer's raw output), 1 = GATHER     */
+    int32_t mode;
+    const float* zin;          /* ACT: (rows, zin_pitch)                                         */
+    int32_t zin_pitch;
+    int32_t c_in;              /* ACT: channels read from zin;  GATHER: 3 + feat_c + act_c       */
+    const float* scale;        /* ACT: per-channel affine (NULL -> identity)                     */
+    const float* shift;
+    int32_t relu;              /* ACT: apply max(.,0) after the affine                           */
+    const float* extra;        /* ACT: optional extra input column (rows) placed at index c_in   */
+    int32_t ones_col;          /* column holding 1.0 (bias), or -1                               */
+    /* GATHER: row r = [src_xyz[pt]-ctr_xyz[grp] (3), feat[pt] (feat_c), action[grp/grp_per_sample] (act_c)] */
+    const float* src_xyz;      /* (points,3)                                                     */
+    const float* ctr_xyz;      /* (groups,3) or NULL (GroupAll: no recentring)                   */
+    const float* feat;         /* (points, feat_c) point-major                                   */
+    int32_t feat_c;
+    const float* action;       /* (samples, act_c) or NULL                                       */
+    int32_t act_c;
+    int32_t grp_per_sample;
+    const int32_t* row_pt;
+    const int32_t* row_grp;
+    /* groups (blockIdx.z): independent GEMMs sharing the row set (e.g. the three critic trunks) */
+    int32_t n_groups;
+    int32_t zin_off[GAD_MAX_GROUPS]; /* channel offset into zin (ACT)                            */
+    int32_t w_off[GAD_MAX_GROUPS];   /* element offset into W                                    */
+    int32_t out_off[GAD_MAX_GROUPS]; /* channel offset into zout / stats                         */
+    int32_t n_out[GAD_MAX_GROUPS];
+    const float* W;
+    int32_t Kp;
+    /* outputs */
+    float* zout;               /* (rows, zout_pitch) raw pre-activation output (bias included)   */
+    int32_t zout_pitch;
+    double* stat_sum;          /* per output channel sum_r w*z and sum_r w*z^2 (f64 atomics),    */
+    double* stat_sq;           /*   NULL -> no statistics                                        */
+} gad_gemm_fwd_args;
+
+int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);
+
+/* train-mode BatchNorm finalisation: mean/var from the f64 sums over `count` rows (duplicates
+ * included), scale = gamma*istd, shift = beta - mean*scale, running stats momentum update
+ * (unbiased variance), saves mean/istd for the backward pass.                                   */
+int gad_bn_finalize(const double* stat_sum, const double* stat_sq, const float* gamma,
+                    const float* beta, int C, double count, float eps, float momentum,
+                    float* running_mean /*nullable*/, float* running_var /*nullable*/,
+                    float* scale, float* shift, float* mean, float* istd, void* stream);
+/* eval-mode: scale/shift from the running statistics */
+int gad_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, int C, float eps, float* scale, float* shift,
+                       void* stream);
+
+/* segment max-pool over each group's rows of act(scale*z+shift): out (G,C) point-major,
+ * argmax (G,C) = global row index of the first maximum.                                          */
+int gad_segment_pool(const float* z, int z_pitch, int C, const float* scale, const float* shift,
+                     const int32_t* grp_off, int G, float* out, int32_t* argmax, void* stream);
+
+/* apply act(scale*z+shift) elementwise -> out (rows,C) (used at API boundaries only)            */
+int gad_affine_act(const float* z, int z_pitch, int rows, int C, const float* scale,
+                   const float* shift, int relu, float* out, int out_pitch, void* stream);
+
+/* backward source of dY for a layer: dense G (rows,C) or routed from the pooled gradient        */
+typedef struct {
+    const float* z;            /* (rows, z_pitch) raw output of THIS layer                       */
+    int32_t z_pitch;
+    const float* scale;        /* this layer's forward affine (mask = scale*z+shift > 0); NULL = identity */
+    const float* shift;
+    int32_t relu;              /* 0: no activation after this layer (dY = G)                     */
+    const float* coefP;        /* BN backward: dZ = P*dY - w*(Q + S*z); NULL -> dZ = dY          */
+    const float* coefQ;
+    const float* coefS;
+    const float* row_w;
+    int32_t gmode;             /* 0 dense G, 1 pooled (argmax routing)                           */
+    const float* G;            /* dense: (rows, g_pitch)                                         */
+    int32_t g_pitch;
+    const int32_t* argmax;     /* pooled: (groups, C) global row index                           */
+    const float* dout;         /* pooled: (groups, C)                                            */
+    const int32_t* row_grp;    /* pooled: (rows)                                                 */
+    int32_t c;                 /* channels of this layer (n_out)                                 */
+} gad_dz_src;
+
+/* pooled-gradient statistics for the BN that feeds a segment pool: dbeta/dgamma f64 sums        */
+int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int G, int C, const float* z,
+                       int z_pitch, const float* scale, const float* shift, const float* mean,
+                       const float* istd, double* dbeta, double* dgamma, void* stream);
+
+/* BN backward coefficients from (dbeta,dgamma): P,Q,S above; also accumulates dgamma/dbeta into
+ * the f64 gradient arena slots gacc_gamma/gacc_beta (nullable).                                 */
+int gad_bn_bwd_coef(const double* dbeta, const double* dgamma, const float* scale,
+                    const float* mean, const float* istd, int C, double count, float* coefP,
+                    float* coefQ, float* coefS, double* gacc_gamma, double* gacc_beta,
+                    void* stream);
+
+typedef struct {
+    const int32_t* n_rows_dev;
+    int32_t n_rows;
+    gad_dz_src dz;
+    int32_t n_groups;
+    int32_t dz_off[GAD_MAX_GROUPS];  /* channel offset of the group inside dz (z, G, coef)       */
+    int32_t w_off[GAD_MAX_GROUPS];
+    int32_t n_out[GAD_MAX_GROUPS];
+    int32_t gout_off[GAD_MAX_GROUPS];/* channel offset into gout                                  */
+    int32_t accumulate;              /* groups add into the same gout columns (shared input)      */
+    const float* W;
+    int32_t Kp;
+    int32_t k_valid;                 /* input channels to produce (columns >= k_valid are skipped)*/
+    /* epilogue 0: store gout (rows, gout_pitch)                                                  */
+    int32_t epilogue;
+    float* gout;
+    int32_t gout_pitch;
+    /* epilogue 0 + statistics for the PREVIOUS layer's BN backward (nullable)                    */
+    const float* zprev; int32_t zprev_pitch;
+    const float* prev_scale; const float* prev_shift; const float* prev_mean; const float* prev_istd;
+    double* prev_dbeta; double* prev_dgamma;
+    /* epilogue 1: gather-layer scatter: columns [3,3+feat_c) atomically added to dfeat[row_pt],
+     * columns [3+feat_c, 3+feat_c+act_c) to daction[row_grp/grp_per_sample]                      */
+    float* dfeat; int32_t feat_c; const int32_t* row_pt; const int32_t* row_grp;
+    float* daction; int32_t act_c; int32_t grp_per_sample;
+} gad_gemm_dx_args;
+
+int gad_gemm_dx(const gad_gemm_dx_args* host_args, void* stream);
+
+typedef struct {
+    gad_gemm_fwd_args in;      /* describes how the layer's INPUT rows are produced (W/zout unused) */
+    gad_dz_src dz;
+    int32_t dz_off[GAD_MAX_GROUPS];
+    double* gacc;              /* f64 gradient arena, packed layout; group g at gacc + in.w_off[g] */
+    int32_t row_splits;        /* rows are divided over this many blocks (0 -> auto)               */
+} gad_gemm_dw_args;
+
+int gad_gemm_dw(const gad_gemm_dw_args* host_args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * D. heads' losses (forward value + gradient wrt head outputs in one pass)
+ * ------------------------------------------------------------------------------------------- */
+
+/* Critic phase (core/ddpg.py:61-88,119-130): TD3 target y = r + (1-done)*gamma*min(q1t,q2t),
+ * masked smooth-L1 on both Q heads, control-point L1 on the quaternion-normalised aux head.
+ *   out9 (B,9) raw head outputs [q1, q2, aux7];  tgt_out9 (B,9) target-critic raw outputs.
+ *   g_out9 (B,9) receives dLoss/d(out9).  scalars[0]=critic_loss, [1]=critic_grasp_aux_loss,
+ *   [2]=#kept, [3]=#goal rows.  inv_n_* (nullable device scalars) override 1/count with a
+ *   globally reduced value for data-parallel runs.                                               */
+int gad_critic_loss(const float* out9, const float* tgt_out9, const float* reward,
+                    const float* done, const float* perturb_flag, const float* ret,
+                    const float* goal, int B, float gamma, int critic_aux, const float* inv_n,
+                    float* y, float* aux_norm, float* g_out9, float* scalars, void* stream);
+
+/* Actor phase (core/agent.py:127-139, core/ddpg.py:169-177, core/loss.py): outputs of the policy
+ * head pol13 (B,13) = [mean6 raw, extra7 raw].  pi = tanh(mean)*scale.  bc_loss over expert rows
+ * scaled by bc_scale, goal aux over return>0 rows, and (optional) the gradient of
+ * -ratio*mean(min(q1_pi,q2_pi)) wrt pi arriving as g_pi_critic (B,6) (already scaled).
+ *   g_pol13 receives dLoss/d(pol13); scalars[0]=bc_loss (scaled), [1]=policy_grasp_aux_loss.     */
+int gad_policy_outputs(const float* pol13, int B, const float* action_scale, float* pi,
+                       float* aux_norm, void* stream);
+int gad_actor_loss(const float* pol13, const float* pi, const float* expert_action,
+                   const float* expert_flag, const float* ret, const float* goal, int B,
+                   float bc_scale, int policy_aux, const float* action_scale,
+                   const float* g_pi_critic /*nullable*/, const float* inv_n, float* g_pol13,
+                   float* scalars, void* stream);
+/* -ratio * mean over rows NOT (expert & return>0) of min(q1,q2): value + dLoss/d(out9[:, :2])    */
+int gad_actor_critic_loss(const float* out9, const float* expert_flag, const float* ret, int B,
+                          float ratio, const float* inv_n, float* g_out9, float* scalars,
+                          void* stream);
+/* TD3 target-policy smoothing (core/utils.py:568-576 + core/ddpg.py:80-82, quirk preserved):
+ * a = pi + clamp3(((u*3-6)*level) * [1,1,1,5,5,5])                                               */
+int gad_target_noise(const float* pi, const float* u, int B, float level, float* out,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * E. optimiser / bookkeeping over flat parameter buffers
+ * ------------------------------------------------------------------------------------------- */
+
+/* grad[i] = (float) gacc[m2p[i]] for the n master parameters (m2p[i] < 0 -> 0); accumulate != 0
+ * adds to the existing grad instead (a second backward into the same .grad, as autograd does).   */
+int gad_grad_from_arena(const double* gacc, const int32_t* m2p, int n, float* grad, int accumulate,
+                        void* stream);
+/* sum of squares of grad[0..n) into *out (f64, atomically accumulated; zero it first)           */
+int gad_sumsq(const float* grad, int n, double* out, void* stream);
+/* max |x| over segments: out[s] = max |x[seg_off[s] .. seg_off[s+1])|                           */
+int gad_absmax_segments(const float* x, const int32_t* seg_off, int n_seg, float* out,
+                        void* stream);
+/* Adam with L2 weight decay folded into the gradient (torch.optim.Adam, amsgrad=False), over a
+ * flat buffer; `hyper` is a device array {lr, beta1, beta2, eps, weight_decay, bias_c1, bias_c2,
+ * grad_scale}; active[i]==0 skips an element (parameters that never receive a gradient);
+ * clip_sumsq/clip_max (nullable) apply clip_grad_norm_ on the fly:
+ *   g *= min(1, clip_max / (sqrt(*clip_sumsq) + 1e-6)).
+ * Updated values are written to the master buffer p and mirrored into the packed compute buffer
+ * packed[m2p[i]].                                                                               */
+int gad_adam_step(float* p, const float* grad, float* exp_avg, float* exp_avg_sq,
+                  const uint8_t* active, const int32_t* m2p, float* packed, int n,
+                  const float* hyper, const double* clip_sumsq, float clip_max, void* stream);
+/* target <- (1-tau)*target + tau*source where sel[i]==1, target <- source where sel[i]==2        */
+int gad_polyak(float* target, const float* source, const uint8_t* sel, const int32_t* m2p,
+               float* target_packed, int n, float tau, int hard_enable, void* stream);
+/* packed[m2p[i]] = p[i] (refresh the compute layout after an external parameter change)          */
+int gad_pack_params(const float* p, const int32_t* m2p, int n, float* packed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GADDPG_H */

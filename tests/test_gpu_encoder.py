@@ -1,0 +1,284 @@
+"""Fused encoder / heads plans on the GPU against golden vectors produced by the reference's own
+PointNetFeature (tests/golden, oracle/make_golden.py) and against the CPU oracle's heads.
+Tolerance: the north-star 1e-4 relative (float32; different summation order, de-duplicated rows)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, check_summaries
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+
+
+class _Shell(torch.nn.Module):
+    def __init__(self, net):
+        super().__init__()
+        self.module = net
+
+
+def _feature_net():
+    from ga_ddpg_amd.core import networks
+    from oracle.detfill import fill_module_
+    net = networks.PointNetFeature(input_dim=5, extra_latent=1, action_concat=True)
+    fill_module_(_Shell(net), "state_feature_extractor", SEED)
+    return net
+
+
+def _geometry(B):
+    from ga_ddpg_amd import engine
+    return engine.Geometry(B, 1024, engine.SAConfig(32, 0.02, 64), engine.SAConfig(32, 0.04, 128),
+                           torch.device("cuda"))
+
+
+def _run_encoder(enc, slot, action, probe, want_daction):
+    from ga_ddpg_amd import engine, hip
+    engine.plan_encoder_forward(enc, slot, action=action).run()
+    fc2 = enc.fc_mats[1]
+    o = enc.bn_off[fc2.bn_index]
+    sc, sh = slot.scale[o:o + 512], slot.shift[o:o + 512]
+    z = torch.empty(slot.B, 512, device="cuda")
+    hip.call("gad_affine_act", slot.Zfc[1], 512, slot.B, 512, sc, sh, 1, z, 512)
+    # the consumer's dX epilogue normally provides fc[1]'s BN-backward sums; emulate it (test scaffolding)
+    engine.plan_zero_backward(enc, slot).run()
+    mask = (slot.Zfc[1] * sc + sh) > 0
+    xhat = (slot.Zfc[1] - slot.mean[o:o + 512]) * slot.istd[o:o + 512]
+    slot.bstats[o:o + 512] = (probe * mask).double().sum(0)
+    slot.bstats[slot.tot + o:slot.tot + o + 512] = (probe * mask * xhat).double().sum(0)
+    enc.flat.gacc.zero_()
+    engine.plan_encoder_backward(enc, slot, probe, action=action, want_dw=True, want_daction=want_daction).run()
+    hip.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
+    torch.cuda.synchronize()
+    return z
+
+
+def test_geometry_matches_oracle(golden_dir):
+    from oracle import cref
+    g = np.load(os.path.join(golden_dir, "encoder_B4.npz"))
+    ps = g["point_state"]
+    B = ps.shape[0]
+    geo = _geometry(B)
+    geo.run(torch.from_numpy(ps).cuda())
+    xyz = np.ascontiguousarray(ps[:, :3, 6:].transpose(0, 2, 1))
+    np.testing.assert_array_equal(geo.xyz.cpu().numpy(), xyz)
+    f1 = cref.fps(xyz, 32)
+    np.testing.assert_array_equal(geo.fps1.cpu().numpy(), f1)
+    nx1 = np.take_along_axis(xyz, f1[..., None].astype(np.int64), 1)
+    np.testing.assert_array_equal(geo.new_xyz1.cpu().numpy(), nx1)
+    i1, c1 = cref.ball_query(nx1, xyz, 0.02, 64, True)
+    np.testing.assert_array_equal(geo.idx1.cpu().numpy(), i1)
+    f2 = cref.fps(nx1, 32)
+    np.testing.assert_array_equal(geo.fps2.cpu().numpy(), f2)
+    nx2 = np.take_along_axis(nx1, f2[..., None].astype(np.int64), 1)
+    i2, c2 = cref.ball_query(nx2, nx1, 0.04, 128, True)
+    np.testing.assert_array_equal(geo.idx2.cpu().numpy(), i2)
+    assert int(geo.rows[0]["n"].item()) == int(np.maximum(c1, 1).sum())
+    assert int(geo.rows[1]["n"].item()) == int(np.maximum(c2, 1).sum())
+    assert int(geo.rows[2]["n"].item()) == B * 32
+
+
+def test_encoder_forward_backward_vs_reference(golden_dir):
+    from ga_ddpg_amd import engine
+    g = np.load(os.path.join(golden_dir, "encoder_B4.npz"))
+    dev = torch.device("cuda")
+    net = _feature_net()
+    enc = engine.EncoderNet(net.encoder, dev)
+    venc = engine.EncoderNet(net.value_encoder, dev)
+    B = g["point_state"].shape[0]
+    geo = _geometry(B)
+    geo.run(torch.from_numpy(g["point_state"]).cuda())
+    probe = torch.from_numpy(g["probe"]).cuda()
+    action = torch.from_numpy(g["action"]).cuda()
+
+    slot = engine.EncoderSlot(geo, enc, dev)
+    z_pol = _run_encoder(enc, slot, None, probe, False)
+    assert_close(z_pol.cpu().numpy(), g["z_policy"], 1e-4, 2e-5, "z_policy")
+    vslot = engine.EncoderSlot(geo, venc, dev)
+    z_val = _run_encoder(venc, vslot, action, probe.flip(1).contiguous(), True)
+    assert_close(z_val.cpu().numpy(), g["z_value"], 1e-4, 2e-5, "z_value")
+    assert_close(vslot.daction.cpu().numpy(), g["action_grad"], 2e-4, 1e-5, "action grad")
+
+    skip = (".1.0.bias", ".1.3.bias")          # bias in front of train-mode BN: analytically zero gradient
+    check_summaries(g, "grad/", ((n, p.grad) for n, p in net.named_parameters()), 3e-4, 2e-5, skip=skip)
+    check_summaries(g, "state/", ((n, t) for n, t in net.state_dict().items() if "running" in n), 1e-4, 1e-6)
+    for n, p in net.named_parameters():
+        if any(s in n for s in skip):
+            assert float(p.grad.abs().max()) < 1e-3, n
+
+
+def test_heads_forward_backward_vs_oracle():
+    """critic / policy heads + loss kernels against the CPU oracle's heads and torch autograd."""
+    from ga_ddpg_amd import engine, heads, hip
+    from ga_ddpg_amd.core import networks
+    from ga_ddpg_amd.synth_data import PandaTaskSpace6D
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    dev = torch.device("cuda")
+    rng = np.random.default_rng(7)
+    B = 24
+    feat = torch.tensor(np.abs(rng.normal(size=(B, 512))), dtype=torch.float32)      # post-ReLU features
+    feat[:, ::5] = 0
+    time = torch.tensor(rng.integers(1, 20, size=B), dtype=torch.float32)
+    net = _feature_net()
+    enc = engine.EncoderNet(net.encoder, dev)
+    geo = _geometry(B)
+    slot = engine.EncoderSlot(geo, enc, dev)
+    fc2 = enc.fc_mats[1]
+    o = enc.bn_off[fc2.bn_index]
+    slot.scale[o:o + 512] = 1.0
+    slot.shift[o:o + 512] = 0.0
+    slot.mean[o:o + 512] = 0.0
+    slot.istd[o:o + 512] = 1.0
+    slot.Zfc[1][:B] = feat.cuda()
+    d_time = time.cuda()
+    crit = fill_module_(networks.QNetwork(513, 0, 256, extra_pred_dim=7), "critic", SEED)
+    pol = fill_module_(networks.GaussianPolicy(513, 6, 256, PandaTaskSpace6D(), extra_pred_dim=7), "policy", SEED)
+    cr, po = heads.CriticNet(crit, dev), heads.PolicyNet(pol, dev)
+    hs_c = heads.HeadSlot(B, cr.width, 9, dev)
+    hs_p = heads.HeadSlot(B, po.hidden, 13, dev)
+    heads.plan_critic_forward(cr, hs_c, enc, slot, d_time).run()
+    heads.plan_policy_forward(po, hs_p, enc, slot, d_time).run()
+
+    # ---- oracle side
+    oq = fill_module_(ref_step.QNet(513, 256, 7), "critic", SEED)
+    op = fill_module_(ref_step.PolicyNet(513, 6, 256, 7), "policy", SEED)
+    f = feat.clone().requires_grad_(True)
+    xin = torch.cat([f, time[:, None]], 1)
+    q1, q2, aux = oq(xin)
+    reward = torch.tensor(rng.random(B), dtype=torch.float32)
+    done = torch.tensor(rng.random(B) < 0.3, dtype=torch.float32)
+    perturb = torch.tensor(rng.random(B) < 0.2, dtype=torch.float32)
+    ret = torch.tensor(np.where(rng.random(B) < 0.5, rng.random(B), 0.0), dtype=torch.float32)
+    gq = rng.normal(size=(B, 4)); gq /= np.linalg.norm(gq, axis=1, keepdims=True)
+    goal = torch.tensor(np.concatenate([gq, rng.uniform(-0.15, 0.15, (B, 3))], 1), dtype=torch.float32)
+    tgt = torch.tensor(rng.normal(size=(B, 9)), dtype=torch.float32)
+    y = reward + (1 - done) * 0.95 * torch.min(tgt[:, 0], tgt[:, 1])
+    keep, gm = perturb < 1, ret > 0
+    closs = torch.nn.functional.smooth_l1_loss(q1.squeeze()[keep], y[keep]) + \
+        torch.nn.functional.smooth_l1_loss(q2.squeeze()[keep], y[keep])
+    aloss = ref_step.goal_pred_loss(aux[gm, :7], goal[gm])
+    (closs + aloss).backward()
+
+    # ---- device side
+    dv = lambda t: t.cuda().contiguous()
+    yb = torch.empty(B, device="cuda"); an = torch.empty(B, 7, device="cuda"); sc = torch.zeros(4, device="cuda")
+    hip.call("gad_critic_loss", hs_c.out, dv(tgt), dv(reward), dv(done), dv(perturb), dv(ret), dv(goal), B, 0.95, 1,
+             None, yb, an, hs_c.g_out, sc)
+    out = hs_c.out.cpu().numpy()
+    assert_close(out[:, 0], q1.detach().numpy()[:, 0], 1e-4, 1e-5, "q1")
+    assert_close(out[:, 1], q2.detach().numpy()[:, 0], 1e-4, 1e-5, "q2")
+    assert_close(an.cpu().numpy(), aux.detach().numpy(), 1e-4, 1e-5, "critic aux")
+    assert_close(yb.cpu().numpy(), y.numpy(), 1e-5, 1e-6, "td target")
+    s = sc.cpu().numpy()
+    assert_close(s[0], closs.item(), 1e-4, 1e-6, "critic loss")
+    assert_close(s[1], aloss.item(), 1e-4, 1e-6, "critic aux loss")
+    assert s[2] == keep.sum().item() and s[3] == gm.sum().item()
+    engine.plan_zero_backward(enc, slot).run()
+    cr.flat.gacc.zero_()
+    heads.plan_critic_backward(cr, hs_c, enc, slot, d_time).run()
+    hip.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 0)
+    torch.cuda.synchronize()
+    for (n, p), (n2, p2) in zip(crit.named_parameters(), oq.named_parameters()):
+        assert n == n2
+        assert_close(p.grad.cpu().numpy(), p2.grad.numpy(), 2e-4, 2e-6, "critic grad " + n)
+    # dLoss/dfeature: only where the feature is > 0 (the heads' ReLU mask on relu(bn(z)) input)
+    gf = hs_c.g_feat.cpu().numpy()
+    assert_close(gf, f.grad.numpy() , 2e-4, 2e-6, "critic dfeature")
+    # fc[1] BN-backward sums accumulated by the dX epilogue: dbeta = sum(g*mask), dgamma = sum(g*mask*xhat)
+    mask = (feat > 0).numpy()
+    assert_close(slot.bstats[o:o + 512].cpu().numpy(), (f.grad.numpy() * mask).sum(0), 2e-4, 2e-6, "dbeta")
+    assert_close(slot.bstats[slot.tot + o:slot.tot + o + 512].cpu().numpy(), (f.grad.numpy() * mask * feat.numpy()).sum(0),
+                 2e-4, 2e-6, "dgamma")
+
+    # ---- policy: outputs, BC + aux loss, gradients
+    f2 = feat.clone().requires_grad_(True)
+    pi_o, aux_o = op(torch.cat([f2, time[:, None]], 1))
+    expert_flag = torch.tensor(rng.random(B) < 0.6, dtype=torch.float32)
+    hi = np.array([0.06] * 3 + [np.pi / 6] * 3)
+    expert_act = torch.tensor(rng.uniform(-hi, hi, (B, 6)), dtype=torch.float32)
+    em = expert_flag >= 1
+    bc = ref_step.pose_bc_loss(pi_o[em], expert_act[em]) * 0.9
+    pa = ref_step.goal_pred_loss(aux_o[gm, :7], goal[gm, :7])
+    gpc = torch.tensor(rng.normal(size=(B, 6)) * 0.01, dtype=torch.float32)     # pretend dQ/dpi term
+    (bc + pa + (pi_o * gpc).sum()).backward()
+    ascale = torch.tensor(np.asarray(pol.action_scale), dtype=torch.float32, device="cuda")
+    pi = torch.empty(B, 6, device="cuda"); auxn = torch.empty(B, 7, device="cuda"); sp = torch.zeros(4, device="cuda")
+    hip.call("gad_policy_outputs", hs_p.out, B, ascale, pi, auxn)
+    assert_close(pi.cpu().numpy(), pi_o.detach().numpy(), 1e-4, 1e-6, "pi")
+    assert_close(auxn.cpu().numpy(), aux_o.detach().numpy(), 1e-4, 1e-5, "policy aux")
+    hip.call("gad_actor_loss", hs_p.out, pi, dv(expert_act), dv(expert_flag), dv(ret), dv(goal), B, 0.9, 1, ascale,
+             dv(gpc), None, hs_p.g_out, sp)
+    s = sp.cpu().numpy()
+    assert_close(s[0], bc.item(), 1e-4, 1e-6, "bc loss")
+    assert_close(s[1], pa.item(), 1e-4, 1e-6, "policy aux loss")
+    engine.plan_zero_backward(enc, slot).run()
+    po.flat.gacc.zero_()
+    heads.plan_policy_backward(po, hs_p, enc, slot, d_time).run()
+    hip.call("gad_grad_from_arena", po.flat.gacc, po.flat.m2p, po.flat.n, po.flat.grad, 0)
+    torch.cuda.synchronize()
+    for (n, p), (n2, p2) in zip(pol.named_parameters(), op.named_parameters()):
+        assert n == n2
+        if p2.grad is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert_close(p.grad.cpu().numpy(), p2.grad.numpy(), 2e-4, 2e-6, "policy grad " + n)
+    assert_close(hs_p.g_feat.cpu().numpy(), f2.grad.numpy(), 2e-4, 2e-6, "policy dfeature")
+
+    # ---- actor-critic term: -ratio * mean(min(q1,q2)) over non (expert & return>0) rows
+    q1d, q2d = q1.detach().squeeze(), q2.detach().squeeze()
+    keep2 = ~(em & gm)
+    want = -0.1 * torch.min(q1d[keep2], q2d[keep2]).mean()
+    g9 = torch.empty(B, 9, device="cuda"); s2 = torch.zeros(2, device="cuda")
+    hip.call("gad_actor_critic_loss", hs_c.out, dv(expert_flag), dv(ret), B, 0.1, None, g9, s2)
+    assert_close(s2.cpu().numpy()[0], want.item(), 1e-4, 1e-6, "actor-critic loss")
+    g9 = g9.cpu().numpy()
+    assert np.allclose(g9[:, :2].sum(), -0.1, rtol=1e-5) and (g9[~keep2.numpy()] == 0).all()
+
+
+def test_target_noise_and_optimizer_kernels():
+    from ga_ddpg_amd import hip
+    rng = np.random.default_rng(11)
+    B = 33
+    pi = torch.tensor(rng.normal(size=(B, 6)) * 0.03, dtype=torch.float32)
+    u = torch.tensor(rng.random((B, 6)), dtype=torch.float32)
+    out = torch.empty(B, 6, device="cuda")
+    hip.call("gad_target_noise", pi.cuda(), u.cuda(), B, 0.03, out)
+    from oracle import ref_step
+    d = ref_step.target_noise(u.clone(), 0.03)
+    d[:, :3] = torch.clamp(d[:, :3], -0.01, 0.01)
+    assert_close(out.cpu().numpy(), (pi + d).numpy(), 1e-6, 1e-8, "target noise")
+
+    # Adam (+ weight decay, + clip) against torch.optim.Adam over a few steps
+    n = 5000
+    p0 = torch.tensor(rng.normal(size=n), dtype=torch.float32)
+    ref_p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref_p], lr=3e-4, eps=1e-5, weight_decay=1e-5)
+    p = p0.clone().cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    hyper = torch.zeros(8, device="cuda")
+    for t in range(1, 4):
+        g = torch.tensor(rng.normal(size=n) * (10.0 if t == 2 else 0.01), dtype=torch.float32)
+        ref_p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 0.5)
+        opt.step()
+        gd = g.clone().cuda()
+        ss = torch.zeros(1, dtype=torch.float64, device="cuda")
+        hip.call("gad_sumsq", gd, n, ss)
+        hyper.copy_(torch.tensor([3e-4, 0.9, 0.999, 1e-5, 1e-5, 1 - 0.9 ** t, np.sqrt(1 - 0.999 ** t), 1.0]))
+        hip.call("gad_adam_step", p, gd, m, v, None, None, None, n, hyper, ss, 0.5)
+        assert_close(gd.cpu().numpy(), ref_p.grad.numpy(), 1e-5, 1e-9, "clipped grad step %d" % t)
+        assert_close(p.cpu().numpy(), ref_p.detach().numpy(), 1e-5, 1e-7, "adam step %d" % t)
+    # polyak / hard select
+    tgt = torch.tensor(rng.normal(size=n), dtype=torch.float32)
+    sel = torch.tensor(rng.integers(0, 3, size=n), dtype=torch.uint8)
+    tg = tgt.clone().cuda()
+    hip.call("gad_polyak", tg, p, sel.cuda(), None, None, n, 1e-4, 1)
+    pc = p.cpu()
+    want = torch.where(sel == 1, tgt * (1 - 1e-4) + pc * 1e-4, torch.where(sel == 2, pc, tgt))
+    assert_close(tg.cpu().numpy(), want.numpy(), 1e-6, 1e-8, "polyak")
+    seg = torch.tensor([0, 10, 4000, n], dtype=torch.int32).cuda()
+    am = torch.empty(3, device="cuda")
+    hip.call("gad_absmax_segments", p, seg, 3, am)
+    wa = [pc[0:10].abs().max(), pc[10:4000].abs().max(), pc[4000:].abs().max()]
+    assert_close(am.cpu().numpy(), np.array([float(x) for x in wa]), 0, 0, "absmax")
