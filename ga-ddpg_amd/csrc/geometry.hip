@@ -29,10 +29,12 @@ __device__ __forceinline__ bool fps_better(float v, unsigned key, float bv, unsi
 
 // One workgroup (WAVES wavefronts) per cloud; thread t keeps points k = s*T + t (s < NPL) in
 // registers.  The cloud is also staged in LDS so the coordinates of the last pick are a broadcast
-// LDS read.  Tie rule: (value desc, k mod tie_bs asc, k asc) == the upstream block reduction.
+// LDS read.  Tie rule == the upstream block reduction: "thread" t = k mod tie_bs keeps its lowest k
+// (strict >), and the pairwise tree `v2 > v1 ? i2 : i1` over strides bs/2..1 lets the candidate with
+// the smallest BIT-REVERSED thread id win among equal values (slot t beats slot t+s at every level).
 template <int NPL, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict__ xyz, int N, int M,
-                                                          int tie_bs, int32_t* __restrict__ idx,
+                                                          int tie_bits, int32_t* __restrict__ idx,
                                                           float* __restrict__ new_xyz) {
     constexpr int T = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -60,7 +62,9 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             const float mag = __fadd_rn(__fadd_rn(__fmul_rn(px[s], px[s]), __fmul_rn(py[s], py[s])),
                                         __fmul_rn(pz[s], pz[s]));
             if (mag > 1e-3f) valid |= 1u << s;
-            key[s] = ((unsigned)(k % tie_bs) << 16) | (unsigned)k;
+            const unsigned t = (unsigned)k & ((1u << tie_bits) - 1u);          // k mod tie_bs
+            const unsigned rev = tie_bits ? (__brev(t) >> (32 - tie_bits)) : 0u;
+            key[s] = (rev << 16) | (unsigned)k;
         }
     }
     int old = 0;
@@ -110,19 +114,19 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
     }
 }
 
-static int fps_tie_block(int n) {  // upstream opt_n_threads()
-    int p = 1;
-    while ((p << 1) <= n && (p << 1) <= 512) p <<= 1;
-    return p;
+static int fps_tie_bits(int n) {  // log2 of upstream opt_n_threads(n) = pow2 <= min(n, 512)
+    int bits = 0;
+    while ((2 << bits) <= n && (2 << bits) <= 512) ++bits;
+    return bits;
 }
 
 extern "C" int gad_furthest_point_sampling(const float* xyz, int B, int N, int M, int32_t* idx,
                                            float* new_xyz, void* stream) {
     GAD_REQUIRE(xyz && idx, GAD_ERR_NULL, "fps: null pointer");
-    GAD_REQUIRE(B >= 0 && N >= 1 && M >= 0 && N <= 16384, GAD_ERR_SHAPE, "fps: unsupported shape B=%d N=%d M=%d", B, N, M);
+    GAD_REQUIRE(B >= 0 && N >= 1 && M >= 0 && N <= 16384 && N <= 65535, GAD_ERR_SHAPE, "fps: unsupported shape B=%d N=%d M=%d", B, N, M);
     if (B == 0 || M == 0) return GAD_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int tie = fps_tie_block(N);
+    const int tie = fps_tie_bits(N);
     const size_t lds = (size_t)(((N * 3 + 3) & ~3) + 64) * sizeof(float);
     if (N <= 64) {
         hipLaunchKernelGGL((fps_kernel<1, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);

@@ -116,13 +116,13 @@ class FlatNet(object):
         hip.call("gad_pack_params", self.master, self.m2p, self.n, self.packed)
 
     def p_w(self, m):
-        return self.packed.data_ptr() + 4 * m.w_off
+        return hip.Ptr(self.packed.data_ptr() + 4 * m.w_off)
 
     def p_gamma(self, m):
-        return self.packed.data_ptr() + 4 * m.g_off
+        return hip.Ptr(self.packed.data_ptr() + 4 * m.g_off)
 
     def p_beta(self, m):
-        return self.packed.data_ptr() + 4 * m.b_off
+        return hip.Ptr(self.packed.data_ptr() + 4 * m.b_off)
 
     def set_adam_hyper(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
         self.step_count += 1
@@ -269,7 +269,8 @@ class EncoderSlot(object):
 
 
 def _ptr(t, off_elems=0, size=4):
-    return None if t is None else t.data_ptr() + size * off_elems
+    """raw device address of element `off_elems` of tensor t (element size in bytes)"""
+    return None if t is None else hip.Ptr(t.data_ptr() + size * off_elems)
 
 
 def _fwd_args(**kw):

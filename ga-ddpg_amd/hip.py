@@ -78,13 +78,17 @@ EXPORTS = (
     "gad_pack_params")
 
 
-def ptr(t):
+class Ptr(int):
+    """a raw device address (crosses the ABI as void*, never as a 32-bit int)"""
+
+
+def ptr(t, offset_bytes=0):
     """device pointer of a tensor (None -> NULL)."""
     if t is None:
         return None
     if isinstance(t, int):
-        return t
-    return t.data_ptr()
+        return Ptr(t + offset_bytes)
+    return Ptr(t.data_ptr() + offset_bytes)
 
 
 def stream():
@@ -103,6 +107,8 @@ def _args(*a):
             out.append(C.c_void_p(None))
         elif torch.is_tensor(x):
             out.append(C.c_void_p(x.data_ptr()))
+        elif isinstance(x, Ptr):
+            out.append(C.c_void_p(int(x)))
         elif isinstance(x, float):
             out.append(C.c_float(x))
         elif isinstance(x, Dbl):

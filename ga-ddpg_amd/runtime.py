@@ -1,0 +1,317 @@
+"""Fused runtime of one agent: owns the engine objects (flat nets, geometry, activation slots, head
+slots, static batch buffers) and runs the DDPG / BC update step as a sequence of libgaddpg calls.
+
+Step structure mirrored from the reference: DDPG.update_parameters (core/ddpg.py:146-185) =
+critic phase (extract_feature -> target_value -> compute_critic_loss -> critic_optimize) then
+actor phase (extract_feature -> policy.sample -> [actor-critic term every policy_update_gap
+steps] -> compute_loss -> optimize -> target updates) and BC.update_parameters (core/bc.py:71-87).
+Host <-> device traffic per step: one pinned upload of the minibatch, one 32-float download.
+"""
+import numpy as np
+import torch
+
+from . import engine, heads, hip
+from .engine import Plan
+
+BATCH_KEYS = ("point_state_batch", "next_point_state_batch", "action_batch", "expert_action_batch", "reward_batch",
+              "return_batch", "mask_batch", "time_batch", "goal_batch", "expert_flag_batch", "perturb_flag_batch")
+
+
+class FusedRuntime(object):
+    def __init__(self, agent, B, NP, device=None):
+        dev = self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+        self.agent, self.B, self.NP = agent, B, NP
+        self.has_critic = agent.has_critic
+        fe = agent.state_feature_extractor.module
+        self.N = NP - 6 if NP != 1024 else NP
+        self.enc = engine.EncoderNet(fe.encoder, dev)
+        self.venc = engine.EncoderNet(fe.value_encoder, dev)
+        self.pol = heads.PolicyNet(agent.policy, dev)
+        self.pol_t = heads.PolicyNet(agent.policy_target, dev)
+        if self.has_critic:
+            self.cr = heads.CriticNet(agent.critic, dev)
+            self.cr_t = heads.CriticNet(agent.critic_target, dev)
+        sa1 = engine.SAConfig(fe.pointnet_nclusters, fe.pointnet_radius, 64)
+        sa2 = engine.SAConfig(32, 0.04, 128)
+        self.geo = engine.Geometry(B, self.N, sa1, sa2, dev)
+        self.slot_p = engine.EncoderSlot(self.geo, self.enc, dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        if self.has_critic:
+            self.geo_next = engine.Geometry(B, self.N, sa1, sa2, dev)
+            self.slot_v = engine.EncoderSlot(self.geo, self.venc, dev)
+            self.slot_t = engine.EncoderSlot(self.geo_next, self.enc, dev, with_backward=False)
+            self.hs_c = heads.HeadSlot(B, self.cr.width, 9, dev)
+            self.hs_ct = heads.HeadSlot(B, self.cr.width, 9, dev)
+            self.hs_pt = heads.HeadSlot(B, self.pol.hidden, self.pol.n_heads, dev)
+            self.pi_t = torch.zeros(B, 6, **f32)
+            self.a_next = torch.zeros(B, 6, **f32)
+            self.noise_u = torch.zeros(B, 6, **f32)
+            self.y = torch.zeros(B, **f32)
+            self.critic_aux_norm = torch.zeros(B, 7, **f32)
+            self.clip_sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+            sel = np.zeros(self.cr.flat.n, dtype=np.uint8)              # polyak map (core/utils.py:757-770)
+            for name, p, o in zip(self.cr.flat.names, self.cr.flat.params, self.cr.flat.offsets[:-1]):
+                k = 1 if name[:7] in ("linear1", "linear2", "linear3") else (2 if name[:7] in ("linear4", "linear5", "linear6") else 0)
+                sel[int(o):int(o) + p.numel()] = k
+            self.critic_sel = torch.from_numpy(sel).to(dev)
+        self.hs_p = heads.HeadSlot(B, self.pol.hidden, self.pol.n_heads, dev)
+        self.pi = torch.zeros(B, 6, **f32)
+        self.aux_pred = torch.zeros(B, 7, **f32)
+        self.action_scale = torch.as_tensor(np.asarray(agent.policy.action_scale, dtype=np.float32)).to(dev)
+        # static batch buffers + pinned staging
+        shapes = {"point_state_batch": (B, 4, NP), "next_point_state_batch": (B, 4, NP), "action_batch": (B, 6),
+                  "expert_action_batch": (B, 6), "goal_batch": (B, 7)}
+        self.dbuf, self.hbuf = {}, {}
+        for k in BATCH_KEYS + ("time_m1",):
+            shp = shapes.get(k, (B,))
+            self.dbuf[k] = torch.zeros(*shp, **f32)
+            self.hbuf[k] = torch.zeros(*shp, dtype=torch.float32).pin_memory()
+        self.scal = torch.zeros(32, **f32)
+        self.scal_host = torch.zeros(32, dtype=torch.float32).pin_memory()
+        self.seg = {}
+        for nm, fl in (("pol", self.pol.flat),) + ((("cr", self.cr.flat),) if self.has_critic else ()):
+            self.seg[nm] = torch.tensor([0, fl.n], dtype=torch.int32, device=dev)
+        self._build_plans()
+        self.world_size = 1
+        self.allreduce = None            # set by parallel.attach(): callable(list of flat grad tensors)
+        self.inv_n = None
+
+    # ------------------------------------------------------------------ plans over static buffers
+    def _build_plans(self):
+        d = self.dbuf
+        enc, pol = self.enc, self.pol
+        P = self.plans = {}
+        P["geo"] = None
+        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None)
+        P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
+        bw = Plan()
+        bw.zero(pol.flat.gacc)
+        bw.zero(enc.flat.gacc)
+        bw.zero(self.slot_p.bstats)
+        bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
+        bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True))
+        bw.call("gad_grad_from_arena", pol.flat.gacc, pol.flat.m2p, pol.flat.n, pol.flat.grad, 0)
+        bw.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
+        P["p_bwd"] = bw
+        if not self.has_critic:
+            return
+        venc, cr = self.venc, self.cr
+        c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"])
+        c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
+        t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
+        t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.action_scale, self.pi_t, None)
+        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next)
+        t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
+        P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
+        cb = Plan()
+        cb.zero(cr.flat.gacc)
+        cb.zero(venc.flat.gacc)
+        cb.zero(self.slot_v.bstats)
+        cb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        cb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=d["action_batch"], want_dw=True))
+        cb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 0)
+        cb.call("gad_grad_from_arena", venc.flat.gacc, venc.flat.m2p, venc.flat.n, venc.flat.grad, 0)
+        P["c_bwd"] = cb
+        # actor-critic term: Q(s, pi(s)) through the freshly updated critic, gradient back to pi
+        v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi)
+        v.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        P["v_fwd"] = v
+        vb = Plan()
+        vb.zero(cr.flat.gacc)
+        vb.zero(self.slot_v.bstats)
+        vb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        # the reference's backward also leaves the actor-loss gradient in critic.grad (logged as critic_grad)
+        vb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 1)
+        vb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=self.pi, want_dw=False,
+                                               want_daction=True))
+        P["v_bwd"] = vb
+
+    # ------------------------------------------------------------------ host -> device
+    def upload(self, batch):
+        B = self.B
+        for k in BATCH_KEYS:
+            if k not in batch or (not self.has_critic and k in ("next_point_state_batch",)):
+                continue
+            a = np.asarray(batch[k])
+            if a.shape[0] != B:
+                raise RuntimeError("batch size changed: runtime was built for B=%d, got %d" % (B, a.shape[0]))
+            h = self.hbuf[k]
+            np.copyto(h.numpy(), a.reshape(h.shape), casting="same_kind")
+            self.dbuf[k].copy_(h, non_blocking=True)
+        h = self.hbuf["time_m1"]
+        np.subtract(self.hbuf["time_batch"].numpy(), 1.0, out=h.numpy())
+        self.dbuf["time_m1"].copy_(h, non_blocking=True)
+
+    def _adam(self, flat, optim, clip=None):
+        g = optim.param_groups[0]
+        flat.set_adam_hyper(g["lr"], g["betas"], g["eps"], g["weight_decay"])
+        hip.call("gad_adam_step", flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq, flat.active, flat.m2p,
+                 flat.packed, flat.n, flat.hyper, clip, float(self.agent.clip_grad) if clip is not None else 0.0)
+
+    def _reduce(self, flats):
+        if self.allreduce is not None:
+            self.allreduce([f.grad for f in flats])
+
+    # ------------------------------------------------------------------ the update steps
+    def ddpg_step(self, batch, noise_u=None):
+        ag, d, P = self.agent, self.dbuf, self.plans
+        B = self.B
+        ratio = float(ag.mix_policy_ratio)
+        policy_step = ag.update_step % ag.policy_update_gap == 0
+        self.upload(batch)
+        if noise_u is None:
+            self.noise_u.uniform_(0.0, 1.0)                         # torch.rand_like in the reference
+        else:
+            self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
+        self.scal.zero_()
+        self.geo.run(d["point_state_batch"])
+        self.geo_next.run(d["next_point_state_batch"])
+        # ---- critic phase
+        P["c_fwd"].run()
+        P["t1"].run()
+        idx = int((ag.update_step > np.array(ag.mix_milestones)).sum())
+        level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
+        hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), self.a_next)
+        P["t2"].run()
+        hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
+                 d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
+                 self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
+        P["c_bwd"].run()
+        self._reduce([self.cr.flat, self.venc.flat])
+        self.clip_sumsq.zero_()
+        hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
+        self._adam(self.venc.flat, ag.state_feat_val_encoder_optim)
+        self._adam(self.cr.flat, ag.critic_optim, clip=self.clip_sumsq)
+        # ---- actor phase
+        P["p_fwd"].run()
+        hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
+        g_pi = None
+        if policy_step:
+            P["v_fwd"].run()
+            hip.call("gad_actor_critic_loss", self.hs_c.out, d["expert_flag_batch"], d["return_batch"], B, ratio,
+                     self.inv_n_actor_critic(), self.hs_c.g_out, engine._ptr(self.scal, 8))
+            P["v_bwd"].run()
+            g_pi = self.slot_v.daction
+        hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
+                 d["return_batch"], d["goal_batch"], B, 1.0 - ratio, int(bool(ag.policy_aux)), self.action_scale, g_pi,
+                 self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
+        P["p_bwd"].run()
+        self._reduce([self.pol.flat, self.enc.flat])
+        self._adam(self.pol.flat, ag.policy_optim)
+        if ag.train_feature:
+            self._adam(self.enc.flat, ag.state_feat_encoder_optim)
+        self._target_updates()
+        self._stats()
+        self.enc.bump_batches_tracked(2)
+        self.venc.bump_batches_tracked(3 if policy_step else 2)
+        return self._download()
+
+    def bc_step(self, batch):
+        ag, d, P = self.agent, self.dbuf, self.plans
+        B = self.B
+        self.upload(batch)
+        self.scal.zero_()
+        self.geo.run(d["point_state_batch"])
+        P["p_fwd"].run()
+        hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
+        hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
+                 d["return_batch"], d["goal_batch"], B, 1.0, int(bool(ag.policy_aux)), self.action_scale, None,
+                 self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
+        P["p_bwd"].run()
+        self._reduce([self.pol.flat, self.enc.flat])
+        self._adam(self.pol.flat, ag.policy_optim)
+        if ag.train_feature:
+            self._adam(self.enc.flat, ag.state_feat_encoder_optim)
+        self._target_updates()
+        self._stats()
+        self.enc.bump_batches_tracked(1)
+        return self._download()
+
+    # data-parallel hooks: device pointers to globally reduced 1/count pairs (None = local counts)
+    def inv_n_critic(self):
+        return None if self.inv_n is None else engine._ptr(self.inv_n, 0)
+
+    def inv_n_actor(self):
+        return None if self.inv_n is None else engine._ptr(self.inv_n, 2)
+
+    def inv_n_actor_critic(self):
+        return None if self.inv_n is None else engine._ptr(self.inv_n, 4)
+
+    def _target_updates(self):
+        ag = self.agent
+        pt, p = self.pol_t.flat, self.pol.flat
+        hip.call("gad_polyak", pt.master, p.master, None, pt.m2p, pt.packed, p.n, float(ag.tau), 0)
+        if self.has_critic:
+            ct, c = self.cr_t.flat, self.cr.flat
+            hard = int(ag.update_step % ag.target_update_interval == 0)
+            hip.call("gad_polyak", ct.master, c.master, self.critic_sel, ct.m2p, ct.packed, c.n, float(ag.tau), hard)
+
+    def _stats(self):
+        hip.call("gad_absmax_segments", self.pol.flat.master, self.seg["pol"], 1, engine._ptr(self.scal, 10))
+        if self.has_critic:
+            hip.call("gad_absmax_segments", self.cr.flat.grad, self.seg["cr"], 1, engine._ptr(self.scal, 11))
+            hip.call("gad_absmax_segments", self.cr.flat.master, self.seg["cr"], 1, engine._ptr(self.scal, 12))
+
+    def _download(self):
+        self.scal_host.copy_(self.scal, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        return self.scal_host.numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# module-level forward helpers (inference / feature extraction through the same kernels)
+# ----------------------------------------------------------------------------------------------
+def _module_runtime(mod, key, builder):
+    rt = getattr(mod, "_gad_rt", None)
+    if rt is None:
+        rt = {}
+        object.__setattr__(mod, "_gad_rt", rt)
+    if key not in rt:
+        rt[key] = builder()
+    return rt[key]
+
+
+def feature_forward(fe, pc, value=False):
+    """PointNetFeature.forward: pc (B,C,NP) -> z (B,512); train-mode BatchNorm when fe.training."""
+    hip.require_cuda(pc)
+    B, C, NP = pc.shape
+    dev = pc.device
+    N = NP - 6 if NP != 1024 else NP
+
+    def build():
+        encs = {False: engine.EncoderNet(fe.encoder, dev), True: engine.EncoderNet(fe.value_encoder, dev)}
+        return dict(encs=encs)
+    base = _module_runtime(fe, "nets", build)
+
+    def build_b():
+        geo = engine.Geometry(B, N, engine.SAConfig(fe.pointnet_nclusters, fe.pointnet_radius, 64),
+                              engine.SAConfig(32, 0.04, 128), dev)
+        slot = engine.EncoderSlot(geo, base["encs"][False], dev, with_backward=False)
+        return dict(geo=geo, slot=slot, action=torch.zeros(B, 6, device=dev), out=torch.empty(B, 512, device=dev))
+    rt = _module_runtime(fe, ("shape", B, NP), build_b)
+    enc = base["encs"][bool(value)]
+    if not fe.training:
+        raise NotImplementedError("eval-mode (running-statistics) encoder forward is SURVEY 8f N3 (select_action)")
+    ps = pc[:, :4].contiguous()
+    rt["geo"].run(ps)
+    action = None
+    if value:
+        rt["action"].copy_(pc[:, 4:10, 0])
+        action = rt["action"]
+    engine.plan_encoder_forward(enc, rt["slot"], action=action, train=True).run()
+    enc.bump_batches_tracked(1)
+    fc2 = enc.fc_mats[1]
+    o = enc.bn_off[fc2.bn_index]
+    slot = rt["slot"]
+    hip.call("gad_affine_act", slot.Zfc[1], 512, B, 512, engine._ptr(slot.scale, o), engine._ptr(slot.shift, o), 1,
+             rt["out"], 512)
+    return rt["out"].clone()
+
+
+def critic_forward(module, state):
+    raise NotImplementedError("stand-alone QNetwork.forward: use Agent.update_parameters (fused path)")
+
+
+def policy_forward(module, state):
+    raise NotImplementedError("stand-alone GaussianPolicy.sample: use Agent.update_parameters / select_action")

@@ -324,7 +324,7 @@ def gen_heads():
     np.savez_compressed(os.path.join(OUT, "heads.npz"), **out)
 
 
-def gen_encoder(B=4):
+def gen_encoder(B=16):
     """PointNetFeature forward (both encoders) + grads of a scalar probe, via the reference's class."""
     from core import networks as rn
     from oracle.detfill import fill_module_, summarize_named
@@ -335,12 +335,17 @@ def gen_encoder(B=4):
     pc = torch.tensor(batch["point_state_batch"], dtype=torch.float32)
     act = torch.tensor(batch["action_batch"], dtype=torch.float32, requires_grad=True)
     out = {"point_state": _np(pc), "action": _np(act)}
+    taps = {}
+    for tag, enc in (("policy", net.encoder), ("value", net.value_encoder)):
+        for i, sa in enumerate(enc[0]):
+            sa.register_forward_hook(lambda m, a, o, k="%s_sa%d" % (tag, i + 1): taps.__setitem__(k, _np(o[1]).copy()))
     z_pol, _ = net(pc, feature_2=False)
     pc10 = torch.cat((pc, act.unsqueeze(2).expand(-1, -1, pc.shape[2])), 1)
     z_val, _ = net(pc10, feature_2=True)
     probe = torch.tensor(np.random.default_rng(SEED).normal(size=(B, 512)), dtype=torch.float32)
     ((z_pol * probe).sum() + (z_val * probe.flip(1)).sum()).backward()
     out.update(z_policy=_np(z_pol), z_value=_np(z_val), probe=_np(probe), action_grad=_np(act.grad))
+    out.update(taps)                       # pooled SA outputs (B,C,npoint): well-conditioned check points
     summarize_named(((n, p.grad) for n, p in net.named_parameters()), out, "grad/")
     summarize_named(net.state_dict().items(), out, "state/")
     np.savez_compressed(os.path.join(OUT, "encoder_B%d.npz" % B), **out)

@@ -56,7 +56,7 @@ def _run_encoder(enc, slot, action, probe, want_daction):
 
 def test_geometry_matches_oracle(golden_dir):
     from oracle import cref
-    g = np.load(os.path.join(golden_dir, "encoder_B4.npz"))
+    g = np.load(os.path.join(golden_dir, "encoder_B16.npz"))
     ps = g["point_state"]
     B = ps.shape[0]
     geo = _geometry(B)
@@ -81,7 +81,7 @@ def test_geometry_matches_oracle(golden_dir):
 
 def test_encoder_forward_backward_vs_reference(golden_dir):
     from ga_ddpg_amd import engine
-    g = np.load(os.path.join(golden_dir, "encoder_B4.npz"))
+    g = np.load(os.path.join(golden_dir, "encoder_B16.npz"))
     dev = torch.device("cuda")
     net = _feature_net()
     enc = engine.EncoderNet(net.encoder, dev)
@@ -92,11 +92,19 @@ def test_encoder_forward_backward_vs_reference(golden_dir):
     probe = torch.from_numpy(g["probe"]).cuda()
     action = torch.from_numpy(g["action"]).cuda()
 
+    def taps(slot, tag):
+        # pooled SA outputs are (groups, C) point-major here, (B, C, npoint) in the reference
+        for s, npnt in enumerate((32, 32, 1)):
+            got = slot.F[s].view(B, npnt, -1).transpose(1, 2).cpu().numpy()
+            assert_close(got, g["%s_sa%d" % (tag, s + 1)], 1e-4, 1e-5, "%s SA%d output" % (tag, s + 1))
+
     slot = engine.EncoderSlot(geo, enc, dev)
     z_pol = _run_encoder(enc, slot, None, probe, False)
+    taps(slot, "policy")
     assert_close(z_pol.cpu().numpy(), g["z_policy"], 1e-4, 2e-5, "z_policy")
     vslot = engine.EncoderSlot(geo, venc, dev)
     z_val = _run_encoder(venc, vslot, action, probe.flip(1).contiguous(), True)
+    taps(vslot, "value")
     assert_close(z_val.cpu().numpy(), g["z_value"], 1e-4, 2e-5, "z_value")
     assert_close(vslot.daction.cpu().numpy(), g["action_grad"], 2e-4, 1e-5, "action grad")
 

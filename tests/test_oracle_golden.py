@@ -59,7 +59,7 @@ def test_heads(golden_dir):
 
 
 def test_encoder_forward_backward(golden_dir):
-    g = np.load(os.path.join(golden_dir, "encoder_B4.npz"))
+    g = np.load(os.path.join(golden_dir, "encoder_B16.npz"))
     net = ref_step.PointFeature(extra_latent=1, action_concat=True)
     shell = fill_module_(ref_step._DataParallelShell(net), "state_feature_extractor", SEED)
     shell.train()
