@@ -1,0 +1,101 @@
+"""Full update steps through the HIP path against (a) golden vectors produced by the reference's own
+DDPG / BC code and (b) the CPU oracle on fresh seeded batches.  Tolerances are the north-star 1e-4
+relative on losses / Q-values / actions; gradients and post-step parameters get 5e-4 because
+train-mode BatchNorm1d over B=8 rows amplifies float rounding."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, check_summaries, golden_batch
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+SKIP = (".1.0.bias", ".1.3.bias")     # biases in front of a train-mode BN: zero gradient analytically
+
+
+def _filled_agent(cfg_name, seed):
+    from ga_ddpg_amd.api import make_agent
+    from oracle.detfill import fill_module_
+    agent, cfg = make_agent(cfg_name)
+    nets = {"policy": agent.policy, "policy_target": agent.policy_target,
+            "state_feature_extractor": agent.state_feature_extractor}
+    if hasattr(agent, "critic"):
+        nets.update(critic=agent.critic, critic_target=agent.critic_target)
+    for name, net in nets.items():
+        fill_module_(net, name, seed)
+    return agent, nets
+
+
+@pytest.mark.parametrize("kind", ["ddpg", "bc"])
+def test_steps_vs_reference_golden(golden_dir, kind):
+    if kind == "ddpg":
+        g = np.load(os.path.join(golden_dir, "ddpg_steps_B8.npz"))
+        agent, nets = _filled_agent("ddpg_td3_aux.yaml", SEED)
+        nsteps = 3
+    else:
+        g = np.load(os.path.join(golden_dir, "bc_steps_B8.npz"))
+        agent, nets = _filled_agent("bc_dagger_aux.yaml", SEED + 1)
+        nsteps = 2
+    for s in range(nsteps):
+        p = "step%d/" % s
+        batch = golden_batch(g, p)
+        if kind == "ddpg":
+            ret = agent.update_parameters(batch, agent.update_step, s, noise_u=g[p + "noise_u"])
+        else:
+            ret = agent.update_parameters(batch, agent.update_step, s)
+        agent.step_scheduler(agent.update_step)
+        torch.cuda.synchronize()
+        assert set(ret.keys()) == set(k[len(p + "ret/"):] for k in g.files if k.startswith(p + "ret/"))
+        assert_close(agent.pi.cpu().numpy(), g[p + "t/pi"], 1e-4, 1e-6, p + "pi")
+        assert_close(agent.aux_pred.cpu().numpy(), g[p + "t/aux_pred"], 1e-4, 2e-5, p + "aux_pred")
+        if kind == "ddpg":
+            assert_close(agent.qf1.cpu().numpy(), g[p + "t/qf1"], 1e-4, 2e-5, p + "qf1")
+            assert_close(agent.qf2.cpu().numpy(), g[p + "t/qf2"], 1e-4, 2e-5, p + "qf2")
+            assert_close(agent.next_q_value.cpu().numpy(), g[p + "t/next_q_value"], 1e-4, 2e-5, p + "y")
+            assert_close(agent.critic_grasp_aux.cpu().numpy(), g[p + "t/critic_grasp_aux"], 1e-4, 2e-5, p + "caux")
+        for k, v in ret.items():
+            tol = 1e-4 if "loss" in k else 5e-4
+            assert_close(v, g[p + "ret/" + k], tol, 1e-6, p + k)
+        which = ["policy", "state_feature_extractor"] + (["critic"] if kind == "ddpg" else [])
+        for name in which:
+            skip = SKIP + (("value_encoder",) if (kind == "ddpg" and s == 1) else ())
+            check_summaries(g, p + "end/grad/" + name + "/",
+                            ((n, q.grad) for n, q in nets[name].named_parameters()
+                             if not (name == "policy" and n.startswith("log_std"))),
+                            2e-4, 2e-6, skip=skip, normwise=True)
+        for name, net in nets.items():
+            check_summaries(g, p + "end/param/" + name + "/",
+                            ((n, t) for n, t in net.state_dict().items() if "num_batches" not in n), 5e-4, 5e-6,
+                            skip=SKIP)
+        if kind == "ddpg":
+            lr = agent.get_lr()
+            assert_close([lr["policy_lr"], lr["feature_lr"], lr["value_lr"]], g[p + "lr"], 1e-7, 0, p + "lr")
+
+
+def test_steps_vs_oracle_fresh_batches():
+    """B=32 DDPG steps on fresh synthetic batches: HIP agent and CPU oracle advance side by side."""
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    agent, nets = _filled_agent("ddpg_td3_aux.yaml", 77)
+    c = load_cfg("ddpg_td3_aux.yaml")
+    oracle = ref_step.OracleAgent(c.RL_TRAIN)
+    for name, net in oracle.nets().items():
+        fill_module_(net, name, 77)
+    mem = BaseMemory(1500, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 1500, seed=5)
+    rng = np.random.default_rng(9)
+    for s in range(2):
+        batch = sample_valid_batch(mem, 32, rng)
+        u = rng.random((32, 6)).astype(np.float32)
+        got = agent.update_parameters(batch, agent.update_step, s, noise_u=u)
+        want = oracle.update_parameters(batch, noise_u=u)
+        for k in want:
+            tol = 1e-4 if "loss" in k else 5e-4
+            assert_close(got[k], want[k], tol, 1e-6, "step %d %s" % (s, k))
+        assert_close(agent.qf1.cpu().numpy(), oracle.dbg["q1"].numpy(), 1e-4, 2e-5, "q1")
+        assert_close(agent.pi.cpu().numpy(), oracle.dbg["pi"].numpy(), 1e-4, 1e-6, "pi")
