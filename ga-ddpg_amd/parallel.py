@@ -1,0 +1,77 @@
+"""Data-parallel update step: one process per GPU, batch rows sharded across ranks, gradients summed
+with ONE all-reduce per optimiser phase over the flat gradient buffers (RCCL over xGMI with backend
+'nccl'; 'gloo' works for the CPU tests).
+
+What the reference does: nn.DataParallel around the feature extractors only (core/utils.py:202):
+replicas normalise their own chunk (per-replica BatchNorm statistics), heads and losses see the
+whole batch, so every masked mean is a GLOBAL-batch mean.  To reproduce that with independent ranks:
+  * BatchNorm statistics stay local to the rank (= a DataParallel replica);
+  * each rank's loss kernels divide by the GLOBAL mask counts (all-reduced 5-float vector per
+    step), so the SUM of the ranks' gradients is the global-mean gradient -- no post-division;
+  * clip_grad_norm_ is evaluated after the all-reduce, identically on every rank;
+  * optimiser / target-network state is replicated and advances identically (no exchange).
+Bucket sizes: critic phase 594 441 + 1 398 720 floats, actor phase 202 259 + 1 398 336 floats
+(2.4 MB + 5.6 MB): each is a single flat tensor, already contiguous, so there is nothing to bucket.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def mask_counts(batch):
+    """local counts the masked means divide by: [kept, goal rows, expert rows, non-(expert&reward) rows]"""
+    ret = np.asarray(batch["return_batch"]).reshape(-1)
+    exp = np.asarray(batch["expert_flag_batch"]).reshape(-1)
+    per = np.asarray(batch["perturb_flag_batch"]).reshape(-1)
+    reward = ret > 0
+    expert = exp >= 1
+    return np.array([(per < 1).sum(), reward.sum(), expert.sum(), (~(reward & expert)).sum()], dtype=np.float64)
+
+
+def inverse_counts(c):
+    """[1/kept, 1/(6*goal), 1/(6*expert), 1/(6*goal), 1/rows_ac, 0] -- layout read by the loss kernels:
+    critic at +0, actor at +2, actor-critic at +4 (runtime.inv_n_*).  Division by zero gives inf/NaN
+    on purpose: the reference's mean over an empty mask is NaN as well (core/loss.py:23,31)."""
+    with np.errstate(divide="ignore"):
+        return np.array([1.0 / c[0], 1.0 / (6.0 * c[1]), 1.0 / (6.0 * c[2]), 1.0 / (6.0 * c[1]), 1.0 / c[3], 0.0, 0.0, 0.0])
+
+
+class DataParallelContext(object):
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed must be initialised before DataParallelContext")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.rt = None
+
+    def attach(self, rt):
+        self.rt = rt
+        rt.world_size = self.world
+        rt.dp = self
+        rt.allreduce = self.allreduce_grads
+        rt.inv_n = torch.zeros(8, dtype=torch.float32, device=rt.dev)
+        self._counts = torch.zeros(4, dtype=torch.float64, device=rt.dev)
+
+    def allreduce_grads(self, tensors):
+        for t in tensors:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def set_counts(self, batch):
+        """global mask counts -> rt.inv_n (one tiny all-reduce per step)"""
+        c = self.global_counts(mask_counts(batch), self._counts.device)
+        self.rt.inv_n.copy_(torch.from_numpy(inverse_counts(c).astype(np.float32)), non_blocking=False)
+
+    def global_counts(self, local, device):
+        t = torch.as_tensor(local, dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t.cpu().numpy()
+
+    def reduce_scalars(self, scal):
+        """losses / counts are partial sums per rank (already divided by the global counts)"""
+        dist.all_reduce(scal[0:10], op=dist.ReduceOp.SUM, group=self.group)
+
+    def broadcast_parameters(self, flats):
+        for f in flats:
+            dist.broadcast(f.master, src=0, group=self.group)
+            f.sync_packed()

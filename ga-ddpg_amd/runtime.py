@@ -67,14 +67,18 @@ class FusedRuntime(object):
             self.dbuf[k] = torch.zeros(*shp, **f32)
             self.hbuf[k] = torch.zeros(*shp, dtype=torch.float32).pin_memory()
         self.scal = torch.zeros(32, **f32)
+        self._one = torch.ones(1, **f32)
+        self._minus_one = -torch.ones(1, **f32)
         self.scal_host = torch.zeros(32, dtype=torch.float32).pin_memory()
         self.seg = {}
         for nm, fl in (("pol", self.pol.flat),) + ((("cr", self.cr.flat),) if self.has_critic else ()):
             self.seg[nm] = torch.tensor([0, fl.n], dtype=torch.int32, device=dev)
         self._build_plans()
         self.world_size = 1
-        self.allreduce = None            # set by parallel.attach(): callable(list of flat grad tensors)
+        self.dp = None                   # parallel.DataParallelContext (set by its attach())
+        self.allreduce = None            # callable(list of flat grad tensors)
         self.inv_n = None
+        self.resident = False            # True: the static batch buffers were filled on the device
 
     # ------------------------------------------------------------------ plans over static buffers
     def _build_plans(self):
@@ -128,7 +132,18 @@ class FusedRuntime(object):
         P["v_bwd"] = vb
 
     # ------------------------------------------------------------------ host -> device
+    def load_device_batch(self, dbatch):
+        """device-resident minibatch (dict of CUDA float32 tensors with the BATCH_KEYS layout):
+        device-to-device copies into the static buffers, no host traffic."""
+        for k in BATCH_KEYS:
+            if k in dbatch:
+                self.dbuf[k].copy_(dbatch[k], non_blocking=True)
+        hip.call("gad_affine_act", self.dbuf["time_batch"], 1, self.B, 1, self._one, self._minus_one, 0,
+                 self.dbuf["time_m1"], 1)
+
     def upload(self, batch):
+        if batch is None:
+            return
         B = self.B
         for k in BATCH_KEYS:
             if k not in batch or (not self.has_critic and k in ("next_point_state_batch",)):
@@ -160,6 +175,8 @@ class FusedRuntime(object):
         ratio = float(ag.mix_policy_ratio)
         policy_step = ag.update_step % ag.policy_update_gap == 0
         self.upload(batch)
+        if self.dp is not None:
+            self.dp.set_counts(batch if batch is not None else self._host_flags())
         if noise_u is None:
             self.noise_u.uniform_(0.0, 1.0)                         # torch.rand_like in the reference
         else:
@@ -211,6 +228,8 @@ class FusedRuntime(object):
         ag, d, P = self.agent, self.dbuf, self.plans
         B = self.B
         self.upload(batch)
+        if self.dp is not None:
+            self.dp.set_counts(batch if batch is not None else self._host_flags())
         self.scal.zero_()
         self.geo.run(d["point_state_batch"])
         P["p_fwd"].run()
@@ -253,7 +272,12 @@ class FusedRuntime(object):
             hip.call("gad_absmax_segments", self.cr.flat.grad, self.seg["cr"], 1, engine._ptr(self.scal, 11))
             hip.call("gad_absmax_segments", self.cr.flat.master, self.seg["cr"], 1, engine._ptr(self.scal, 12))
 
+    def _host_flags(self):
+        return {k: self.dbuf[k].cpu().numpy() for k in ("return_batch", "expert_flag_batch", "perturb_flag_batch")}
+
     def _download(self):
+        if self.dp is not None:
+            self.dp.reduce_scalars(self.scal)
         self.scal_host.copy_(self.scal, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return self.scal_host.numpy()

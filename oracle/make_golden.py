@@ -185,84 +185,88 @@ def _make_agent(kind, ref_yaml):
     return agent, cfg
 
 
-def gen_ddpg(B=8, steps=3):
-    agent, cfg = _make_agent("DDPG", "td3_critic_aux_policy_aux.yaml")
-    _fill_agent(agent, SEED)
-    out = {}
-    _record_state(agent, out, "init/")
-    feats, rands = [], []
-
+def _hooked(agent, feats, rands, crit_snap):
     orig_extract = agent.extract_feature
     def extract(*a, **k):
         f = orig_extract(*a, **k)
         feats.append(_np(f).copy())
         return f
     agent.extract_feature = extract
+    if hasattr(agent, "critic_optimize"):
+        orig_co = agent.critic_optimize
+        def critic_optimize():
+            orig_co()
+            crit_snap.clear()
+            _record_grads(agent, crit_snap, "", ["critic", "state_feature_extractor"])
+        agent.critic_optimize = critic_optimize
 
+
+def gen_ddpg(B=32):
+    """Runs: 'a' starts at update_step 1 (no actor-critic term), 'b' at update_step 2 (policy step) and
+    continues for a second step.  a0 and b0 start from identical det-filled parameters, so they pin the
+    arithmetic of one step tightly; b1 additionally exercises optimiser state / schedulers."""
+    out = {}
     orig_rand_like = torch.rand_like
+    rands = []
     def rand_like(x, *a, **k):
         r = orig_rand_like(x, *a, **k)
         rands.append(_np(r).copy())
         return r
     torch.rand_like = rand_like
-
-    crit_snap = {}
-    orig_co = agent.critic_optimize
-    def critic_optimize():
-        orig_co()
-        crit_snap.clear()
-        _record_grads(agent, crit_snap, "", ["critic", "state_feature_extractor"])
-    agent.critic_optimize = critic_optimize
-
-    torch.manual_seed(SEED)
-    for s in range(steps):
-        batch = make_batch("ddpg_td3_aux.yaml", B, 600, SEED + 10 * s)
-        feats.clear(); rands.clear()
-        p = "step%d/" % s
-        for k, v in batch.items():
-            out[p + "batch/" + k] = np.asarray(v)
-        out[p + "update_step"] = np.int64(agent.update_step)
-        ret = agent.update_parameters(batch, agent.update_step, s)
-        agent.step_scheduler(agent.update_step)
-        assert len(rands) == 1
-        out[p + "noise_u"] = rands[0]
-        for i, f in enumerate(feats):
-            out[p + "feat%d" % i] = f          # order: value_feat, next_state, next_target, policy_feat[, value_pi]
-        for k, v in ret.items():
-            out[p + "ret/" + k] = np.float64(v)
-        for k in ("qf1", "qf2", "next_q_value", "critic_grasp_aux", "pi", "aux_pred"):
-            out[p + "t/" + k] = _np(getattr(agent, k))
-        if isinstance(getattr(agent, "qf1_pi", None), torch.Tensor) and agent.update_step % 2 == 1:
-            out[p + "t/qf1_pi"] = _np(agent.qf1_pi)   # update_step was incremented: even step just ran
-            out[p + "t/qf2_pi"] = _np(agent.qf2_pi)
-        for k, v in crit_snap.items():
-            out[p + "critic_phase/" + k] = v
-        _record_grads(agent, out, p + "end/", ["policy", "critic", "state_feature_extractor"])
-        _record_state(agent, out, p + "end/")
-        out[p + "lr"] = np.array([agent.get_lr()[k] for k in ("policy_lr", "feature_lr", "value_lr")])
+    ret = None
+    for run, start, nsteps in (("a", 1, 1), ("b", 2, 2)):
+        agent, cfg = _make_agent("DDPG", "td3_critic_aux_policy_aux.yaml")
+        _fill_agent(agent, SEED)
+        agent.update_step = start
+        feats, crit_snap = [], {}
+        _hooked(agent, feats, rands, crit_snap)
+        torch.manual_seed(SEED)
+        for s in range(nsteps):
+            batch = make_batch("ddpg_td3_aux.yaml", B, 1200, SEED + 10 * s + (100 if run == "b" else 0))
+            feats.clear(); rands.clear()
+            p = "%s%d/" % (run, s)
+            for k, v in batch.items():
+                if k not in ("state_pose_batch", "grasp_sample_batch", "image_state_batch", "next_image_state_batch"):
+                    out[p + "batch/" + k] = np.asarray(v)
+            out[p + "update_step"] = np.int64(agent.update_step)
+            ret = agent.update_parameters(batch, agent.update_step, s)
+            agent.step_scheduler(agent.update_step)
+            assert len(rands) == 1
+            out[p + "noise_u"] = rands[0]
+            for i, f in enumerate(feats):
+                out[p + "feat%d" % i] = f      # value_feat, next_state, next_target, policy_feat[, value_pi]
+            for k, v in ret.items():
+                out[p + "ret/" + k] = np.float64(v)
+            for k in ("qf1", "qf2", "next_q_value", "critic_grasp_aux", "pi", "aux_pred"):
+                out[p + "t/" + k] = _np(getattr(agent, k))
+            if agent.update_step % 2 == 1:         # update_step was incremented: an even (policy) step just ran
+                out[p + "t/qf1_pi"] = _np(agent.qf1_pi)
+                out[p + "t/qf2_pi"] = _np(agent.qf2_pi)
+            for k, v in crit_snap.items():
+                out[p + "critic_phase/" + k] = v
+            _record_grads(agent, out, p + "end/", ["policy", "critic", "state_feature_extractor"])
+            _record_state(agent, out, p + "end/")
+            out[p + "lr"] = np.array([agent.get_lr()[k] for k in ("policy_lr", "feature_lr", "value_lr")])
     torch.rand_like = orig_rand_like
     np.savez_compressed(os.path.join(OUT, "ddpg_steps_B%d.npz" % B), **out)
     return ret
 
 
-def gen_bc(B=8, steps=2):
+def gen_bc(B=32, steps=2):
     agent, cfg = _make_agent("BC", "bc_aux_dagger.yaml")
     _fill_agent(agent, SEED + 1)
     out = {}
     feats = []
-    orig_extract = agent.extract_feature
-    def extract(*a, **k):
-        f = orig_extract(*a, **k)
-        feats.append(_np(f).copy())
-        return f
-    agent.extract_feature = extract
+    _hooked(agent, feats, [], {})
     torch.manual_seed(SEED)
     for s in range(steps):
-        batch = make_batch("bc_dagger_aux.yaml", B, 600, SEED + 100 + 10 * s)
+        batch = make_batch("bc_dagger_aux.yaml", B, 1200, SEED + 100 + 10 * s)
         feats.clear()
-        p = "step%d/" % s
+        p = "a%d/" % s
         for k, v in batch.items():
-            out[p + "batch/" + k] = np.asarray(v)
+            if k not in ("state_pose_batch", "grasp_sample_batch", "image_state_batch", "next_image_state_batch",
+                         "next_point_state_batch"):
+                out[p + "batch/" + k] = np.asarray(v)
         ret = agent.update_parameters(batch, agent.update_step, s)
         agent.step_scheduler(agent.update_step)
         out[p + "feat0"] = feats[0]

@@ -77,46 +77,51 @@ def test_encoder_forward_backward(golden_dir):
     check_summaries(g, "state/", net.state_dict().items(), RT, 1e-6)
 
 
-@pytest.mark.parametrize("kind", ["ddpg", "bc"])
-def test_update_steps(golden_dir, kind):
+def _check_step(a, g, p, kind):
+    batch = golden_batch(g, p)
+    ret = a.update_parameters(batch, noise_u=g[p + "noise_u"] if kind == "ddpg" else None)
+    a.step_scheduler()
+    for k, v in ret.items():
+        assert_close(v, g[p + "ret/" + k], 1e-4, 1e-6, p + k)
+    d = a.dbg
+    assert_close(d["pi"].numpy(), g[p + "t/pi"], 1e-4, 1e-6, p + "pi")
+    assert_close(d["aux_pred"].numpy(), g[p + "t/aux_pred"], 1e-4, 1e-6, p + "aux_pred")
     if kind == "ddpg":
-        g = np.load(os.path.join(golden_dir, "ddpg_steps_B8.npz"))
+        for mine, theirs in (("value_feat", "feat0"), ("next_state", "feat1"), ("next_target", "feat2"),
+                             ("policy_feat", "feat3")):
+            assert_close(d[mine].numpy(), g[p + theirs], 1e-4, 1e-6, p + mine)
+        assert_close(d["q1"].numpy(), g[p + "t/qf1"], 1e-4, 1e-6, p + "qf1")
+        assert_close(d["q2"].numpy(), g[p + "t/qf2"], 1e-4, 1e-6, p + "qf2")
+        assert_close(d["y"].numpy(), g[p + "t/next_q_value"], 1e-4, 1e-6, p + "y")
+        if p + "t/qf1_pi" in g.files:
+            assert_close(d["q1_pi"].numpy(), g[p + "t/qf1_pi"], 1e-4, 1e-6, p + "qf1_pi")
+    nets = a.nets()
+    # FC-layer biases in front of a train-mode BatchNorm have an analytically zero gradient; what
+    # the reference holds there is float noise (1e-9) which Adam then amplifies -> excluded.
+    skip = (".1.0.bias", ".1.3.bias")
+    for name in (["policy", "state_feature_extractor"] + (["critic"] if kind == "ddpg" else [])):
+        check_summaries(g, p + "end/grad/" + name + "/", ((n, q.grad) for n, q in nets[name].named_parameters()),
+                        2e-4, 1e-7, skip=skip)
+    for name, net in nets.items():
+        check_summaries(g, p + "end/param/" + name + "/", net.state_dict().items(), 1e-4, 2e-6, skip=skip)
+
+
+def test_ddpg_steps(golden_dir):
+    g = np.load(os.path.join(golden_dir, "ddpg_steps_B32.npz"))
+    for run, start, nsteps in (("a", 1, 1), ("b", 2, 2)):
         a = _agent("ddpg_td3_aux.yaml", SEED)
-        check_summaries(g, "init/param/policy/", a.policy.state_dict().items(), 0, 0)
-        nsteps = 3
-    else:
-        g = np.load(os.path.join(golden_dir, "bc_steps_B8.npz"))
-        a = _agent("bc_dagger_aux.yaml", SEED + 1)
-        nsteps = 2
-    for s in range(nsteps):
-        p = "step%d/" % s
-        batch = golden_batch(g, p)
-        ret = a.update_parameters(batch, noise_u=g[p + "noise_u"] if kind == "ddpg" else None)
-        a.step_scheduler()
-        for k, v in ret.items():
-            assert_close(v, g[p + "ret/" + k], 1e-4, 1e-6, p + k)
-        d = a.dbg
-        assert_close(d["pi"].numpy(), g[p + "t/pi"], 1e-4, 1e-6, p + "pi")
-        assert_close(d["aux_pred"].numpy(), g[p + "t/aux_pred"], 1e-4, 1e-6, p + "aux_pred")
-        if kind == "ddpg":
-            assert_close(d["value_feat"].numpy(), g[p + "feat0"], 1e-4, 1e-6, p + "value_feat")
-            assert_close(d["next_state"].numpy(), g[p + "feat1"], 1e-4, 1e-6, p + "next_state")
-            assert_close(d["next_target"].numpy(), g[p + "feat2"], 1e-4, 1e-6, p + "next_target")
-            assert_close(d["policy_feat"].numpy(), g[p + "feat3"], 1e-4, 1e-6, p + "policy_feat")
-            assert_close(d["q1"].numpy(), g[p + "t/qf1"], 1e-4, 1e-6, p + "qf1")
-            assert_close(d["q2"].numpy(), g[p + "t/qf2"], 1e-4, 1e-6, p + "qf2")
-            assert_close(d["y"].numpy(), g[p + "t/next_q_value"], 1e-4, 1e-6, p + "y")
-            if p + "t/qf1_pi" in g.files:
-                assert_close(d["q1_pi"].numpy(), g[p + "t/qf1_pi"], 1e-4, 1e-6, p + "qf1_pi")
-        nets = a.nets()
-        # FC-layer biases in front of a train-mode BatchNorm have an analytically zero gradient; what
-        # the reference holds there is float noise (1e-9) which Adam then amplifies -> excluded.
-        skip = (".1.0.bias", ".1.3.bias")
-        for name in (["policy", "state_feature_extractor"] + (["critic"] if kind == "ddpg" else [])):
-            check_summaries(g, p + "end/grad/" + name + "/", ((n, q.grad) for n, q in nets[name].named_parameters()),
-                            2e-4, 1e-7, skip=skip)
-        for name, net in nets.items():
-            check_summaries(g, p + "end/param/" + name + "/", net.state_dict().items(), 1e-4, 2e-6, skip=skip)
+        a.update_step = start
+        for s in range(nsteps):
+            assert a.update_step == int(g["%s%d/update_step" % (run, s)])
+            _check_step(a, g, "%s%d/" % (run, s), "ddpg")
+    assert "b0/t/qf1_pi" in g.files and "a0/t/qf1_pi" not in g.files     # b0 is the policy-update step
+
+
+def test_bc_steps(golden_dir):
+    g = np.load(os.path.join(golden_dir, "bc_steps_B32.npz"))
+    a = _agent("bc_dagger_aux.yaml", SEED + 1)
+    for s in range(2):
+        _check_step(a, g, "a%d/" % s, "bc")
 
 
 def test_config_matches_reference(golden_dir):
