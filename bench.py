@@ -1,0 +1,197 @@
+"""bench.py -- DDPG gradient steps / second of the fused MI355X path (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 50
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY 8d "config 2"): DDPG/TD3 update with goal-auxiliary heads
+(ddpg_td3_aux.yaml), batch 256 per GPU, 1024-point clouds, synthetic seeded replay buffer, random-init
+weights, alternating policy / non-policy steps.  A "step" = one Agent.update_parameters call.
+`value` is measured with the minibatches already resident in HBM (a ring of pre-sampled batches);
+the host-sampling + PCIe inclusive rate is reported separately as `value_host_inclusive`.
+N > 1: one process per GPU, batch rows sharded (256 per rank -> weak scaling), one RCCL all-reduce of
+the flat gradients per optimiser phase (ga_ddpg_amd.parallel).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel: algorithmic FLOPs of the layer as the reference computes it (dense
+                padded neighbourhoods) / measured launch duration (HIP events on the launch
+                stream), against the FP32 MFMA peak; `executed_frac` is the same with the FLOPs the
+                de-duplicated kernel really executes.
+  cpu_baseline  the CPU oracle (pure-PyTorch port of the reference step) timed on this box's cores,
+                rank 0 / N=1 only, on a bounded sample (one B=256 step).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK = 157.3e12     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+SEED = 20260928
+
+# dense algorithmic MACs per sample of each shared-MLP layer, as the reference computes them
+# (rows = npoint * nsample incl. padded duplicates), keyed by launch tag.
+def dense_layer_macs(tag, c_in):
+    sa = {"sa1": (32 * 64, [(3 + c_in, 64), (64, 64), (64, 128)]),
+          "sa2": (32 * 128, [(131, 128), (128, 128), (128, 256)]),
+          "sa3": (32, [(259, 256), (256, 256), (256, 512)])}
+    kind, stage, layer = tag.split(".")
+    rows, dims = sa[stage]
+    k, n = dims[int(layer[1:]) - 1]
+    return rows * k * n
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--buffer", type=int, default=20000, help="synthetic replay transitions per rank")
+    ap.add_argument("--ring", type=int, default=8, help="pre-sampled minibatches kept resident in HBM")
+    ap.add_argument("--roofline-tag", default="fwd.sa1.l3", help="launch tag of the kernel priced against the roofline")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-rate", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, batch, noise):
+    """One B=256 DDPG step of the CPU oracle ('port' of the reference step) on the host cores."""
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from oracle import ref_step
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    oracle = ref_step.OracleAgent(load_cfg("ddpg_td3_aux.yaml").RL_TRAIN)
+    small = {k: (v[:8] if hasattr(v, "shape") and v.ndim > 0 and v.shape[0] == len(batch["reward_batch"]) else v)
+             for k, v in batch.items()}
+    oracle.update_parameters(small, noise_u=noise[:8])                 # page-in / warm-up on 8 rows
+    t0 = time.time()
+    oracle.update_parameters(batch, noise_u=noise)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "1 DDPG update step (non-policy step) at B=%d, N=1024 after an 8-row warm-up; %.1f s"
+                      % (len(batch["reward_batch"]), dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dp = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from ga_ddpg_amd import engine
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.parallel import DataParallelContext, mask_counts
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+
+    torch.manual_seed(1234)                      # identical initial weights on every rank
+    agent, cfg = make_agent("ddpg_td3_aux.yaml")
+    B = args.batch
+    mem = BaseMemory(args.buffer, cfg, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, args.buffer, seed=SEED + rank)
+    rng = np.random.default_rng(SEED + 1000 + rank)
+    host_batches = [sample_valid_batch(mem, B, rng) for _ in range(args.ring)]
+    rt = agent.runtime(B, host_batches[0]["point_state_batch"].shape[2])
+    if world > 1:
+        dp = DataParallelContext()
+        agent._dp = dp
+        dp.attach(rt)
+        dp.broadcast_parameters([rt.pol.flat, rt.pol_t.flat, rt.cr.flat, rt.cr_t.flat, rt.enc.flat, rt.venc.flat])
+    from ga_ddpg_amd.runtime import BATCH_KEYS
+    ring = []
+    for hb in host_batches:
+        d = {k: torch.as_tensor(np.ascontiguousarray(hb[k], dtype=np.float32)).cuda() for k in BATCH_KEYS}
+        d["mask_counts"] = mask_counts(hb)
+        ring.append(d)
+
+    def step(i):
+        out = agent.update_parameters(ring[i % len(ring)], agent.update_step, i)
+        agent.step_scheduler(agent.update_step)
+        return out
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    engine.TIMING.update(enabled=True, tag=args.roofline_tag, events=[])
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    engine.TIMING["enabled"] = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank != 0:
+        return
+    ev = engine.TIMING["events"]
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+    n_launch = len(ev) / max(args.steps, 1)
+    # roofline of the tagged launch: which encoder does it belong to? both encoders run it; use the
+    # critic encoder's input width (C=10) for SA1 layer 1, irrelevant for the others.
+    macs = dense_layer_macs(args.roofline_tag, 10) * B
+    mult = {"fwd": 1}.get(args.roofline_tag.split(".")[0], 1)
+    flops = 2.0 * macs * mult
+    stage = int(args.roofline_tag.split(".")[1][2:]) - 1
+    n_rows = int(rt.geo.rows[stage]["n"].item())
+    dense_rows = rt.geo.counts[stage]
+    roof = None
+    if kernel_ms:
+        ach = flops / (kernel_ms * 1e-3)
+        roof = {"bound": "mfma", "kernel": "gemm_fwd_kernel (%s: shared-MLP layer, FP32 MFMA)" % args.roofline_tag,
+                "achieved": ach / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK,
+                "traffic": None, "launch_ms": kernel_ms, "launches_per_step": n_launch,
+                "algorithmic_flops_per_launch": flops,
+                "executed_frac": ach / FP32_MFMA_PEAK * n_rows / dense_rows,
+                "dedup_rows": n_rows, "dense_rows": int(dense_rows)}
+    steps_per_s = args.steps * 1.0 / dt
+    res = {"metric": "DDPG grad-steps/sec (B=256, N=1024 pts)", "value": steps_per_s * 1.0, "unit": "steps/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[1]: DDPG/TD3 offline update (td3_critic_aux_policy_aux), "
+                                  "batch=%d per GPU, 1024-pt clouds, synthetic replay buffer" % B,
+                      "batch_per_gpu": B, "global_batch": B * world, "points": 1024,
+                      "parallelism": "dp%d" % world, "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
+           "losses": {k: out[k] for k in ("critic_loss", "bc_loss", "actor_critic_loss")},
+           "roofline": roof}
+    # step-level view against the dense-FP32 roofline: mean 5.5078 GFLOP per sample and step
+    res["step_dense_tflops"] = steps_per_s * B * 5.5078e9 / 1e12
+    if world == 1 and not args.no_host_rate:
+        rng2 = np.random.default_rng(7)
+        n = max(10, args.steps // 10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            b = sample_valid_batch(mem, B, rng2)
+            agent.update_parameters(b, agent.update_step, i)
+        torch.cuda.synchronize()
+        res["value_host_inclusive"] = n / (time.perf_counter() - t0)
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(cfg, host_batches[0], np.random.default_rng(3).random((B, 6)).astype(np.float32))
+    else:
+        res["cpu_baseline"] = None
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -295,12 +295,19 @@ def _dz(**kw):
     return d
 
 
+TIMING = {"enabled": False, "tag": None, "events": []}     # bench.py: HIP-event bracket of one tagged launch
+
+
 class Plan(object):
     """A recorded sequence of C-ABI calls over static buffers."""
 
     def __init__(self):
         self.calls = []
         self.keep = []       # keeps ctypes structs / tensors alive
+        self.tags = {}       # call index -> tag (layer name) for profiling
+
+    def tag_last(self, tag):
+        self.tags[len(self.calls) - 1] = tag
 
     def call(self, name, *a):
         f = getattr(hip.lib(), name)
@@ -321,13 +328,21 @@ class Plan(object):
         self.calls.append(("py", f, None, None))
 
     def extend(self, other):
+        n = len(self.calls)
         self.calls += other.calls
         self.keep += other.keep
+        for i, t in other.tags.items():
+            self.tags[n + i] = t
 
     def run(self):
         import ctypes as C
         st = hip.stream()
-        for name, f, args, s in self.calls:
+        timed = TIMING["enabled"]
+        for i, (name, f, args, s) in enumerate(self.calls):
+            ev = None
+            if timed and self.tags.get(i) == TIMING["tag"]:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             if name == "zero":
                 args.zero_()
             elif name == "py":
@@ -336,6 +351,9 @@ class Plan(object):
                 hip.check(f(C.byref(s), st), name)
             else:
                 hip.check(f(*(args + [st])), name)
+            if ev is not None:
+                ev[1].record()
+                TIMING["events"].append(ev)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -405,6 +423,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True):
                           zout_pitch=m.n_out, stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8),
                           **_layer_input(enc, slot, geo, s, l, action))
             plan.call_struct("gad_gemm_fwd", a)
+            plan.tag_last("fwd.sa%d.l%d" % (s + 1, l + 1))
             _finalize(plan, enc, slot, m, geo.counts[s], train)
         m = enc.sa_mats[s][2]
         plan.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, _bn_vec(slot, enc, m, "scale"),
@@ -415,6 +434,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True):
                       stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8),
                       **_layer_input(enc, slot, geo, 3, l, action))
         plan.call_struct("gad_gemm_fwd", a)
+        plan.tag_last("fwd.fc%d" % (l + 1))
         _finalize(plan, enc, slot, m, float(slot.B), train)
     return plan
 
@@ -475,6 +495,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         for k, v in epi.items():
             setattr(a, k, v)
         plan.call_struct("gad_gemm_dx", a)
+        plan.tag_last("dx.%s" % rows_kw.get("name", "fc"))
 
     def dw(s, l, dz, m, action):
         if not want_dw:
@@ -484,6 +505,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.dz = dz
         a.gacc = _ptr(enc.flat.gacc)
         plan.call_struct("gad_gemm_dw", a)
+        plan.tag_last("dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1))
 
     # ---- FC head ----
     fc1, fc2 = enc.fc_mats
@@ -499,7 +521,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     # ---- SA3 -> SA1 ----
     for s in (2, 1, 0):
         r = geo.rows[s]
-        rows_kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"])
+        rows_kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], name="sa%d" % (s + 1))
         m1, m2, m3 = enc.sa_mats[s]
         o3 = enc.bn_off[m3.bn_index]
         plan.call("gad_pool_bwd_stats", slot.dF[s], slot.argmax[s], r["G"], m3.n_out, slot.Z[s][2], m3.n_out,

@@ -20,6 +20,12 @@ import torch.distributed as dist
 
 def mask_counts(batch):
     """local counts the masked means divide by: [kept, goal rows, expert rows, non-(expert&reward) rows]"""
+    if "mask_counts" in batch:               # precomputed for a device-resident batch
+        return np.asarray(batch["mask_counts"], dtype=np.float64)
+
+    def host(x):
+        return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+    batch = {k: host(batch[k]) for k in ("return_batch", "expert_flag_batch", "perturb_flag_batch")}
     ret = np.asarray(batch["return_batch"]).reshape(-1)
     exp = np.asarray(batch["expert_flag_batch"]).reshape(-1)
     per = np.asarray(batch["perturb_flag_batch"]).reshape(-1)

@@ -144,6 +144,8 @@ class FusedRuntime(object):
     def upload(self, batch):
         if batch is None:
             return
+        if torch.is_tensor(batch["point_state_batch"]):
+            return self.load_device_batch(batch)
         B = self.B
         for k in BATCH_KEYS:
             if k not in batch or (not self.has_critic and k in ("next_point_state_batch",)):
