@@ -42,6 +42,7 @@ class FusedRuntime(object):
             self.slot_t = engine.EncoderSlot(self.geo_next, self.enc, dev, with_backward=False)
             self.hs_c = heads.HeadSlot(B, self.cr.width, 9, dev)
             self.hs_ct = heads.HeadSlot(B, self.cr.width, 9, dev)
+            self.hs_cpi = heads.HeadSlot(B, self.cr.width, 9, dev)      # Q(s, pi(s)) of the actor phase
             self.hs_pt = heads.HeadSlot(B, self.pol.hidden, self.pol.n_heads, dev)
             self.pi_t = torch.zeros(B, 6, **f32)
             self.a_next = torch.zeros(B, 6, **f32)
@@ -119,15 +120,15 @@ class FusedRuntime(object):
         P["c_bwd"] = cb
         # actor-critic term: Q(s, pi(s)) through the freshly updated critic, gradient back to pi
         v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi)
-        v.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
         P["v_fwd"] = v
         vb = Plan()
         vb.zero(cr.flat.gacc)
         vb.zero(self.slot_v.bstats)
-        vb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        vb.extend(heads.plan_critic_backward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
         # the reference's backward also leaves the actor-loss gradient in critic.grad (logged as critic_grad)
         vb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 1)
-        vb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=self.pi, want_dw=False,
+        vb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_cpi.g_feat, action=self.pi, want_dw=False,
                                                want_daction=True))
         P["v_bwd"] = vb
 
@@ -208,8 +209,8 @@ class FusedRuntime(object):
         g_pi = None
         if policy_step:
             P["v_fwd"].run()
-            hip.call("gad_actor_critic_loss", self.hs_c.out, d["expert_flag_batch"], d["return_batch"], B, ratio,
-                     self.inv_n_actor_critic(), self.hs_c.g_out, engine._ptr(self.scal, 8))
+            hip.call("gad_actor_critic_loss", self.hs_cpi.out, d["expert_flag_batch"], d["return_batch"], B, ratio,
+                     self.inv_n_actor_critic(), self.hs_cpi.g_out, engine._ptr(self.scal, 8))
             P["v_bwd"].run()
             g_pi = self.slot_v.daction
         hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],

@@ -7,7 +7,7 @@ import numpy as np
 import torch
 
 
-def one(B, policy_step, seed=5):
+def one(B, policy_step, seed=5, freeze_critic=False):
     from ga_ddpg_amd.api import make_agent
     from ga_ddpg_amd.core.replay_memory import BaseMemory
     from ga_ddpg_amd.experiments.config import load_cfg
@@ -24,6 +24,9 @@ def one(B, policy_step, seed=5):
         fill_module_(net, name, 3)
     if policy_step:
         agent.update_step = oracle.update_step = 2
+    if freeze_critic:     # no parameter change between the critic phase and the actor phase's Q(s,pi(s))
+        for o in (agent.state_feat_val_encoder_optim, agent.critic_optim, oracle.val_encoder_optim, oracle.critic_optim):
+            o.param_groups[0]["lr"] = 0.0
     mem = BaseMemory(3000, cfg, point_dtype=np.float32)
     fill_synthetic_buffer(mem, 3000, seed=seed)
     rng = np.random.default_rng(1)
@@ -48,15 +51,20 @@ def one(B, policy_step, seed=5):
     for name in ("policy", "critic", "state_feature_extractor"):
         on = dict(oracle.nets()[name].named_parameters())
         worst = 0.0
+        per = []
         for n, p in nets[name].named_parameters():
             if on[n].grad is None or ".1.0.bias" in n or ".1.3.bias" in n:
                 continue
             if policy_step and "value_encoder" in n:
                 continue
             g, w = p.grad.cpu().numpy().astype(np.float64), on[n].grad.numpy().astype(np.float64)
-            worst = max(worst, np.abs(g - w).max() / max(np.abs(w).max(), 1e-30))
+            r = np.abs(g - w).max() / max(np.abs(w).max(), 1e-30)
+            per.append((r, n, np.abs(w).max()))
+            worst = max(worst, r)
         rows.append(("grad(%s) worst tensor" % name, float("nan"), worst))
-    print("B=%d policy_step=%s" % (B, policy_step))
+        for r, n, m in sorted(per, reverse=True)[:4]:
+            rows.append(("    " + n[-24:], m, r))
+    print("B=%d policy_step=%s freeze_critic=%s" % (B, policy_step, freeze_critic))
     for n, e, r in rows:
         print("   %-28s max|err| %.3e   /max|ref| %.3e" % (n, e, r))
 
@@ -65,3 +73,4 @@ if __name__ == "__main__":
     for b in [int(x) for x in sys.argv[1:]] or [32]:
         one(b, False)
         one(b, True)
+        one(b, True, freeze_critic=True)

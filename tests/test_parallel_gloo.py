@@ -1,0 +1,95 @@
+"""Data-parallel bookkeeping (ga_ddpg_amd/parallel.py) on CPU with gloo, world_size 2: the sum over
+ranks of per-shard gradients that were normalised by the GLOBAL mask counts equals the full-batch
+gradient, and scalar losses reduce to the full-batch values.  Heads only (no BatchNorm), because
+BatchNorm statistics are per replica by design (== nn.DataParallel in the reference)."""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+B = 12
+
+
+def _batch(seed=0):
+    rng = np.random.default_rng(seed)
+    return {"feat": rng.normal(size=(B, 513)).astype(np.float32),
+            "return_batch": np.where(rng.random(B) < 0.5, rng.random(B), 0.0).astype(np.float32),
+            "expert_flag_batch": (rng.random(B) < 0.6).astype(np.float32),
+            "perturb_flag_batch": (rng.random(B) < 0.3).astype(np.float32),
+            "y": rng.normal(size=B).astype(np.float32)}
+
+
+def _critic():
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    return fill_module_(ref_step.QNet(513, 256, 7), "critic", 5)
+
+
+def _loss_sum(q, batch, rows, inv_keep):
+    """what the loss kernel computes on a shard: sum over kept rows * (1 / global count)"""
+    f = torch.tensor(batch["feat"][rows])
+    keep = torch.tensor(batch["perturb_flag_batch"][rows]) < 1
+    y = torch.tensor(batch["y"][rows])
+    q1, q2, _ = q(f)
+    l = torch.nn.functional.smooth_l1_loss(q1.squeeze(1)[keep], y[keep], reduction="sum") + \
+        torch.nn.functional.smooth_l1_loss(q2.squeeze(1)[keep], y[keep], reduction="sum")
+    return l * inv_keep
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ga_ddpg_amd.parallel import DataParallelContext, inverse_counts, mask_counts
+    batch = _batch()
+    rows = np.arange(B)[rank::world]
+    shard = {k: v[rows] for k, v in batch.items()}
+
+    class RT(object):
+        dev = torch.device("cpu")
+    rt = RT()
+    ctx = DataParallelContext()
+    ctx.attach(rt)
+    ctx.set_counts(shard)
+    gc = mask_counts(batch)
+    np.testing.assert_allclose(rt.inv_n.numpy(), inverse_counts(gc).astype(np.float32), rtol=1e-6)
+    q = _critic()
+    loss = _loss_sum(q, batch, rows, float(rt.inv_n[0]))
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in q.parameters() if p.grad is not None])
+    ctx.allreduce_grads([flat])
+    scal = torch.zeros(32)
+    scal[0] = loss.detach()
+    scal[10] = 3.0                      # replicated statistic: must NOT be summed
+    ctx.reduce_scalars(scal)
+    if rank == 0:
+        torch.save({"grad": flat, "loss": scal[0].clone(), "stat": scal[10].clone()}, out)
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_sum_equals_full_batch(tmp_path):
+    port = 29500 + os.getpid() % 2000
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    batch = _batch()
+    q = _critic()
+    keep = batch["perturb_flag_batch"] < 1
+    loss = _loss_sum(q, batch, np.arange(B), 1.0 / keep.sum())
+    loss.backward()
+    want = torch.cat([p.grad.reshape(-1) for p in q.parameters() if p.grad is not None])
+    torch.testing.assert_close(got["grad"], want, rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(got["loss"], loss.detach(), rtol=1e-5, atol=1e-7)
+    assert float(got["stat"]) == 3.0
+
+
+def test_mask_counts_and_inverse_layout():
+    from ga_ddpg_amd.parallel import inverse_counts, mask_counts
+    b = {"return_batch": np.array([0.0, 0.5, 0.2, 0.0]), "expert_flag_batch": np.array([1.0, 1.0, 0.0, 0.0]),
+         "perturb_flag_batch": np.array([0.0, 1.0, 0.0, 0.0])}
+    c = mask_counts(b)
+    np.testing.assert_array_equal(c, [3, 2, 2, 3])
+    inv = inverse_counts(c)
+    np.testing.assert_allclose(inv[:5], [1 / 3, 1 / 12, 1 / 12, 1 / 12, 1 / 3])
+    assert np.isinf(inverse_counts(np.array([0.0, 1, 1, 1]))[0])    # empty mask -> NaN loss, like the reference
