@@ -145,7 +145,7 @@ def main():
     if rank != 0:
         return
     ev = engine.TIMING["events"]
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+    kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if ev else None
     n_launch = len(ev) / max(args.steps, 1)
     # roofline of the tagged launch: which encoder does it belong to? both encoders run it; use the
     # critic encoder's input width (C=10) for SA1 layer 1, irrelevant for the others.

@@ -340,7 +340,7 @@ class Plan(object):
         timed = TIMING["enabled"]
         for i, (name, f, args, s) in enumerate(self.calls):
             ev = None
-            if timed and self.tags.get(i) == TIMING["tag"]:
+            if timed and i in self.tags and TIMING["tag"] in (self.tags[i], "*"):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
             if name == "zero":
@@ -353,7 +353,7 @@ class Plan(object):
                 hip.check(f(*(args + [st])), name)
             if ev is not None:
                 ev[1].record()
-                TIMING["events"].append(ev)
+                TIMING["events"].append(ev + (self.tags[i],))
 
 
 # ----------------------------------------------------------------------------------------------

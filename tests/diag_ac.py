@@ -49,6 +49,18 @@ def main(B=64):
     rel(rt.hs_cpi.g_feat.cpu().numpy(), vf.grad[:, :512].numpy(), "dL/dfeature")
     rel(rt.slot_v.daction.cpu().numpy(), pi.grad.numpy(), "dL/dpi")
     print("daction sample", rt.slot_v.daction[:2].cpu().numpy(), "\noracle", pi.grad[:2].numpy())
+    # total dLoss/dpi = BC + AC, against what the policy backward consumed (hs_p.g_out / tanh')
+    pi2 = rt.pi.cpu().clone().requires_grad_(True)
+    em = m["expert"]
+    bc = ref_step.pose_bc_loss(pi2[em], t["expert_action_batch"][em]) * 0.9
+    bc.backward()
+    g_tot = pi2.grad + pi.grad
+    scale = torch.tensor(ref_step.ACTION_HIGH, dtype=torch.float32)
+    th = rt.pi.cpu() / scale
+    mine = rt.hs_p.g_out[:, :6].cpu() / (scale * (1 - th * th))
+    rel(mine.numpy(), g_tot.numpy(), "dL/dpi total (from g_out)")
+    rel((mine - pi2.grad).numpy(), pi.grad.numpy(), "  minus BC = AC part")
+    rel(rt.slot_v.daction.cpu().numpy(), (mine - pi2.grad).numpy(), "  daction vs consumed AC")
     # forward features
     fc2 = rt.venc.fc_mats[1]; o = rt.venc.bn_off[fc2.bn_index]
     z = torch.relu(rt.slot_v.Zfc[1] * rt.slot_v.scale[o:o + 512] + rt.slot_v.shift[o:o + 512]).cpu().numpy()
