@@ -10,14 +10,23 @@
 // Hardware mapping (gfx950): v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD), 4 wavefronts
 // per workgroup, operands staged k-major in LDS ([k][row], pitch = tile+1 or tile+4 so both the
 // transposing ds_write_b32 and the fragment ds_read_b32 are bank-conflict free), next K-tile's
-// global loads issued before the current tile's MFMAs (register-staged software pipeline),
-// producers (BN affine + ReLU, neighbourhood gather, BN-backward dZ) fused into the operand load,
-// BatchNorm statistics / parameter gradients reduced in registers then f64 device atomics.
+// global loads issued before the current tile's MFMAs (register-staged software pipeline).
+// Producers (BN affine + ReLU, neighbourhood gather, BN-backward dZ) are fused into the operand load
+// and written BRANCH-FREE (clamped addresses + selects): every 16-byte load of a tile is issued
+// before the first wait, instead of one s_waitcnt per predicated load.
+// BatchNorm statistics: registers -> __shfl_xor -> LDS across wavefronts -> f64 device atomics
+// into one of GAD_STAT_REPLICAS accumulators (blockIdx % replicas) to bound same-address contention.
 #include "common.hpp"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define KT 32   // reduction tile
+
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4sel(bool c, float4 a, float4 b) {
+    return make_float4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
+}
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ------------------------------------------------------------------------------------------------
 // operand producers
@@ -42,50 +51,67 @@ static XSrc make_xsrc(const gad_gemm_fwd_args& a) {
     return x;
 }
 
-__device__ __forceinline__ float x_elem(const XSrc& x, int r, int zoff, int c, int pt, int grp) {
-    if (x.mode == 0) {
-        if (c < x.c_in) {
-            float v = x.zin[(size_t)r * x.zin_pitch + zoff + c];
-            if (x.scale) v = fmaf(v, x.scale[zoff + c], x.shift[zoff + c]);
-            if (x.relu) v = fmaxf(v, 0.f);
-            return v;
-        }
-        if (c == x.c_in && x.extra) return x.extra[r];
-        return c == x.ones_col ? 1.f : 0.f;
+// ACT input: columns [0,c_in) = act(scale*z+shift) of the previous layer's raw output (c_in % 4 == 0),
+// column c_in = extra[r] (optional), column ones_col = 1, everything else 0.
+__device__ __forceinline__ float4 x_act4(const XSrc& x, int r, bool valid, int zoff, int c) {
+    const int rr = valid ? r : 0;
+    const bool inside = c < x.c_in;
+    const int cc = inside ? c : x.c_in - 4;
+    float4 v = ldg4(x.zin + (size_t)rr * x.zin_pitch + zoff + cc);
+    if (x.scale) {
+        const float4 s = ldg4(x.scale + zoff + cc), t = ldg4(x.shift + zoff + cc);
+        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
     }
-    if (c < 3) {
-        const float p = x.src_xyz[(size_t)pt * 3 + c];
-        return x.ctr_xyz ? __fsub_rn(p, x.ctr_xyz[(size_t)grp * 3 + c]) : p;
-    }
-    c -= 3;
-    if (c < x.feat_c) return x.feat[(size_t)pt * x.feat_c + c];
-    c -= x.feat_c;
-    if (c < x.act_c) return x.action[(size_t)(grp / x.gps) * x.act_c + c];
-    return (c + 3 + x.feat_c) == x.ones_col ? 1.f : 0.f;
+    if (x.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    float e = 0.f;
+    if (x.extra) e = x.extra[rr];
+    float4 sp;
+    sp.x = (c + 0 == x.c_in && x.extra) ? e : (c + 0 == x.ones_col ? 1.f : 0.f);
+    sp.y = (c + 1 == x.c_in && x.extra) ? e : (c + 1 == x.ones_col ? 1.f : 0.f);
+    sp.z = (c + 2 == x.c_in && x.extra) ? e : (c + 2 == x.ones_col ? 1.f : 0.f);
+    sp.w = (c + 3 == x.c_in && x.extra) ? e : (c + 3 == x.ones_col ? 1.f : 0.f);
+    return f4sel(valid, f4sel(inside, v, sp), f4zero());
 }
 
-// four consecutive input columns c..c+3 of row r (c % 4 == 0)
-__device__ __forceinline__ float4 x_load4(const XSrc& x, int r, bool valid, int zoff, int c) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!valid) return v;
-    if (x.mode == 0 && c + 3 < x.c_in) {
-        v = *reinterpret_cast<const float4*>(x.zin + (size_t)r * x.zin_pitch + zoff + c);
-        if (x.scale) {
-            const float4 s = *reinterpret_cast<const float4*>(x.scale + zoff + c);
-            const float4 t = *reinterpret_cast<const float4*>(x.shift + zoff + c);
-            v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y);
-            v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+// GATHER input (packed column order: features first so they are 16-byte aligned):
+//   [ feat[pt] (feat_c, multiple of 4) | src_xyz[pt]-ctr_xyz[grp] (3) | action[grp/gps] (act_c) | 0.. ]
+// `tail` (wave-uniform) says whether this K-tile reaches beyond the feature block.
+__device__ __forceinline__ float4 x_gather4(const XSrc& x, int r, bool valid, int c, bool tail) {
+    const int rr = valid ? r : 0;
+    const int pt = x.row_pt[rr];
+    const bool inside = c < x.feat_c;
+    const int cc = inside ? c : x.feat_c - 4;
+    float4 v = ldg4(x.feat + (size_t)pt * x.feat_c + cc);
+    if (tail) {
+        const int grp = x.row_grp[rr];
+        const float* p = x.src_xyz + (size_t)pt * 3;
+        float q0 = p[0], q1 = p[1], q2 = p[2];
+        if (x.ctr_xyz) {
+            const float* cp = x.ctr_xyz + (size_t)grp * 3;
+            q0 = __fsub_rn(q0, cp[0]); q1 = __fsub_rn(q1, cp[1]); q2 = __fsub_rn(q2, cp[2]);
         }
-        if (x.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        return v;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const int t0 = c - x.feat_c;                       // tail-relative index of this unit's first column
+        if (x.action) {
+            const float* ap = x.action + (size_t)(grp / x.gps) * x.act_c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ai = t0 + j - 3;
+                const int aic = ai < 0 ? 0 : (ai >= x.act_c ? x.act_c - 1 : ai);
+                const float av = ap[aic];
+                a[j] = (ai >= 0 && ai < x.act_c) ? av : 0.f;
+            }
+        }
+        float4 sp;
+        float* spv = &sp.x;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + j;
+            spv[j] = t == 0 ? q0 : (t == 1 ? q1 : (t == 2 ? q2 : a[j]));
+        }
+        v = f4sel(inside, v, sp);
     }
-    int pt = 0, grp = 0;
-    if (x.mode != 0) { pt = x.row_pt[r]; grp = x.row_grp[r]; }
-    v.x = x_elem(x, r, zoff, c + 0, pt, grp);
-    v.y = x_elem(x, r, zoff, c + 1, pt, grp);
-    v.z = x_elem(x, r, zoff, c + 2, pt, grp);
-    v.w = x_elem(x, r, zoff, c + 3, pt, grp);
-    return v;
+    return f4sel(valid, v, f4zero());
 }
 
 struct DzSrc {   // gad_dz_src on the device
@@ -104,38 +130,78 @@ static DzSrc make_dzsrc(const gad_dz_src& d) {
     return s;
 }
 
-// dZ[r][n] for one element; `off` = channel offset of the group inside the layer
-__device__ __forceinline__ float dz_elem(const DzSrc& d, int r, int off, int n, int nmax) {
-    if (n >= nmax) return 0.f;
-    const int ch = off + n;
-    float z = 0.f;
-    if (d.z) z = d.z[(size_t)r * d.z_pitch + ch];
-    float g;
-    if (d.gmode == 0) {
-        g = d.G[(size_t)r * d.g_pitch + ch];
+// dZ[r][n..n+3] of a layer (VEC: all pitches / offsets multiples of 4, n+3 < nmax when n < nmax).
+//   dY = G (dense) or the pooled gradient routed through the arg-max; masked by the layer's ReLU;
+//   BatchNorm backward dZ = P*dY - w*(Q + S*z) when coefficients are given.
+template <bool VEC>
+__device__ __forceinline__ float4 dz_load4(const DzSrc& d, int r, bool valid, int off, int n, int nmax) {
+    if (VEC) {
+        const int rr = valid ? r : 0;
+        const bool inside = n < nmax;
+        const int ch = off + (inside ? n : 0);
+        float4 z = f4zero();
+        if (d.z) z = ldg4(d.z + (size_t)rr * d.z_pitch + ch);
+        float4 g;
+        if (d.gmode == 0) {
+            g = ldg4(d.G + (size_t)rr * d.g_pitch + ch);
+        } else {
+            const int grp = d.row_grp[rr];
+            const int4 a = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * d.c + ch);
+            const float4 o = ldg4(d.dout + (size_t)grp * d.c + ch);
+            g = make_float4(a.x == r ? o.x : 0.f, a.y == r ? o.y : 0.f, a.z == r ? o.z : 0.f, a.w == r ? o.w : 0.f);
+        }
+        if (d.relu) {
+            float4 y = z;
+            if (d.scale) {
+                const float4 s = ldg4(d.scale + ch), t = ldg4(d.shift + ch);
+                y.x = fmaf(z.x, s.x, t.x); y.y = fmaf(z.y, s.y, t.y); y.z = fmaf(z.z, s.z, t.z); y.w = fmaf(z.w, s.w, t.w);
+            }
+            g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
+            g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+        }
+        if (d.P) {
+            float w = 1.f;
+            if (d.row_w) w = d.row_w[rr];
+            const float4 P = ldg4(d.P + ch), Q = ldg4(d.Q + ch), S = ldg4(d.S + ch);
+            g.x = P.x * g.x - w * fmaf(S.x, z.x, Q.x); g.y = P.y * g.y - w * fmaf(S.y, z.y, Q.y);
+            g.z = P.z * g.z - w * fmaf(S.z, z.z, Q.z); g.w = P.w * g.w - w * fmaf(S.w, z.w, Q.w);
+        }
+        return f4sel(valid && inside, g, f4zero());
     } else {
-        const int grp = d.row_grp[r];
-        g = d.argmax[(size_t)grp * d.c + ch] == r ? d.dout[(size_t)grp * d.c + ch] : 0.f;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nn = n + j;
+            const bool ok = valid && nn < nmax;
+            const int rr = ok ? r : 0;
+            const int ch = off + (ok ? nn : 0);
+            float z = 0.f;
+            if (d.z) z = d.z[(size_t)rr * d.z_pitch + ch];
+            float g;
+            if (d.gmode == 0) {
+                g = d.G[(size_t)rr * d.g_pitch + ch];
+            } else {
+                const int grp = d.row_grp[rr];
+                g = d.argmax[(size_t)grp * d.c + ch] == r ? d.dout[(size_t)grp * d.c + ch] : 0.f;
+            }
+            if (d.relu) {
+                const float y = d.scale ? fmaf(z, d.scale[ch], d.shift[ch]) : z;
+                g = y > 0.f ? g : 0.f;
+            }
+            if (d.P) {
+                const float w = d.row_w ? d.row_w[rr] : 1.f;
+                g = d.P[ch] * g - w * fmaf(d.S[ch], z, d.Q[ch]);
+            }
+            v[j] = ok ? g : 0.f;
+        }
+        return make_float4(v[0], v[1], v[2], v[3]);
     }
-    if (d.relu) {
-        const float y = d.scale ? fmaf(z, d.scale[ch], d.shift[ch]) : z;
-        if (!(y > 0.f)) g = 0.f;
-    }
-    if (d.P) {
-        const float w = d.row_w ? d.row_w[r] : 1.f;
-        g = d.P[ch] * g - w * fmaf(d.S[ch], z, d.Q[ch]);
-    }
-    return g;
 }
 
-__device__ __forceinline__ float4 dz_load4(const DzSrc& d, int r, bool valid, int off, int n, int nmax) {
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!valid) return v;
-    v.x = dz_elem(d, r, off, n + 0, nmax);
-    v.y = dz_elem(d, r, off, n + 1, nmax);
-    v.z = dz_elem(d, r, off, n + 2, nmax);
-    v.w = dz_elem(d, r, off, n + 3, nmax);
-    return v;
+static bool dz_vectorizable(const gad_dz_src& d, const int32_t* off, const int32_t* n_out, int ng) {
+    bool ok = (d.z == nullptr || d.z_pitch % 4 == 0) && (d.gmode != 0 || d.g_pitch % 4 == 0) && (d.gmode == 0 || d.c % 4 == 0);
+    for (int i = 0; i < ng; ++i) ok = ok && off[i] % 4 == 0 && n_out[i] % 4 == 0;
+    return ok;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -146,9 +212,7 @@ __device__ __forceinline__ float4 dz_load4(const DzSrc& d, int r, bool valid, in
 template <int DIM> struct PitchT { static constexpr int v = DIM + 1; };
 template <int DIM> struct PitchD { static constexpr int v = DIM + 4; };
 
-// units of a (DIM x KT) tile whose source is contiguous along kk: u -> (i = u/8, kk4 = (u%8)*4)
 template <int DIM> __device__ __forceinline__ void unit_T(int u, int& i, int& kk) { i = u >> 3; kk = (u & 7) << 2; }
-// units of a (KT x DIM) tile whose source is contiguous along i: u -> (kk = u/(DIM/4), i4)
 template <int DIM> __device__ __forceinline__ void unit_D(int u, int& kk, int& i) { kk = u / (DIM / 4); i = (u % (DIM / 4)) << 2; }
 
 template <int DIM> __device__ __forceinline__ void store_T(float* t, int i, int kk, float4 v) {
@@ -160,7 +224,6 @@ template <int DIM> __device__ __forceinline__ void store_D(float* t, int kk, int
     *reinterpret_cast<float4*>(t + kk * P + i) = v;
 }
 
-// one K-tile of MFMAs: acc[tm][tn] += A^T-tile x B-tile
 template <int TM, int TN, int PA, int PB>
 __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const float* __restrict__ Bs, int am0,
                                            int bn0, int lane, f32x16 (&acc)[TM][TN]) {
@@ -180,27 +243,56 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
     }
 }
 
-// accumulator element v of a 32x32 tile -> row inside the tile (column is lane & 31)
 __device__ __forceinline__ int acc_row(int v, int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }
 
 struct Groups {
     int n; int aoff[GAD_MAX_GROUPS]; int woff[GAD_MAX_GROUPS]; int ooff[GAD_MAX_GROUPS]; int nout[GAD_MAX_GROUPS];
 };
 
+// per-column partial sums held by lanes 0..31 of each wavefront -> one f64 atomic per column and block
+template <int WM, int WN, int TN>
+__device__ __forceinline__ void block_column_atomics(float* red, const float (&c0)[TN], const float (&c1)[TN], int lane,
+                                                     int wm, int wn, int col0, int col_limit, double* out0,
+                                                     double* out1) {
+    constexpr int BN = WN * TN * 32;
+    __syncthreads();
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const float s0 = c0[tn] + __shfl_xor(c0[tn], 32, 64);
+        const float s1 = c1[tn] + __shfl_xor(c1[tn], 32, 64);
+        if (lane < 32) {
+            const int cl = wn * TN * 32 + tn * 32 + lane;
+            red[wm * BN + cl] = s0;
+            red[(WM + wm) * BN + cl] = s1;
+        }
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < BN && col0 + tid < col_limit) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s0 += red[w * BN + tid]; s1 += red[(WM + w) * BN + tid]; }
+        atomic_add_f64(out0 + col0 + tid, (double)s0);
+        atomic_add_f64(out1 + col0 + tid, (double)s1);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward:  zout[r][n] = sum_k X[r][k] * W[n][k]      (+ weighted BatchNorm statistics)
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int XM>
 __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                         int n_rows_static, const float* __restrict__ row_w,
                                                         const float* __restrict__ W, int Kp,
                                                         float* __restrict__ zout, int zout_pitch,
                                                         double* __restrict__ stat_sum,
-                                                        double* __restrict__ stat_sq) {
+                                                        double* __restrict__ stat_sq, int stat_stride) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchT<BM>::v, PB = PitchT<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
-    __shared__ __attribute__((aligned(16))) float smem[KT * PA + KT * PB + BM];
+    constexpr int SM = KT * PA + KT * PB + BM;
+    static_assert(SM >= 2 * WM * BN, "reduction scratch must fit in the tile LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SM];
     float* As = smem;
     float* Bs = smem + KT * PA;
     float* wS = Bs + KT * PB;
@@ -213,7 +305,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
     const int n0 = blockIdx.y * BN;
     if (n0 >= n_out) return;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    const int nk = Kp / KT + ((Kp % KT) ? 1 : 0);
+    const int nk = (Kp + KT - 1) / KT;
 
     float csum[TN], csq[TN];
 #pragma unroll
@@ -231,19 +323,21 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
         float4 ra[UA], rb[UB];
         auto load_tile = [&](int kt) {
             const int k0 = kt * KT;
+            const bool tail = XM == 1 && (k0 + KT > x.feat_c);
 #pragma unroll
             for (int it = 0; it < UA; ++it) {
                 int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
                 const int r = row0 + i;
-                ra[it] = (k0 + kk < Kp) ? x_load4(x, r, r < n_rows, zoff, k0 + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool ok = r < n_rows && (k0 + kk < Kp);
+                ra[it] = XM == 0 ? x_act4(x, r, ok, zoff, k0 + kk) : x_gather4(x, r, ok, k0 + kk, tail);
             }
 #pragma unroll
             for (int it = 0; it < UB; ++it) {
                 int j, kk; unit_T<BN>(it * 256 + tid, j, kk);
                 const int n = n0 + j;
-                rb[it] = (n < n_out && k0 + kk < Kp)
-                             ? *reinterpret_cast<const float4*>(Wg + (size_t)n * Kp + k0 + kk)
-                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool ok = n < n_out && (k0 + kk < Kp);
+                const float4 w = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k0 + kk : 0));
+                rb[it] = f4sel(ok, w, f4zero());
             }
         };
         load_tile(0);
@@ -261,7 +355,6 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
             __syncthreads();
         }
-        // epilogue: store + statistics
         const int l31 = lane & 31, half = lane >> 5;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -284,18 +377,11 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
         }
         __syncthreads();   // wS reuse
     }
-    if (stat_sum) {
-        const int l31 = lane & 31;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            float s1 = csum[tn] + __shfl_xor(csum[tn], 32, 64);
-            float s2 = csq[tn] + __shfl_xor(csq[tn], 32, 64);
-            const int n = n0 + wn * TN * 32 + tn * 32 + l31;
-            if (lane < 32 && n < n_out) {
-                atomic_add_f64(stat_sum + ooff + n, (double)s1);
-                atomic_add_f64(stat_sq + ooff + n, (double)s2);
-            }
-        }
+    if (stat_sum && (int)(blockIdx.x * BM) < n_rows) {          // block-uniform: idle blocks add nothing
+        const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+        block_column_atomics<WM, WN, TN>(smem, csum, csq, lane, wm, wn, n0, n_out,
+                                         stat_sum + (size_t)rep * stat_stride + ooff,
+                                         stat_sq + (size_t)rep * stat_stride + ooff);
     }
 }
 
@@ -311,27 +397,40 @@ static Groups make_groups(int n, const int32_t* a, const int32_t* w, const int32
 
 static int max_nout(const Groups& g) { int m = 0; for (int i = 0; i < g.n; ++i) m = g.nout[i] > m ? g.nout[i] : m; return m; }
 
+static int check_input(const gad_gemm_fwd_args& a, const char* who) {
+    if (a.mode == 0) {
+        GAD_REQUIRE(a.zin && a.c_in % 4 == 0 && a.c_in >= 4 && a.zin_pitch % 4 == 0, GAD_ERR_SHAPE,
+                    "%s: ACT input needs c_in >= 4, c_in and pitch multiples of 4", who);
+        for (int i = 0; i < a.n_groups; ++i)
+            GAD_REQUIRE(a.zin_off[i] % 4 == 0, GAD_ERR_SHAPE, "%s: zin_off must be a multiple of 4", who);
+    } else {
+        GAD_REQUIRE(a.src_xyz && a.row_pt && a.row_grp && a.feat, GAD_ERR_NULL, "%s: gather inputs", who);
+        GAD_REQUIRE(a.feat_c % 4 == 0 && a.feat_c >= 4, GAD_ERR_SHAPE, "%s: feat_c must be a positive multiple of 4", who);
+        GAD_REQUIRE(a.act_c == 0 || a.action, GAD_ERR_NULL, "%s: action", who);
+    }
+    return GAD_OK;
+}
+
 extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     GAD_REQUIRE(a && a->W && a->zout, GAD_ERR_NULL, "gemm_fwd: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_fwd: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0 && a->Kp >= 8, GAD_ERR_SHAPE, "gemm_fwd: Kp=%d must be a multiple of 8", a->Kp);
-    GAD_REQUIRE(a->mode == 1 || (a->zin && a->c_in % 4 == 0 && a->zin_pitch % 4 == 0), GAD_ERR_SHAPE,
-                "gemm_fwd: ACT input needs c_in, pitch multiples of 4");
-    GAD_REQUIRE(a->mode == 0 || (a->src_xyz && a->row_pt && a->row_grp), GAD_ERR_NULL, "gemm_fwd: gather inputs");
+    if (int e = check_input(*a, "gemm_fwd")) return e;
     if (a->n_rows <= 0) return GAD_OK;
     XSrc x = make_xsrc(*a);
     Groups gr = make_groups(a->n_groups, a->zin_off, a->w_off, a->out_off, a->n_out);
     const int nmax = max_nout(gr);
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows;
-#define LAUNCH_FWD(WM, WN, TM, TN)                                                                         \
+#define LAUNCH_FWD2(WM, WN, TM, TN, XM)                                                                    \
     do {                                                                                                   \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                                \
         int gx = gad_cdiv(rows, BM); if (gx > 2048) gx = 2048;                                             \
-        hipLaunchKernelGGL((gemm_fwd_kernel<WM, WN, TM, TN>), dim3(gx, gad_cdiv(nmax, BN), gr.n), dim3(256), \
+        hipLaunchKernelGGL((gemm_fwd_kernel<WM, WN, TM, TN, XM>), dim3(gx, gad_cdiv(nmax, BN), gr.n), dim3(256), \
                            0, st, x, gr, a->n_rows_dev, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, \
-                           a->stat_sum, a->stat_sq);                                                       \
+                           a->stat_sum, a->stat_sq, a->stat_stride);                                       \
     } while (0)
+#define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0); else LAUNCH_FWD2(WM, WN, TM, TN, 1); } while (0)
     if (rows <= 1024) {
         if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);     // many small tiles: fill the CUs
     } else if (nmax <= 64) {
@@ -340,6 +439,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         LAUNCH_FWD(2, 2, 2, 2);                                                   // 128 x 128
     }
 #undef LAUNCH_FWD
+#undef LAUNCH_FWD2
     GAD_CHECK_LAUNCH("gemm_fwd");
     return GAD_OK;
 }
@@ -350,18 +450,20 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 struct DxEpi {
     int mode; float* gout; int gout_pitch; int k_valid;
     const float* zprev; int zprev_pitch; const float* ps; const float* pt; const float* pm; const float* pi;
-    double* dbeta; double* dgamma;
-    float* dfeat; int feat_c; const int32_t* row_pt; const int32_t* row_grp; float* daction; int act_c; int gps;
+    double* dbeta; double* dgamma; int stat_stride;
+    float* dfeat; int feat_c; const int32_t* row_pt; const int32_t* row_grp; double* daction; int act_c; int gps;
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                        int n_rows_static, const float* __restrict__ W, int Kp,
                                                        DxEpi e) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchT<BM>::v, PB = PitchD<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
-    __shared__ __attribute__((aligned(16))) float smem[KT * PA + 3 + KT * PB + 2 * BM];
+    constexpr int SM = ((KT * PA + 3) & ~3) + KT * PB + 2 * BM;
+    static_assert(SM >= 2 * WM * BN, "reduction scratch must fit in the tile LDS");
+    __shared__ __attribute__((aligned(16))) float smem[SM];
     float* As = smem;
     float* Bs = smem + ((KT * PA + 3) & ~3);
     int32_t* ptS = reinterpret_cast<int32_t*>(Bs + KT * PB);
@@ -396,14 +498,15 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
             for (int it = 0; it < UA; ++it) {
                 int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
                 const int r = row0 + i;
-                ra[it] = dz_load4(d, r, r < n_rows, doff, nb + kk, n_out);
+                ra[it] = dz_load4<VEC>(d, r, r < n_rows, doff, nb + kk, n_out);
             }
 #pragma unroll
             for (int it = 0; it < UB; ++it) {
                 int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
                 const int n = nb + kk, k = k0out + j;
-                rb[it] = (n < n_out && k < Kp) ? *reinterpret_cast<const float4*>(Wg + (size_t)n * Kp + k)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
+                const bool ok = n < n_out && k < Kp;
+                const float4 w = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k : 0));
+                rb[it] = f4sel(ok, w, f4zero());
             }
         };
         load_tile(0);
@@ -446,11 +549,12 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
                             if (fmaf(zp, sc, sh) > 0.f) { sb += gv; sg = fmaf(gv, (zp - mu) * is, sg); }
                         }
                     } else {
-                        const int c = k - 3;
-                        if (c >= 0 && c < e.feat_c) {
-                            if (e.dfeat) atomic_add_f32(e.dfeat + (size_t)ptS[il] * e.feat_c + c, gv);
-                        } else if (c >= e.feat_c && c < e.feat_c + e.act_c) {
-                            if (e.daction) atomic_add_f32(e.daction + (size_t)(grS[il] / e.gps) * e.act_c + (c - e.feat_c), gv);
+                        // gather-layer columns: [feat (feat_c) | xyz (3) | action (act_c)]
+                        if (k < e.feat_c) {
+                            if (e.dfeat) atomic_add_f32(e.dfeat + (size_t)ptS[il] * e.feat_c + k, gv);
+                        } else if (k >= e.feat_c + 3 && k < e.feat_c + 3 + e.act_c) {
+                            if (e.daction)
+                                atomic_add_f64(e.daction + (size_t)(grS[il] / e.gps) * e.act_c + (k - e.feat_c - 3), (double)gv);
                         }
                     }
                 }
@@ -458,18 +562,11 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
         }
         __syncthreads();
     }
-    if (e.dbeta) {
-        const int l31 = lane & 31;
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            float s1 = cb[tn] + __shfl_xor(cb[tn], 32, 64);
-            float s2 = cg[tn] + __shfl_xor(cg[tn], 32, 64);
-            const int k = k0out + wn * TN * 32 + tn * 32 + l31;
-            if (lane < 32 && k < e.k_valid) {
-                atomic_add_f64(e.dbeta + goff + k, (double)s1);
-                atomic_add_f64(e.dgamma + goff + k, (double)s2);
-            }
-        }
+    if (e.dbeta && (int)(blockIdx.x * BM) < n_rows) {
+        const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+        block_column_atomics<WM, WN, TN>(smem, cb, cg, lane, wm, wn, k0out, e.k_valid,
+                                         e.dbeta + (size_t)rep * e.stat_stride + goff,
+                                         e.dgamma + (size_t)rep * e.stat_stride + goff);
     }
 }
 
@@ -487,19 +584,22 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     e.mode = a->epilogue; e.gout = a->gout; e.gout_pitch = a->gout_pitch; e.k_valid = a->k_valid;
     e.zprev = a->zprev; e.zprev_pitch = a->zprev_pitch; e.ps = a->prev_scale; e.pt = a->prev_shift;
     e.pm = a->prev_mean; e.pi = a->prev_istd; e.dbeta = a->prev_dbeta; e.dgamma = a->prev_dgamma;
+    e.stat_stride = a->stat_stride;
     e.dfeat = a->dfeat; e.feat_c = a->feat_c; e.row_pt = a->row_pt; e.row_grp = a->row_grp;
     e.daction = a->daction; e.act_c = a->act_c; e.gps = a->grp_per_sample > 0 ? a->grp_per_sample : 1;
     GAD_REQUIRE(e.mode == 0 || (e.row_pt && e.row_grp), GAD_ERR_NULL, "gemm_dx: scatter epilogue needs row maps");
     GAD_REQUIRE(!e.dbeta || (e.zprev && e.ps && e.pt && e.pm && e.pi && e.dgamma), GAD_ERR_NULL, "gemm_dx: prev BN stats inputs");
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows, kv = a->k_valid;
-#define LAUNCH_DX(WM, WN, TM, TN)                                                                        \
+    const bool vec = dz_vectorizable(a->dz, a->dz_off, a->n_out, a->n_groups);
+#define LAUNCH_DX2(WM, WN, TM, TN, V)                                                                    \
     do {                                                                                                 \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                              \
         int gx = gad_cdiv(rows, BM); if (gx > 2048) gx = 2048;                                           \
-        hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
+        hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
                            st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                              \
     } while (0)
+#define LAUNCH_DX(WM, WN, TM, TN) do { if (vec) LAUNCH_DX2(WM, WN, TM, TN, true); else LAUNCH_DX2(WM, WN, TM, TN, false); } while (0)
     if (rows <= 1024) {
         if (kv <= 32) LAUNCH_DX(4, 1, 1, 1); else LAUNCH_DX(2, 2, 1, 1);
     } else if (kv <= 32) {
@@ -510,17 +610,21 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
         LAUNCH_DX(2, 2, 2, 2);
     }
 #undef LAUNCH_DX
+#undef LAUNCH_DX2
     GAD_CHECK_LAUNCH("gemm_dx");
     return GAD_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward wrt the weights:  gacc[n][k] += sum_r dZ[r][n] * X[r][k]     (f64 atomics, split rows)
+// backward wrt the weights:  gacc[n][k] = sum_r dZ[r][n] * X[r][k]
+// split over rows: every (tile, split) block writes its partial tile to the caller's workspace, a
+// second kernel sums the splits in f64 (deterministic).  Without a workspace: f64 atomics.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int XM, bool VEC>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr,
                                                        const int32_t* __restrict__ n_rows_dev, int n_rows_static,
-                                                       int Kp, int k_used, int n_ktiles, double* __restrict__ gacc) {
+                                                       int Kp, int k_used, int n_ktiles, double* __restrict__ gacc,
+                                                       float* __restrict__ partial, long long group_stride) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchD<BM>::v, PB = PitchD<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
@@ -532,7 +636,6 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     const int wm = wave / WN, wn = wave % WN;
     const int g = blockIdx.z;
     const int doff = gr.aoff[g], zoff = gr.ooff[g], n_out = gr.nout[g];
-    double* out = gacc + gr.woff[g];
     const int tile_n = blockIdx.x / n_ktiles, tile_k = blockIdx.x % n_ktiles;
     const int n0 = tile_n * BM, k0 = tile_k * BN;
     if (n0 >= n_out) return;
@@ -541,7 +644,7 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     chunk = (chunk + KT - 1) / KT * KT;
     const int r_begin = blockIdx.y * chunk;
     const int r_end = min(r_begin + chunk, n_rows);
-    if (r_begin >= r_end) return;
+    if (r_begin >= r_end) return;     // the reducer skips the same splits (same chunk arithmetic)
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -551,18 +654,20 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
     float4 ra[UA], rb[UB];
+    const bool tail = XM == 1 && (k0 + BN > x.feat_c);
     auto load_tile = [&](int rb0) {
 #pragma unroll
         for (int it = 0; it < UA; ++it) {
             int kk, i; unit_D<BM>(it * 256 + tid, kk, i);
             const int r = rb0 + kk;
-            ra[it] = dz_load4(d, r, r < r_end, doff, n0 + i, n_out);
+            ra[it] = dz_load4<VEC>(d, r, r < r_end, doff, n0 + i, n_out);
         }
 #pragma unroll
         for (int it = 0; it < UB; ++it) {
             int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
             const int r = rb0 + kk;
-            rb[it] = (k0 + j < Kp) ? x_load4(x, r, r < r_end, zoff, k0 + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = r < r_end && (k0 + j < Kp);
+            rb[it] = XM == 0 ? x_act4(x, r, ok, zoff, k0 + j) : x_gather4(x, r, ok, k0 + j, tail);
         }
     };
     load_tile(r_begin);
@@ -577,6 +682,8 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
         __syncthreads();
     }
     const int l31 = lane & 31, half = lane >> 5;
+    float* pout = partial ? partial + (size_t)g * group_stride + (size_t)blockIdx.y * n_out * Kp : nullptr;
+    double* aout = gacc + gr.woff[g];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int k = k0 + wn * TN * 32 + tn * 32 + l31;
@@ -586,9 +693,31 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int n = n0 + wm * TM * 32 + tm * 32 + acc_row(v, half);
-                if (n < n_out) atomic_add_f64(out + (size_t)n * Kp + k, (double)acc[tm][tn][v]);
+                if (n >= n_out) continue;
+                if (pout) pout[(size_t)n * Kp + k] = acc[tm][tn][v];
+                else atomic_add_f64(aout + (size_t)n * Kp + k, (double)acc[tm][tn][v]);
             }
     }
+}
+
+__global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partial, long long group_stride,
+                                                        Groups gr, const int32_t* __restrict__ n_rows_dev,
+                                                        int n_rows_static, int splits, int Kp, int k_used,
+                                                        double* __restrict__ gacc) {
+    const int g = blockIdx.y;
+    const int n_out = gr.nout[g];
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long long)n_out * Kp) return;
+    const int k = (int)(e % Kp);
+    if (k >= k_used) return;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    int chunk = (n_rows + splits - 1) / splits;
+    chunk = (chunk + KT - 1) / KT * KT;
+    const int active = chunk > 0 ? (n_rows + chunk - 1) / chunk : 0;
+    const float* p = partial + (size_t)g * group_stride + e;
+    double s = 0.0;
+    for (int sidx = 0; sidx < active; ++sidx) s += (double)p[(size_t)sidx * n_out * Kp];
+    gacc[gr.woff[g] + e] += s;
 }
 
 extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
@@ -596,7 +725,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     const gad_gemm_fwd_args& in = a->in;
     GAD_REQUIRE(in.n_groups >= 1 && in.n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_dw: n_groups");
     GAD_REQUIRE(in.Kp % 8 == 0, GAD_ERR_SHAPE, "gemm_dw: Kp must be a multiple of 8");
-    GAD_REQUIRE(in.mode == 1 || (in.zin && in.c_in % 4 == 0 && in.zin_pitch % 4 == 0), GAD_ERR_SHAPE, "gemm_dw: ACT input");
+    if (int e = check_input(in, "gemm_dw")) return e;
     GAD_REQUIRE(a->dz.gmode == 0 ? a->dz.G != nullptr : (a->dz.argmax && a->dz.dout && a->dz.row_grp), GAD_ERR_NULL,
                 "gemm_dw: gradient source");
     if (in.n_rows <= 0) return GAD_OK;
@@ -605,34 +734,48 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     // group g: dz channel offset dz_off[g], input channel offset zin_off[g], weights at w_off[g]
     Groups gr = make_groups(in.n_groups, a->dz_off, in.w_off, in.zin_off, in.n_out);
     const int nmax = max_nout(gr);
-    // number of real input columns (the rest of Kp is zero padding: skip its atomics)
-    int k_used = in.mode == 0 ? in.c_in + (in.extra ? 1 : 0) : 3 + in.feat_c + in.act_c;
+    int k_used = in.mode == 0 ? in.c_in + (in.extra ? 1 : 0) : in.feat_c + 3 + in.act_c;
     if (in.ones_col >= k_used) k_used = in.ones_col + 1;
     if (k_used > in.Kp) k_used = in.Kp;
     hipStream_t st = (hipStream_t)stream;
     const int rows = in.n_rows;
+    const bool vec = dz_vectorizable(a->dz, a->dz_off, in.n_out, in.n_groups);
+    long long group_stride = 0;
+#define LAUNCH_DW3(WM, WN, TM, TN, XM, V)                                                                  \
+    hipLaunchKernelGGL((gemm_dw_kernel<WM, WN, TM, TN, XM, V>), dim3(tn_ * tk_, splits, gr.n), dim3(256), 0, st, d, \
+                       x, gr, in.n_rows_dev, rows, in.Kp, k_used, tk_, a->gacc, part, group_stride)
 #define LAUNCH_DW(WM, WN, TM, TN)                                                                          \
     do {                                                                                                   \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                                \
         const int tn_ = gad_cdiv(nmax, BM), tk_ = gad_cdiv(k_used, BN);                                    \
-        int splits = a->row_splits;                                                                        \
+        splits = a->row_splits;                                                                            \
         if (splits <= 0) {                                                                                 \
-            splits = gad_cdiv(1024, tn_ * tk_ * gr.n);                                                     \
-            const int by_rows = gad_cdiv(rows, 4 * KT);                                                    \
+            splits = gad_cdiv(768, tn_ * tk_ * gr.n);                                                      \
+            const int by_rows = gad_cdiv(rows, 8 * KT);                                                    \
             if (splits > by_rows) splits = by_rows;                                                        \
             if (splits < 1) splits = 1;                                                                    \
         }                                                                                                  \
-        hipLaunchKernelGGL((gemm_dw_kernel<WM, WN, TM, TN>), dim3(tn_ * tk_, splits, gr.n), dim3(256), 0, st, \
-                           d, x, gr, in.n_rows_dev, rows, in.Kp, k_used, tk_, a->gacc);                    \
+        group_stride = (long long)splits * nmax * in.Kp;                                                   \
+        if (part && (splits == 1 || group_stride * gr.n > a->partial_elems)) part = nullptr;               \
+        if (in.mode == 0) { if (vec) LAUNCH_DW3(WM, WN, TM, TN, 0, true); else LAUNCH_DW3(WM, WN, TM, TN, 0, false); } \
+        else              { if (vec) LAUNCH_DW3(WM, WN, TM, TN, 1, true); else LAUNCH_DW3(WM, WN, TM, TN, 1, false); } \
     } while (0)
+    int splits = 1;
+    float* part = a->partial;
     if (nmax <= 32) {
-        if (k_used <= 32) LAUNCH_DW(1, 4, 1, 1); else LAUNCH_DW(1, 4, 1, 1);   // 32 x 128
+        LAUNCH_DW(1, 4, 1, 1);      // 32 x 128
     } else if (k_used <= 32) {
-        LAUNCH_DW(4, 1, 1, 1);                                                  // 128 x 32
+        LAUNCH_DW(4, 1, 1, 1);      // 128 x 32
     } else {
-        LAUNCH_DW(2, 2, 1, 1);                                                  // 64 x 64
+        LAUNCH_DW(2, 2, 1, 1);      // 64 x 64
     }
 #undef LAUNCH_DW
+#undef LAUNCH_DW3
     GAD_CHECK_LAUNCH("gemm_dw");
+    if (part) {
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gr.n), dim3(256), 0, st, part,
+                           group_stride, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
+        GAD_CHECK_LAUNCH("dw_reduce");
+    }
     return GAD_OK;
 }

@@ -5,7 +5,7 @@
 #include "common.hpp"
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ssum,
-                                                          const double* __restrict__ ssq,
+                                                          const double* __restrict__ ssq, int stride,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int C, double count,
                                                           float eps, float momentum, float* __restrict__ rmean,
@@ -14,8 +14,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                           float* __restrict__ istd_o) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const double mean = ssum[c] / count;
-    double var = ssq[c] / count - mean * mean;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < GAD_STAT_REPLICAS; ++r) { s1 += ssum[(size_t)r * stride + c]; s2 += ssq[(size_t)r * stride + c]; }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
     const float istd = (float)(1.0 / sqrt(var + (double)eps));
     const float sc = gamma[c] * istd;
@@ -30,14 +32,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     }
 }
 
-extern "C" int gad_bn_finalize(const double* stat_sum, const double* stat_sq, const float* gamma,
+extern "C" int gad_bn_finalize(const double* stat_sum, const double* stat_sq, int stat_stride, const float* gamma,
                                const float* beta, int C, double count, float eps, float momentum,
                                float* running_mean, float* running_var, float* scale, float* shift, float* mean,
                                float* istd, void* stream) {
     GAD_REQUIRE(stat_sum && stat_sq && gamma && beta && scale && shift, GAD_ERR_NULL, "bn_finalize: null pointer");
     GAD_REQUIRE(C >= 1 && count >= 1.0, GAD_ERR_SHAPE, "bn_finalize: bad shape");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stat_sum,
-                       stat_sq, gamma, beta, C, count, eps, momentum, running_mean, running_var, scale, shift, mean,
+                       stat_sq, stat_stride, gamma, beta, C, count, eps, momentum, running_mean, running_var, scale, shift, mean,
                        istd);
     GAD_CHECK_LAUNCH("bn_finalize");
     return GAD_OK;
@@ -130,7 +132,7 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ istd,
                                                              double* __restrict__ dbeta,
-                                                             double* __restrict__ dgamma) {
+                                                             double* __restrict__ dgamma, int stride) {
     const int cpb = C < 256 ? C : 256;          // channels per block (C is a multiple of 32)
     const int gl = 256 / cpb;                   // groups processed side by side
     const int c = blockIdx.x * cpb + threadIdx.x % cpb;
@@ -144,13 +146,14 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __rest
         const float zp = z[(size_t)r * z_pitch + c];
         if (fmaf(zp, sc, sh) > 0.f) { sb += v; sg = fmaf(v, (zp - mu) * is, sg); }
     }
-    atomic_add_f64(dbeta + c, (double)sb);
-    atomic_add_f64(dgamma + c, (double)sg);
+    const int rep = blockIdx.y % GAD_STAT_REPLICAS;
+    atomic_add_f64(dbeta + (size_t)rep * stride + c, (double)sb);
+    atomic_add_f64(dgamma + (size_t)rep * stride + c, (double)sg);
 }
 
 extern "C" int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int G, int C, const float* z,
                                   int z_pitch, const float* scale, const float* shift, const float* mean,
-                                  const float* istd, double* dbeta, double* dgamma, void* stream) {
+                                  const float* istd, double* dbeta, double* dgamma, int stat_stride, void* stream) {
     GAD_REQUIRE(dout && argmax && z && scale && shift && mean && istd && dbeta && dgamma, GAD_ERR_NULL,
                 "pool_bwd_stats: null pointer");
     GAD_REQUIRE(C % 32 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), GAD_ERR_SHAPE, "pool_bwd_stats: C=%d", C);
@@ -160,13 +163,13 @@ extern "C" int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int 
     if (gy > 64) gy = 64;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(C / cpb, gy), dim3(256), 0, (hipStream_t)stream, dout, argmax, G, C,
-                       z, z_pitch, scale, shift, mean, istd, dbeta, dgamma);
+                       z, z_pitch, scale, shift, mean, istd, dbeta, dgamma, stat_stride);
     GAD_CHECK_LAUNCH("pool_bwd_stats");
     return GAD_OK;
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const double* __restrict__ dbeta,
-                                                          const double* __restrict__ dgamma,
+                                                          const double* __restrict__ dgamma, int stride,
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ mean,
                                                           const float* __restrict__ istd, int C, double count,
@@ -175,7 +178,8 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const double* __restri
                                                           double* __restrict__ gb) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const double db = dbeta[c], dg = dgamma[c];
+    double db = 0.0, dg = 0.0;
+    for (int r = 0; r < GAD_STAT_REPLICAS; ++r) { db += dbeta[(size_t)r * stride + c]; dg += dgamma[(size_t)r * stride + c]; }
     const double sc = scale[c], is = istd[c], mu = mean[c];
     P[c] = (float)sc;
     Q[c] = (float)(sc * (db - mu * is * dg) / count);
@@ -184,11 +188,11 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const double* __restri
     if (gb) gb[c] += db;
 }
 
-extern "C" int gad_bn_bwd_coef(const double* dbeta, const double* dgamma, const float* scale, const float* mean,
+extern "C" int gad_bn_bwd_coef(const double* dbeta, const double* dgamma, int stat_stride, const float* scale, const float* mean,
                                const float* istd, int C, double count, float* coefP, float* coefQ, float* coefS,
                                double* gacc_gamma, double* gacc_beta, void* stream) {
     GAD_REQUIRE(dbeta && dgamma && scale && mean && istd && coefP && coefQ && coefS, GAD_ERR_NULL, "bn_bwd_coef: null pointer");
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dbeta, dgamma, scale,
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dbeta, dgamma, stat_stride, scale,
                        mean, istd, C, count, coefP, coefQ, coefS, gacc_gamma, gacc_beta);
     GAD_CHECK_LAUNCH("bn_bwd_coef");
     return GAD_OK;

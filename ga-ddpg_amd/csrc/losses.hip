@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
                                                          const float* __restrict__ ret, const float* __restrict__ goal,
                                                          int B, float bc_scale, int policy_aux,
                                                          const float* __restrict__ ascale,
-                                                         const float* __restrict__ g_pi_critic,
+                                                         const double* __restrict__ g_pi_critic,
                                                          const float* __restrict__ inv_n, float* __restrict__ g13,
                                                          float* __restrict__ scalars) {
     __shared__ float red[4];
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
         float* g = g13 + (size_t)i * 13;
         const float* p = pi + (size_t)i * 6;
         float gpi[6];
-        for (int c = 0; c < 6; ++c) gpi[c] = g_pi_critic ? g_pi_critic[(size_t)i * 6 + c] : 0.f;
+        for (int c = 0; c < 6; ++c) gpi[c] = g_pi_critic ? (float)g_pi_critic[(size_t)i * 6 + c] : 0.f;
         if (expert_flag[i] >= 1.f) {
             float ga[6];
             lb += bc_point_loss(p, expert_action + (size_t)i * 6, ga);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
 
 extern "C" int gad_actor_loss(const float* pol13, const float* pi, const float* expert_action,
                               const float* expert_flag, const float* ret, const float* goal, int B, float bc_scale,
-                              int policy_aux, const float* action_scale, const float* g_pi_critic, const float* inv_n,
+                              int policy_aux, const float* action_scale, const double* g_pi_critic, const float* inv_n,
                               float* g_pol13, float* scalars, void* stream) {
     GAD_REQUIRE(pol13 && pi && expert_action && expert_flag && ret && goal && action_scale && g_pol13 && scalars,
                 GAD_ERR_NULL, "actor_loss: null pointer");

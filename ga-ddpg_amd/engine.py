@@ -28,8 +28,11 @@ def round8(k):
 class MatSpec(object):
     """One Conv2d-1x1 / Linear weight (n_out, k_in) [+ bias] and an optional BatchNorm after it."""
 
-    def __init__(self, weight, bias=None, bn=None):
+    def __init__(self, weight, bias=None, bn=None, gather_feat_c=None):
+        """gather_feat_c: for an SA stage's first conv (input [xyz(3), feat, action]) the number of
+        feature channels; its packed columns are permuted to [feat, xyz, action] (16-B aligned gather)."""
         self.weight, self.bias, self.bn = weight, bias, bn
+        self.gather_feat_c = gather_feat_c
         self.n_out = weight.shape[0]
         self.k_in = int(np.prod(weight.shape[1:]))
         self.ones_col = self.k_in if bias is not None else -1
@@ -59,7 +62,11 @@ class FlatNet(object):
         for m in self.mats:
             m.w_off = pk
             rows = np.arange(m.n_out, dtype=np.int64)[:, None]
-            cols = np.arange(m.k_in, dtype=np.int64)[None, :]
+            cols = np.arange(m.k_in, dtype=np.int64)
+            if m.gather_feat_c is not None:
+                fc = m.gather_feat_c
+                cols = np.where(cols < 3, cols + fc, np.where(cols < 3 + fc, cols - 3, cols))
+            cols = cols[None, :]
             mo = off_of[id(m.weight)]
             m2p[mo:mo + m.n_out * m.k_in] = (pk + rows * m.Kp + cols).reshape(-1)
             if m.bias is not None:
@@ -201,10 +208,11 @@ class EncoderNet(object):
         """module = nn.ModuleList([ModuleList(SA1,SA2,SA3), Sequential(fc)]) as core.networks builds."""
         sa_mods, fc = module[0], module[1]
         self.sa_mats = []
-        for sa in sa_mods:
+        feat_cs = (4, sa_mods[0].mlps[0][6].weight.shape[0], sa_mods[1].mlps[0][6].weight.shape[0])
+        for sa, fc in zip(sa_mods, feat_cs):
             seq = sa.mlps[0]
-            self.sa_mats.append([MatSpec(seq[0].weight, None, seq[1]), MatSpec(seq[3].weight, None, seq[4]),
-                                 MatSpec(seq[6].weight, None, seq[7])])
+            self.sa_mats.append([MatSpec(seq[0].weight, None, seq[1], gather_feat_c=fc),
+                                 MatSpec(seq[3].weight, None, seq[4]), MatSpec(seq[6].weight, None, seq[7])])
         self.fc_mats = [MatSpec(fc[0].weight, fc[0].bias, fc[1]), MatSpec(fc[3].weight, fc[3].bias, fc[4])]
         self.mats = [m for st in self.sa_mats for m in st] + self.fc_mats
         for i, m in enumerate(self.mats):
@@ -252,19 +260,20 @@ class EncoderSlot(object):
                        for s in range(3)]
         self.Zfc = [torch.empty(B, m.n_out, **f32) for m in enc.fc_mats]
         tot = enc.bn_total
-        self.stats = torch.zeros(2 * tot, dtype=torch.float64, device=device)      # fwd sums | sq sums
+        R = hip.STAT_REPLICAS
+        self.stats = torch.zeros(R * 2 * tot, dtype=torch.float64, device=device)  # [replica][sum | sq][channel]
         self.scale = torch.empty(tot, **f32)
         self.shift = torch.empty(tot, **f32)
         self.mean = torch.empty(tot, **f32)
         self.istd = torch.empty(tot, **f32)
         if with_backward:
-            self.bstats = torch.zeros(2 * tot, dtype=torch.float64, device=device)  # dbeta | dgamma
+            self.bstats = torch.zeros(R * 2 * tot, dtype=torch.float64, device=device)  # [replica][dbeta | dgamma]
             self.coef = torch.empty(3 * tot, **f32)                                  # P | Q | S
             gmax = max(caps[s] * max(m.n_out for m in enc.sa_mats[s]) for s in range(3))
             gmax = max(gmax, B * 1024)
             self.G = [torch.empty(gmax, **f32), torch.empty(gmax, **f32)]
             self.dF = [torch.zeros(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, **f32) for s in range(3)]
-            self.daction = torch.zeros(B, 6, **f32)
+            self.daction = torch.zeros(B, 6, dtype=torch.float64, device=device)
         self.tot = tot
 
 
@@ -296,6 +305,17 @@ def _dz(**kw):
 
 
 TIMING = {"enabled": False, "tag": None, "events": []}     # bench.py: HIP-event bracket of one tagged launch
+
+
+_DW_WS = {}
+
+
+def dw_workspace(device, elems=48 * 1024 * 1024):
+    """scratch for the weight-gradient split-K partial tiles (one per device; launches are stream-ordered)"""
+    key = str(device)
+    if key not in _DW_WS:
+        _DW_WS[key] = torch.empty(elems, dtype=torch.float32, device=device)
+    return _DW_WS[key]
 
 
 class Plan(object):
@@ -365,7 +385,7 @@ def _bn_vec(slot, enc, m, which):
 
 def _finalize(plan, enc, slot, m, count, train=True):
     o, tot = enc.bn_off[m.bn_index], slot.tot
-    plan.call("gad_bn_finalize", _ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), enc.flat.p_gamma(m),
+    plan.call("gad_bn_finalize", _ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), 2 * tot, enc.flat.p_gamma(m),
               enc.flat.p_beta(m), m.n_out, hip.Dbl(count), BN_EPS, BN_MOMENTUM,
               _ptr(enc.running_mean, o) if train else None, _ptr(enc.running_var, o) if train else None,
               _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "shift"), _bn_vec(slot, enc, m, "mean"),
@@ -421,7 +441,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True):
             o = enc.bn_off[m.bn_index]
             a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(slot.Z[s][l]),
                           zout_pitch=m.n_out, stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8),
-                          **_layer_input(enc, slot, geo, s, l, action))
+                          stat_stride=2 * tot, **_layer_input(enc, slot, geo, s, l, action))
             plan.call_struct("gad_gemm_fwd", a)
             plan.tag_last("fwd.sa%d.l%d" % (s + 1, l + 1))
             _finalize(plan, enc, slot, m, geo.counts[s], train)
@@ -431,7 +451,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True):
     for l, m in enumerate(enc.fc_mats):
         o = enc.bn_off[m.bn_index]
         a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(slot.Zfc[l]), zout_pitch=m.n_out,
-                      stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8),
+                      stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot,
                       **_layer_input(enc, slot, geo, 3, l, action))
         plan.call_struct("gad_gemm_fwd", a)
         plan.tag_last("fwd.fc%d" % (l + 1))
@@ -448,7 +468,7 @@ def _bn_coef(plan, enc, slot, m, count, want_dw):
     o, tot = enc.bn_off[m.bn_index], slot.tot
     P, Q, S = _coef_ptrs(slot, enc, m)
     gacc = enc.flat.gacc
-    plan.call("gad_bn_bwd_coef", _ptr(slot.bstats, o, 8), _ptr(slot.bstats, tot + o, 8),
+    plan.call("gad_bn_bwd_coef", _ptr(slot.bstats, o, 8), _ptr(slot.bstats, tot + o, 8), 2 * tot,
               _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "mean"), _bn_vec(slot, enc, m, "istd"),
               m.n_out, hip.Dbl(count), P, Q, S, _ptr(gacc, m.g_off, 8) if want_dw else None,
               _ptr(gacc, m.b_off, 8) if want_dw else None)
@@ -469,7 +489,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         return dict(zprev=_ptr(zprev), zprev_pitch=pm.n_out, prev_scale=_bn_vec(slot, enc, pm, "scale"),
                     prev_shift=_bn_vec(slot, enc, pm, "shift"), prev_mean=_bn_vec(slot, enc, pm, "mean"),
                     prev_istd=_bn_vec(slot, enc, pm, "istd"), prev_dbeta=_ptr(slot.bstats, o, 8),
-                    prev_dgamma=_ptr(slot.bstats, tot + o, 8))
+                    prev_dgamma=_ptr(slot.bstats, tot + o, 8), stat_stride=2 * tot)
 
     def bn_dz(m, z, G=None, pooled=None, row_w=None):
         P, Q, S = _coef_ptrs(slot, enc, m)
@@ -504,6 +524,8 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **_layer_input(enc, slot, geo, s, l, action))
         a.dz = dz
         a.gacc = _ptr(enc.flat.gacc)
+        ws = dw_workspace(enc.flat.device)
+        a.partial, a.partial_elems = _ptr(ws), ws.numel()
         plan.call_struct("gad_gemm_dw", a)
         plan.tag_last("dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1))
 
@@ -526,7 +548,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         o3 = enc.bn_off[m3.bn_index]
         plan.call("gad_pool_bwd_stats", slot.dF[s], slot.argmax[s], r["G"], m3.n_out, slot.Z[s][2], m3.n_out,
                   _bn_vec(slot, enc, m3, "scale"), _bn_vec(slot, enc, m3, "shift"), _bn_vec(slot, enc, m3, "mean"),
-                  _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8))
+                  _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8), 2 * tot)
         _bn_coef(plan, enc, slot, m3, geo.counts[s], want_dw)
         d = bn_dz(m3, slot.Z[s][2], pooled=(slot.argmax[s], slot.dF[s], r["grp"]), row_w=_ptr(r["w"]))
         dw(s, 2, d, m3, action)
@@ -541,7 +563,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         if s > 0:
             fc = slot.F[s - 1].shape[1]
             plan.zero(slot.dF[s - 1])
-            dx(rows_kw, d, m1, 3 + fc, epilogue=1, dfeat=_ptr(slot.dF[s - 1]), feat_c=fc, row_pt=_ptr(r["pt"]),
+            dx(rows_kw, d, m1, fc, epilogue=1, dfeat=_ptr(slot.dF[s - 1]), feat_c=fc, row_pt=_ptr(r["pt"]),
                row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
         elif want_daction and action is not None:
             plan.zero(slot.daction)

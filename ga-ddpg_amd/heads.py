@@ -5,7 +5,7 @@ grouped GEMMs (blockIdx.z = trunk); the policy's mean and aux heads are one (13 
 import torch
 
 from . import hip
-from .engine import FlatNet, MatSpec, Plan, _bn_vec, _dz, _fwd_args, _ptr
+from .engine import FlatNet, MatSpec, Plan, _bn_vec, _dz, _fwd_args, _ptr, dw_workspace
 
 
 class CriticNet(object):
@@ -112,6 +112,8 @@ def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True):
         for i, o in enumerate(dz_off):
             a.dz_off[i] = o
         a.gacc = _ptr(fl.gacc)
+        ws = dw_workspace(fl.device)
+        a.partial, a.partial_elems = _ptr(ws), ws.numel()
         plan.call_struct("gad_gemm_dw", a)
 
     def dx(dz, dz_off, mats, k_valid, gout, gout_off, **epi):
@@ -152,7 +154,7 @@ def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True):
     dx(d1, [0], [cat], fc2.n_out, hs.g_feat, [0], zprev=_ptr(eslot.Zfc[1]), zprev_pitch=fc2.n_out,
        prev_scale=_bn_vec(eslot, enc, fc2, "scale"), prev_shift=_bn_vec(eslot, enc, fc2, "shift"),
        prev_mean=_bn_vec(eslot, enc, fc2, "mean"), prev_istd=_bn_vec(eslot, enc, fc2, "istd"),
-       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8))
+       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8), stat_stride=2 * tot)
     return plan
 
 
@@ -195,6 +197,8 @@ def plan_policy_backward(po, hs, enc, eslot, time):
         a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **inp)
         a.dz = dz
         a.gacc = _ptr(fl.gacc)
+        ws = dw_workspace(fl.device)
+        a.partial, a.partial_elems = _ptr(ws), ws.numel()
         plan.call_struct("gad_gemm_dw", a)
 
     def dx(dz, m, k_valid, gout, **epi):
@@ -228,5 +232,5 @@ def plan_policy_backward(po, hs, enc, eslot, time):
     dx(d1, po.l1, fc2.n_out, hs.g_feat, zprev=_ptr(eslot.Zfc[1]), zprev_pitch=fc2.n_out,
        prev_scale=_bn_vec(eslot, enc, fc2, "scale"), prev_shift=_bn_vec(eslot, enc, fc2, "shift"),
        prev_mean=_bn_vec(eslot, enc, fc2, "mean"), prev_istd=_bn_vec(eslot, enc, fc2, "istd"),
-       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8))
+       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8), stat_stride=2 * tot)
     return plan

@@ -9,6 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgaddpg.so")
 MAX_GROUPS = 3
+STAT_REPLICAS = 8
 
 _i32, _f32, _f64, _vp = C.c_int32, C.c_float, C.c_double, C.c_void_p
 
@@ -23,7 +24,7 @@ class GemmFwdArgs(C.Structure):
                 ("n_groups", _i32), ("zin_off", _i32 * MAX_GROUPS), ("w_off", _i32 * MAX_GROUPS),
                 ("out_off", _i32 * MAX_GROUPS), ("n_out", _i32 * MAX_GROUPS),
                 ("W", _vp), ("Kp", _i32), ("zout", _vp), ("zout_pitch", _i32),
-                ("stat_sum", _vp), ("stat_sq", _vp)]
+                ("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32)]
 
 
 class DzSrc(C.Structure):
@@ -40,13 +41,13 @@ class GemmDxArgs(C.Structure):
                 ("k_valid", _i32), ("epilogue", _i32), ("gout", _vp), ("gout_pitch", _i32),
                 ("zprev", _vp), ("zprev_pitch", _i32), ("prev_scale", _vp), ("prev_shift", _vp),
                 ("prev_mean", _vp), ("prev_istd", _vp), ("prev_dbeta", _vp), ("prev_dgamma", _vp),
-                ("dfeat", _vp), ("feat_c", _i32), ("row_pt", _vp), ("row_grp", _vp),
+                ("stat_stride", _i32), ("dfeat", _vp), ("feat_c", _i32), ("row_pt", _vp), ("row_grp", _vp),
                 ("daction", _vp), ("act_c", _i32), ("grp_per_sample", _i32)]
 
 
 class GemmDwArgs(C.Structure):
     _fields_ = [("inp", GemmFwdArgs), ("dz", DzSrc), ("dz_off", _i32 * MAX_GROUPS), ("gacc", _vp),
-                ("row_splits", _i32)]
+                ("row_splits", _i32), ("partial", _vp), ("partial_elems", C.c_int64)]
 
 
 _lib = None

@@ -102,6 +102,9 @@ int gad_rows_group_all(int G, int pts_per_group, int32_t* grp_off, int32_t* row_
  * ------------------------------------------------------------------------------------------- */
 
 #define GAD_MAX_GROUPS 3
+/* BatchNorm statistic accumulators are replicated: a block adds into replica blockIdx.x % 8 (bounds
+ * same-address atomic contention); gad_bn_finalize / gad_bn_bwd_coef sum the replicas.               */
+#define GAD_STAT_REPLICAS 8
 
 typedef struct {
     /* rows */
@@ -118,7 +121,10 @@ typedef struct {
     int32_t relu;              /* ACT: apply max(.,0) after the affine                           */
     const float* extra;        /* ACT: optional extra input column (rows) placed at index c_in   */
     int32_t ones_col;          /* column holding 1.0 (bias), or -1                               */
-    /* GATHER: row r = [src_xyz[pt]-ctr_xyz[grp] (3), feat[pt] (feat_c), action[grp/grp_per_sample] (act_c)] */
+    /* GATHER: row r = [feat[pt] (feat_c, multiple of 4), src_xyz[pt]-ctr_xyz[grp] (3),
+     *                  action[grp/grp_per_sample] (act_c)]  -- PACKED column order (features first so
+     *                  they are 16-byte aligned); the host's master->packed map permutes the
+     *                  reference's [xyz, features] conv-weight columns accordingly                  */
     const float* src_xyz;      /* (points,3)                                                     */
     const float* ctr_xyz;      /* (groups,3) or NULL (GroupAll: no recentring)                   */
     const float* feat;         /* (points, feat_c) point-major                                   */
@@ -141,6 +147,7 @@ typedef struct {
     int32_t zout_pitch;
     double* stat_sum;          /* per output channel sum_r w*z and sum_r w*z^2 (f64 atomics),    */
     double* stat_sq;           /*   NULL -> no statistics                                        */
+    int32_t stat_stride;       /* elements between the GAD_STAT_REPLICAS replicas of the sums     */
 } gad_gemm_fwd_args;
 
 int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);
@@ -148,7 +155,7 @@ int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);
 /* train-mode BatchNorm finalisation: mean/var from the f64 sums over `count` rows (duplicates
  * included), scale = gamma*istd, shift = beta - mean*scale, running stats momentum update
  * (unbiased variance), saves mean/istd for the backward pass.                                   */
-int gad_bn_finalize(const double* stat_sum, const double* stat_sq, const float* gamma,
+int gad_bn_finalize(const double* stat_sum, const double* stat_sq, int stat_stride, const float* gamma,
                     const float* beta, int C, double count, float eps, float momentum,
                     float* running_mean /*nullable*/, float* running_var /*nullable*/,
                     float* scale, float* shift, float* mean, float* istd, void* stream);
@@ -189,11 +196,12 @@ typedef struct {
 /* pooled-gradient statistics for the BN that feeds a segment pool: dbeta/dgamma f64 sums        */
 int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int G, int C, const float* z,
                        int z_pitch, const float* scale, const float* shift, const float* mean,
-                       const float* istd, double* dbeta, double* dgamma, void* stream);
+                       const float* istd, double* dbeta, double* dgamma, int stat_stride,
+                       void* stream);
 
 /* BN backward coefficients from (dbeta,dgamma): P,Q,S above; also accumulates dgamma/dbeta into
  * the f64 gradient arena slots gacc_gamma/gacc_beta (nullable).                                 */
-int gad_bn_bwd_coef(const double* dbeta, const double* dgamma, const float* scale,
+int gad_bn_bwd_coef(const double* dbeta, const double* dgamma, int stat_stride, const float* scale,
                     const float* mean, const float* istd, int C, double count, float* coefP,
                     float* coefQ, float* coefS, double* gacc_gamma, double* gacc_beta,
                     void* stream);
@@ -218,11 +226,12 @@ typedef struct {
     /* epilogue 0 + statistics for the PREVIOUS layer's BN backward (nullable)                    */
     const float* zprev; int32_t zprev_pitch;
     const float* prev_scale; const float* prev_shift; const float* prev_mean; const float* prev_istd;
-    double* prev_dbeta; double* prev_dgamma;
-    /* epilogue 1: gather-layer scatter: columns [3,3+feat_c) atomically added to dfeat[row_pt],
-     * columns [3+feat_c, 3+feat_c+act_c) to daction[row_grp/grp_per_sample]                      */
+    double* prev_dbeta; double* prev_dgamma; int32_t stat_stride;
+    /* epilogue 1: gather-layer scatter (packed column order): columns [0,feat_c) atomically added to
+     * dfeat[row_pt], columns [feat_c+3, feat_c+3+act_c) to daction[row_grp/grp_per_sample] (f64:
+     * the per-sample action gradient is a sum of many cancelling terms)                            */
     float* dfeat; int32_t feat_c; const int32_t* row_pt; const int32_t* row_grp;
-    float* daction; int32_t act_c; int32_t grp_per_sample;
+    double* daction; int32_t act_c; int32_t grp_per_sample;
 } gad_gemm_dx_args;
 
 int gad_gemm_dx(const gad_gemm_dx_args* host_args, void* stream);
@@ -231,8 +240,10 @@ typedef struct {
     gad_gemm_fwd_args in;      /* describes how the layer's INPUT rows are produced (W/zout unused) */
     gad_dz_src dz;
     int32_t dz_off[GAD_MAX_GROUPS];
-    double* gacc;              /* f64 gradient arena, packed layout; group g at gacc + in.w_off[g] */
+    double* gacc;              /* f64 gradient arena, packed layout; group g at gacc + in.w_off[g]; ADDED to */
     int32_t row_splits;        /* rows are divided over this many blocks (0 -> auto)               */
+    float* partial;            /* caller workspace for the per-split partial tiles (NULL -> f64 atomics) */
+    int64_t partial_elems;     /* capacity of `partial` in floats                                   */
 } gad_gemm_dw_args;
 
 int gad_gemm_dw(const gad_gemm_dw_args* host_args, void* stream);
@@ -262,7 +273,7 @@ int gad_policy_outputs(const float* pol13, int B, const float* action_scale, flo
 int gad_actor_loss(const float* pol13, const float* pi, const float* expert_action,
                    const float* expert_flag, const float* ret, const float* goal, int B,
                    float bc_scale, int policy_aux, const float* action_scale,
-                   const float* g_pi_critic /*nullable*/, const float* inv_n, float* g_pol13,
+                   const double* g_pi_critic /*nullable*/, const float* inv_n, float* g_pol13,
                    float* scalars, void* stream);
 /* -ratio * mean over rows NOT (expert & return>0) of min(q1,q2): value + dLoss/d(out9[:, :2])    */
 int gad_actor_critic_loss(const float* out9, const float* expert_flag, const float* ret, int B,

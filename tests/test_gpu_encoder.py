@@ -196,9 +196,9 @@ def test_heads_forward_backward_vs_oracle():
     assert_close(gf, f.grad.numpy() , 2e-4, 2e-6, "critic dfeature")
     # fc[1] BN-backward sums accumulated by the dX epilogue: dbeta = sum(g*mask), dgamma = sum(g*mask*xhat)
     mask = (feat > 0).numpy()
-    assert_close(slot.bstats[o:o + 512].cpu().numpy(), (f.grad.numpy() * mask).sum(0), 2e-4, 2e-6, "dbeta")
-    assert_close(slot.bstats[slot.tot + o:slot.tot + o + 512].cpu().numpy(), (f.grad.numpy() * mask * feat.numpy()).sum(0),
-                 2e-4, 2e-6, "dgamma")
+    bs = slot.bstats.view(-1, 2, slot.tot).sum(0).cpu().numpy()      # sum the accumulator replicas
+    assert_close(bs[0, o:o + 512], (f.grad.numpy() * mask).sum(0), 2e-4, 2e-6, "dbeta")
+    assert_close(bs[1, o:o + 512], (f.grad.numpy() * mask * feat.numpy()).sum(0), 2e-4, 2e-6, "dgamma")
 
     # ---- policy: outputs, BC + aux loss, gradients
     f2 = feat.clone().requires_grad_(True)
