@@ -209,9 +209,9 @@ class EncoderNet(object):
         sa_mods, fc = module[0], module[1]
         self.sa_mats = []
         feat_cs = (4, sa_mods[0].mlps[0][6].weight.shape[0], sa_mods[1].mlps[0][6].weight.shape[0])
-        for sa, fc in zip(sa_mods, feat_cs):
+        for sa, nfeat in zip(sa_mods, feat_cs):
             seq = sa.mlps[0]
-            self.sa_mats.append([MatSpec(seq[0].weight, None, seq[1], gather_feat_c=fc),
+            self.sa_mats.append([MatSpec(seq[0].weight, None, seq[1], gather_feat_c=nfeat),
                                  MatSpec(seq[3].weight, None, seq[4]), MatSpec(seq[6].weight, None, seq[7])])
         self.fc_mats = [MatSpec(fc[0].weight, fc[0].bias, fc[1]), MatSpec(fc[3].weight, fc[3].bias, fc[4])]
         self.mats = [m for st in self.sa_mats for m in st] + self.fc_mats

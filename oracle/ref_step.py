@@ -118,6 +118,7 @@ class PolicyNet(nn.Module):
         self.extra_pred_dim = extra_pred_dim
         self.apply(_xavier)
         self.register_buffer("action_scale", torch.tensor(ACTION_HIGH, dtype=torch.float32), persistent=False)
+        # (a buffer, so .double() converts it together with the weights)
 
     def forward(self, s):
         h = F.relu(self.linear2(F.relu(self.linear1(s))))
@@ -133,12 +134,12 @@ _CP = np.array([[0, 0, 0], [0, 0, 0], [0.053, -0., 0.075], [-0.053, 0., 0.075],
                 [0.053, -0., 0.105], [-0.053, 0., 0.105]], dtype=np.float32)   # core/utils.py:819-824
 
 
-def control_points(rotz, device):
+def control_points(rotz, device, dtype=torch.float32):
     cp = _CP
     if rotz:                                                        # core/utils.py:826-827, rotZ(pi/2)
         c, s = np.cos(np.pi / 2), np.sin(np.pi / 2)
         cp = cp @ np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
-    return torch.tensor(cp, dtype=torch.float32, device=device)
+    return torch.tensor(cp, dtype=torch.float32, device=device).to(dtype)
 
 
 def quat_rotate(q, v):
@@ -151,7 +152,7 @@ def quat_rotate(q, v):
 
 def goal_pred_loss(pred, gt):
     """core/loss.py:17-23: mean over (rows, 6 pts) of sum_xyz |P(pred) - P(gt)|, P = q-rotate + t."""
-    cp = control_points(True, pred.device)[None]                     # (1,6,3)
+    cp = control_points(True, pred.device, pred.dtype)[None]          # (1,6,3)
 
     def pts(g):
         return quat_rotate(g[:, None, :4].expand(-1, 6, -1), cp.expand(g.shape[0], -1, -1)) + g[:, None, 4:]
@@ -170,7 +171,7 @@ def euler_matrix(az, el, th):
 
 def pose_bc_loss(pi, act):
     """core/loss.py:25-31: control points moved by euler rotation pi[3:] and translation pi[:3]."""
-    cp = control_points(False, pi.device)[None]
+    cp = control_points(False, pi.device, pi.dtype)[None]
 
     def pts(a):
         R = euler_matrix(a[:, 3], a[:, 4], a[:, 5])
@@ -194,8 +195,11 @@ def _max_abs(tensors):
 class OracleAgent(object):
     """DDPG / BC update step of the reference (core/agent.py, core/ddpg.py, core/bc.py)."""
 
-    def __init__(self, train_cfg, spec=None, kind=None, device="cpu"):
+    def __init__(self, train_cfg, spec=None, kind=None, device="cpu", dtype=torch.float32):
+        """dtype=torch.float64 gives a higher-precision yardstick (tests/test_gpu_step.py uses it to
+        judge float32 gradient error; call .double() on the nets after filling them)."""
         c = self.c = train_cfg
+        self.dtype = dtype
         self.kind = kind or ("DDPG" if c.RL else "BC")
         self.has_critic = self.kind != "BC"
         self.device = torch.device(device)
@@ -236,7 +240,7 @@ class OracleAgent(object):
         return min(r, c.ddpg_coefficients[4])
 
     def _load(self, batch):
-        t = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=self.device)
+        t = {k: torch.as_tensor(np.asarray(v), dtype=torch.float32, device=self.device).to(self.dtype)
              for k, v in batch.items() if k not in ("grasp_sample_batch",)}
         m = {}
         m["reward"] = (t["return_batch"] > 0).view(-1)               # core/agent.py:224-229
@@ -267,7 +271,7 @@ class OracleAgent(object):
             level = c.action_noise * c.noise_ratio_list[min(len(c.noise_ratio_list) - 1, idx)]
             if noise_u is None:
                 noise_u = torch.rand_like(a_next)
-            d = target_noise(torch.as_tensor(noise_u, dtype=torch.float32, device=self.device).clone(), level)
+            d = target_noise(torch.as_tensor(noise_u, dtype=torch.float32, device=self.device).to(self.dtype).clone(), level)
             d[:, :3] = torch.clamp(d[:, :3], -0.01, 0.01)
             a_next = a_next + d
             nt = self.features(nxt, time - 1, a_next)
@@ -367,6 +371,13 @@ class OracleAgent(object):
             self.critic_scheduler.step()
         self.policy_scheduler.step()
         self.encoder_scheduler.step()
+
+    def to_dtype(self, dtype):
+        """convert every network (after a deterministic float32 fill) to `dtype`"""
+        self.dtype = dtype
+        for n in self.nets().values():
+            n.to(dtype)
+        return self
 
     def nets(self):
         d = {"policy": self.policy, "policy_target": self.policy_target,

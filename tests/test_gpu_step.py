@@ -133,3 +133,56 @@ def test_steps_vs_oracle_fresh_batches():
             assert_close(got[k], want[k], tol, 1e-6, "step %d %s" % (s, k))
         assert_close(agent.qf1.cpu().numpy(), oracle.dbg["q1"].numpy(), rt, 2e-5, "q1")
         assert_close(agent.pi.cpu().numpy(), oracle.dbg["pi"].numpy(), rt, 2e-6, "pi")
+
+
+def test_policy_step_gradient_accuracy_vs_float64():
+    """The actor-critic step's gradients are ill-conditioned in float32 (torch's own float32 and
+    float64 evaluations of the reference arithmetic differ by 1e-2 norm-wise on some tensors, see
+    DESIGN.md 6), so a fixed 1e-4 bound against a float32 reference is not meaningful there.  Yardstick:
+    the HIP gradient must be as close to the float64 truth as torch-float32 is (factor 3 + 1e-4)."""
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    B = 64
+    c = load_cfg("ddpg_td3_aux.yaml")
+    mem = BaseMemory(3000, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 3000, seed=5)
+    rng = np.random.default_rng(1)
+    batch = sample_valid_batch(mem, B, rng)
+    u = rng.random((B, 6)).astype(np.float32)
+
+    def oracle_grads(dtype):
+        o = ref_step.OracleAgent(c.RL_TRAIN)
+        for n, net in o.nets().items():
+            fill_module_(net, n, 3)
+        o.to_dtype(dtype)
+        o.update_step = 2
+        for opt in (o.val_encoder_optim, o.critic_optim):
+            opt.param_groups[0]["lr"] = 0.0          # same critic in both phases: isolates the arithmetic
+        out = o.update_ddpg(batch, noise_u=u)
+        return out, {nn + "/" + n: p.grad.double() for nn, net in o.nets().items()
+                     for n, p in net.named_parameters() if p.grad is not None}
+    out32, g32 = oracle_grads(torch.float32)
+    out64, g64 = oracle_grads(torch.float64)
+    agent, nets = _filled_agent("ddpg_td3_aux.yaml", 3)
+    agent.update_step = 2
+    for opt in (agent.state_feat_val_encoder_optim, agent.critic_optim):
+        opt.param_groups[0]["lr"] = 0.0
+    got = agent.update_parameters(batch, agent.update_step, 0, noise_u=u)
+    torch.cuda.synchronize()
+    for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss", "actor_critic_loss"):
+        assert_close(got[k], out64[k], 1e-4, 1e-6, k)
+    worst = 0.0
+    for key, ref in g64.items():
+        nn, n = key.split("/", 1)
+        if any(x in n for x in SKIP) or "value_encoder" in n:
+            continue
+        mine = dict(nets[nn].named_parameters())[n].grad.double().cpu()
+        scale = float(ref.abs().max()) + 1e-30
+        e_hip = float((mine - ref).abs().max()) / scale
+        e_t32 = float((g32[key] - ref).abs().max()) / scale
+        worst = max(worst, e_hip / (3 * e_t32 + 1e-4))
+        assert e_hip <= 3 * e_t32 + 1e-4, (key, e_hip, e_t32)
+    print("worst HIP-error / allowance ratio:", worst)
