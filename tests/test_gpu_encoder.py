@@ -106,7 +106,11 @@ def test_encoder_forward_backward_vs_reference(golden_dir):
     z_val = _run_encoder(venc, vslot, action, probe.flip(1).contiguous(), True)
     taps(vslot, "value")
     assert_close(z_val.cpu().numpy(), g["z_value"], 1e-4, 2e-5, "z_value")
-    assert_close(vslot.daction.cpu().numpy(), g["action_grad"], 2e-4, 1e-5, "action grad")
+    skip = (".1.0.bias", ".1.3.bias")          # bias in front of train-mode BN: analytically zero gradient
+    check_summaries(g, "grad/", ((n, p.grad) for n, p in net.named_parameters()), 1e-4, 2e-6, skip=skip, normwise=True)
+    da = vslot.daction.cpu().numpy()
+    print("action grad rel err per sample:", np.abs(da - g["action_grad"]).max(1) / np.abs(g["action_grad"]).max(1))
+    assert_close(da, g["action_grad"], 2e-4, 1e-5, "action grad")
 
     skip = (".1.0.bias", ".1.3.bias")          # bias in front of train-mode BN: analytically zero gradient
     check_summaries(g, "grad/", ((n, p.grad) for n, p in net.named_parameters()), 1e-4, 2e-6, skip=skip, normwise=True)
@@ -217,7 +221,7 @@ def test_heads_forward_backward_vs_oracle():
     assert_close(pi.cpu().numpy(), pi_o.detach().numpy(), 1e-4, 1e-6, "pi")
     assert_close(auxn.cpu().numpy(), aux_o.detach().numpy(), 1e-4, 1e-5, "policy aux")
     hip.call("gad_actor_loss", hs_p.out, pi, dv(expert_act), dv(expert_flag), dv(ret), dv(goal), B, 0.9, 1, ascale,
-             dv(gpc), None, hs_p.g_out, sp)
+             dv(gpc.double()), None, hs_p.g_out, sp)
     s = sp.cpu().numpy()
     assert_close(s[0], bc.item(), 1e-4, 1e-6, "bc loss")
     assert_close(s[1], pa.item(), 1e-4, 1e-6, "policy aux loss")
