@@ -107,8 +107,8 @@ def test_encoder_forward_backward_vs_reference(golden_dir):
     taps(vslot, "value")
     assert_close(z_val.cpu().numpy(), g["z_value"], 1e-4, 2e-5, "z_value")
     da = vslot.daction.cpu().numpy()
-    np.set_printoptions(linewidth=200, precision=5, suppress=True)
-    print("mine\n", da, "\ngolden\n", g["action_grad"])
+    os.makedirs("gpurun_out", exist_ok=True)
+    np.savez("gpurun_out/enc_grads.npz", daction=da, **{n: p.grad.cpu().numpy() for n, p in net.named_parameters()})
     print("action grad rel err per sample:", np.abs(da - g["action_grad"]).max(1) / np.abs(g["action_grad"]).max(1))
     assert_close(da, g["action_grad"], 2e-4, 1e-5, "action grad")
 
