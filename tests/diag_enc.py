@@ -25,7 +25,7 @@ def main(order):
                 _run_encoder(enc, slot, None, probe, False)
             else:
                 _run_encoder(venc, vslot, action, probe.flip(1).contiguous(), True)
-        out = {n: p.grad.cpu().numpy() for n, p in net.named_parameters()}
+        out = {n: p.grad.cpu().numpy() for n, p in net.named_parameters() if p.numel() < 40000}
         out["daction"] = vslot.daction.cpu().numpy()
         np.savez("gpurun_out/enc_grads_%s_%d.npz" % (order, rep), **out)
 
