@@ -115,7 +115,7 @@ def test_encoder_forward_backward_vs_reference(golden_dir):
     # 3e-3: the float32 golden itself is up to 1.1e-3 (norm-wise) away from a float64 evaluation of the same
     # reference arithmetic on the SA1 tensors (measured; the HIP path is within 1e-5 of float64 there).  The
     # accuracy claim proper is tests/test_gpu_step.py::test_gradient_accuracy_vs_float64.
-    check_summaries(g, "grad/", ((n, p.grad) for n, p in net.named_parameters()), 3e-3, 2e-6, skip=skip, normwise=True)
+    check_summaries(g, "grad/", ((n, p.grad) for n, p in net.named_parameters()), 1e-3, 2e-6, skip=skip, normwise=True)
     check_summaries(g, "state/", ((n, t) for n, t in net.state_dict().items() if "running" in n), 1e-4, 1e-6)
     for n, p in net.named_parameters():
         if any(s in n for s in skip):
