@@ -700,11 +700,12 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     }
 }
 
+#define DW_RED_CHUNK 16
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partial, long long group_stride,
                                                         Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                         int n_rows_static, int splits, int Kp, int k_used,
                                                         double* __restrict__ gacc) {
-    const int g = blockIdx.y;
+    const int g = blockIdx.z;
     const int n_out = gr.nout[g];
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)n_out * Kp) return;
@@ -714,10 +715,14 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
     int chunk = (n_rows + splits - 1) / splits;
     chunk = (chunk + KT - 1) / KT * KT;
     const int active = chunk > 0 ? (n_rows + chunk - 1) / chunk : 0;
+    const int s0 = blockIdx.y * DW_RED_CHUNK, s1 = min(s0 + DW_RED_CHUNK, active);
+    if (s0 >= s1) return;
     const float* p = partial + (size_t)g * group_stride + e;
+    const size_t stride = (size_t)n_out * Kp;
     double s = 0.0;
-    for (int sidx = 0; sidx < active; ++sidx) s += (double)p[(size_t)sidx * n_out * Kp];
-    gacc[gr.woff[g] + e] += s;
+#pragma unroll 4
+    for (int sidx = s0; sidx < s1; ++sidx) s += (double)p[(size_t)sidx * stride];
+    atomic_add_f64(gacc + gr.woff[g] + e, s);
 }
 
 extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
@@ -750,7 +755,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         const int tn_ = gad_cdiv(nmax, BM), tk_ = gad_cdiv(k_used, BN);                                    \
         splits = a->row_splits;                                                                            \
         if (splits <= 0) {                                                                                 \
-            splits = gad_cdiv(768, tn_ * tk_ * gr.n);                                                      \
+            splits = gad_cdiv(512, tn_ * tk_ * gr.n);                                                      \
             const int by_rows = gad_cdiv(rows, 8 * KT);                                                    \
             if (splits > by_rows) splits = by_rows;                                                        \
             if (splits < 1) splits = 1;                                                                    \
@@ -773,7 +778,8 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
 #undef LAUNCH_DW3
     GAD_CHECK_LAUNCH("gemm_dw");
     if (part) {
-        hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gr.n), dim3(256), 0, st, part,
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n),
+                           dim3(256), 0, st, part,
                            group_stride, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
         GAD_CHECK_LAUNCH("dw_reduce");
     }

@@ -159,8 +159,8 @@ extern "C" int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int 
     GAD_REQUIRE(C % 32 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), GAD_ERR_SHAPE, "pool_bwd_stats: C=%d", C);
     if (G == 0) return GAD_OK;
     const int cpb = C < 256 ? C : 256, gl = 256 / cpb;
-    int gy = gad_cdiv(G, gl * 8);
-    if (gy > 64) gy = 64;
+    int gy = gad_cdiv(G, gl * 4);
+    if (gy > 512) gy = 512;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(C / cpb, gy), dim3(256), 0, (hipStream_t)stream, dout, argmax, G, C,
                        z, z_pitch, scale, shift, mean, istd, dbeta, dgamma, stat_stride);

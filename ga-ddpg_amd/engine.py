@@ -225,21 +225,22 @@ class EncoderNet(object):
         self.running_mean = torch.zeros(tot, dtype=torch.float32, device=device)
         self.running_var = torch.ones(tot, dtype=torch.float32, device=device)
         self.bn_off = []
+        self.batches_tracked = torch.zeros(len(self.mats), dtype=torch.int64, device=device)
         o = 0
-        for m in self.mats:
+        for i_m, m in enumerate(self.mats):
             self.bn_off.append(o)
             with torch.no_grad():
                 self.running_mean[o:o + m.n_out].copy_(m.bn.running_mean.to(device))
                 self.running_var[o:o + m.n_out].copy_(m.bn.running_var.to(device))
             m.bn.running_mean = self.running_mean[o:o + m.n_out]
             m.bn.running_var = self.running_var[o:o + m.n_out]
-            m.bn.num_batches_tracked = m.bn.num_batches_tracked.to(device)
+            self.batches_tracked[i_m] = int(m.bn.num_batches_tracked)
+            m.bn.num_batches_tracked = self.batches_tracked[i_m]      # 0-d view of the flat counter buffer
             o += m.n_out
         self.bn_total = tot
 
     def bump_batches_tracked(self, k=1):
-        for m in self.mats:
-            m.bn.num_batches_tracked += k
+        self.batches_tracked += k           # one launch for all BatchNorm counters of the encoder
 
 
 class EncoderSlot(object):
