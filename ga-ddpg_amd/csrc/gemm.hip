@@ -29,8 +29,13 @@ __device__ __forceinline__ float4 f4sel(bool c, float4 a, float4 b) {
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
 // ------------------------------------------------------------------------------------------------
-// operand producers
+// operand producers.  Every producer is split in two so that global loads overlap the MFMAs:
+//   *_raw    issues the 16-byte loads of the NEXT tile into registers (no arithmetic on them),
+//   *_finish runs after the current tile's MFMAs, right before the LDS store: BatchNorm affine /
+//            ReLU / BatchNorm-backward with the per-channel vectors read from LDS.
 // ------------------------------------------------------------------------------------------------
+#define VMAX 1024            // max channels of one layer side (per-channel vectors staged in LDS)
+
 struct XSrc {   // how a layer's INPUT row r, column c is produced (gad_gemm_fwd_args subset)
     int mode;
     const float* zin; int zin_pitch; int c_in;
@@ -51,67 +56,86 @@ static XSrc make_xsrc(const gad_gemm_fwd_args& a) {
     return x;
 }
 
-// ACT input: columns [0,c_in) = act(scale*z+shift) of the previous layer's raw output (c_in % 4 == 0),
-// column c_in = extra[r] (optional), column ones_col = 1, everything else 0.
-__device__ __forceinline__ float4 x_act4(const XSrc& x, int r, bool valid, int zoff, int c) {
-    const int rr = valid ? r : 0;
-    const bool inside = c < x.c_in;
-    const int cc = inside ? c : x.c_in - 4;
-    float4 v = ldg4(x.zin + (size_t)rr * x.zin_pitch + zoff + cc);
-    if (x.scale) {
-        const float4 s = ldg4(x.scale + zoff + cc), t = ldg4(x.shift + zoff + cc);
-        v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
-    }
-    if (x.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    float e = 0.f;
-    if (x.extra) e = x.extra[rr];
-    float4 sp;
-    sp.x = (c + 0 == x.c_in && x.extra) ? e : (c + 0 == x.ones_col ? 1.f : 0.f);
-    sp.y = (c + 1 == x.c_in && x.extra) ? e : (c + 1 == x.ones_col ? 1.f : 0.f);
-    sp.z = (c + 2 == x.c_in && x.extra) ? e : (c + 2 == x.ones_col ? 1.f : 0.f);
-    sp.w = (c + 3 == x.c_in && x.extra) ? e : (c + 3 == x.ones_col ? 1.f : 0.f);
-    return f4sel(valid, f4sel(inside, v, sp), f4zero());
-}
+struct XRaw { float4 a; float4 s; };     // a: the 16 raw bytes; s: special columns (tail tiles only)
 
-// GATHER input (packed column order: features first so they are 16-byte aligned):
-//   [ feat[pt] (feat_c, multiple of 4) | src_xyz[pt]-ctr_xyz[grp] (3) | action[grp/gps] (act_c) | 0.. ]
-// `tail` (wave-uniform) says whether this K-tile reaches beyond the feature block.
-__device__ __forceinline__ float4 x_gather4(const XSrc& x, int r, bool valid, int c, bool tail) {
+// number of leading "bulk" columns served by aligned 16-byte loads
+__device__ __forceinline__ int x_bulk(const XSrc& x) { return x.mode == 0 ? x.c_in : x.feat_c; }
+
+// ACT input: columns [0,c_in) = act(scale*z+shift) of the previous layer's raw output (c_in % 4 == 0),
+//            column c_in = extra[r] (optional), column ones_col = 1, everything else 0.
+// GATHER input (packed order, features first): [feat[pt] (feat_c) | src_xyz[pt]-ctr_xyz[grp] (3) |
+//            action[grp/gps] (act_c) | 0..].
+// `tail` (wave-uniform): this K-tile reaches beyond the bulk columns.  `pt`: point index of the row.
+template <int XM>
+__device__ __forceinline__ XRaw x_raw(const XSrc& x, int r, bool valid, int zoff, int c, bool tail, int pt) {
+    XRaw o;
+    o.s = f4zero();
     const int rr = valid ? r : 0;
-    const int pt = x.row_pt[rr];
-    const bool inside = c < x.feat_c;
-    const int cc = inside ? c : x.feat_c - 4;
-    float4 v = ldg4(x.feat + (size_t)pt * x.feat_c + cc);
-    if (tail) {
-        const int grp = x.row_grp[rr];
-        const float* p = x.src_xyz + (size_t)pt * 3;
-        float q0 = p[0], q1 = p[1], q2 = p[2];
-        if (x.ctr_xyz) {
-            const float* cp = x.ctr_xyz + (size_t)grp * 3;
-            q0 = __fsub_rn(q0, cp[0]); q1 = __fsub_rn(q1, cp[1]); q2 = __fsub_rn(q2, cp[2]);
+    if (XM == 0) {
+        const int cc = c < x.c_in ? c : x.c_in - 4;
+        o.a = ldg4(x.zin + (size_t)rr * x.zin_pitch + zoff + cc);
+        if (tail) {
+            float e = 0.f;
+            if (x.extra) e = x.extra[rr];
+            o.s.x = (c + 0 == x.c_in && x.extra) ? e : (c + 0 == x.ones_col ? 1.f : 0.f);
+            o.s.y = (c + 1 == x.c_in && x.extra) ? e : (c + 1 == x.ones_col ? 1.f : 0.f);
+            o.s.z = (c + 2 == x.c_in && x.extra) ? e : (c + 2 == x.ones_col ? 1.f : 0.f);
+            o.s.w = (c + 3 == x.c_in && x.extra) ? e : (c + 3 == x.ones_col ? 1.f : 0.f);
         }
-        float a[4] = {0.f, 0.f, 0.f, 0.f};
-        const int t0 = c - x.feat_c;                       // tail-relative index of this unit's first column
-        if (x.action) {
-            const float* ap = x.action + (size_t)(grp / x.gps) * x.act_c;
+    } else {
+        const int cc = c < x.feat_c ? c : x.feat_c - 4;
+        o.a = ldg4(x.feat + (size_t)pt * x.feat_c + cc);
+        if (tail) {
+            const int grp = x.row_grp[rr];
+            const float* p = x.src_xyz + (size_t)pt * 3;
+            float q0 = p[0], q1 = p[1], q2 = p[2];
+            if (x.ctr_xyz) {
+                const float* cp = x.ctr_xyz + (size_t)grp * 3;
+                q0 = __fsub_rn(q0, cp[0]); q1 = __fsub_rn(q1, cp[1]); q2 = __fsub_rn(q2, cp[2]);
+            }
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            const int t0 = c - x.feat_c;
+            if (x.action) {
+                const float* ap = x.action + (size_t)(grp / x.gps) * x.act_c;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int ai = t0 + j - 3;
+                    const int aic = ai < 0 ? 0 : (ai >= x.act_c ? x.act_c - 1 : ai);
+                    const float av = ap[aic];
+                    a[j] = (ai >= 0 && ai < x.act_c) ? av : 0.f;
+                }
+            }
+            float* spv = &o.s.x;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int ai = t0 + j - 3;
-                const int aic = ai < 0 ? 0 : (ai >= x.act_c ? x.act_c - 1 : ai);
-                const float av = ap[aic];
-                a[j] = (ai >= 0 && ai < x.act_c) ? av : 0.f;
+                const int t = t0 + j;
+                spv[j] = t == 0 ? q0 : (t == 1 ? q1 : (t == 2 ? q2 : a[j]));
             }
         }
-        float4 sp;
-        float* spv = &sp.x;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = t0 + j;
-            spv[j] = t == 0 ? q0 : (t == 1 ? q1 : (t == 2 ? q2 : a[j]));
-        }
-        v = f4sel(inside, v, sp);
     }
-    return f4sel(valid, v, f4zero());
+    return o;
+}
+
+// sv/tv: the layer-input BatchNorm scale/shift of this group's channels, staged in LDS
+template <int XM>
+__device__ __forceinline__ float4 x_finish(const XSrc& x, const XRaw& raw, bool valid, int c, const float* sv,
+                                           const float* tv) {
+    const int bulk = XM == 0 ? x.c_in : x.feat_c;
+    const bool inside = c < bulk;
+    float4 v = raw.a;
+    if (XM == 0) {
+        const int cc = inside ? c : x.c_in - 4;
+        if (x.scale) {
+            const float4 s = *reinterpret_cast<const float4*>(sv + cc), t = *reinterpret_cast<const float4*>(tv + cc);
+            v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
+        }
+        if (x.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    }
+    return f4sel(valid, f4sel(inside, v, raw.s), f4zero());
+}
+
+__device__ __forceinline__ void stage_vec(float* dst, const float* src, int off, int n, float fill) {
+    for (int i = threadIdx.x; i < n; i += 256) dst[i] = src ? src[off + i] : fill;
 }
 
 struct DzSrc {   // gad_dz_src on the device
@@ -130,77 +154,100 @@ static DzSrc make_dzsrc(const gad_dz_src& d) {
     return s;
 }
 
-// dZ[r][n..n+3] of a layer (VEC: all pitches / offsets multiples of 4, n+3 < nmax when n < nmax).
-//   dY = G (dense) or the pooled gradient routed through the arg-max; masked by the layer's ReLU;
-//   BatchNorm backward dZ = P*dY - w*(Q + S*z) when coefficients are given.
-template <bool VEC>
-__device__ __forceinline__ float4 dz_load4(const DzSrc& d, int r, bool valid, int off, int n, int nmax) {
-    if (VEC) {
-        const int rr = valid ? r : 0;
-        const bool inside = n < nmax;
-        const int ch = off + (inside ? n : 0);
-        float4 z = f4zero();
-        if (d.z) z = ldg4(d.z + (size_t)rr * d.z_pitch + ch);
-        float4 g;
+struct DzRaw { float4 z; float4 g; int4 a; };
+
+// scalar (unaligned) evaluation of dZ[r][n..n+3], used for the tiny last layers of the heads
+__device__ __forceinline__ float4 dz_scalar4(const DzSrc& d, int r, bool valid, int off, int n, int nmax) {
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nn = n + j;
+        const bool ok = valid && nn < nmax;
+        const int rr = ok ? r : 0;
+        const int ch = off + (ok ? nn : 0);
+        float z = 0.f;
+        if (d.z) z = d.z[(size_t)rr * d.z_pitch + ch];
+        float g;
         if (d.gmode == 0) {
-            g = ldg4(d.G + (size_t)rr * d.g_pitch + ch);
+            g = d.G[(size_t)rr * d.g_pitch + ch];
         } else {
             const int grp = d.row_grp[rr];
-            const int4 a = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * d.c + ch);
-            const float4 o = ldg4(d.dout + (size_t)grp * d.c + ch);
-            g = make_float4(a.x == r ? o.x : 0.f, a.y == r ? o.y : 0.f, a.z == r ? o.z : 0.f, a.w == r ? o.w : 0.f);
+            g = d.argmax[(size_t)grp * d.c + ch] == r ? d.dout[(size_t)grp * d.c + ch] : 0.f;
         }
         if (d.relu) {
-            float4 y = z;
-            if (d.scale) {
-                const float4 s = ldg4(d.scale + ch), t = ldg4(d.shift + ch);
-                y.x = fmaf(z.x, s.x, t.x); y.y = fmaf(z.y, s.y, t.y); y.z = fmaf(z.z, s.z, t.z); y.w = fmaf(z.w, s.w, t.w);
-            }
-            g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
-            g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+            const float y = d.scale ? fmaf(z, d.scale[ch], d.shift[ch]) : z;
+            g = y > 0.f ? g : 0.f;
         }
         if (d.P) {
-            float w = 1.f;
-            if (d.row_w) w = d.row_w[rr];
-            const float4 P = ldg4(d.P + ch), Q = ldg4(d.Q + ch), S = ldg4(d.S + ch);
-            g.x = P.x * g.x - w * fmaf(S.x, z.x, Q.x); g.y = P.y * g.y - w * fmaf(S.y, z.y, Q.y);
-            g.z = P.z * g.z - w * fmaf(S.z, z.z, Q.z); g.w = P.w * g.w - w * fmaf(S.w, z.w, Q.w);
+            const float w = d.row_w ? d.row_w[rr] : 1.f;
+            g = d.P[ch] * g - w * fmaf(d.S[ch], z, d.Q[ch]);
         }
-        return f4sel(valid && inside, g, f4zero());
-    } else {
-        float v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nn = n + j;
-            const bool ok = valid && nn < nmax;
-            const int rr = ok ? r : 0;
-            const int ch = off + (ok ? nn : 0);
-            float z = 0.f;
-            if (d.z) z = d.z[(size_t)rr * d.z_pitch + ch];
-            float g;
-            if (d.gmode == 0) {
-                g = d.G[(size_t)rr * d.g_pitch + ch];
-            } else {
-                const int grp = d.row_grp[rr];
-                g = d.argmax[(size_t)grp * d.c + ch] == r ? d.dout[(size_t)grp * d.c + ch] : 0.f;
-            }
-            if (d.relu) {
-                const float y = d.scale ? fmaf(z, d.scale[ch], d.shift[ch]) : z;
-                g = y > 0.f ? g : 0.f;
-            }
-            if (d.P) {
-                const float w = d.row_w ? d.row_w[rr] : 1.f;
-                g = d.P[ch] * g - w * fmaf(d.S[ch], z, d.Q[ch]);
-            }
-            v[j] = ok ? g : 0.f;
-        }
-        return make_float4(v[0], v[1], v[2], v[3]);
+        v[j] = ok ? g : 0.f;
     }
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// raw loads of dZ's ingredients for row r, channels off+n..+3 (VEC: everything 16-byte aligned)
+template <bool VEC>
+__device__ __forceinline__ DzRaw dz_raw(const DzSrc& d, int r, bool valid, int off, int n, int nmax, int grp) {
+    DzRaw o;
+    o.z = f4zero(); o.a = make_int4(0, 0, 0, 0);
+    if (!VEC) { o.g = dz_scalar4(d, r, valid, off, n, nmax); return o; }
+    const int rr = valid ? r : 0;
+    const int ch = off + (n < nmax ? n : 0);
+    if (d.z) o.z = ldg4(d.z + (size_t)rr * d.z_pitch + ch);
+    if (d.gmode == 0) {
+        o.g = ldg4(d.G + (size_t)rr * d.g_pitch + ch);
+    } else {
+        o.a = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * d.c + ch);
+        o.g = ldg4(d.dout + (size_t)grp * d.c + ch);
+    }
+    return o;
+}
+
+// vec: LDS copies of {scale, shift, P, Q, S} of this group's channels (VMAX floats each)
+template <bool VEC>
+__device__ __forceinline__ float4 dz_finish(const DzSrc& d, const DzRaw& raw, int r, bool valid, int n, int nmax, float w,
+                                            const float* vec) {
+    if (!VEC) return raw.g;
+    const bool inside = n < nmax;
+    const int nn = inside ? n : 0;
+    float4 g = raw.g;
+    const float4 z = raw.z;
+    if (d.gmode != 0) {
+        g.x = raw.a.x == r ? g.x : 0.f; g.y = raw.a.y == r ? g.y : 0.f;
+        g.z = raw.a.z == r ? g.z : 0.f; g.w = raw.a.w == r ? g.w : 0.f;
+    }
+    if (d.relu) {
+        float4 y = z;
+        if (d.scale) {
+            const float4 s = *reinterpret_cast<const float4*>(vec + nn), t = *reinterpret_cast<const float4*>(vec + VMAX + nn);
+            y.x = fmaf(z.x, s.x, t.x); y.y = fmaf(z.y, s.y, t.y); y.z = fmaf(z.z, s.z, t.z); y.w = fmaf(z.w, s.w, t.w);
+        }
+        g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
+        g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
+    }
+    if (d.P) {
+        const float4 P = *reinterpret_cast<const float4*>(vec + 2 * VMAX + nn);
+        const float4 Q = *reinterpret_cast<const float4*>(vec + 3 * VMAX + nn);
+        const float4 S = *reinterpret_cast<const float4*>(vec + 4 * VMAX + nn);
+        g.x = P.x * g.x - w * fmaf(S.x, z.x, Q.x); g.y = P.y * g.y - w * fmaf(S.y, z.y, Q.y);
+        g.z = P.z * g.z - w * fmaf(S.z, z.z, Q.z); g.w = P.w * g.w - w * fmaf(S.w, z.w, Q.w);
+    }
+    return f4sel(valid && inside, g, f4zero());
+}
+
+__device__ __forceinline__ void stage_dz_vecs(float* vec, const DzSrc& d, int off, int n) {
+    stage_vec(vec, d.scale, off, n, 1.f);
+    stage_vec(vec + VMAX, d.shift, off, n, 0.f);
+    stage_vec(vec + 2 * VMAX, d.P, off, n, 1.f);
+    stage_vec(vec + 3 * VMAX, d.Q, off, n, 0.f);
+    stage_vec(vec + 4 * VMAX, d.S, off, n, 0.f);
 }
 
 static bool dz_vectorizable(const gad_dz_src& d, const int32_t* off, const int32_t* n_out, int ng) {
     bool ok = (d.z == nullptr || d.z_pitch % 4 == 0) && (d.gmode != 0 || d.g_pitch % 4 == 0) && (d.gmode == 0 || d.c % 4 == 0);
-    for (int i = 0; i < ng; ++i) ok = ok && off[i] % 4 == 0 && n_out[i] % 4 == 0;
+    for (int i = 0; i < ng; ++i) ok = ok && off[i] % 4 == 0 && n_out[i] % 4 == 0 && n_out[i] <= VMAX;
     return ok;
 }
 
@@ -290,12 +337,16 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchT<BM>::v, PB = PitchT<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
-    constexpr int SM = KT * PA + KT * PB + BM;
-    static_assert(SM >= 2 * WM * BN, "reduction scratch must fit in the tile LDS");
+    constexpr int TILE = KT * PA + KT * PB;
+    constexpr int SM = ((TILE + 3) & ~3) + 2 * BM + 2 * VMAX;
+    static_assert(TILE >= 2 * WM * BN, "reduction scratch must fit in the tile LDS");
     __shared__ __attribute__((aligned(16))) float smem[SM];
     float* As = smem;
     float* Bs = smem + KT * PA;
-    float* wS = Bs + KT * PB;
+    float* wS = smem + ((TILE + 3) & ~3);
+    int32_t* ptS = reinterpret_cast<int32_t*>(wS + BM);
+    float* sv = wS + 2 * BM;
+    float* tv = sv + VMAX;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -305,7 +356,10 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
     const int n0 = blockIdx.y * BN;
     if (n0 >= n_out) return;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    if ((int)(blockIdx.x * BM) >= n_rows) return;          // idle block (grid sized for the worst case)
     const int nk = (Kp + KT - 1) / KT;
+    const int bulk = XM == 0 ? x.c_in : x.feat_c;
+    if (XM == 0 && x.scale) { stage_vec(sv, x.scale, zoff, x.c_in, 1.f); stage_vec(tv, x.shift, zoff, x.c_in, 0.f); }
 
     float csum[TN], csq[TN];
 #pragma unroll
@@ -319,37 +373,52 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+        if (tid < BM) {
+            const int r = row0 + tid;
+            wS[tid] = r < n_rows ? (row_w ? row_w[r] : 1.f) : 0.f;
+            if (XM == 1) ptS[tid] = r < n_rows ? x.row_pt[r] : 0;
+        }
+        __syncthreads();                                   // wS / ptS / sv / tv visible
 
-        float4 ra[UA], rb[UB];
+        XRaw ra[UA];
+        float4 rb[UB];
         auto load_tile = [&](int kt) {
             const int k0 = kt * KT;
-            const bool tail = XM == 1 && (k0 + KT > x.feat_c);
+            const bool tail = k0 + KT > bulk;
 #pragma unroll
             for (int it = 0; it < UA; ++it) {
                 int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
                 const int r = row0 + i;
                 const bool ok = r < n_rows && (k0 + kk < Kp);
-                ra[it] = XM == 0 ? x_act4(x, r, ok, zoff, k0 + kk) : x_gather4(x, r, ok, k0 + kk, tail);
+                ra[it] = x_raw<XM>(x, r, ok, zoff, k0 + kk, tail, XM == 1 ? ptS[i] : 0);
             }
 #pragma unroll
             for (int it = 0; it < UB; ++it) {
                 int j, kk; unit_T<BN>(it * 256 + tid, j, kk);
                 const int n = n0 + j;
                 const bool ok = n < n_out && (k0 + kk < Kp);
-                const float4 w = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k0 + kk : 0));
-                rb[it] = f4sel(ok, w, f4zero());
+                rb[it] = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k0 + kk : 0));
+            }
+        };
+        auto store_tile = [&](int kt) {
+            const int k0 = kt * KT;
+#pragma unroll
+            for (int it = 0; it < UA; ++it) {
+                int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
+                const int r = row0 + i;
+                const bool ok = r < n_rows && (k0 + kk < Kp);
+                store_T<BM>(As, i, kk, x_finish<XM>(x, ra[it], ok, k0 + kk, sv, tv));
+            }
+#pragma unroll
+            for (int it = 0; it < UB; ++it) {
+                int j, kk; unit_T<BN>(it * 256 + tid, j, kk);
+                const bool ok = (n0 + j) < n_out && (k0 + kk < Kp);
+                store_T<BN>(Bs, j, kk, f4sel(ok, rb[it], f4zero()));
             }
         };
         load_tile(0);
-        if (tid < BM) {
-            const int r = row0 + tid;
-            wS[tid] = r < n_rows ? (row_w ? row_w[r] : 1.f) : 0.f;
-        }
         for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-            for (int it = 0; it < UA; ++it) { int i, kk; unit_T<BM>(it * 256 + tid, i, kk); store_T<BM>(As, i, kk, ra[it]); }
-#pragma unroll
-            for (int it = 0; it < UB; ++it) { int j, kk; unit_T<BN>(it * 256 + tid, j, kk); store_T<BN>(Bs, j, kk, rb[it]); }
+            store_tile(kt);
             __syncthreads();
             if (kt + 1 < nk) load_tile(kt + 1);
             mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
@@ -375,9 +444,9 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             csum[tn] += s1;
             csq[tn] += s2;
         }
-        __syncthreads();   // wS reuse
+        __syncthreads();   // wS / ptS reuse
     }
-    if (stat_sum && (int)(blockIdx.x * BM) < n_rows) {          // block-uniform: idle blocks add nothing
+    if (stat_sum) {
         const int rep = blockIdx.x % GAD_STAT_REPLICAS;
         block_column_atomics<WM, WN, TN>(smem, csum, csq, lane, wm, wn, n0, n_out,
                                          stat_sum + (size_t)rep * stat_stride + ooff,
@@ -399,8 +468,8 @@ static int max_nout(const Groups& g) { int m = 0; for (int i = 0; i < g.n; ++i) 
 
 static int check_input(const gad_gemm_fwd_args& a, const char* who) {
     if (a.mode == 0) {
-        GAD_REQUIRE(a.zin && a.c_in % 4 == 0 && a.c_in >= 4 && a.zin_pitch % 4 == 0, GAD_ERR_SHAPE,
-                    "%s: ACT input needs c_in >= 4, c_in and pitch multiples of 4", who);
+        GAD_REQUIRE(a.zin && a.c_in % 4 == 0 && a.c_in >= 4 && a.c_in <= VMAX && a.zin_pitch % 4 == 0, GAD_ERR_SHAPE,
+                    "%s: ACT input needs 4 <= c_in <= %d, c_in and pitch multiples of 4", who, VMAX);
         for (int i = 0; i < a.n_groups; ++i)
             GAD_REQUIRE(a.zin_off[i] % 4 == 0, GAD_ERR_SHAPE, "%s: zin_off must be a multiple of 4", who);
     } else {
@@ -461,13 +530,17 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchT<BM>::v, PB = PitchD<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
-    constexpr int SM = ((KT * PA + 3) & ~3) + KT * PB + 2 * BM;
-    static_assert(SM >= 2 * WM * BN, "reduction scratch must fit in the tile LDS");
+    constexpr int OFFB = (KT * PA + 3) & ~3;
+    constexpr int TILE = OFFB + KT * PB;
+    constexpr int SM = TILE + 3 * BM + (VEC ? 5 * VMAX : 4);
+    static_assert(TILE >= 2 * WM * BN, "reduction scratch must fit in the tile LDS");
     __shared__ __attribute__((aligned(16))) float smem[SM];
     float* As = smem;
-    float* Bs = smem + ((KT * PA + 3) & ~3);
-    int32_t* ptS = reinterpret_cast<int32_t*>(Bs + KT * PB);
+    float* Bs = smem + OFFB;
+    int32_t* ptS = reinterpret_cast<int32_t*>(smem + TILE);
     int32_t* grS = ptS + BM;
+    float* wS = reinterpret_cast<float*>(grS + BM);
+    float* vec = wS + BM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -477,7 +550,10 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
     const int k0out = blockIdx.y * BN;
     if (k0out >= e.k_valid) return;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    if ((int)(blockIdx.x * BM) >= n_rows) return;
     const int nk = gad_cdiv_dev(n_out, KT);
+    if (VEC) stage_dz_vecs(vec, d, doff, n_out);
+    const bool need_grp = e.mode == 1 || d.gmode != 0;
 
     float cb[TN], cg[TN];
 #pragma unroll
@@ -491,35 +567,51 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
             for (int b = 0; b < TN; ++b)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
-        float4 ra[UA], rb[UB];
+        if (tid < BM) {
+            const int r = row0 + tid;
+            const bool ok = r < n_rows;
+            wS[tid] = (ok && d.row_w) ? d.row_w[r] : 1.f;
+            if (e.mode == 1) ptS[tid] = ok ? e.row_pt[r] : 0;
+            if (need_grp) grS[tid] = ok ? (e.mode == 1 ? e.row_grp[r] : d.row_grp[r]) : 0;
+        }
+        __syncthreads();
+
+        DzRaw ra[UA];
+        float4 rb[UB];
         auto load_tile = [&](int kt) {
             const int nb = kt * KT;
 #pragma unroll
             for (int it = 0; it < UA; ++it) {
                 int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
                 const int r = row0 + i;
-                ra[it] = dz_load4<VEC>(d, r, r < n_rows, doff, nb + kk, n_out);
+                ra[it] = dz_raw<VEC>(d, r, r < n_rows, doff, nb + kk, n_out, need_grp ? grS[i] : 0);
             }
 #pragma unroll
             for (int it = 0; it < UB; ++it) {
                 int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
                 const int n = nb + kk, k = k0out + j;
                 const bool ok = n < n_out && k < Kp;
-                const float4 w = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k : 0));
-                rb[it] = f4sel(ok, w, f4zero());
+                rb[it] = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k : 0));
+            }
+        };
+        auto store_tile = [&](int kt) {
+            const int nb = kt * KT;
+#pragma unroll
+            for (int it = 0; it < UA; ++it) {
+                int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
+                const int r = row0 + i;
+                store_T<BM>(As, i, kk, dz_finish<VEC>(d, ra[it], r, r < n_rows, nb + kk, n_out, wS[i], vec));
+            }
+#pragma unroll
+            for (int it = 0; it < UB; ++it) {
+                int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
+                const bool ok = (nb + kk) < n_out && (k0out + j) < Kp;
+                store_D<BN>(Bs, kk, j, f4sel(ok, rb[it], f4zero()));
             }
         };
         load_tile(0);
-        if (e.mode == 1 && tid < BM) {
-            const int r = row0 + tid;
-            ptS[tid] = r < n_rows ? e.row_pt[r] : 0;
-            grS[tid] = r < n_rows ? e.row_grp[r] : 0;
-        }
         for (int kt = 0; kt < nk; ++kt) {
-#pragma unroll
-            for (int it = 0; it < UA; ++it) { int i, kk; unit_T<BM>(it * 256 + tid, i, kk); store_T<BM>(As, i, kk, ra[it]); }
-#pragma unroll
-            for (int it = 0; it < UB; ++it) { int kk, j; unit_D<BN>(it * 256 + tid, kk, j); store_D<BN>(Bs, kk, j, rb[it]); }
+            store_tile(kt);
             __syncthreads();
             if (kt + 1 < nk) load_tile(kt + 1);
             mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
@@ -562,7 +654,7 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
         }
         __syncthreads();
     }
-    if (e.dbeta && (int)(blockIdx.x * BM) < n_rows) {
+    if (e.dbeta) {
         const int rep = blockIdx.x % GAD_STAT_REPLICAS;
         block_column_atomics<WM, WN, TN>(smem, cb, cg, lane, wm, wn, k0out, e.k_valid,
                                          e.dbeta + (size_t)rep * e.stat_stride + goff,
@@ -616,9 +708,9 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward wrt the weights:  gacc[n][k] = sum_r dZ[r][n] * X[r][k]
+// backward wrt the weights:  gacc[n][k] += sum_r dZ[r][n] * X[r][k]
 // split over rows: every (tile, split) block writes its partial tile to the caller's workspace, a
-// second kernel sums the splits in f64 (deterministic).  Without a workspace: f64 atomics.
+// second kernel sums the splits in f64.  Without a workspace: f64 atomics.
 // ------------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, int XM, bool VEC>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr,
@@ -628,9 +720,14 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchD<BM>::v, PB = PitchD<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
-    __shared__ __attribute__((aligned(16))) float smem[KT * PA + KT * PB];
+    constexpr int TILE = KT * PA + KT * PB;
+    constexpr int SM = TILE + (VEC ? 5 * VMAX : 4) + 2 * VMAX;
+    __shared__ __attribute__((aligned(16))) float smem[SM];
     float* As = smem;
     float* Bs = smem + KT * PA;
+    float* vec = smem + TILE;
+    float* sv = vec + (VEC ? 5 * VMAX : 4);
+    float* tv = sv + VMAX;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -645,6 +742,9 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     const int r_begin = blockIdx.y * chunk;
     const int r_end = min(r_begin + chunk, n_rows);
     if (r_begin >= r_end) return;     // the reducer skips the same splits (same chunk arithmetic)
+    if (VEC) stage_dz_vecs(vec, d, doff, n_out);
+    if (XM == 0 && x.scale) { stage_vec(sv, x.scale, zoff, x.c_in, 1.f); stage_vec(tv, x.shift, zoff, x.c_in, 0.f); }
+    __syncthreads();
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -653,29 +753,51 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
-    float4 ra[UA], rb[UB];
-    const bool tail = XM == 1 && (k0 + BN > x.feat_c);
+    DzRaw ra[UA];
+    float wa[UA];
+    XRaw rb[UB];
+    const int bulk = XM == 0 ? x.c_in : x.feat_c;
+    const bool tail = k0 + BN > bulk;
     auto load_tile = [&](int rb0) {
 #pragma unroll
         for (int it = 0; it < UA; ++it) {
             int kk, i; unit_D<BM>(it * 256 + tid, kk, i);
             const int r = rb0 + kk;
-            ra[it] = dz_load4<VEC>(d, r, r < r_end, doff, n0 + i, n_out);
+            const bool ok = r < r_end;
+            const int rr = ok ? r : 0;
+            int grp = 0;
+            if (d.gmode != 0) grp = d.row_grp[rr];
+            wa[it] = d.row_w ? d.row_w[rr] : 1.f;
+            ra[it] = dz_raw<VEC>(d, r, ok, doff, n0 + i, n_out, grp);
         }
 #pragma unroll
         for (int it = 0; it < UB; ++it) {
             int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
             const int r = rb0 + kk;
             const bool ok = r < r_end && (k0 + j < Kp);
-            rb[it] = XM == 0 ? x_act4(x, r, ok, zoff, k0 + j) : x_gather4(x, r, ok, k0 + j, tail);
+            int pt = 0;
+            if (XM == 1) pt = x.row_pt[ok ? r : 0];
+            rb[it] = x_raw<XM>(x, r, ok, zoff, k0 + j, tail, pt);
+        }
+    };
+    auto store_tile = [&](int rb0) {
+#pragma unroll
+        for (int it = 0; it < UA; ++it) {
+            int kk, i; unit_D<BM>(it * 256 + tid, kk, i);
+            const int r = rb0 + kk;
+            store_D<BM>(As, kk, i, dz_finish<VEC>(d, ra[it], r, r < r_end, n0 + i, n_out, wa[it], vec));
+        }
+#pragma unroll
+        for (int it = 0; it < UB; ++it) {
+            int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
+            const int r = rb0 + kk;
+            const bool ok = r < r_end && (k0 + j < Kp);
+            store_D<BN>(Bs, kk, j, x_finish<XM>(x, rb[it], ok, k0 + j, sv, tv));
         }
     };
     load_tile(r_begin);
     for (int rb0 = r_begin; rb0 < r_end; rb0 += KT) {
-#pragma unroll
-        for (int it = 0; it < UA; ++it) { int kk, i; unit_D<BM>(it * 256 + tid, kk, i); store_D<BM>(As, kk, i, ra[it]); }
-#pragma unroll
-        for (int it = 0; it < UB; ++it) { int kk, j; unit_D<BN>(it * 256 + tid, kk, j); store_D<BN>(Bs, kk, j, rb[it]); }
+        store_tile(rb0);
         __syncthreads();
         if (rb0 + KT < r_end) load_tile(rb0 + KT);
         mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
