@@ -18,7 +18,7 @@ def assert_close(a, b, rtol, atol, what=""):
                                                    tol.ravel()[i], err.max()))
 
 
-def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise=False):
+def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise=False, l2_rtol=2e-2):
     """Compare tensors against fingerprints written by oracle.detfill.summarize_named.
     The tolerance on the aggregate stats is scaled by the tensor's abs-sum / l2.
     normwise=True: entries are compared with tolerance rtol * max|tensor| (+atol) instead of
@@ -42,7 +42,7 @@ def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise
             err = np.abs(np.asarray(vals, np.float64) - g_vals)
             assert np.median(err) <= atol + rtol * scale, "%s: median err %.3g > %.3g" % (kv, np.median(err), rtol * scale)
             assert err.max() <= atol + 5e-2 * scale, "%s: max err %.3g (scale %.3g)" % (kv, err.max(), scale)
-            assert abs(stats[2] - g_stats[2]) <= 2e-2 * g_stats[2] + atol, ks + " l2"
+            assert abs(stats[2] - g_stats[2]) <= l2_rtol * g_stats[2] + atol, ks + " l2"
             n += 1
             continue
         else:
