@@ -57,14 +57,21 @@ def _check_step(agent, nets, g, p, kind, s, tight):
     torch.cuda.synchronize()
     rt, at = (1e-4, 4e-6) if tight else (5e-2, 3e-4)
     assert set(ret.keys()) == set(k[len(p + "ret/"):] for k in g.files if k.startswith(p + "ret/"))
-    assert_close(agent.pi.cpu().numpy(), g[p + "t/pi"], rt, at, p + "pi")
-    assert_close(agent.aux_pred.cpu().numpy(), g[p + "t/aux_pred"], rt, 10 * at, p + "aux_pred")
+    def nclose(a, b, what, extra=1.0):
+        # tight steps: entry-wise rt + at; follow-up steps (after an Adam step the float32 trajectories of ANY two
+        # implementations separate: torch-f32 vs torch-f64 differ by 1.25e-2 in pi at BC step 1): norm-wise
+        if tight:
+            assert_close(a, b, rt, extra * at, what)
+        else:
+            assert_close(a, b, 0.0, rt * np.abs(b).max() + at, what)
+    nclose(agent.pi.cpu().numpy(), g[p + "t/pi"], p + "pi")
+    nclose(agent.aux_pred.cpu().numpy(), g[p + "t/aux_pred"], p + "aux_pred", 10)
     if kind == "ddpg":
-        assert_close(agent.qf1.cpu().numpy(), g[p + "t/qf1"], rt, 10 * at, p + "qf1")
-        assert_close(agent.qf2.cpu().numpy(), g[p + "t/qf2"], rt, 10 * at, p + "qf2")
+        nclose(agent.qf1.cpu().numpy(), g[p + "t/qf1"], p + "qf1", 10)
+        nclose(agent.qf2.cpu().numpy(), g[p + "t/qf2"], p + "qf2", 10)
         yref = g[p + "t/next_q_value"]
         assert_close(agent.next_q_value.cpu().numpy(), yref, 0.0, (1e-4 if tight else 3e-3) * np.abs(yref).max() + 2e-5, p + "y")
-        assert_close(agent.critic_grasp_aux.cpu().numpy(), g[p + "t/critic_grasp_aux"], rt, 10 * at, p + "caux")
+        nclose(agent.critic_grasp_aux.cpu().numpy(), g[p + "t/critic_grasp_aux"], p + "caux", 10)
     for k, v in ret.items():
         tol = rt if "loss" in k else 5 * rt
         assert_close(v, g[p + "ret/" + k], tol, 1e-6, p + k)
@@ -87,8 +94,8 @@ def _check_step(agent, nets, g, p, kind, s, tight):
         sd = [(n, t) for n, t in net.state_dict().items() if "num_batches" not in n and not any(x in n for x in SKIP)]
         _check_params_after_adam(g, p + "end/param/" + name + "/", [(n, t) for n, t in sd if "running" not in n], 1e-3)
         running = [(n, t) for n, t in sd if "running" in n]
-        if running:
-            check_summaries(g, p + "end/param/" + name + "/", running, rt, 10 * at)
+        if running:     # policy steps re-run the value encoder after its Adam step -> looser
+            check_summaries(g, p + "end/param/" + name + "/", running, 2e-3 if (policy_step or not tight) else rt, 10 * at)
     if kind == "ddpg":
         lr = agent.get_lr()
         assert_close([lr["policy_lr"], lr["feature_lr"], lr["value_lr"]], g[p + "lr"], 1e-7, 0, p + "lr")
