@@ -500,7 +500,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
                            a->stat_sum, a->stat_sq, a->stat_stride);                                       \
     } while (0)
 #define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0); else LAUNCH_FWD2(WM, WN, TM, TN, 1); } while (0)
-    if (rows <= 1024) {
+    if (rows <= 16384) {
         if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);     // many small tiles: fill the CUs
     } else if (nmax <= 64) {
         LAUNCH_FWD(4, 1, 1, 2);                                                   // 128 x 64
@@ -692,7 +692,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
                            st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                              \
     } while (0)
 #define LAUNCH_DX(WM, WN, TM, TN) do { if (vec) LAUNCH_DX2(WM, WN, TM, TN, true); else LAUNCH_DX2(WM, WN, TM, TN, false); } while (0)
-    if (rows <= 1024) {
+    if (rows <= 16384) {
         if (kv <= 32) LAUNCH_DX(4, 1, 1, 1); else LAUNCH_DX(2, 2, 1, 1);
     } else if (kv <= 32) {
         LAUNCH_DX(4, 1, 1, 1);
