@@ -62,23 +62,28 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, batch, noise):
-    """One B=256 DDPG step of the CPU oracle ('port' of the reference step) on the host cores."""
+def cpu_baseline(cfg, batch, noise, rows=64):
+    """Bounded sample of the same workload on the host cores: ONE DDPG step of the CPU oracle (a port of the
+    reference step; the reference itself cannot travel) on the first `rows` rows of a bench minibatch, scaled
+    to B=256-step units (the step is linear in rows).  Threads capped at 64: torch's CPU kernels get slower
+    beyond that on this many-core host (256 threads: 185 s for a B=256 step)."""
     from ga_ddpg_amd.experiments.config import load_cfg
     from oracle import ref_step
-    cores = os.cpu_count()
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     torch.manual_seed(1234)
     oracle = ref_step.OracleAgent(load_cfg("ddpg_td3_aux.yaml").RL_TRAIN)
-    small = {k: (v[:8] if hasattr(v, "shape") and v.ndim > 0 and v.shape[0] == len(batch["reward_batch"]) else v)
-             for k, v in batch.items()}
-    oracle.update_parameters(small, noise_u=noise[:8])                 # page-in / warm-up on 8 rows
+    B = len(batch["reward_batch"])
+
+    def head(n):
+        return {k: (v[:n] if hasattr(v, "shape") and v.ndim > 0 and v.shape[0] == B else v) for k, v in batch.items()}
+    oracle.update_parameters(head(8), noise_u=noise[:8])                 # page-in / warm-up on 8 rows
     t0 = time.time()
-    oracle.update_parameters(batch, noise_u=noise)
+    oracle.update_parameters(head(rows), noise_u=noise[:rows])
     dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "1 DDPG update step (non-policy step) at B=%d, N=1024 after an 8-row warm-up; %.1f s"
-                      % (len(batch["reward_batch"]), dt)}
+    return {"value": (rows / float(B)) / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "1 DDPG update step of the CPU oracle on %d of the %d rows (N=1024), %.1f s, scaled by %d/%d"
+                      % (rows, B, dt, rows, B)}
 
 
 def main():
