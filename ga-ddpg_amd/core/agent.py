@@ -90,6 +90,26 @@ class Agent(object):
     def update_parameters(self, batch_data, updates, k):
         return {}
 
+    @torch.no_grad()
+    def select_action(self, state, actions=None, goal_state=None, vis=False, remain_timestep=0, grasp_set=None,
+                      gt_goal_rollout=False, repeat=False):
+        """Rollout-side inference (reference core/agent.py:82-125): eval-mode BatchNorm (running statistics),
+        batch of one.  Returns (action = squashed mean, log-prob placeholder 0.0, action sample, aux pose).
+        The reparameterised draw of the reference is not evaluated: `action sample` is the mean."""
+        from ..runtime import feature_forward, policy_forward
+        self.state_feature_extractor.eval()
+        self.policy.eval()
+        pc = torch.as_tensor(np.asarray(state[0][0], dtype=np.float32)[None]).cuda()
+        z = feature_forward(self.state_feature_extractor.module, pc, value=False)
+        feat = torch.cat((z, torch.full((1, 1), float(remain_timestep), device=z.device)), dim=1)
+        pi, aux = policy_forward(self.policy, feat)
+        action = pi[0].cpu().numpy()
+        if self.policy_aux:
+            aux_pred = aux[0].cpu().numpy()
+        else:
+            aux_pred = np.asarray(goal_state, dtype=np.float32).reshape(-1) if goal_state is not None else None
+        return action, 0.0, action.copy(), aux_pred
+
     def _result(self, s, has_critic):
         """map the runtime's scalar block to the reference's 11-key dict (core/utils.py:1008-1020)"""
         out = {k: 0.0 for k in self.loss_info}

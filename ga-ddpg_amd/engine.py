@@ -386,6 +386,10 @@ def _bn_vec(slot, enc, m, which):
 
 def _finalize(plan, enc, slot, m, count, train=True):
     o, tot = enc.bn_off[m.bn_index], slot.tot
+    if not train:        # eval mode: affine from the running statistics (torch BatchNorm eval semantics)
+        plan.call("gad_bn_eval_affine", enc.flat.p_gamma(m), enc.flat.p_beta(m), _ptr(enc.running_mean, o),
+                  _ptr(enc.running_var, o), m.n_out, BN_EPS, _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "shift"))
+        return
     plan.call("gad_bn_finalize", _ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), 2 * tot, enc.flat.p_gamma(m),
               enc.flat.p_beta(m), m.n_out, hip.Dbl(count), BN_EPS, BN_MOMENTUM,
               _ptr(enc.running_mean, o) if train else None, _ptr(enc.running_var, o) if train else None,

@@ -287,10 +287,10 @@ class FusedRuntime(object):
 
 
 # ----------------------------------------------------------------------------------------------
-# module-level forward helpers (inference / feature extraction through the same kernels)
+# module-level forward helpers (inference / feature extraction through the same kernels, no autograd)
 # ----------------------------------------------------------------------------------------------
 def _module_runtime(mod, key, builder):
-    rt = getattr(mod, "_gad_rt", None)
+    rt = mod.__dict__.get("_gad_rt")
     if rt is None:
         rt = {}
         object.__setattr__(mod, "_gad_rt", rt)
@@ -299,35 +299,39 @@ def _module_runtime(mod, key, builder):
     return rt[key]
 
 
+def _encoder_nets(fe, dev):
+    """EncoderNet views of a PointNetFeature's two encoders (shared with the agent's fused runtime if
+    the parameters were already re-homed into flat buffers)."""
+    def build():
+        return {False: engine.EncoderNet(fe.encoder, dev), True: engine.EncoderNet(fe.value_encoder, dev)}
+    return _module_runtime(fe, "nets", build)
+
+
 def feature_forward(fe, pc, value=False):
-    """PointNetFeature.forward: pc (B,C,NP) -> z (B,512); train-mode BatchNorm when fe.training."""
+    """PointNetFeature.forward: pc (B,C,NP) -> z (B,512).  BatchNorm uses batch statistics (and updates the
+    running ones) when fe.training, the running statistics otherwise -- as torch modules do."""
     hip.require_cuda(pc)
     B, C, NP = pc.shape
     dev = pc.device
     N = NP - 6 if NP != 1024 else NP
-
-    def build():
-        encs = {False: engine.EncoderNet(fe.encoder, dev), True: engine.EncoderNet(fe.value_encoder, dev)}
-        return dict(encs=encs)
-    base = _module_runtime(fe, "nets", build)
+    encs = _encoder_nets(fe, dev)
 
     def build_b():
         geo = engine.Geometry(B, N, engine.SAConfig(fe.pointnet_nclusters, fe.pointnet_radius, 64),
                               engine.SAConfig(32, 0.04, 128), dev)
-        slot = engine.EncoderSlot(geo, base["encs"][False], dev, with_backward=False)
-        return dict(geo=geo, slot=slot, action=torch.zeros(B, 6, device=dev), out=torch.empty(B, 512, device=dev))
+        slot = engine.EncoderSlot(geo, encs[False], dev, with_backward=False)
+        act = torch.zeros(B, 6, device=dev)
+        plans = {(v, t): engine.plan_encoder_forward(encs[v], slot, action=act if v else None, train=t)
+                 for v in (False, True) for t in (False, True)}
+        return dict(geo=geo, slot=slot, action=act, out=torch.empty(B, 512, device=dev), plans=plans)
     rt = _module_runtime(fe, ("shape", B, NP), build_b)
-    enc = base["encs"][bool(value)]
-    if not fe.training:
-        raise NotImplementedError("eval-mode (running-statistics) encoder forward is SURVEY 8f N3 (select_action)")
-    ps = pc[:, :4].contiguous()
-    rt["geo"].run(ps)
-    action = None
+    enc = encs[bool(value)]
+    rt["geo"].run(pc[:, :4].contiguous())
     if value:
         rt["action"].copy_(pc[:, 4:10, 0])
-        action = rt["action"]
-    engine.plan_encoder_forward(enc, rt["slot"], action=action, train=True).run()
-    enc.bump_batches_tracked(1)
+    rt["plans"][(bool(value), bool(fe.training))].run()
+    if fe.training:
+        enc.bump_batches_tracked(1)
     fc2 = enc.fc_mats[1]
     o = enc.bn_off[fc2.bn_index]
     slot = rt["slot"]
@@ -336,9 +340,81 @@ def feature_forward(fe, pc, value=False):
     return rt["out"].clone()
 
 
+class _FeatureSource(object):
+    """Stands in for an (encoder, slot) pair when a head is evaluated on a plain feature tensor: identity
+    'BatchNorm' (scale 1, shift 0) over a raw buffer that already holds the post-ReLU features."""
+
+    def __init__(self, B, dev):
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.B, self.tot = B, 512
+        self.Zfc = [None, torch.zeros(B, 512, **f32)]
+        self.scale, self.shift = torch.ones(512, **f32), torch.zeros(512, **f32)
+        self.mean, self.istd = torch.zeros(512, **f32), torch.ones(512, **f32)
+        self.bstats = torch.zeros(hip.STAT_REPLICAS * 2 * 512, dtype=torch.float64, device=dev)
+        self.time = torch.zeros(B, **f32)
+
+        class _M(object):
+            n_out, bn_index = 512, 0
+        self.fc_mats = [None, _M()]
+        self.bn_off = [0]
+
+    def load(self, state):
+        """state (B,513) = [feature (512, >= 0), remaining time]"""
+        self.Zfc[1].copy_(state[:, :512])
+        self.time.copy_(state[:, 512])
+
+
+def _head_runtime(module, kind, state):
+    hip.require_cuda(state)
+    B, dev = state.shape[0], state.device
+    if state.shape[1] != 513:
+        raise RuntimeError("heads take (B,513) = [512-d feature, remaining time]")
+
+    def build_net():
+        return heads.CriticNet(module, dev) if kind == "critic" else heads.PolicyNet(module, dev)
+    net = _module_runtime(module, "net", build_net)
+
+    def build_b():
+        src = _FeatureSource(B, dev)
+        if kind == "critic":
+            hs = heads.HeadSlot(B, net.width, 9, dev)
+            plan = heads.plan_critic_forward(net, hs, src, src, src.time)
+        else:
+            hs = heads.HeadSlot(B, net.hidden, net.n_heads, dev)
+            plan = heads.plan_policy_forward(net, hs, src, src, src.time)
+        return dict(src=src, hs=hs, plan=plan)
+    rt = _module_runtime(module, ("B", B), build_b)
+    rt["src"].load(state)
+    rt["plan"].run()
+    return net, rt
+
+
 def critic_forward(module, state):
-    raise NotImplementedError("stand-alone QNetwork.forward: use Agent.update_parameters (fused path)")
+    """QNetwork.forward(state) -> (q1 (B,1), q2 (B,1), aux (B,7) with a unit quaternion | None)"""
+    net, rt = _head_runtime(module, "critic", state)
+    out = rt["hs"].out
+    B = out.shape[0]
+    aux = None
+    if net.aux:
+        aux = torch.empty(B, 7, device=out.device)
+        z = torch.zeros(B, device=out.device)
+        goal = torch.zeros(B, 7, device=out.device)
+        hip.call("gad_critic_loss", out, out, z, z, z, z, goal, B, 0.0, 0, None, torch.empty(B, device=out.device), aux,
+                 torch.empty(B, 9, device=out.device), torch.empty(4, device=out.device))
+    return out[:, 0:1].clone(), out[:, 1:2].clone(), aux
 
 
 def policy_forward(module, state):
-    raise NotImplementedError("stand-alone GaussianPolicy.sample: use Agent.update_parameters / select_action")
+    """GaussianPolicy: squashed mean action (B,6) and the aux head (B,7 unit-quaternion pose, or raw)."""
+    net, rt = _head_runtime(module, "policy", state)
+    out = rt["hs"].out
+    B, dev = out.shape[0], out.device
+    pi = torch.empty(B, 6, device=dev)
+    scale = torch.as_tensor(np.asarray(module.action_scale, dtype=np.float32)).to(dev)
+    if net.extra_dim == 7:
+        aux = torch.empty(B, 7, device=dev)
+        hip.call("gad_policy_outputs", out, B, scale, pi, aux)
+    else:
+        hip.call("gad_policy_outputs", out, B, scale, pi, None)
+        aux = out[:, 6:6 + net.extra_dim].clone()
+    return pi, aux

@@ -1,0 +1,102 @@
+"""Module-level API (the reference's nn.Module surface evaluated through libgaddpg, forward only) against the
+CPU oracle: PointnetSAModule, PointNetFeature (train + eval BatchNorm), QNetwork, GaussianPolicy, select_action."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+SEED = 99
+
+
+def _copy_params(dst, src):
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    dst.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("group_all", [False, True])
+def test_sa_module_forward_matches_oracle(group_all):
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    from oracle.pointnet2_ops import pointnet2_modules as opm
+    from oracle.detfill import fill_module_
+    rng = np.random.default_rng(0)
+    B, N, C = 3, 512, 8
+    kw = dict(mlp=[C, 32, 32, 64]) if group_all else dict(npoint=16, radius=0.08, nsample=32, mlp=[C, 32, 32, 64])
+    ref = fill_module_(opm.PointnetSAModule(**kw), "sa", SEED).train()
+    mine = fill_module_(pm.PointnetSAModule(**kw), "sa", SEED).train()
+    xyz = torch.tensor(rng.random((B, N, 3)) * 0.3 + 0.2, dtype=torch.float32)
+    feats = torch.tensor(rng.normal(size=(B, C, N)), dtype=torch.float32)
+    with torch.no_grad():
+        w_xyz, w_out = ref(xyz, feats)
+        g_xyz, g_out = mine(xyz.cuda(), feats.cuda())
+    if group_all:
+        assert g_xyz is None and w_xyz is None
+    else:
+        np.testing.assert_array_equal(g_xyz.cpu().numpy(), w_xyz.numpy())
+    assert_close(g_out.cpu().numpy(), w_out.numpy(), 1e-4, 2e-5, "SA output")
+    for (n, a), (_, b) in zip(mine.state_dict().items(), ref.state_dict().items()):
+        if "running" in n:
+            assert_close(a.cpu().numpy(), b.numpy(), 1e-4, 1e-6, n)
+    # eval mode uses the running statistics
+    ref.eval(); mine.eval()
+    with torch.no_grad():
+        _, w2 = ref(xyz, feats)
+        _, g2 = mine(xyz.cuda(), feats.cuda())
+    assert_close(g2.cpu().numpy(), w2.numpy(), 1e-4, 2e-5, "SA output (eval)")
+
+
+def test_feature_heads_and_select_action():
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    agent, cfg = make_agent("ddpg_td3_aux.yaml")
+    oracle = ref_step.OracleAgent(load_cfg("ddpg_td3_aux.yaml").RL_TRAIN)
+    nets = {"policy": agent.policy, "policy_target": agent.policy_target, "critic": agent.critic,
+            "critic_target": agent.critic_target, "state_feature_extractor": agent.state_feature_extractor}
+    for name, net in nets.items():
+        fill_module_(net, name, SEED)
+    for name, net in oracle.nets().items():
+        fill_module_(net, name, SEED)
+    mem = BaseMemory(600, cfg, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 600, seed=4)
+    batch = sample_valid_batch(mem, 16, np.random.default_rng(2))
+    pc = torch.tensor(batch["point_state_batch"])
+    fe, ofe = agent.state_feature_extractor, oracle.state_feature_extractor
+    # train-mode feature extraction (policy encoder), then eval-mode with the updated running statistics
+    fe.train(); ofe.train()
+    with torch.no_grad():
+        z, _ = fe(pc.cuda(), feature_2=False)
+        wz = ofe(pc, value=False)
+    assert_close(z.cpu().numpy(), wz.numpy(), 1e-4, 2e-5, "train-mode feature")
+    fe.eval(); ofe.eval()
+    with torch.no_grad():
+        z2, _ = fe(pc.cuda(), feature_2=False)
+        wz2 = ofe(pc, value=False)
+    assert_close(z2.cpu().numpy(), wz2.numpy(), 1e-4, 2e-5, "eval-mode feature")
+    # heads on a plain (B,513) tensor
+    state = torch.cat([wz2, torch.tensor(batch["time_batch"])[:, None]], 1)
+    with torch.no_grad():
+        q1, q2, aux = agent.critic(state.cuda())
+        wq1, wq2, waux = oracle.critic(state)
+        pi, _, _, paux = agent.policy.sample(state.cuda())
+        wpi, wpaux = oracle.policy(state)
+    assert_close(q1.cpu().numpy(), wq1.numpy(), 1e-4, 2e-5, "q1")
+    assert_close(q2.cpu().numpy(), wq2.numpy(), 1e-4, 2e-5, "q2")
+    assert_close(aux.cpu().numpy(), waux.numpy(), 1e-4, 2e-5, "critic aux")
+    assert_close(pi.cpu().numpy(), wpi.numpy(), 1e-4, 2e-6, "pi")
+    assert_close(paux.cpu().numpy(), wpaux.numpy(), 1e-4, 2e-5, "policy aux")
+    # select_action: one cloud, eval mode
+    one = batch["point_state_batch"][3]
+    action, _, sample, aux_pred = agent.select_action([[one, None]], remain_timestep=7)
+    with torch.no_grad():
+        wz1 = ofe(torch.tensor(one[None]), value=False)
+        wa, wx = oracle.policy(torch.cat([wz1, torch.tensor([[7.0]])], 1))
+    assert_close(action, wa[0].numpy(), 1e-4, 2e-6, "select_action")
+    assert_close(aux_pred, wx[0].numpy(), 1e-4, 2e-5, "select_action aux")
+    # the agent still trains after these inference calls (parameters were re-homed once)
+    out = agent.update_parameters(batch, agent.update_step, 0)
+    assert np.isfinite(list(out.values())).all()
