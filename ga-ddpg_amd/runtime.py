@@ -24,13 +24,14 @@ class FusedRuntime(object):
         self.has_critic = agent.has_critic
         fe = agent.state_feature_extractor.module
         self.N = NP - 6 if NP != 1024 else NP
-        self.enc = engine.EncoderNet(fe.encoder, dev)
-        self.venc = engine.EncoderNet(fe.value_encoder, dev)
-        self.pol = heads.PolicyNet(agent.policy, dev)
-        self.pol_t = heads.PolicyNet(agent.policy_target, dev)
+        # one packed view per module, shared with the module-level forward helpers below
+        encs = _encoder_nets(fe, dev)
+        self.enc, self.venc = encs[False], encs[True]
+        self.pol = _head_net(agent.policy, "policy", dev)
+        self.pol_t = _head_net(agent.policy_target, "policy", dev)
         if self.has_critic:
-            self.cr = heads.CriticNet(agent.critic, dev)
-            self.cr_t = heads.CriticNet(agent.critic_target, dev)
+            self.cr = _head_net(agent.critic, "critic", dev)
+            self.cr_t = _head_net(agent.critic_target, "critic", dev)
         sa1 = engine.SAConfig(fe.pointnet_nclusters, fe.pointnet_radius, 64)
         sa2 = engine.SAConfig(32, 0.04, 128)
         self.geo = engine.Geometry(B, self.N, sa1, sa2, dev)
@@ -299,6 +300,11 @@ def _module_runtime(mod, key, builder):
     return rt[key]
 
 
+def _head_net(module, kind, dev):
+    return _module_runtime(module, "net", lambda: heads.CriticNet(module, dev) if kind == "critic"
+                           else heads.PolicyNet(module, dev))
+
+
 def _encoder_nets(fe, dev):
     """EncoderNet views of a PointNetFeature's two encoders (shared with the agent's fused runtime if
     the parameters were already re-homed into flat buffers)."""
@@ -370,9 +376,7 @@ def _head_runtime(module, kind, state):
     if state.shape[1] != 513:
         raise RuntimeError("heads take (B,513) = [512-d feature, remaining time]")
 
-    def build_net():
-        return heads.CriticNet(module, dev) if kind == "critic" else heads.PolicyNet(module, dev)
-    net = _module_runtime(module, "net", build_net)
+    net = _head_net(module, kind, dev)
 
     def build_b():
         src = _FeatureSource(B, dev)
