@@ -108,9 +108,8 @@ def _polyak(target, source, tau, select):
         k = select(tn)
         if k:
             hip.call("gad_polyak", tp.data, sp.data, None, None, None, tp.numel(), float(tau) if k == 1 else 1.0, 0)
-    sync = getattr(target, "_gad_sync_packed", None)
-    if sync:
-        sync()
+    from ..runtime import sync_module
+    sync_module(target)
 
 
 def soft_update(target, source, tau):

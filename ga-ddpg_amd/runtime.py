@@ -300,16 +300,38 @@ def _module_runtime(mod, key, builder):
     return rt[key]
 
 
+def sync_module(mod):
+    """mirror a module's (externally modified) parameters into its packed compute copy, if it has one"""
+    rt = mod.__dict__.get("_gad_rt") or {}
+    if "net" in rt:
+        rt["net"].flat.sync_packed()
+    for net in (rt.get("nets") or {}).values():
+        net.flat.sync_packed()
+
+
+def _resync_on_load(module, flats):
+    """load_state_dict() copies into the flat master views; mirror them into the packed compute copies"""
+    def hook(mod, incompatible_keys):
+        for f in flats:
+            f.sync_packed()
+    module.register_load_state_dict_post_hook(hook)
+
+
 def _head_net(module, kind, dev):
-    return _module_runtime(module, "net", lambda: heads.CriticNet(module, dev) if kind == "critic"
-                           else heads.PolicyNet(module, dev))
+    def build():
+        net = heads.CriticNet(module, dev) if kind == "critic" else heads.PolicyNet(module, dev)
+        _resync_on_load(module, [net.flat])
+        return net
+    return _module_runtime(module, "net", build)
 
 
 def _encoder_nets(fe, dev):
     """EncoderNet views of a PointNetFeature's two encoders (shared with the agent's fused runtime if
     the parameters were already re-homed into flat buffers)."""
     def build():
-        return {False: engine.EncoderNet(fe.encoder, dev), True: engine.EncoderNet(fe.value_encoder, dev)}
+        nets = {False: engine.EncoderNet(fe.encoder, dev), True: engine.EncoderNet(fe.value_encoder, dev)}
+        _resync_on_load(fe, [nets[False].flat, nets[True].flat])
+        return nets
     return _module_runtime(fe, "nets", build)
 
 
