@@ -421,7 +421,11 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             store_tile(kt);
             __syncthreads();
             if (kt + 1 < nk) load_tile(kt + 1);
+#ifndef GAD_EXP_NOMFMA
             mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+#else
+            acc[0][0][0] += As[lane] + Bs[lane];
+#endif
             __syncthreads();
         }
         const int l31 = lane & 31, half = lane >> 5;
@@ -436,7 +440,11 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
                     const int il = wm * TM * 32 + tm * 32 + acc_row(v, half);
                     const int r = row0 + il;
                     const float zv = acc[tm][tn][v];
+#ifndef GAD_EXP_NOSTORE
                     if (r < n_rows && n < n_out) zout[(size_t)r * zout_pitch + ooff + n] = zv;
+#else
+                    if (r < n_rows && n < n_out && zv == 12345.678f) zout[(size_t)r * zout_pitch + ooff + n] = zv;
+#endif
                     const float w = wS[il];
                     s1 = fmaf(w, zv, s1);
                     s2 = fmaf(w * zv, zv, s2);
@@ -452,6 +460,190 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
                                          stat_sum + (size_t)rep * stat_stride + ooff,
                                          stat_sq + (size_t)rep * stat_stride + ooff);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// streaming forward for the wide-and-shallow SA1 layers (rows ~ 2e5, Kp <= 64, n_out <= 128):
+// HBM-bound (SA1 layer 3: 192 B/row moved vs 16 kFLOP/row), so the kernel is built around bytes in
+// flight rather than around a block tile:
+//   * W (<= 34 KB) is staged ONCE per workgroup in LDS, row-major [n][Kp+4] (ds_read_b128, conflict-free);
+//   * every wavefront owns 32-row slabs: lane (r = lane%32, h = lane/32) loads X[r][8j+4h..+3] as 16-byte
+//     loads straight into the MFMA A-operand registers (no LDS round trip, no workgroup barrier in the
+//     loop) -- the reduction index is visited in the order k = 8j+4h+i, identically for A and B;
+//   * the next slab's loads are issued before the current slab's MFMAs (register double buffer) and the
+//     grid is persistent at 2 wavefronts per SIMD, so loads, MFMAs and the epilogue stores of different
+//     wavefronts overlap.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// NOTE (measured, tests/ubench/mfma_valu.hip): on gfx950 the f32 MFMA shares the vector ALU -- every VALU
+// instruction issued between MFMAs adds its ~4 clocks to the 64 of the MFMA, also with 2 wavefronts per SIMD.
+// So the loop below is written for a minimal VALU instruction count: packed (2-wide) f32 math for the BatchNorm
+// affine and the statistics, buffer stores whose row offset lives in an SGPR (no per-store address arithmetic),
+// clamped row indices instead of per-element selects.
+template <int KJ, int TN, int XM>
+__global__ __launch_bounds__(256, 2) void gemm_fwd_stream_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                                  int n_rows_static, const float* __restrict__ row_w,
+                                                                  const float* __restrict__ W, float* __restrict__ zout,
+                                                                  double* __restrict__ stat_sum,
+                                                                  double* __restrict__ stat_sq, int stat_stride) {
+    constexpr int KP = 8 * KJ, NO = 32 * TN, PW = KP + 4;
+    __shared__ __attribute__((aligned(16))) float Ws[NO * PW];
+    __shared__ __attribute__((aligned(16))) float sv[KP], tv[KP];
+    __shared__ float red[2 * 4 * NO];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    {   // stage W: all 16-byte loads in flight before the first LDS store
+        constexpr int UNITS = NO * KJ * 2, UW = (UNITS + 255) / 256;
+        float4 wr[UW];
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 256 + tid;
+            wr[it] = ldg4(W + (size_t)(u < UNITS ? u : 0) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 256 + tid;
+            const int n = u / (KJ * 2), c = (u % (KJ * 2)) * 4;
+            if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
+        }
+    }
+    if (XM == 0 && tid < KP) { sv[tid] = x.scale[tid]; tv[tid] = x.shift[tid]; }
+    __syncthreads();
+
+    const int n_slabs = (n_rows + 31) >> 5;
+    const int stride = gridDim.x * 4;
+    int slab = blockIdx.x * 4 + wave;                    // wave-uniform (SGPR)
+    // output through a buffer descriptor: rows >= n_rows fall outside num_records and are dropped by the hardware
+    const __amdgpu_buffer_rsrc_t zrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(zout, 0, n_rows * NO * 4, 0x00020000);
+    const int zlane = (4 * half * NO + l31) * 4;         // byte offset of (row 4*half, column l31)
+
+    f32x2 csum[TN], csq[TN];                             // .x/.y: even / odd accumulator rows, summed at the end
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { csum[t] = f32x2{0.f, 0.f}; csq[t] = f32x2{0.f, 0.f}; }
+
+    XRaw ra[KJ], rn[KJ];
+    int pt_nxt = 0;
+    auto load_pt = [&](int sl) {          // point index of the lane's row in slab sl (gather input only)
+        const int r = min(sl * 32 + l31, n_rows - 1);
+        return (XM == 1 && sl < n_slabs) ? x.row_pt[r] : 0;
+    };
+    auto load_slab = [&](int sl, int pt, XRaw (&dst)[KJ]) {
+        const int r = min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1);      // clamped: ragged rows repeat the last row
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) dst[j] = x_raw<XM>(x, r, true, 0, 8 * j + 4 * half, XM == 1, pt);
+    };
+    auto lds_b = [&](int j, float4 (&b4)[TN]) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) b4[t] = *reinterpret_cast<const float4*>(Ws + (t * 32 + l31) * PW + 8 * j + 4 * half);
+    };
+    {
+        const int pt0 = load_pt(slab);
+        load_slab(slab, pt0, ra);
+        pt_nxt = load_pt(slab + stride);
+    }
+    for (; slab < n_slabs; slab += stride) {
+        load_slab(slab + stride, pt_nxt, rn);
+        pt_nxt = load_pt(slab + 2 * stride);
+        // the 16 rows this lane owns in the accumulator layout: 4 runs of 4 consecutive rows -> 4 aligned loads
+        float4 w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r0 = slab * 32 + 8 * q + 4 * half;
+            w4[q] = row_w ? ldg4(row_w + (r0 + 3 < n_rows_static ? r0 : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+        if (slab * 32 + 32 > n_rows) {                   // ragged last slab (wave-uniform branch): zero the missing rows
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float* wq = &w4[q].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wq[e] = (slab * 32 + 8 * q + 4 * half + e < n_rows) ? wq[e] : 0.f;
+            }
+        }
+        __asm__ volatile("" ::: "memory");        // keep the (loop-invariant) LDS reads of W inside the loop: registers
+        f32x16 acc[TN];
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        float4 bn[TN];
+        lds_b(0, bn);
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+            float4 b4[TN];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) b4[t] = bn[t];
+            float4 a4;
+            if (XM == 0) {          // relu(scale * z + shift): two packed FMAs + four max
+                const float4 s4 = *reinterpret_cast<const float4*>(sv + 8 * j + 4 * half);
+                const float4 t4 = *reinterpret_cast<const float4*>(tv + 8 * j + 4 * half);
+                const f32x2 lo = f32x2{ra[j].a.x, ra[j].a.y} * f32x2{s4.x, s4.y} + f32x2{t4.x, t4.y};
+                const f32x2 hi = f32x2{ra[j].a.z, ra[j].a.w} * f32x2{s4.z, s4.w} + f32x2{t4.z, t4.w};
+                a4 = make_float4(__builtin_fmaxf(lo.x, 0.f), __builtin_fmaxf(lo.y, 0.f), __builtin_fmaxf(hi.x, 0.f),
+                                 __builtin_fmaxf(hi.y, 0.f));
+            } else {
+                a4 = x_finish<XM>(x, ra[j], true, 8 * j + 4 * half, sv, tv);
+            }
+            if (j + 1 < KJ) lds_b(j + 1, bn);      // next group's fragments land under this group's MFMAs
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
+        }
+        // epilogue: raw layer output (SGPR row offset + immediate column offset: no address arithmetic) and the
+        // weighted BatchNorm partial sums, two accumulator rows per packed instruction
+        const int zrow = slab * 32 * NO * 4;
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+            const int rb = ((v & 3) + 8 * (v >> 2)) * NO * 4;
+            const f32x2 wr = f32x2{(&w4[v >> 2].x)[v & 3], (&w4[v >> 2].x)[(v & 3) + 1]};
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const f32x2 zv = f32x2{acc[t][v], acc[t][v + 1]};
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + NO * 4, 0);
+                const f32x2 wz = wr * zv;
+                csum[t] += wz;
+                csq[t] += wz * zv;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) ra[j] = rn[j];
+    }
+    if (stat_sum) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const float c0 = csum[t].x + csum[t].y, c1 = csq[t].x + csq[t].y;
+            const float s0 = c0 + __shfl_xor(c0, 32, 64);
+            const float s1 = c1 + __shfl_xor(c1, 32, 64);
+            if (lane < 32) { red[wave * NO + t * 32 + lane] = s0; red[(4 + wave) * NO + t * 32 + lane] = s1; }
+        }
+        __syncthreads();
+        if (tid < NO) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s0 += red[w * NO + tid]; s1 += red[(4 + w) * NO + tid]; }
+            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+            atomic_add_f64(stat_sum + (size_t)rep * stat_stride + tid, (double)s0);
+            atomic_add_f64(stat_sq + (size_t)rep * stat_stride + tid, (double)s1);
+        }
+    }
+}
+
+// the streaming kernel covers: one group, no bias / extra column, Kp in {16, 64}, n_out in {64, 128}
+static bool fwd_streamable(const gad_gemm_fwd_args& a) {
+    if (a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
+    if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || a.zout_pitch != a.n_out[0]) return false;
+    if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
+    if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && a.scale && a.shift && a.relu;
+    return a.Kp == 16 && a.feat_c + 3 + a.act_c <= 16;
 }
 
 static Groups make_groups(int n, const int32_t* a, const int32_t* w, const int32_t* o, const int32_t* no) {
@@ -500,6 +692,26 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
                            a->stat_sum, a->stat_sq, a->stat_stride);                                       \
     } while (0)
 #define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0); else LAUNCH_FWD2(WM, WN, TM, TN, 1); } while (0)
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("GAD_FWD_TILE"); force = e ? atoi(e) : 0; }
+    if (force == 0 && fwd_streamable(*a)) {
+        const int slabs = gad_cdiv(rows, 32);
+        static int gmax = 0;
+        if (!gmax) { const char* e = getenv("GAD_STREAM_GRID"); gmax = e ? atoi(e) : 512; }
+        int gx = gad_cdiv(slabs, 4); if (gx > gmax) gx = gmax;
+#define LAUNCH_STREAM(KJ, TN, XM)                                                                          \
+        hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM>), dim3(gx), dim3(256), 0, st, x, a->n_rows_dev, rows, \
+                           a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride)
+        if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0); else LAUNCH_STREAM(8, 4, 0); }
+        else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1); else LAUNCH_STREAM(2, 4, 1); }
+#undef LAUNCH_STREAM
+        GAD_CHECK_LAUNCH("gemm_fwd(stream)");
+        return GAD_OK;
+    }
+    if (force == 1) LAUNCH_FWD(2, 2, 1, 1);
+    else if (force == 2) LAUNCH_FWD(4, 1, 1, 2);
+    else if (force == 3) LAUNCH_FWD(2, 2, 2, 2);
+    else
     if (rows <= 16384) {
         if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);     // many small tiles: fill the CUs
     } else if (nmax <= 64) {

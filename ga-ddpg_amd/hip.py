@@ -7,7 +7,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgaddpg.so")
+LIB_PATH = os.environ.get("GAD_LIB_PATH") or os.path.join(_HERE, "libgaddpg.so")   # env override: kernel experiments
 MAX_GROUPS = 3
 STAT_REPLICAS = 8
 

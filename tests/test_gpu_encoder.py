@@ -101,11 +101,12 @@ def test_encoder_forward_backward_vs_reference(golden_dir):
     slot = engine.EncoderSlot(geo, enc, dev)
     z_pol = _run_encoder(enc, slot, None, probe, False)
     taps(slot, "policy")
-    assert_close(z_pol.cpu().numpy(), g["z_policy"], 1e-4, 2e-5, "z_policy")
+    # (B,512) features behind two BatchNorm1d over B=16 samples: 1e-4 relative per entry + 1e-5 of the tensor scale
+    assert_close(z_pol.cpu().numpy(), g["z_policy"], 1e-4, 1e-5 * np.abs(g["z_policy"]).max(), "z_policy")
     vslot = engine.EncoderSlot(geo, venc, dev)
     z_val = _run_encoder(venc, vslot, action, probe.flip(1).contiguous(), True)
     taps(vslot, "value")
-    assert_close(z_val.cpu().numpy(), g["z_value"], 1e-4, 2e-5, "z_value")
+    assert_close(z_val.cpu().numpy(), g["z_value"], 1e-4, 1e-5 * np.abs(g["z_value"]).max(), "z_value")
     da = vslot.daction.cpu().numpy()
     # norm-wise 5e-3: the per-sample action gradient inherits any ReLU-kink flip upstream (helpers.py)
     assert_close(da, g["action_grad"], 0.0, 5e-3 * np.abs(g["action_grad"]).max(), "action grad")
