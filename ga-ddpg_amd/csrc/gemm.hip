@@ -17,6 +17,7 @@
 // BatchNorm statistics: registers -> __shfl_xor -> LDS across wavefronts -> f64 device atomics
 // into one of GAD_STAT_REPLICAS accumulators (blockIdx % replicas) to bound same-address contention.
 #include "common.hpp"
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -421,11 +422,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             store_tile(kt);
             __syncthreads();
             if (kt + 1 < nk) load_tile(kt + 1);
-#ifndef GAD_EXP_NOMFMA
             mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
-#else
-            acc[0][0][0] += As[lane] + Bs[lane];
-#endif
             __syncthreads();
         }
         const int l31 = lane & 31, half = lane >> 5;
@@ -440,11 +437,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
                     const int il = wm * TM * 32 + tm * 32 + acc_row(v, half);
                     const int r = row0 + il;
                     const float zv = acc[tm][tn][v];
-#ifndef GAD_EXP_NOSTORE
                     if (r < n_rows && n < n_out) zout[(size_t)r * zout_pitch + ooff + n] = zv;
-#else
-                    if (r < n_rows && n < n_out && zv == 12345.678f) zout[(size_t)r * zout_pitch + ooff + n] = zv;
-#endif
                     const float w = wS[il];
                     s1 = fmaf(w, zv, s1);
                     s2 = fmaf(w * zv, zv, s2);
@@ -482,7 +475,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // affine and the statistics, buffer stores whose row offset lives in an SGPR (no per-store address arithmetic),
 // clamped row indices instead of per-element selects.
 template <int KJ, int TN, int XM>
-__global__ __launch_bounds__(256, 2) void gemm_fwd_stream_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
+__global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
                                                                   int n_rows_static, const float* __restrict__ row_w,
                                                                   const float* __restrict__ W, float* __restrict__ zout,
                                                                   double* __restrict__ stat_sum,
@@ -490,22 +483,22 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     constexpr int KP = 8 * KJ, NO = 32 * TN, PW = KP + 4;
     __shared__ __attribute__((aligned(16))) float Ws[NO * PW];
     __shared__ __attribute__((aligned(16))) float sv[KP], tv[KP];
-    __shared__ float red[2 * 4 * NO];
+    __shared__ float red[2 * 8 * NO];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     {   // stage W: all 16-byte loads in flight before the first LDS store
-        constexpr int UNITS = NO * KJ * 2, UW = (UNITS + 255) / 256;
+        constexpr int UNITS = NO * KJ * 2, UW = (UNITS + 511) / 512;
         float4 wr[UW];
 #pragma unroll
         for (int it = 0; it < UW; ++it) {
-            const int u = it * 256 + tid;
+            const int u = it * 512 + tid;
             wr[it] = ldg4(W + (size_t)(u < UNITS ? u : 0) * 4);
         }
 #pragma unroll
         for (int it = 0; it < UW; ++it) {
-            const int u = it * 256 + tid;
+            const int u = it * 512 + tid;
             const int n = u / (KJ * 2), c = (u % (KJ * 2)) * 4;
             if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
         }
@@ -514,8 +507,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     __syncthreads();
 
     const int n_slabs = (n_rows + 31) >> 5;
-    const int stride = gridDim.x * 4;
-    int slab = blockIdx.x * 4 + wave;                    // wave-uniform (SGPR)
+    // 8 wavefronts per workgroup, one workgroup per CU: wavefronts w and w+4 share a SIMD (cyclic placement).  Slabs
+    // are dealt wave-major (w * gridDim + block), so the left-over slabs of the last round go to w = 0..3 first and
+    // every SIMD ends up with the same slab count +-1 (dealing block-major left whole CUs a round short: -20 %).
+    const int stride = gridDim.x * 8;
+    int slab = wave * gridDim.x + blockIdx.x;            // wave-uniform (SGPR)
     // output through a buffer descriptor: rows >= n_rows fall outside num_records and are dropped by the hardware
     const __amdgpu_buffer_rsrc_t zrsrc =
         __builtin_amdgcn_make_buffer_rsrc(zout, 0, n_rows * NO * 4, 0x00020000);
@@ -623,13 +619,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             const float c0 = csum[t].x + csum[t].y, c1 = csq[t].x + csq[t].y;
             const float s0 = c0 + __shfl_xor(c0, 32, 64);
             const float s1 = c1 + __shfl_xor(c1, 32, 64);
-            if (lane < 32) { red[wave * NO + t * 32 + lane] = s0; red[(4 + wave) * NO + t * 32 + lane] = s1; }
+            if (lane < 32) { red[wave * NO + t * 32 + lane] = s0; red[(8 + wave) * NO + t * 32 + lane] = s1; }
         }
         __syncthreads();
         if (tid < NO) {
             float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { s0 += red[w * NO + tid]; s1 += red[(4 + w) * NO + tid]; }
+            for (int w = 0; w < 8; ++w) { s0 += red[w * NO + tid]; s1 += red[(8 + w) * NO + tid]; }
             const int rep = blockIdx.x % GAD_STAT_REPLICAS;
             atomic_add_f64(stat_sum + (size_t)rep * stat_stride + tid, (double)s0);
             atomic_add_f64(stat_sq + (size_t)rep * stat_stride + tid, (double)s1);
@@ -637,8 +633,17 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     }
 }
 
+static int g_opt_fwd_stream = 1;
+extern "C" int gad_set_option(const char* name, int value) {
+    GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
+    if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
+    GAD_REQUIRE(false, GAD_ERR_SHAPE, "set_option: unknown option '%s'", name);
+    return GAD_OK;
+}
+
 // the streaming kernel covers: one group, no bias / extra column, Kp in {16, 64}, n_out in {64, 128}
 static bool fwd_streamable(const gad_gemm_fwd_args& a) {
+    if (!g_opt_fwd_stream) return false;
     if (a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
     if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || a.zout_pitch != a.n_out[0]) return false;
     if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
@@ -692,15 +697,11 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
                            a->stat_sum, a->stat_sq, a->stat_stride);                                       \
     } while (0)
 #define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0); else LAUNCH_FWD2(WM, WN, TM, TN, 1); } while (0)
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("GAD_FWD_TILE"); force = e ? atoi(e) : 0; }
-    if (force == 0 && fwd_streamable(*a)) {
+    if (fwd_streamable(*a)) {
         const int slabs = gad_cdiv(rows, 32);
-        static int gmax = 0;
-        if (!gmax) { const char* e = getenv("GAD_STREAM_GRID"); gmax = e ? atoi(e) : 512; }
-        int gx = gad_cdiv(slabs, 4); if (gx > gmax) gx = gmax;
+        int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;              // one 8-wavefront workgroup per CU
 #define LAUNCH_STREAM(KJ, TN, XM)                                                                          \
-        hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM>), dim3(gx), dim3(256), 0, st, x, a->n_rows_dev, rows, \
+        hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
                            a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride)
         if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0); else LAUNCH_STREAM(8, 4, 0); }
         else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1); else LAUNCH_STREAM(2, 4, 1); }
@@ -708,17 +709,9 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         GAD_CHECK_LAUNCH("gemm_fwd(stream)");
         return GAD_OK;
     }
-    if (force == 1) LAUNCH_FWD(2, 2, 1, 1);
-    else if (force == 2) LAUNCH_FWD(4, 1, 1, 2);
-    else if (force == 3) LAUNCH_FWD(2, 2, 2, 2);
-    else
-    if (rows <= 16384) {
-        if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);     // many small tiles: fill the CUs
-    } else if (nmax <= 64) {
-        LAUNCH_FWD(4, 1, 1, 2);                                                   // 128 x 64
-    } else {
-        LAUNCH_FWD(2, 2, 2, 2);                                                   // 128 x 128
-    }
+    // 64 x 64 tiles throughout: with K <= 1024 these launches are prologue/epilogue-bound, more and smaller
+    // workgroups win over the 128-wide tiles at every shape of the step (tests/diag_gemm.py)
+    if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);
 #undef LAUNCH_FWD
 #undef LAUNCH_FWD2
     GAD_CHECK_LAUNCH("gemm_fwd");

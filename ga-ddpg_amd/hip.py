@@ -65,11 +65,14 @@ def lib():
         L.gad_last_error.restype = C.c_char_p
         L.gad_abi_version.restype = C.c_int
         _lib = L
+        for k, v in os.environ.items():          # GAD_OPT_<name>=<int>: kernel-selection switches for A/B diagnostics
+            if k.startswith("GAD_OPT_"):
+                check(L.gad_set_option(k[8:].encode(), int(v)), "gad_set_option(%s)" % k[8:])
     return _lib
 
 
 EXPORTS = (
-    "gad_abi_version", "gad_last_error", "gad_furthest_point_sampling", "gad_gather_points",
+    "gad_abi_version", "gad_last_error", "gad_set_option", "gad_furthest_point_sampling", "gad_gather_points",
     "gad_gather_points_grad", "gad_ball_query", "gad_group_points", "gad_group_points_grad",
     "gad_query_and_group", "gad_prep_points", "gad_rows_from_ball_query", "gad_rows_group_all",
     "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_affine_act",
@@ -147,3 +150,8 @@ def require_cuda(*tensors):
             raise RuntimeError("CPU tensor passed to a libgaddpg operator (CPU not supported)")
         if t is not None and not t.is_contiguous():
             raise RuntimeError("libgaddpg operators need contiguous tensors")
+
+
+def set_option(name, value):
+    """kernel-selection switch for A/B diagnostics (include/gaddpg.h: gad_set_option)"""
+    check(lib().gad_set_option(name.encode(), int(value)), "gad_set_option")

@@ -18,7 +18,7 @@ def assert_close(a, b, rtol, atol, what=""):
                                                    tol.ravel()[i], err.max()))
 
 
-def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise=False, l2_rtol=2e-2):
+def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise=False, l2_rtol=2e-2, max_rtol=5e-2):
     """Compare tensors against fingerprints written by oracle.detfill.summarize_named.
     The tolerance on the aggregate stats is scaled by the tensor's abs-sum / l2.
     normwise=True: entries are compared with tolerance rtol * max|tensor| (+atol) instead of
@@ -37,11 +37,11 @@ def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise
             # float32 evaluations resolve differently reroutes one row's contribution (expected ~10 such
             # flips per pass among SA1's 1.4e7 pre-activations, ~1 in SA3 where a row is 1/1024 of the
             # batch; measured between torch-float32 and torch-float64 as well).  Hence:
-            # median entry error within rtol*max|tensor|, every entry within 5e-2*max|tensor|.
+            # median entry error within rtol*max|tensor|, every entry within max_rtol*max|tensor|.
             scale = float(g_stats[3])
             err = np.abs(np.asarray(vals, np.float64) - g_vals)
             assert np.median(err) <= atol + rtol * scale, "%s: median err %.3g > %.3g" % (kv, np.median(err), rtol * scale)
-            assert err.max() <= atol + 5e-2 * scale, "%s: max err %.3g (scale %.3g)" % (kv, err.max(), scale)
+            assert err.max() <= atol + max_rtol * scale, "%s: max err %.3g (scale %.3g)" % (kv, err.max(), scale)
             assert abs(stats[2] - g_stats[2]) <= l2_rtol * g_stats[2] + atol, ks + " l2"
             n += 1
             continue
