@@ -272,22 +272,38 @@ template <int DIM> __device__ __forceinline__ void store_D(float* t, int kk, int
     *reinterpret_cast<float4*>(t + kk * P + i) = v;
 }
 
+// One K-tile of MFMAs.  The operand fragments are read from LDS one CHUNK (4 k-steps) ahead of the MFMAs that
+// consume them: written naively (read, wait, MFMA) hipcc emits `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per step and
+// a lone wavefront per SIMD (the small-M layers) spends as long waiting for LDS as issuing MFMAs.
 template <int TM, int TN, int PA, int PB>
 __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const float* __restrict__ Bs, int am0,
                                            int bn0, int lane, f32x16 (&acc)[TM][TN]) {
     const int l31 = lane & 31, half = lane >> 5;
+    constexpr int CH = 4, NCH = KT / 2 / CH;
+    const float* ap = As + half * PA + am0 + l31;
+    const float* bp = Bs + half * PB + bn0 + l31;
+    float a[2][CH][TM], b[2][CH][TN];
+    auto fetch = [&](int c, int buf) {
 #pragma unroll
-    for (int s = 0; s < KT / 2; ++s) {
-        float a[TM], b[TN];
+        for (int s = 0; s < CH; ++s) {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) a[tm] = As[(2 * s + half) * PA + am0 + tm * 32 + l31];
+            for (int tm = 0; tm < TM; ++tm) a[buf][s][tm] = ap[(2 * (c * CH + s)) * PA + tm * 32];
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) b[tn] = Bs[(2 * s + half) * PB + bn0 + tn * 32 + l31];
+            for (int tn = 0; tn < TN; ++tn) b[buf][s][tn] = bp[(2 * (c * CH + s)) * PB + tn * 32];
+        }
+    };
+    fetch(0, 0);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
+    for (int c = 0; c < NCH; ++c) {
+        if (c + 1 < NCH) fetch(c + 1, (c + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);       // keep the next chunk's ds_reads ABOVE this chunk's MFMAs
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tm], b[tn], acc[tm][tn], 0, 0, 0);
+        for (int s = 0; s < CH; ++s)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+                    acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c & 1][s][tm], b[c & 1][s][tn], acc[tm][tn], 0, 0, 0);
     }
 }
 
@@ -633,10 +649,114 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// skinny forward for the small-M layers (FC head and actor/critic heads: M = batch rows <= 1024, K up to 1032).
+// A 64x64-tile launch has M/64 * N/64 = 32..64 workgroups for 256 CUs and walks K serially: 33 K-tiles of
+// (global load -> LDS -> barrier -> 16 MFMA -> barrier) at ~1.2 us each (load latency, nothing to overlap with).
+// Here every workgroup owns one 32x32 output tile and its 8 wavefronts split K: each wavefront issues ALL the
+// 16-byte loads of its K slice (A and B operand straight in MFMA register layout, k visited as 8j+4h+i like the
+// streaming kernel, no LDS staging, no barrier) before its first MFMA, so the load latency is paid about once;
+// the partial tiles are summed through LDS.  256 rows x 1024 -> 512: 37.8 us -> see tests/diag_gemm.py.
+// ------------------------------------------------------------------------------------------------
+#define SK_NW 8          // wavefronts per workgroup (K split); 16 -> 128-VGPR budget -> spills, 2x slower
+#define SK_CH 6          // 8-wide k groups per register chunk
+#define SK_MAXCH 3       // chunks per wavefront: K <= 8 * SK_NW * SK_CH * SK_MAXCH = 1152
+__global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Groups gr, int n_rows,
+                                                                     const float* __restrict__ row_w,
+                                                                     const float* __restrict__ W, int Kp,
+                                                                     float* __restrict__ zout, int zout_pitch,
+                                                                     double* __restrict__ stat_sum,
+                                                                     double* __restrict__ stat_sq, int stat_stride) {
+    __shared__ float part[SK_NW * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int g = blockIdx.z;
+    const int zoff = gr.aoff[g], n_out = gr.nout[g], ooff = gr.ooff[g];
+    const int n0 = blockIdx.y * 32, row0 = blockIdx.x * 32;
+    if (n0 >= n_out) return;                                  // workgroup-uniform
+    const float* Wg = W + gr.woff[g] + (size_t)min(n0 + l31, n_out - 1) * Kp + 4 * half;   // clamped: extra columns unused
+    const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are neither stored nor counted
+    const float* sv = x.scale ? x.scale + zoff : nullptr;
+    const float* tv = x.shift ? x.shift + zoff : nullptr;
+    const int nj = Kp >> 3;
+    const int per = (nj + SK_NW - 1) / SK_NW;
+    const int j0 = wave * per, j1 = min(nj, j0 + per);        // this wavefront's k groups (wave-uniform)
+
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    XRaw ra[SK_MAXCH > 1 ? 2 : 1][SK_CH];
+    float4 rb[SK_MAXCH > 1 ? 2 : 1][SK_CH];
+    auto load_chunk = [&](int c, int buf) {
+#pragma unroll
+        for (int u = 0; u < SK_CH; ++u) {
+            const int j = min(j0 + c * SK_CH + u, nj - 1);    // clamped; masked out at the MFMA
+            const int col = 8 * j + 4 * half;
+            ra[buf][u] = x_raw<0>(x, r, true, zoff, col, col + 4 > x.c_in, 0);
+            rb[buf][u] = ldg4(Wg + 8 * j);
+        }
+    };
+    load_chunk(0, 0);
+#pragma unroll
+    for (int c = 0; c < SK_MAXCH; ++c) {
+        if (j0 + c * SK_CH < j1) {                            // wave-uniform
+            if (c + 1 < SK_MAXCH && j0 + (c + 1) * SK_CH < j1) load_chunk(c + 1, (c + 1) & 1);
+#pragma unroll
+            for (int u = 0; u < SK_CH; ++u) {
+                const int j = j0 + c * SK_CH + u;
+                if (j < j1) {                                 // wave-uniform
+                    const float4 a4 = x_finish<0>(x, ra[c & 1][u], true, 8 * j + 4 * half, sv, tv);
+                    const float4 b4 = rb[c & 1][u];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) part[(wave * 16 + v) * 64 + lane] = acc[v];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < SK_NW; ++w)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += part[(w * 16 + v) * 64 + lane];
+    const int n = n0 + l31;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int rr = row0 + acc_row(v, half);
+        const float zv = acc[v];
+        const bool live = rr < n_rows;
+        if (live && n < n_out) zout[(size_t)rr * zout_pitch + ooff + n] = zv;
+        const float w = live ? (row_w ? row_w[rr] : 1.f) : 0.f;
+        s1 = fmaf(w, zv, s1);
+        s2 = fmaf(w * zv, zv, s2);
+    }
+    if (stat_sum) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (lane < 32 && n < n_out) {
+            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+            atomic_add_f64(stat_sum + (size_t)rep * stat_stride + ooff + n, (double)s1);
+            atomic_add_f64(stat_sq + (size_t)rep * stat_stride + ooff + n, (double)s2);
+        }
+    }
+}
+
+static int g_opt_fwd_skinny = 1;
+static bool fwd_skinny(const gad_gemm_fwd_args& a) {
+    return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
+}
+
 static int g_opt_fwd_stream = 1;
 extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
+    if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     GAD_REQUIRE(false, GAD_ERR_SHAPE, "set_option: unknown option '%s'", name);
     return GAD_OK;
 }
@@ -688,6 +808,12 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     const int nmax = max_nout(gr);
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows;
+    if (fwd_skinny(*a)) {
+        hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(nmax, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
+                           gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride);
+        GAD_CHECK_LAUNCH("gemm_fwd(skinny)");
+        return GAD_OK;
+    }
 #define LAUNCH_FWD2(WM, WN, TM, TN, XM)                                                                    \
     do {                                                                                                   \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                                \
