@@ -747,7 +747,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     }
 }
 
-static int g_opt_fwd_skinny = 1;
+static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
 }
@@ -757,6 +757,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
+    if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     GAD_REQUIRE(false, GAD_ERR_SHAPE, "set_option: unknown option '%s'", name);
     return GAD_OK;
 }
@@ -993,6 +994,109 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
     }
 }
 
+// skinny dX for the small-M layers (same idea as gemm_fwd_skinny_kernel): one 32x32 tile of gout per workgroup, the 8
+// wavefronts split the reduction over the layer's output channels n.  A operand = dZ[r][8j+4h..+3] (16-byte loads of
+// z and G, BatchNorm-backward applied in registers), B operand = W[8j+4h+i][k0+lane%32]: four 4-byte loads per group
+// of 8 channels, each a fully coalesced 128-byte row segment -- no transposed weight copy needed.
+__global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Groups gr, int n_rows,
+                                                                    const float* __restrict__ W, int Kp, DxEpi e) {
+    __shared__ float part[SK_NW * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float vec[5 * VMAX];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int g = blockIdx.z;
+    const int doff = gr.aoff[g], n_out = gr.nout[g], goff = gr.ooff[g];
+    const int k0 = blockIdx.y * 32, row0 = blockIdx.x * 32;
+    for (int i = tid; i < n_out; i += 64 * SK_NW) {
+        vec[i] = d.scale ? d.scale[doff + i] : 1.f;
+        vec[VMAX + i] = d.shift ? d.shift[doff + i] : 0.f;
+        vec[2 * VMAX + i] = d.P ? d.P[doff + i] : 1.f;
+        vec[3 * VMAX + i] = d.Q ? d.Q[doff + i] : 0.f;
+        vec[4 * VMAX + i] = d.S ? d.S[doff + i] : 0.f;
+    }
+    __syncthreads();
+    const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are not stored
+    const int k = min(k0 + l31, Kp - 1);
+    const float* Wg = W + gr.woff[g] + k;
+    const float wrow = d.row_w ? d.row_w[r] : 1.f;
+    const int nj = (n_out + 7) >> 3;
+    const int per = (nj + SK_NW - 1) / SK_NW;
+    const int j0 = wave * per, j1 = min(nj, j0 + per);
+
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    float4 rz[2][SK_CH], rg[2][SK_CH], rb[2][SK_CH];
+    auto load_chunk = [&](int c, int buf) {
+#pragma unroll
+        for (int u = 0; u < SK_CH; ++u) {
+            const int j = min(j0 + c * SK_CH + u, nj - 1);
+            const int n = 8 * j + 4 * half;
+            const int nc = n < n_out ? n : 0;                 // clamped; dz_finish zeroes n >= n_out
+            rz[buf][u] = d.z ? ldg4(d.z + (size_t)r * d.z_pitch + doff + nc) : f4zero();
+            rg[buf][u] = ldg4(d.G + (size_t)r * d.g_pitch + doff + nc);
+            const float* wp = Wg + (size_t)nc * Kp;
+            rb[buf][u] = make_float4(wp[0], wp[Kp], wp[2 * (size_t)Kp], wp[3 * (size_t)Kp]);
+        }
+    };
+    load_chunk(0, 0);
+#pragma unroll
+    for (int c = 0; c < SK_MAXCH; ++c) {
+        if (j0 + c * SK_CH < j1) {
+            if (c + 1 < SK_MAXCH && j0 + (c + 1) * SK_CH < j1) load_chunk(c + 1, (c + 1) & 1);
+#pragma unroll
+            for (int u = 0; u < SK_CH; ++u) {
+                const int j = j0 + c * SK_CH + u;
+                if (j < j1) {
+                    DzRaw raw;
+                    raw.z = rz[c & 1][u]; raw.g = rg[c & 1][u]; raw.a = make_int4(0, 0, 0, 0);
+                    const float4 a4 = dz_finish<true>(d, raw, r, true, 8 * j + 4 * half, n_out, wrow, vec);
+                    const float4 b4 = rb[c & 1][u];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) part[(wave * 16 + v) * 64 + lane] = acc[v];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < SK_NW; ++w)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += part[(w * 16 + v) * 64 + lane];
+    const int kk = k0 + l31;
+    const bool kok = kk < e.k_valid;
+    const bool stats = e.dbeta != nullptr && kok;
+    float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+    if (stats) { sc = e.ps[goff + kk]; sh = e.pt[goff + kk]; mu = e.pm[goff + kk]; is = e.pi[goff + kk]; }
+    float sb = 0.f, sg = 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int rr = row0 + acc_row(v, half);
+        if (rr >= n_rows || !kok) continue;
+        const float gv = acc[v];
+        e.gout[(size_t)rr * e.gout_pitch + goff + kk] = gv;
+        if (stats) {
+            const float zp = e.zprev[(size_t)rr * e.zprev_pitch + goff + kk];
+            if (fmaf(zp, sc, sh) > 0.f) { sb += gv; sg = fmaf(gv, (zp - mu) * is, sg); }
+        }
+    }
+    if (e.dbeta) {
+        sb += __shfl_xor(sb, 32, 64);
+        sg += __shfl_xor(sg, 32, 64);
+        if (lane < 32 && kok) {
+            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+            atomic_add_f64(e.dbeta + (size_t)rep * e.stat_stride + goff + kk, (double)sb);
+            atomic_add_f64(e.dgamma + (size_t)rep * e.stat_stride + goff + kk, (double)sg);
+        }
+    }
+}
+
 extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     GAD_REQUIRE(a && a->W, GAD_ERR_NULL, "gemm_dx: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_dx: n_groups");
@@ -1015,6 +1119,15 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows, kv = a->k_valid;
     const bool vec = dz_vectorizable(a->dz, a->dz_off, a->n_out, a->n_groups);
+    int nmax_dx = 0;
+    for (int i = 0; i < a->n_groups; ++i) nmax_dx = a->n_out[i] > nmax_dx ? a->n_out[i] : nmax_dx;
+    if (g_opt_dx_skinny && vec && e.mode == 0 && a->dz.gmode == 0 && !a->n_rows_dev && rows <= 1024 &&
+        nmax_dx <= 8 * SK_NW * SK_CH * SK_MAXCH && nmax_dx <= VMAX) {
+        hipLaunchKernelGGL(gemm_dx_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(kv, 32), gr.n), dim3(64 * SK_NW), 0, st, d, gr,
+                           rows, a->W, a->Kp, e);
+        GAD_CHECK_LAUNCH("gemm_dx(skinny)");
+        return GAD_OK;
+    }
 #define LAUNCH_DX2(WM, WN, TM, TN, V)                                                                    \
     do {                                                                                                 \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                              \
