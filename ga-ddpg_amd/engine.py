@@ -270,9 +270,10 @@ class EncoderSlot(object):
         if with_backward:
             self.bstats = torch.zeros(R * 2 * tot, dtype=torch.float64, device=device)  # [replica][dbeta | dgamma]
             self.coef = torch.empty(3 * tot, **f32)                                  # P | Q | S
-            gmax = max(caps[s] * max(m.n_out for m in enc.sa_mats[s]) for s in range(3))
-            gmax = max(gmax, B * 1024)
-            self.G = [torch.empty(gmax, **f32), torch.empty(gmax, **f32)]
+            # dY scratch: one pair per SA stage + one for the FC head, so a weight-gradient GEMM running on the side
+            # stream never reads a buffer that the dX chain of the NEXT stage is already overwriting
+            self.G = [[torch.empty(caps[s] * enc.sa_mats[s][l].n_out, **f32) for l in (1, 0)] for s in range(3)]
+            self.Gfc = torch.empty(B * 1024, **f32)
             self.dF = [torch.zeros(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, **f32) for s in range(3)]
             self.daction = torch.zeros(B, 6, dtype=torch.float64, device=device)
         self.tot = tot
@@ -319,8 +320,24 @@ def dw_workspace(device, elems=48 * 1024 * 1024):
     return _DW_WS[key]
 
 
+_SIDE = {}
+
+
+def side_stream(device=None):
+    """the auxiliary HIP stream weight-gradient GEMMs are forked onto (one per device, created lazily)"""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev not in _SIDE:
+        _SIDE[dev] = torch.cuda.Stream(device=dev)
+    return _SIDE[dev]
+
+
+CONCURRENT_DW = True      # fork dW GEMMs onto the side stream (they feed nothing but the optimiser)
+
+
 class Plan(object):
-    """A recorded sequence of C-ABI calls over static buffers."""
+    """A recorded sequence of C-ABI calls over static buffers.  Calls marked `side` run on the auxiliary stream
+    between a fork (side waits for everything recorded so far on the main stream) and the next join (main waits
+    for the side stream) -- used for the weight-gradient GEMMs, which are off the dX critical path."""
 
     def __init__(self):
         self.calls = []
@@ -330,23 +347,29 @@ class Plan(object):
     def tag_last(self, tag):
         self.tags[len(self.calls) - 1] = tag
 
-    def call(self, name, *a):
+    def call(self, name, *a, side=False):
         f = getattr(hip.lib(), name)
         args = hip._args(*a)
         self.keep.append(a)
-        self.calls.append((name, f, args, None))
+        self.calls.append((name, f, args, None, side))
 
-    def call_struct(self, name, s):
+    def call_struct(self, name, s, side=False):
         f = getattr(hip.lib(), name)
         self.keep.append(s)
-        self.calls.append((name, f, None, s))
+        self.calls.append((name, f, None, s, side))
 
     def zero(self, t):
         self.keep.append(t)
-        self.calls.append(("zero", None, t, None))
+        self.calls.append(("zero", None, t, None, False))
 
     def fn(self, f):
-        self.calls.append(("py", f, None, None))
+        self.calls.append(("py", f, None, None, False))
+
+    def fork(self):
+        self.calls.append(("fork", None, torch.cuda.Event(), None, False))
+
+    def join(self):
+        self.calls.append(("join", None, torch.cuda.Event(), None, False))
 
     def extend(self, other):
         n = len(self.calls)
@@ -357,23 +380,38 @@ class Plan(object):
 
     def run(self):
         import ctypes as C
+        main = torch.cuda.current_stream()
         st = hip.stream()
+        side = side_st = None
         timed = TIMING["enabled"]
-        for i, (name, f, args, s) in enumerate(self.calls):
+        for i, (name, f, args, s, on_side) in enumerate(self.calls):
+            if name == "fork":
+                if side is None:
+                    side = side_stream()
+                    side_st = C.c_void_p(side.cuda_stream)
+                args.record(main)
+                side.wait_event(args)
+                continue
+            if name == "join":
+                if side is not None:
+                    args.record(side)
+                    main.wait_event(args)
+                continue
             ev = None
             if timed and i in self.tags and TIMING["tag"] in (self.tags[i], "*"):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
+                ev[0].record(side if on_side else main)
+            q = side_st if on_side else st
             if name == "zero":
                 args.zero_()
             elif name == "py":
                 f()
             elif s is not None:
-                hip.check(f(C.byref(s), st), name)
+                hip.check(f(C.byref(s), q), name)
             else:
-                hip.check(f(*(args + [st])), name)
+                hip.check(f(*(args + [q])), name)
             if ev is not None:
-                ev[1].record()
+                ev[1].record(side if on_side else main)
                 TIMING["events"].append(ev + (self.tags[i],))
 
 
@@ -487,7 +525,6 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     plan = Plan()
     B = slot.B
     tot = slot.tot
-    gbuf = slot.G
 
     def prev_stats(pm, zprev):
         o = enc.bn_off[pm.bn_index]
@@ -531,7 +568,9 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.gacc = _ptr(enc.flat.gacc)
         ws = dw_workspace(enc.flat.device)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
-        plan.call_struct("gad_gemm_dw", a)
+        if CONCURRENT_DW:
+            plan.fork()
+        plan.call_struct("gad_gemm_dw", a, side=CONCURRENT_DW)
         plan.tag_last("dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1))
 
     # ---- FC head ----
@@ -539,10 +578,10 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     _bn_coef(plan, enc, slot, fc2, float(B), want_dw)
     d = bn_dz(fc2, slot.Zfc[1], G=g_fc2)
     dw(3, 1, d, fc2, action)
-    dx(dict(n_rows=B), d, fc2, fc1.n_out, epilogue=0, gout=_ptr(gbuf[0]), gout_pitch=fc1.n_out,
+    dx(dict(n_rows=B), d, fc2, fc1.n_out, epilogue=0, gout=_ptr(slot.Gfc), gout_pitch=fc1.n_out,
        **prev_stats(fc1, slot.Zfc[0]))
     _bn_coef(plan, enc, slot, fc1, float(B), want_dw)
-    d = bn_dz(fc1, slot.Zfc[0], G=gbuf[0])
+    d = bn_dz(fc1, slot.Zfc[0], G=slot.Gfc)
     dw(3, 0, d, fc1, action)
     dx(dict(n_rows=B), d, fc1, slot.F[2].shape[1], epilogue=0, gout=_ptr(slot.dF[2]), gout_pitch=slot.F[2].shape[1])
     # ---- SA3 -> SA1 ----
@@ -550,6 +589,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         r = geo.rows[s]
         rows_kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], name="sa%d" % (s + 1))
         m1, m2, m3 = enc.sa_mats[s]
+        gbuf = slot.G[s]
         o3 = enc.bn_off[m3.bn_index]
         plan.call("gad_pool_bwd_stats", slot.dF[s], slot.argmax[s], r["G"], m3.n_out, slot.Z[s][2], m3.n_out,
                   _bn_vec(slot, enc, m3, "scale"), _bn_vec(slot, enc, m3, "shift"), _bn_vec(slot, enc, m3, "mean"),
@@ -574,6 +614,8 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
             plan.zero(slot.daction)
             dx(rows_kw, d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),
                daction=_ptr(slot.daction), act_c=6, grp_per_sample=geo.M1)
+    if want_dw and CONCURRENT_DW:
+        plan.join()
     return plan
 
 
