@@ -67,6 +67,33 @@ extern "C" int gad_bn_eval_affine(const float* gamma, const float* beta, const f
     return GAD_OK;
 }
 
+// running statistics update from SAVED batch statistics (mean, 1/sqrt(var+eps)) -- used when the pass that produced
+// them ran concurrently with another pass of the same network on a second stream and the momentum updates have to be
+// applied afterwards in the reference's order.  count[c] = rows behind channel c's statistics.
+__global__ __launch_bounds__(256) void bn_running_update_kernel(const float* __restrict__ mean, const float* __restrict__ istd,
+                                                                const float* __restrict__ count, int C, float eps,
+                                                                float momentum, float* __restrict__ rmean,
+                                                                float* __restrict__ rvar) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double is = istd[c], n = count[c];
+    double var = 1.0 / (is * is) - (double)eps;
+    if (var < 0.0) var = 0.0;
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean[c];
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
+}
+
+extern "C" int gad_bn_running_update(const float* mean, const float* istd, const float* count, int C, float eps,
+                                     float momentum, float* running_mean, float* running_var, void* stream) {
+    GAD_REQUIRE(mean && istd && count && running_mean && running_var, GAD_ERR_NULL, "bn_running_update: null pointer");
+    if (C <= 0) return GAD_OK;
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, mean, istd, count,
+                       C, eps, momentum, running_mean, running_var);
+    GAD_CHECK_LAUNCH("bn_running_update");
+    return GAD_OK;
+}
+
 // out[g][c] = max over the group's rows of relu(scale*z+shift); arg-max = first maximal row
 __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ z, int z_pitch, int C,
                                                            const float* __restrict__ scale,

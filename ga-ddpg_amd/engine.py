@@ -323,12 +323,13 @@ def dw_workspace(device, elems=48 * 1024 * 1024):
 _SIDE = {}
 
 
-def side_stream(device=None):
-    """the auxiliary HIP stream weight-gradient GEMMs are forked onto (one per device, created lazily)"""
+def side_stream(device=None, which=0):
+    """auxiliary HIP streams (per device, created lazily): 0 = weight-gradient GEMMs forked off the dX chain,
+    1 / 2 = whole encoder passes overlapped by runtime.FusedRuntime"""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
-    if dev not in _SIDE:
-        _SIDE[dev] = torch.cuda.Stream(device=dev)
-    return _SIDE[dev]
+    if (dev, which) not in _SIDE:
+        _SIDE[(dev, which)] = torch.cuda.Stream(device=dev)
+    return _SIDE[(dev, which)]
 
 
 CONCURRENT_DW = True      # fork dW GEMMs onto the side stream (they feed nothing but the optimiser)
@@ -422,7 +423,7 @@ def _bn_vec(slot, enc, m, which):
     return _ptr(getattr(slot, which), enc.bn_off[m.bn_index])
 
 
-def _finalize(plan, enc, slot, m, count, train=True):
+def _finalize(plan, enc, slot, m, count, train=True, update_running=True):
     o, tot = enc.bn_off[m.bn_index], slot.tot
     if not train:        # eval mode: affine from the running statistics (torch BatchNorm eval semantics)
         plan.call("gad_bn_eval_affine", enc.flat.p_gamma(m), enc.flat.p_beta(m), _ptr(enc.running_mean, o),
@@ -430,7 +431,7 @@ def _finalize(plan, enc, slot, m, count, train=True):
         return
     plan.call("gad_bn_finalize", _ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), 2 * tot, enc.flat.p_gamma(m),
               enc.flat.p_beta(m), m.n_out, hip.Dbl(count), BN_EPS, BN_MOMENTUM,
-              _ptr(enc.running_mean, o) if train else None, _ptr(enc.running_var, o) if train else None,
+              _ptr(enc.running_mean, o) if update_running else None, _ptr(enc.running_var, o) if update_running else None,
               _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "shift"), _bn_vec(slot, enc, m, "mean"),
               _bn_vec(slot, enc, m, "istd"))
 
@@ -472,8 +473,28 @@ def _layer_input(enc, slot, geo, s, l, action):
                 ones_col=enc.fc_mats[1].ones_col)
 
 
-def plan_encoder_forward(enc, slot, action=None, train=True):
-    """SA1 -> SA2 -> SA3 -> FC.  The last BN+ReLU is left to the consumer (scale/shift of fc[1])."""
+def plan_running_update(enc, slot):
+    """apply the momentum update of a forward pass planned with update_running=False (one launch, all layers)"""
+    plan = Plan()
+    if not hasattr(slot, "bn_count"):
+        cnt = torch.empty(slot.tot, dtype=torch.float32)
+        for s in range(3):
+            for m in enc.sa_mats[s]:
+                o = enc.bn_off[m.bn_index]
+                cnt[o:o + m.n_out] = float(slot.geo.counts[s])
+        for m in enc.fc_mats:
+            o = enc.bn_off[m.bn_index]
+            cnt[o:o + m.n_out] = float(slot.B)
+        slot.bn_count = cnt.to(slot.mean.device)
+    plan.call("gad_bn_running_update", slot.mean, slot.istd, slot.bn_count, slot.tot, BN_EPS, BN_MOMENTUM,
+              enc.running_mean, enc.running_var)
+    return plan
+
+
+def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True):
+    """SA1 -> SA2 -> SA3 -> FC.  The last BN+ReLU is left to the consumer (scale/shift of fc[1]).
+    update_running=False: batch statistics only; the running-statistics momentum update is applied later by
+    plan_running_update (for a pass that overlaps another pass of the same network on a second stream)."""
     geo = slot.geo
     plan = Plan()
     plan.zero(slot.stats)
@@ -487,7 +508,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True):
                           stat_stride=2 * tot, **_layer_input(enc, slot, geo, s, l, action))
             plan.call_struct("gad_gemm_fwd", a)
             plan.tag_last("fwd.sa%d.l%d" % (s + 1, l + 1))
-            _finalize(plan, enc, slot, m, geo.counts[s], train)
+            _finalize(plan, enc, slot, m, geo.counts[s], train, update_running)
         m = enc.sa_mats[s][2]
         plan.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, _bn_vec(slot, enc, m, "scale"),
                   _bn_vec(slot, enc, m, "shift"), r["off"], r["G"], slot.F[s], slot.argmax[s])
@@ -498,7 +519,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True):
                       **_layer_input(enc, slot, geo, 3, l, action))
         plan.call_struct("gad_gemm_fwd", a)
         plan.tag_last("fwd.fc%d" % (l + 1))
-        _finalize(plan, enc, slot, m, float(slot.B), train)
+        _finalize(plan, enc, slot, m, float(slot.B), train, update_running)
     return plan
 
 

@@ -17,6 +17,9 @@ BATCH_KEYS = ("point_state_batch", "next_point_state_batch", "action_batch", "ex
               "return_batch", "mask_batch", "time_batch", "goal_batch", "expert_flag_batch", "perturb_flag_batch")
 
 
+OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on side streams
+
+
 class FusedRuntime(object):
     def __init__(self, agent, B, NP, device=None):
         dev = self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -81,6 +84,7 @@ class FusedRuntime(object):
         self.allreduce = None            # callable(list of flat grad tensors)
         self.inv_n = None
         self.resident = False            # True: the static batch buffers were filled on the device
+        self._ev = [torch.cuda.Event() for _ in range(4)]
 
     # ------------------------------------------------------------------ plans over static buffers
     def _build_plans(self):
@@ -107,7 +111,8 @@ class FusedRuntime(object):
         t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
         t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
         t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.action_scale, self.pi_t, None)
-        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next)
+        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES)
+        P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
         P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
         cb = Plan()
@@ -186,18 +191,45 @@ class FusedRuntime(object):
         else:
             self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
         self.scal.zero_()
-        self.geo.run(d["point_state_batch"])
-        self.geo_next.run(d["next_point_state_batch"])
-        # ---- critic phase
-        P["c_fwd"].run()
-        P["t1"].run()
+        main = torch.cuda.current_stream()
         idx = int((ag.update_step > np.array(ag.mix_milestones)).sum())
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
+        # ---- critic phase.  The TD target chain (encoder(next) -> target policy -> value encoder(next, a') -> target
+        # critic) and the value pass on the current state are independent: the latter runs on a second stream.
+        # Both go through value_encoder's BatchNorms; the reference runs the current-state pass first
+        # (core/ddpg.py:145-152, then target_value() inside compute_critic_loss), so the target chain's value-encoder
+        # pass only computes batch statistics and its running-statistics momentum update is applied after the join.
+        if OVERLAP_PASSES:
+            s1 = engine.side_stream(which=1)
+            self._ev[0].record(main)
+            s1.wait_event(self._ev[0])
+            with torch.cuda.stream(s1):
+                self.geo.run(d["point_state_batch"])
+                P["c_fwd"].run()
+            self.geo_next.run(d["next_point_state_batch"])
+        else:
+            self.geo.run(d["point_state_batch"])
+            self.geo_next.run(d["next_point_state_batch"])
+            P["c_fwd"].run()
+        P["t1"].run()
         hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), self.a_next)
         P["t2"].run()
+        if OVERLAP_PASSES:
+            self._ev[1].record(s1)
+            main.wait_event(self._ev[1])
+            P["t2_run"].run()
         hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
                  d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
                  self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
+        if OVERLAP_PASSES:
+            # the policy forward of the actor phase needs nothing from the critic update: overlap it with the critic
+            # backward + Adam (its encoder BatchNorms come after t1's in stream order, as in the reference)
+            s2 = engine.side_stream(which=2)
+            self._ev[2].record(main)
+            s2.wait_event(self._ev[2])
+            with torch.cuda.stream(s2):
+                P["p_fwd"].run()
+                hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
         P["c_bwd"].run()
         self._reduce([self.cr.flat, self.venc.flat])
         self.clip_sumsq.zero_()
@@ -205,8 +237,12 @@ class FusedRuntime(object):
         self._adam(self.venc.flat, ag.state_feat_val_encoder_optim)
         self._adam(self.cr.flat, ag.critic_optim, clip=self.clip_sumsq)
         # ---- actor phase
-        P["p_fwd"].run()
-        hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
+        if OVERLAP_PASSES:
+            self._ev[3].record(s2)
+            main.wait_event(self._ev[3])
+        else:
+            P["p_fwd"].run()
+            hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
         g_pi = None
         if policy_step:
             P["v_fwd"].run()

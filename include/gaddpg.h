@@ -165,6 +165,13 @@ int gad_bn_finalize(const double* stat_sum, const double* stat_sq, int stat_stri
                     float* running_mean /*nullable*/, float* running_var /*nullable*/,
                     float* scale, float* shift, float* mean, float* istd, void* stream);
 /* eval-mode: scale/shift from the running statistics */
+/* momentum update of the running statistics from SAVED batch statistics (mean, istd = 1/sqrt(var_biased+eps)) of a
+ * pass whose gad_bn_finalize ran with running_mean = running_var = NULL (a pass overlapped with another pass of the
+ * same network on a second stream: the updates are then applied in the reference's order).  count: (C) rows behind
+ * each channel's statistics.                                                                                      */
+int gad_bn_running_update(const float* mean, const float* istd, const float* count, int C, float eps,
+                          float momentum, float* running_mean, float* running_var, void* stream);
+
 int gad_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, int C, float eps, float* scale, float* shift,
                        void* stream);
