@@ -163,9 +163,16 @@ def main():
     roof = None
     if kernel_ms:
         ach = flops / (kernel_ms * 1e-3)
-        roof = {"bound": "mfma", "kernel": "gemm_fwd_kernel (%s: shared-MLP layer, FP32 MFMA)" % args.roofline_tag,
+        # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
+        # correction of MI355X_MICROARCH.md + WRITE_SIZE), see profiles/README.md; null when not collected for the tag
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(args.roofline_tag, {}).get("bytes_per_launch")
+        kname = "gemm_fwd_stream_kernel" if args.roofline_tag.startswith("fwd.sa1") else "gemm_fwd_kernel"
+        roof = {"bound": "mfma", "kernel": "%s (%s: shared-MLP layer, FP32 MFMA)" % (kname, args.roofline_tag),
                 "achieved": ach / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK,
-                "traffic": None, "launch_ms": kernel_ms, "launches_per_step": n_launch,
+                "traffic": traffic, "launch_ms": kernel_ms, "launches_per_step": n_launch,
                 "algorithmic_flops_per_launch": flops,
                 "executed_frac": ach / FP32_MFMA_PEAK * n_rows / dense_rows,
                 "dedup_rows": n_rows, "dense_rows": int(dense_rows)}
