@@ -1136,15 +1136,9 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
                            st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                              \
     } while (0)
 #define LAUNCH_DX(WM, WN, TM, TN) do { if (vec) LAUNCH_DX2(WM, WN, TM, TN, true); else LAUNCH_DX2(WM, WN, TM, TN, false); } while (0)
-    if (rows <= 16384) {
-        if (kv <= 32) LAUNCH_DX(4, 1, 1, 1); else LAUNCH_DX(2, 2, 1, 1);
-    } else if (kv <= 32) {
-        LAUNCH_DX(4, 1, 1, 1);
-    } else if (kv <= 64) {
-        LAUNCH_DX(4, 1, 1, 2);
-    } else {
-        LAUNCH_DX(2, 2, 2, 2);
-    }
+    // 64 x 64 tiles (or 128 x 32 for narrow outputs): measured best on the whole step, also for the 2e5-row SA1
+    // layers (128 x 64: -3.7 % steps/s, 128 x 128: -16 %)
+    if (kv <= 32) LAUNCH_DX(4, 1, 1, 1); else LAUNCH_DX(2, 2, 1, 1);
 #undef LAUNCH_DX
 #undef LAUNCH_DX2
     GAD_CHECK_LAUNCH("gemm_dx");
@@ -1321,7 +1315,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         const int tn_ = gad_cdiv(nmax, BM), tk_ = gad_cdiv(k_used, BN);                                    \
         splits = a->row_splits;                                                                            \
         if (splits <= 0) {                                                                                 \
-            splits = gad_cdiv(512, tn_ * tk_ * gr.n);                                                      \
+            splits = gad_cdiv(512, tn_ * tk_ * gr.n);                     /* 256 / 1024 / 2048 measured slower */                                                    \
             const int by_rows = gad_cdiv(rows, 8 * KT);                                                    \
             if (splits > by_rows) splits = by_rows;                                                        \
             if (splits < 1) splits = 1;                                                                    \
