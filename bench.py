@@ -48,9 +48,38 @@ def dense_layer_macs(tag, c_in):
     return rows * k * n
 
 
+def sa_kernel_hbm(iters=30):
+    """BASELINE.json's second metric ("SA-kernel HBM GB/s") on configs[3] (B=128, N=4096, npoint 512, radius 0.1,
+    nsample 64, C=4): the materialising ball-query + group kernel behind pointnet2_utils.query_and_group -- the
+    HBM-bound member of the set-abstraction family (SURVEY 8d "config 4a": 148.9 MB algorithmic bytes per call: points in,
+    indices + grouped (B,7,512,64) tensor out).  HIP events on the launching stream."""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
+    B, N, M, S, C = 128, 4096, 512, 64, 4
+    g = torch.Generator(device="cuda").manual_seed(SEED)
+    xyz = torch.rand(B, N, 3, device="cuda", generator=g)
+    feats = torch.randn(B, C, N, device="cuda", generator=g)
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), pu.furthest_point_sample(xyz, M)).transpose(1, 2).contiguous()
+    for _ in range(3):
+        pu.query_and_group(0.1, S, xyz, new_xyz, feats)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        pu.query_and_group(0.1, S, xyz, new_xyz, feats)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = B * N * (3 + C) * 4 + B * M * S * 4 + B * M * S * (3 + C) * 4
+    gbps = nbytes / (ms * 1e-3) / 1e9
+    return {"kernel": "query_and_group_kernel (configs[3]: B=128, N=4096, npoint=512, r=0.1, nsample=64, C=4)", "bound": "hbm",
+            "algorithmic_bytes": nbytes, "launch_ms": ms, "achieved": gbps, "peak": 8000.0, "unit": "GB/s", "frac": gbps / 8000.0,
+            "note": "launch_ms includes the output allocation of the reference-compatible wrapper"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-sa-kernel", action="store_true", help="skip the configs[3] SA-kernel HBM measurement")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--batch", type=int, default=256)
@@ -198,6 +227,33 @@ def main():
             agent.update_parameters(b, agent.update_step, i)
         torch.cuda.synchronize()
         res["value_host_inclusive"] = n / (time.perf_counter() - t0)
+    if world == 1 and not args.no_sa_kernel:
+        # BASELINE.json's second metric, "SA-kernel HBM GB/s": the streaming set-abstraction forward kernels of THIS
+        # workload (HBM-bound: 0.5-0.75 KB moved per row against 8-16 kFLOP), HIP-event duration from a short extra
+        # pass that brackets every tagged launch, bytes = the committed PMC traffic (profiles/r01_traffic.json) and,
+        # next to it, the algorithmic bytes (rows x (c_in + c_out) x 4); plus the materialising configs[3] kernel.
+        engine.TIMING.update(enabled=True, tag="*", events=[])
+        for i in range(10):
+            step(args.warmup + args.steps + i)
+        torch.cuda.synchronize()
+        engine.TIMING["enabled"] = False
+        by_tag = {}
+        for e0, e1, tag in engine.TIMING["events"]:
+            by_tag.setdefault(tag, []).append(e0.elapsed_time(e1))
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        n1 = int(rt.geo.rows[0]["n"].item())
+        sa = {}
+        for tag, cin, cout in (("fwd.sa1.l2", 64, 64), ("fwd.sa1.l3", 64, 128)):
+            if tag in by_tag:
+                ms = float(np.mean(by_tag[tag]))
+                alg = n1 * (cin + cout) * 4.0
+                pmc = tj.get(tag, {}).get("bytes_per_launch")
+                sa[tag] = {"kernel": "gemm_fwd_stream_kernel", "bound": "hbm", "launch_ms": ms, "rows": n1,
+                           "algorithmic_bytes": alg, "traffic": pmc, "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0,
+                           "unit": "GB/s", "frac": alg / (ms * 1e-3) / 8e12}
+        sa["query_and_group"] = sa_kernel_hbm()
+        res["sa_kernel_hbm"] = sa
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, host_batches[0], np.random.default_rng(3).random((B, 6)).astype(np.float32))
     else:

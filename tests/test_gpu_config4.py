@@ -1,0 +1,104 @@
+"""BASELINE.json configs[3] (large-cloud stress: batch 128, N = 4096, two SA layers with radii 0.1 / 0.2; SURVEY 8d
+"config 4"): stand-alone PointnetSAModule stack through libgaddpg.
+
+* small batch: the whole stack against the CPU oracle (train-mode and eval-mode BatchNorm), 1e-4 relative;
+* full size (B = 128): size-independent properties -- ball-query indices ascending / inside the radius / padded with
+  the first hit, query_and_group bit-equal to gather-by-index, eval-mode outputs of a few samples equal to the oracle
+  run on just those samples (eval BatchNorm is per-sample independent), and de-duplication invariance (the pooled
+  feature of a neighbourhood does not depend on how often a neighbour is repeated)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+SEED = 41
+SA = (dict(npoint=512, radius=0.1, nsample=64, mlp=[4, 64, 64, 128]),
+      dict(npoint=128, radius=0.2, nsample=128, mlp=[128, 128, 128, 256]))
+
+
+def _stacks():
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    from oracle.pointnet2_ops import pointnet2_modules as opm
+    from oracle.detfill import fill_module_
+    mine = [fill_module_(pm.PointnetSAModule(**kw), "sa%d" % i, SEED) for i, kw in enumerate(SA)]
+    ref = [fill_module_(opm.PointnetSAModule(**kw), "sa%d" % i, SEED) for i, kw in enumerate(SA)]
+    return mine, ref
+
+
+def _cloud(B, N, seed):
+    rng = np.random.default_rng(seed)
+    xyz = torch.tensor(rng.random((B, N, 3)), dtype=torch.float32)                 # uniform in the unit cube
+    feats = torch.tensor(rng.normal(size=(B, 4, N)), dtype=torch.float32)
+    return xyz, feats
+
+
+def _run(stack, xyz, feats):
+    with torch.no_grad():
+        x1, f1 = stack[0](xyz, feats)
+        x2, f2 = stack[1](x1, f1)
+    return x1, f1, x2, f2
+
+
+def test_two_layer_stack_matches_oracle_small_batch():
+    mine, ref = _stacks()
+    xyz, feats = _cloud(2, 4096, 0)
+    for train in (True, False):
+        for m in mine + ref:
+            m.train(train)
+        w = _run(ref, xyz, feats)
+        g = _run(mine, xyz.cuda(), feats.cuda())
+        np.testing.assert_array_equal(g[0].cpu().numpy(), w[0].numpy())          # sampled centroids: bit-exact
+        np.testing.assert_array_equal(g[2].cpu().numpy(), w[2].numpy())
+        tag = "train" if train else "eval"
+        assert_close(g[1].cpu().numpy(), w[1].numpy(), 1e-4, 1e-5 * float(w[1].abs().max()), "SA1 features (%s)" % tag)
+        assert_close(g[3].cpu().numpy(), w[3].numpy(), 1e-4, 1e-5 * float(w[3].abs().max()), "SA2 features (%s)" % tag)
+
+
+def test_full_size_properties():
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
+    B, N = 128, 4096
+    mine, ref = _stacks()
+    xyz, feats = _cloud(B, N, 1)
+    xyz_d, feats_d = xyz.cuda(), feats.cuda()
+    # --- index kernels at full size
+    fps = pu.furthest_point_sample(xyz_d, 512)
+    new_xyz = pu.gather_operation(xyz_d.transpose(1, 2).contiguous(), fps).transpose(1, 2).contiguous()
+    idx = pu.ball_query(0.1, 64, xyz_d, new_xyz)
+    i64 = idx.long()
+    assert int(fps.min()) >= 0 and int(fps.max()) < N and int(idx.min()) >= 0 and int(idx.max()) < N
+    assert all(len(set(row.tolist())) == 512 for row in fps[:4].cpu())             # FPS never repeats a point
+    nb = torch.gather(xyz_d.unsqueeze(1).expand(B, 512, N, 3), 2, i64.unsqueeze(-1).expand(B, 512, 64, 3))
+    d2 = ((nb - new_xyz.unsqueeze(2)) ** 2).sum(-1)
+    assert float(d2.max()) < 0.1 ** 2 * (1 + 1e-5)                                 # every neighbour inside the ball
+    first = i64[:, :, :1]
+    asc = (i64[:, :, 1:] > i64[:, :, :-1]) | (i64[:, :, 1:] == first)              # ascending, then padded with the first hit
+    assert bool(asc.all())
+    # --- materialising query_and_group == gather by the indices, bit for bit (config 4a kernel)
+    qidx, grouped = pu.query_and_group(0.1, 64, xyz_d, new_xyz, feats_d)
+    assert torch.equal(qidx, idx)
+    sub = slice(0, 8)
+    want_f = torch.gather(feats_d[sub].unsqueeze(2).expand(8, 4, 512, N), 3, i64[sub].unsqueeze(1).expand(8, 4, 512, 64))
+    assert torch.equal(grouped[sub, 3:], want_f)
+    want_x = (nb[sub] - new_xyz[sub].unsqueeze(2)).permute(0, 3, 1, 2)
+    assert torch.equal(grouped[sub, :3], want_x)
+    # --- fused stack at full size, eval-mode BatchNorm: samples are independent -> oracle on 2 of the 128 samples
+    for m in mine + ref:
+        m.eval()
+    g = _run(mine, xyz_d, feats_d)
+    assert g[3].shape == (B, 256, 128) and bool(torch.isfinite(g[3]).all())
+    pick = [5, 77]
+    w = _run(ref, xyz[pick], feats[pick])
+    assert_close(g[1][pick].cpu().numpy(), w[1].numpy(), 1e-4, 1e-5 * float(w[1].abs().max()), "SA1 features, samples 5/77")
+    assert_close(g[3][pick].cpu().numpy(), w[3].numpy(), 1e-4, 1e-5 * float(w[3].abs().max()), "SA2 features, samples 5/77")
+    # --- de-duplication invariance: nsample 64 vs 256 pads the same neighbourhoods with more repeats of the first hit;
+    # as long as no ball holds more than 64 points the pooled features cannot change
+    cnt = (i64 != first).sum(-1) + 1
+    if int(cnt.max()) < 64:
+        from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+        from oracle.detfill import fill_module_
+        wide = fill_module_(pm.PointnetSAModule(npoint=512, radius=0.1, nsample=256, mlp=[4, 64, 64, 128]), "sa0", SEED).eval()
+        with torch.no_grad():
+            _, f_wide = wide(xyz_d[:16], feats_d[:16])
+        assert_close(f_wide.cpu().numpy(), g[1][:16].cpu().numpy(), 1e-6, 1e-6, "pooled features vs padding amount")
