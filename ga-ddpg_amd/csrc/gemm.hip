@@ -747,7 +747,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     }
 }
 
-static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1;
+static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
 }
@@ -758,6 +758,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
+    if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
     GAD_REQUIRE(false, GAD_ERR_SHAPE, "set_option: unknown option '%s'", name);
     return GAD_OK;
 }
@@ -994,6 +995,195 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// streaming dX for the SA1 layers (rows ~ 2e5, n_out in {64,128} reduced onto 64 input channels): the backward twin
+// of gemm_fwd_stream_kernel.  HBM-bound (1 KB per row: z and dY in, dY out, z_prev for the BatchNorm-backward sums).
+//   * W^T staged once per workgroup in LDS ([k][n_out+4]: B fragments are conflict-free ds_read_b128);
+//   * the A operand dZ[r][8j+4h..+3] is produced in registers from 16-byte loads of z and dY (or of the pooled
+//     arg-max / gradient pair), four k-groups per register chunk, the next chunk (or the next slab's first chunk)
+//     in flight during the current chunk's MFMAs;
+//   * epilogue: dY of the previous layer through buffer stores (SGPR row offsets) + that layer's dbeta / dgamma sums;
+//     its z_prev loads are issued before the last chunk's MFMAs.
+// ------------------------------------------------------------------------------------------------
+template <int NJ, int GM>
+__global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev,
+                                                                 int n_rows_static, const float* __restrict__ W, DxEpi e) {
+    constexpr int NO = 8 * NJ, PW = NO + 4, NCH = NJ / 4;
+    __shared__ __attribute__((aligned(16))) float Wt[64 * PW];
+    __shared__ __attribute__((aligned(16))) float vec[5 * NO];
+    __shared__ float red[2 * 8 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    {   // W (n_out x 64, row-major) -> W^T in LDS
+        constexpr int UW = NO * 16 / 512;
+        float4 wr[UW];
+#pragma unroll
+        for (int it = 0; it < UW; ++it) wr[it] = ldg4(W + (size_t)(it * 512 + tid) * 4);
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 512 + tid;
+            const int n = u >> 4, k4 = (u & 15) * 4;
+            Wt[(k4 + 0) * PW + n] = wr[it].x; Wt[(k4 + 1) * PW + n] = wr[it].y;
+            Wt[(k4 + 2) * PW + n] = wr[it].z; Wt[(k4 + 3) * PW + n] = wr[it].w;
+        }
+    }
+    for (int i = tid; i < NO; i += 512) {
+        vec[i] = d.scale[i]; vec[NO + i] = d.shift[i];
+        vec[2 * NO + i] = d.P[i]; vec[3 * NO + i] = d.Q[i]; vec[4 * NO + i] = d.S[i];
+    }
+    __syncthreads();
+    // previous layer's BatchNorm vectors of this lane's two output columns
+    float ps[2], pt[2], pm[2], pi[2];
+#pragma unroll
+    for (int tk = 0; tk < 2; ++tk) {
+        const int k = tk * 32 + l31;
+        ps[tk] = e.ps[k]; pt[tk] = e.pt[k]; pm[tk] = e.pm[k]; pi[tk] = e.pi[k];
+    }
+    const int n_slabs = (n_rows + 31) >> 5;
+    const int stride = gridDim.x * 8;
+    int slab = wave * gridDim.x + blockIdx.x;                 // wave-uniform; same dealing as the forward kernel
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * 64 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, n_rows_static * 64 * 4, 0x00020000);
+    const int glane = (4 * half * 64 + l31) * 4;
+
+    float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
+    float4 rz[2][4], rg[2][4];
+    int4 ra[2][4];
+    auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+    auto load_chunk = [&](int r, int grp, int c, int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned n = 8 * (4 * c + u) + 4 * half;
+            rz[buf][u] = ldg4(d.z + ((unsigned)r * NO + n));
+            if (GM == 0) {
+                rg[buf][u] = ldg4(d.G + ((unsigned)r * NO + n));
+            } else {
+                ra[buf][u] = *reinterpret_cast<const int4*>(d.argmax + ((unsigned)grp * NO + n));
+                rg[buf][u] = ldg4(d.dout + ((unsigned)grp * NO + n));
+            }
+        }
+    };
+    int r_cur = row_of(slab);
+    int grp_cur = GM == 1 ? d.row_grp[r_cur] : 0;
+    load_chunk(r_cur, grp_cur, 0, 0);
+    for (; slab < n_slabs; slab += stride) {
+        const int r_nxt = row_of(slab + stride);
+        const int grp_nxt = GM == 1 ? d.row_grp[r_nxt] : 0;
+        const float wrow = d.row_w ? d.row_w[r_cur] : 1.f;
+        __asm__ volatile("" ::: "memory");            // keep loop-invariant LDS reads inside the loop (registers)
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        float zp[2][16];
+        const int zrow = slab * 32 * 64 * 4;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            if (c + 1 < NCH) load_chunk(r_cur, grp_cur, c + 1, (c + 1) & 1);
+            else {
+                load_chunk(r_nxt, grp_nxt, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+                        zp[t][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                            zrsrc, glane + t * 128, zrow + ((v & 3) + 8 * (v >> 2)) * 256, 0));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int n = 8 * (4 * c + u) + 4 * half;
+                const float4 z = rz[c & 1][u];
+                float4 g = rg[c & 1][u];
+                if (GM == 1) {
+                    const int4 a = ra[c & 1][u];
+                    const int rr = slab * 32 + l31;                 // true row (clamped rows never match: rr >= n_rows > any arg-max)
+                    g.x = a.x == rr ? g.x : 0.f; g.y = a.y == rr ? g.y : 0.f;
+                    g.z = a.z == rr ? g.z : 0.f; g.w = a.w == rr ? g.w : 0.f;
+                }
+                const float4 sc = *reinterpret_cast<const float4*>(vec + n), sh = *reinterpret_cast<const float4*>(vec + NO + n);
+                g.x = fmaf(z.x, sc.x, sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(z.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
+                g.z = fmaf(z.z, sc.z, sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(z.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
+                const float4 P = *reinterpret_cast<const float4*>(vec + 2 * NO + n);
+                const float4 Q = *reinterpret_cast<const float4*>(vec + 3 * NO + n);
+                const float4 S = *reinterpret_cast<const float4*>(vec + 4 * NO + n);
+                float4 a4;
+                a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
+                a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
+                const float4 b0 = *reinterpret_cast<const float4*>(Wt + l31 * PW + n);
+                const float4 b1 = *reinterpret_cast<const float4*>(Wt + (32 + l31) * PW + n);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
+            }
+        }
+        // epilogue: dY of the previous layer + its BatchNorm-backward sums (rows past n_rows: the store is dropped by
+        // the buffer bounds only for the voffset part, so ragged slabs are predicated; their sums are masked)
+        const bool full = slab * 32 + 32 <= n_rows;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = acc_row(v, half);
+            const bool live = slab * 32 + row < n_rows;
+            const int rb = zrow + ((v & 3) + 8 * (v >> 2)) * 256;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float gv = acc[t][v];
+                if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), grsrc, glane + t * 128, rb, 0);
+                const float zv = zp[t][v];
+                const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
+                const float ga = act ? gv : 0.f;
+                sb[t] += ga;
+                sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
+            }
+        }
+        if (!full) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int rr = slab * 32 + acc_row(v, half);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (rr < n_rows) e.gout[(size_t)rr * 64 + t * 32 + l31] = acc[t][v];
+            }
+        }
+        r_cur = r_nxt;
+        grp_cur = grp_nxt;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float s0 = sb[t] + __shfl_xor(sb[t], 32, 64);
+        const float s1 = sg[t] + __shfl_xor(sg[t], 32, 64);
+        if (lane < 32) { red[wave * 64 + t * 32 + lane] = s0; red[(8 + wave) * 64 + t * 32 + lane] = s1; }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { s0 += red[w * 64 + tid]; s1 += red[(8 + w) * 64 + tid]; }
+        const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+        atomic_add_f64(e.dbeta + (size_t)rep * e.stat_stride + tid, (double)s0);
+        atomic_add_f64(e.dgamma + (size_t)rep * e.stat_stride + tid, (double)s1);
+    }
+}
+
+static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
+    if (!g_opt_dx_stream || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
+    if (a.n_rows < 32768 || a.epilogue != 0 || a.k_valid != 64 || a.Kp != 64 || a.gout_pitch != 64) return false;
+    if (a.n_out[0] != 64 && a.n_out[0] != 128) return false;
+    if (!a.prev_dbeta || a.zprev_pitch != 64) return false;
+    const gad_dz_src& d = a.dz;
+    if (!d.z || d.z_pitch != a.n_out[0] || !d.scale || !d.shift || !d.relu || !d.coefP || !d.coefQ || !d.coefS) return false;
+    if (d.gmode == 0 ? d.g_pitch != a.n_out[0] : d.c != a.n_out[0]) return false;
+    return (long long)a.n_rows * 128 * 4 < (1ll << 31);
+}
+
 // skinny dX for the small-M layers (same idea as gemm_fwd_skinny_kernel): one 32x32 tile of gout per workgroup, the 8
 // wavefronts split the reduction over the layer's output channels n.  A operand = dZ[r][8j+4h..+3] (16-byte loads of
 // z and G, BatchNorm-backward applied in registers), B operand = W[8j+4h+i][k0+lane%32]: four 4-byte loads per group
@@ -1119,6 +1309,16 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows, kv = a->k_valid;
     const bool vec = dz_vectorizable(a->dz, a->dz_off, a->n_out, a->n_groups);
+    if (dx_streamable(*a, vec)) {
+        const int slabs = gad_cdiv(rows, 32);
+        int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;
+#define LAUNCH_DXS(NJ, GM) hipLaunchKernelGGL((gemm_dx_stream_kernel<NJ, GM>), dim3(gx), dim3(512), 0, st, d, a->n_rows_dev, rows, a->W, e)
+        if (a->n_out[0] == 128) { if (a->dz.gmode == 0) LAUNCH_DXS(16, 0); else LAUNCH_DXS(16, 1); }
+        else { if (a->dz.gmode == 0) LAUNCH_DXS(8, 0); else LAUNCH_DXS(8, 1); }
+#undef LAUNCH_DXS
+        GAD_CHECK_LAUNCH("gemm_dx(stream)");
+        return GAD_OK;
+    }
     int nmax_dx = 0;
     for (int i = 0; i < a->n_groups; ++i) nmax_dx = a->n_out[i] > nmax_dx ? a->n_out[i] : nmax_dx;
     if (g_opt_dx_skinny && vec && e.mode == 0 && a->dz.gmode == 0 && !a->n_rows_dev && rows <= 1024 &&
