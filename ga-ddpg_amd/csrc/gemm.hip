@@ -68,7 +68,7 @@ __device__ __forceinline__ int x_bulk(const XSrc& x) { return x.mode == 0 ? x.c_
 //            action[grp/gps] (act_c) | 0..].
 // `tail` (wave-uniform): this K-tile reaches beyond the bulk columns.  `pt`: point index of the row.
 template <int XM>
-__device__ __forceinline__ XRaw x_raw(const XSrc& x, int r, bool valid, int zoff, int c, bool tail, int pt) {
+__device__ __forceinline__ XRaw x_raw(const XSrc& x, int r, bool valid, int zoff, int c, bool tail, int pt, int grp_pre = -1) {
     XRaw o;
     o.s = f4zero();
     const int rr = valid ? r : 0;
@@ -87,7 +87,7 @@ __device__ __forceinline__ XRaw x_raw(const XSrc& x, int r, bool valid, int zoff
         const int cc = c < x.feat_c ? c : x.feat_c - 4;
         o.a = ldg4(x.feat + (size_t)pt * x.feat_c + cc);
         if (tail) {
-            const int grp = x.row_grp[rr];
+            const int grp = grp_pre >= 0 ? grp_pre : x.row_grp[rr];
             const float* p = x.src_xyz + (size_t)pt * 3;
             float q0 = p[0], q1 = p[1], q2 = p[2];
             if (x.ctr_xyz) {
@@ -1396,6 +1396,25 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     XRaw rb[UB];
     const int bulk = XM == 0 ? x.c_in : x.feat_c;
     const bool tail = k0 + BN > bulk;
+    // row -> group / point indices are needed to ADDRESS the pooled-gradient and gather loads: fetched one K-tile
+    // ahead of the data they address, so a tile's load phase is one memory latency, not two chained ones
+    int gq[UA], pq[UB], xq[UB];
+    auto load_idx = [&](int rb0) {
+#pragma unroll
+        for (int it = 0; it < UA; ++it) {
+            int kk, i; unit_D<BM>(it * 256 + tid, kk, i);
+            const int r = rb0 + kk;
+            gq[it] = d.gmode != 0 ? d.row_grp[r < r_end ? r : 0] : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < UB; ++it) {
+            int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
+            const int r = rb0 + kk;
+            const int rr = r < r_end ? r : 0;
+            pq[it] = XM == 1 ? x.row_pt[rr] : 0;
+            xq[it] = (XM == 1 && tail) ? x.row_grp[rr] : -1;
+        }
+    };
     auto load_tile = [&](int rb0) {
 #pragma unroll
         for (int it = 0; it < UA; ++it) {
@@ -1403,20 +1422,17 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
             const int r = rb0 + kk;
             const bool ok = r < r_end;
             const int rr = ok ? r : 0;
-            int grp = 0;
-            if (d.gmode != 0) grp = d.row_grp[rr];
             wa[it] = d.row_w ? d.row_w[rr] : 1.f;
-            ra[it] = dz_raw<VEC>(d, r, ok, doff, n0 + i, n_out, grp);
+            ra[it] = dz_raw<VEC>(d, r, ok, doff, n0 + i, n_out, gq[it]);
         }
 #pragma unroll
         for (int it = 0; it < UB; ++it) {
             int kk, j; unit_D<BN>(it * 256 + tid, kk, j);
             const int r = rb0 + kk;
             const bool ok = r < r_end && (k0 + j < Kp);
-            int pt = 0;
-            if (XM == 1) pt = x.row_pt[ok ? r : 0];
-            rb[it] = x_raw<XM>(x, r, ok, zoff, k0 + j, tail, pt);
+            rb[it] = x_raw<XM>(x, r, ok, zoff, k0 + j, tail, pq[it], xq[it]);
         }
+        load_idx(rb0 + KT);
     };
     auto store_tile = [&](int rb0) {
 #pragma unroll
@@ -1433,6 +1449,7 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
             store_D<BN>(Bs, kk, j, x_finish<XM>(x, rb[it], ok, k0 + j, sv, tv));
         }
     };
+    load_idx(r_begin);
     load_tile(r_begin);
     for (int rb0 = r_begin; rb0 < r_end; rb0 += KT) {
         store_tile(rb0);
