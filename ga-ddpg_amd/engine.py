@@ -312,9 +312,10 @@ TIMING = {"enabled": False, "tag": None, "events": []}     # bench.py: HIP-event
 _DW_WS = {}
 
 
-def dw_workspace(device, elems=48 * 1024 * 1024):
-    """scratch for the weight-gradient split-K partial tiles (one per device; launches are stream-ordered)"""
-    key = str(device)
+def dw_workspace(device, elems=48 * 1024 * 1024, lane=0):
+    """scratch for the weight-gradient split-K partial tiles: one per device and per stream lane (launches of a
+    lane are stream-ordered; lane 0 = the main stream, 1.. = the dW side streams)"""
+    key = (str(device), lane)
     if key not in _DW_WS:
         _DW_WS[key] = torch.empty(elems, dtype=torch.float32, device=device)
     return _DW_WS[key]
@@ -332,7 +333,8 @@ def side_stream(device=None, which=0):
     return _SIDE[(dev, which)]
 
 
-CONCURRENT_DW = True      # fork dW GEMMs onto the side stream (they feed nothing but the optimiser)
+CONCURRENT_DW = True      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
+DW_LANES = 1              # number of dW side streams (2 measured no faster: the overlapped kernels already saturate the GPU) the layers alternate between (each with its own partial workspace)
 
 
 class Plan(object):
@@ -366,11 +368,11 @@ class Plan(object):
     def fn(self, f):
         self.calls.append(("py", f, None, None, False))
 
-    def fork(self):
-        self.calls.append(("fork", None, torch.cuda.Event(), None, False))
+    def fork(self, k=1):
+        self.calls.append(("fork", None, torch.cuda.Event(), None, k))
 
-    def join(self):
-        self.calls.append(("join", None, torch.cuda.Event(), None, False))
+    def join(self, k=1):
+        self.calls.append(("join", None, torch.cuda.Event(), None, k))
 
     def extend(self, other):
         n = len(self.calls)
@@ -383,26 +385,27 @@ class Plan(object):
         import ctypes as C
         main = torch.cuda.current_stream()
         st = hip.stream()
-        side = side_st = None
+        sides = {}            # lane -> (torch stream, raw handle); dW lanes use side_stream(which = 10 + lane)
         timed = TIMING["enabled"]
-        for i, (name, f, args, s, on_side) in enumerate(self.calls):
+        for i, (name, f, args, s, lane) in enumerate(self.calls):
             if name == "fork":
-                if side is None:
-                    side = side_stream()
-                    side_st = C.c_void_p(side.cuda_stream)
+                if lane not in sides:
+                    so = side_stream(which=10 + lane)
+                    sides[lane] = (so, C.c_void_p(so.cuda_stream))
                 args.record(main)
-                side.wait_event(args)
+                sides[lane][0].wait_event(args)
                 continue
             if name == "join":
-                if side is not None:
-                    args.record(side)
+                if lane in sides:
+                    args.record(sides[lane][0])
                     main.wait_event(args)
                 continue
+            lane = int(lane)
             ev = None
             if timed and i in self.tags and TIMING["tag"] in (self.tags[i], "*"):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record(side if on_side else main)
-            q = side_st if on_side else st
+                ev[0].record(sides[lane][0] if lane else main)
+            q = sides[lane][1] if lane else st
             if name == "zero":
                 args.zero_()
             elif name == "py":
@@ -412,7 +415,7 @@ class Plan(object):
             else:
                 hip.check(f(*(args + [q])), name)
             if ev is not None:
-                ev[1].record(side if on_side else main)
+                ev[1].record(sides[lane][0] if lane else main)
                 TIMING["events"].append(ev + (self.tags[i],))
 
 
@@ -580,6 +583,8 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         plan.call_struct("gad_gemm_dx", a)
         plan.tag_last("dx.%s" % rows_kw.get("name", "fc"))
 
+    dw_lanes = []
+
     def dw(s, l, dz, m, action):
         if not want_dw:
             return
@@ -587,11 +592,13 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **_layer_input(enc, slot, geo, s, l, action))
         a.dz = dz
         a.gacc = _ptr(enc.flat.gacc)
-        ws = dw_workspace(enc.flat.device)
+        lane = 1 + (len(dw_lanes) % DW_LANES) if CONCURRENT_DW else 0       # alternate the dW side streams
+        dw_lanes.append(lane)
+        ws = dw_workspace(enc.flat.device, lane=lane)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
-        if CONCURRENT_DW:
-            plan.fork()
-        plan.call_struct("gad_gemm_dw", a, side=CONCURRENT_DW)
+        if lane:
+            plan.fork(lane)
+        plan.call_struct("gad_gemm_dw", a, side=lane)
         plan.tag_last("dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1))
 
     # ---- FC head ----
@@ -635,8 +642,8 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
             plan.zero(slot.daction)
             dx(rows_kw, d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),
                daction=_ptr(slot.daction), act_c=6, grp_per_sample=geo.M1)
-    if want_dw and CONCURRENT_DW:
-        plan.join()
+    for lane in sorted(set(dw_lanes) - {0}):
+        plan.join(lane)
     return plan
 
 

@@ -28,3 +28,53 @@ def main(path, steps):
 
 if __name__ == "__main__":
     main(sys.argv[1], int(sys.argv[2]))
+
+
+def streams(path, steps):
+    """per-queue busy time (which HIP stream is the long pole of a step)"""
+    db = glob.glob(path + "/**/*.db", recursive=True)[0]
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
+    key = "stream_id" if "stream_id" in cols else "queue_id"
+    t0, t1 = c.execute("select min(start), max(end) from %s" % kd).fetchone()
+    print("span %.3f ms, %d steps -> %.3f ms / step; busy per %s:" % ((t1 - t0) / 1e6, steps, (t1 - t0) / 1e6 / steps, key))
+    for q, n, busy in c.execute("select %s, count(*), sum(end-start) from %s group by %s order by 3 desc" % (key, kd, key)):
+        print("   %s %-6s launches %6d  busy %.3f ms / step" % (key, q, n, busy / 1e6 / steps))
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "streams":
+    streams(sys.argv[1], int(sys.argv[2]))
+
+
+def gaps(path, steps):
+    """idle time between consecutive kernels of the busiest stream, split into launch gaps (< 10 us) and waits"""
+    db = glob.glob(path + "/**/*.db", recursive=True)[0]
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
+    key = "stream_id" if "stream_id" in cols else "queue_id"
+    q = c.execute("select %s from %s group by %s order by sum(end-start) desc limit 1" % (key, kd, key)).fetchone()[0]
+    rows = c.execute("select start, end from %s where %s=? order by start" % (kd, key), (q,)).fetchall()
+    small = big = 0.0
+    nsmall = nbig = 0
+    hist = {}
+    for (s0, e0), (s1, e1) in zip(rows[:-1], rows[1:]):
+        g = (s1 - e0) / 1e3
+        if g < 0:
+            continue
+        b = 1 if g < 1 else 2 if g < 2 else 4 if g < 4 else 10 if g < 10 else 50 if g < 50 else 1000
+        hist[b] = hist.get(b, 0) + 1
+        if g < 10:
+            small += g; nsmall += 1
+        else:
+            big += g; nbig += 1
+    print("stream %s: %d kernels; launch gaps (<10 us): %d, %.3f ms / step; waits (>=10 us): %d, %.3f ms / step" % (
+        q, len(rows), nsmall, small / 1e3 / steps, nbig, big / 1e3 / steps))
+    print("gap histogram (upper bound us -> count per step):", {k: round(v / steps, 1) for k, v in sorted(hist.items())})
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "gaps":
+    gaps(sys.argv[1], int(sys.argv[2]))
