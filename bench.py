@@ -227,6 +227,16 @@ def main():
             agent.update_parameters(b, agent.update_step, i)
         torch.cuda.synchronize()
         res["value_host_inclusive"] = n / (time.perf_counter() - t0)
+        # same loop fed by the GPU-resident replay mirror: indices drawn on the host with the
+        # reference's arithmetic, gather in HBM -- the rate a training loop sees without the 17 MB/step host gather
+        from ga_ddpg_amd.core.device_replay import DeviceReplay
+        dmem = DeviceReplay(mem)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            agent.update_parameters(dmem.sample_lazy(B, rng2), agent.update_step, i)
+        torch.cuda.synchronize()
+        res["value_device_replay"] = n / (time.perf_counter() - t0)
     if world == 1 and not args.no_sa_kernel:
         # BASELINE.json's second metric, "SA-kernel HBM GB/s": the streaming set-abstraction forward kernels of THIS
         # workload (HBM-bound: 0.5-0.75 KB moved per row against 8-16 kFLOP), HIP-event duration from a short extra

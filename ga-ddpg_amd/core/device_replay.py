@@ -1,0 +1,139 @@
+"""GPU-resident mirror of the replay buffer ("the step before the path").
+
+The reference samples a minibatch on the host (core/replay_memory.py:166-176: fancy-index every array, two
+(B,4,1030) float64 gathers = 17 MB per step) and ships 22 arrays to the device (core/agent.py:211-240).  At > 200
+update steps/s that costs more than the update itself.  `DeviceReplay` keeps the arrays the update step reads in
+HBM as float32 and performs the gather there; the INDEX arithmetic stays on the host and is the reference's,
+so a minibatch drawn here equals `BaseMemory.sample` with the same `batch_idx` (tests/test_gpu_modules.py:
+test_device_replay_matches_host_sampling).
+
+    mem  = BaseMemory(...); mem.load(...) / filled by the environment loop
+    dmem = DeviceReplay(mem)                     # one upload (cap x 4 x 1030 float32 for the clouds)
+    batch = dmem.sample(256, rng)                # dict of CUDA tensors + host-side mask counts
+    agent.update_parameters(batch, agent.update_step, k)
+
+`refresh(lo, hi)` re-uploads a slice after the host buffer was written to (online training).
+"""
+import numpy as np
+import torch
+
+from .. import hip
+
+_ROW_KEYS = (("action", "action_batch"), ("expert_action", "expert_action_batch"), ("reward", "reward_batch"),
+             ("returns", "return_batch"), ("terminal", "mask_batch"), ("goal", "goal_batch"),
+             ("expert_flags", "expert_flag_batch"), ("perturb_flags", "perturb_flag_batch"))
+
+
+class _Shape(object):
+    """placeholder that only answers `.shape` (the agent sizes its runtime from point_state_batch.shape)"""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class DeviceReplay(object):
+    def __init__(self, memory, device=None):
+        self.memory = memory
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("DeviceReplay needs a GPU (the update path has no CPU fallback)")
+        cap = memory.point_state.shape[0]
+        self.cap = cap
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.point_state = torch.empty(tuple(memory.point_state.shape), **f32)
+        self.rows = {src: torch.empty(tuple(getattr(memory, src).shape), **f32) for src, _ in _ROW_KEYS}
+        self.timestep = torch.empty(cap, **f32)
+        self._stage = {}
+        self.refresh()
+
+    # ------------------------------------------------------------------ host -> device
+    def refresh(self, lo=0, hi=None):
+        """(re-)upload transitions [lo, hi) of the host buffer"""
+        m = self.memory
+        hi = self.cap if hi is None else hi
+        if hi <= lo:
+            return
+        sl = slice(lo, hi)
+        # float64 -> float32 on the host in bounded chunks (the cloud array is 33 KB per transition)
+        step = 4096
+        for a in range(lo, hi, step):
+            b = min(a + step, hi)
+            self.point_state[a:b].copy_(torch.from_numpy(np.ascontiguousarray(m.point_state[a:b], dtype=np.float32)))
+        for src, _ in _ROW_KEYS:
+            self.rows[src][sl].copy_(torch.from_numpy(np.ascontiguousarray(getattr(m, src)[sl], dtype=np.float32)))
+        self.timestep[sl].copy_(torch.from_numpy(np.ascontiguousarray(m.timestep[sl], dtype=np.float32)))
+
+    def _indices(self, name, idx):
+        """pinned staging -> device int64 index vector"""
+        n = idx.shape[0]
+        st = self._stage.get((name, n))
+        if st is None:
+            st = (torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n, dtype=torch.int64, device=self.device))
+            self._stage[(name, n)] = st
+        st[0].numpy()[:] = idx
+        st[1].copy_(st[0], non_blocking=True)
+        return st[1]
+
+    # ------------------------------------------------------------------ sampling
+    def sample_lazy(self, batch_size, rng=None, batch_idx=None):
+        """like sample(), but nothing is gathered yet: the returned dict carries the device index vectors and
+        `FusedRuntime.upload` fills its static input buffers with ONE gad_replay_gather launch (no intermediate
+        tensors, no device-to-device copies).  `point_state_batch` is a shape-only placeholder."""
+        m = self.memory
+        if batch_idx is None:
+            batch_idx = m.draw_indices(batch_size, rng)
+        batch_idx = np.asarray(batch_idx, dtype=np.int64)
+        nxt = m.next_indices(batch_idx)
+        end = np.asarray(m.episode_map[batch_idx], dtype=np.int64)
+        B = batch_idx.shape[0]
+        return {"replay_gather": self, "idx": self._indices("i", batch_idx), "nxt": self._indices("n", nxt),
+                "end": self._indices("e", end), "batch_idx": np.uint8(batch_idx),
+                "point_state_batch": _Shape((B,) + tuple(self.point_state.shape[1:])),
+                "mask_counts": self._mask_counts(batch_idx)}
+
+    def gather_into(self, lazy, dbuf):
+        """fill the runtime's static batch buffers (dict of CUDA float32 tensors) from a sample_lazy() handle"""
+        a = hip.ReplayGatherArgs()
+        a.B = int(lazy["idx"].shape[0])
+        a.cloud_elems = int(self.point_state.shape[1] * self.point_state.shape[2])
+        a.idx, a.nxt, a.end = hip.ptr(lazy["idx"]), hip.ptr(lazy["nxt"]), hip.ptr(lazy["end"])
+        a.point_state = hip.ptr(self.point_state)
+        for src in ("action", "expert_action", "goal", "reward", "returns", "terminal", "expert_flags", "perturb_flags"):
+            setattr(a, src, hip.ptr(self.rows[src]))
+        a.timestep = hip.ptr(self.timestep)
+        a.out_point, a.out_next_point = hip.ptr(dbuf["point_state_batch"]), hip.ptr(dbuf["next_point_state_batch"])
+        for dst, key in (("out_action", "action_batch"), ("out_expert_action", "expert_action_batch"), ("out_goal", "goal_batch"),
+                         ("out_reward", "reward_batch"), ("out_return", "return_batch"), ("out_mask", "mask_batch"),
+                         ("out_time", "time_batch"), ("out_time_m1", "time_m1"), ("out_expert_flag", "expert_flag_batch"),
+                         ("out_perturb_flag", "perturb_flag_batch")):
+            setattr(a, dst, hip.ptr(dbuf[key]))
+        hip.call_struct("gad_replay_gather", a)
+
+    def _mask_counts(self, batch_idx):
+        m = self.memory
+        ret = np.asarray(m.returns[batch_idx]).reshape(-1)
+        exp = np.asarray(m.expert_flags[batch_idx]).reshape(-1)
+        per = np.asarray(m.perturb_flags[batch_idx]).reshape(-1)
+        reward, expert = ret > 0, exp >= 1
+        return np.array([(per < 1).sum(), reward.sum(), expert.sum(), (~(reward & expert)).sum()], dtype=np.float64)
+
+    def sample(self, batch_size, rng=None, batch_idx=None):
+        """the update step's 11 arrays as CUDA float32 tensors (runtime.BATCH_KEYS layout) + `batch_idx` and the
+        host-side `mask_counts` the data-parallel path all-reduces.  Index semantics: BaseMemory.draw_indices /
+        next_indices / post_process_batch (reference core/replay_memory.py:166-176,251-272)."""
+        m = self.memory
+        if batch_idx is None:
+            batch_idx = m.draw_indices(batch_size, rng)
+        batch_idx = np.asarray(batch_idx, dtype=np.int64)
+        nxt = m.next_indices(batch_idx)
+        end = np.asarray(m.episode_map[batch_idx], dtype=np.int64)
+        d_idx, d_nxt, d_end = self._indices("i", batch_idx), self._indices("n", nxt), self._indices("e", end)
+        out = {"point_state_batch": self.point_state.index_select(0, d_idx),
+               "next_point_state_batch": self.point_state.index_select(0, d_nxt)}
+        for src, dst in _ROW_KEYS:
+            out[dst] = self.rows[src].index_select(0, d_idx)
+        # remaining steps to the end of the episode (post_process_batch)
+        out["time_batch"] = self.timestep.index_select(0, d_end) + 1.0 - self.timestep.index_select(0, d_idx)
+        out["batch_idx"] = np.uint8(batch_idx)
+        out["mask_counts"] = self._mask_counts(batch_idx)
+        return out

@@ -153,3 +153,49 @@ extern "C" int gad_pack_params(const float* p, const int32_t* m2p, int n, float*
     GAD_CHECK_LAUNCH("pack_params");
     return GAD_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// replay minibatch gather (include/gaddpg.h section F).  HBM-bound: 2 x B x 16.5 KB of cloud rows, copied as
+// 8-byte pairs (a cloud row is 4120 floats: 8-byte but not 16-byte aligned); blockIdx.y = sample, the first
+// workgroup of each sample also moves its scalar / short-vector fields.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void replay_gather_kernel(gad_replay_gather_args a) {
+    const int b = blockIdx.y;
+    const long long i = a.idx[b], n = a.nxt[b];
+    const int pairs = a.cloud_elems / 2;
+    const float2* s0 = reinterpret_cast<const float2*>(a.point_state + (size_t)i * a.cloud_elems);
+    const float2* s1 = reinterpret_cast<const float2*>(a.point_state + (size_t)n * a.cloud_elems);
+    float2* d0 = reinterpret_cast<float2*>(a.out_point + (size_t)b * a.cloud_elems);
+    float2* d1 = reinterpret_cast<float2*>(a.out_next_point + (size_t)b * a.cloud_elems);
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < pairs; p += gridDim.x * 256) {
+        d0[p] = s0[p];
+        if (a.out_next_point) d1[p] = s1[p];
+    }
+    if (blockIdx.x != 0) return;
+    const int t = threadIdx.x;
+    if (t < 6) { a.out_action[b * 6 + t] = a.action[i * 6 + t]; a.out_expert_action[b * 6 + t] = a.expert_action[i * 6 + t]; }
+    if (t < 7) a.out_goal[b * 7 + t] = a.goal[i * 7 + t];
+    if (t == 8) a.out_reward[b] = a.reward[i];
+    if (t == 9) a.out_return[b] = a.returns[i];
+    if (t == 10) a.out_mask[b] = a.terminal[i];
+    if (t == 11) a.out_expert_flag[b] = a.expert_flags[i];
+    if (t == 12) a.out_perturb_flag[b] = a.perturb_flags[i];
+    if (t == 13) {
+        const float tm = a.timestep[a.end[b]] + 1.f - a.timestep[i];     // remaining steps of the episode
+        a.out_time[b] = tm;
+        a.out_time_m1[b] = tm - 1.f;
+    }
+}
+
+extern "C" int gad_replay_gather(const gad_replay_gather_args* a, void* stream) {
+    GAD_REQUIRE(a && a->idx && a->nxt && a->end && a->point_state && a->out_point, GAD_ERR_NULL, "replay_gather: null pointer");
+    GAD_REQUIRE(a->action && a->expert_action && a->goal && a->reward && a->returns && a->terminal && a->timestep &&
+                a->expert_flags && a->perturb_flags, GAD_ERR_NULL, "replay_gather: null source");
+    GAD_REQUIRE(a->out_action && a->out_expert_action && a->out_goal && a->out_reward && a->out_return && a->out_mask &&
+                a->out_time && a->out_time_m1 && a->out_expert_flag && a->out_perturb_flag, GAD_ERR_NULL, "replay_gather: null output");
+    GAD_REQUIRE(a->B >= 1 && a->cloud_elems >= 2 && a->cloud_elems % 2 == 0, GAD_ERR_SHAPE, "replay_gather: bad shape");
+    hipLaunchKernelGGL(replay_gather_kernel, dim3(4, a->B), dim3(256), 0, (hipStream_t)stream, *a);
+    GAD_CHECK_LAUNCH("replay_gather");
+    return GAD_OK;
+}

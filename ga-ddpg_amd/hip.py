@@ -50,6 +50,15 @@ class GemmDwArgs(C.Structure):
                 ("row_splits", _i32), ("partial", _vp), ("partial_elems", C.c_int64)]
 
 
+class ReplayGatherArgs(C.Structure):
+    _fields_ = [("B", _i32), ("cloud_elems", _i32), ("idx", _vp), ("nxt", _vp), ("end", _vp), ("point_state", _vp),
+                ("action", _vp), ("expert_action", _vp), ("goal", _vp), ("reward", _vp), ("returns", _vp),
+                ("terminal", _vp), ("timestep", _vp), ("expert_flags", _vp), ("perturb_flags", _vp),
+                ("out_point", _vp), ("out_next_point", _vp), ("out_action", _vp), ("out_expert_action", _vp),
+                ("out_goal", _vp), ("out_reward", _vp), ("out_return", _vp), ("out_mask", _vp), ("out_time", _vp),
+                ("out_time_m1", _vp), ("out_expert_flag", _vp), ("out_perturb_flag", _vp)]
+
+
 _lib = None
 
 
@@ -72,7 +81,7 @@ def lib():
 
 
 EXPORTS = (
-    "gad_abi_version", "gad_last_error", "gad_set_option", "gad_bn_running_update", "gad_furthest_point_sampling", "gad_gather_points",
+    "gad_abi_version", "gad_last_error", "gad_set_option", "gad_bn_running_update", "gad_replay_gather", "gad_furthest_point_sampling", "gad_gather_points",
     "gad_gather_points_grad", "gad_ball_query", "gad_group_points", "gad_group_points_grad",
     "gad_query_and_group", "gad_prep_points", "gad_rows_from_ball_query", "gad_rows_group_all",
     "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_affine_act",

@@ -151,6 +151,10 @@ class FusedRuntime(object):
     def upload(self, batch):
         if batch is None:
             return
+        if "replay_gather" in batch:             # DeviceReplay.sample_lazy(): one gather launch into the static buffers
+            if int(batch["idx"].shape[0]) != self.B:
+                raise RuntimeError("batch size changed: runtime was built for B=%d" % self.B)
+            return batch["replay_gather"].gather_into(batch, self.dbuf)
         if torch.is_tensor(batch["point_state_batch"]):
             return self.load_device_batch(batch)
         B = self.B

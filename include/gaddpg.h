@@ -325,6 +325,30 @@ int gad_polyak(float* target, const float* source, const uint8_t* sel, const int
 /* packed[m2p[i]] = p[i] (refresh the compute layout after an external parameter change)          */
 int gad_pack_params(const float* p, const int32_t* m2p, int n, float* packed, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * F. replay minibatch gather (the step before the path: reference core/replay_memory.py:109-127,251-272 run as a
+ *    device-side index gather over a GPU-resident float32 mirror of the buffer; the index arithmetic -- draw,
+ *    successor index, episode end -- stays on the host and is the reference's).  One launch fills the update
+ *    step's input buffers: out_*[b] = src[idx[b]], next cloud = point_state[nxt[b]],
+ *    time[b] = timestep[end[b]] + 1 - timestep[idx[b]], time_m1 = time - 1.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t B;
+    int32_t cloud_elems;                 /* floats per transition of point_state (4 * 1030), multiple of 2 */
+    const int64_t* idx; const int64_t* nxt; const int64_t* end;           /* (B) device index vectors */
+    const float* point_state;            /* (cap, cloud_elems) */
+    const float* action; const float* expert_action;                      /* (cap, 6) */
+    const float* goal;                   /* (cap, 7) */
+    const float* reward; const float* returns; const float* terminal; const float* timestep;
+    const float* expert_flags; const float* perturb_flags;                /* (cap) */
+    float* out_point; float* out_next_point;                              /* (B, cloud_elems) */
+    float* out_action; float* out_expert_action; float* out_goal;
+    float* out_reward; float* out_return; float* out_mask; float* out_time; float* out_time_m1;
+    float* out_expert_flag; float* out_perturb_flag;
+} gad_replay_gather_args;
+
+int gad_replay_gather(const gad_replay_gather_args* host_args, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -140,3 +140,52 @@ def test_checkpoint_roundtrip(tmp_path):
     # differ between two identical runs, in every kernel configuration).  The losses barely see those weights.
     for k in r1:
         assert_close(r2[k], r1[k], 5e-3, 1e-6, "after reload: " + k)
+
+
+def test_device_replay_matches_host_sampling():
+    """the GPU-resident replay mirror returns, for the same indices, exactly the minibatch of
+    BaseMemory.sample (float32 view of it), and an update step fed from it equals one fed from the host batch."""
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.device_replay import DeviceReplay
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.parallel import mask_counts
+    from ga_ddpg_amd.runtime import BATCH_KEYS
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer
+    from oracle.detfill import fill_module_
+    agents = []
+    for _ in range(2):
+        a, cfg = make_agent("ddpg_td3_aux.yaml")
+        for name in ("policy", "policy_target", "critic", "critic_target", "state_feature_extractor"):
+            fill_module_(getattr(a, name), name, 7)
+        agents.append(a)
+    mem = BaseMemory(900, cfg)                                   # float64 clouds, as the reference stores them
+    fill_synthetic_buffer(mem, 900, seed=3)
+    dmem = DeviceReplay(mem)
+    rng_a, rng_b = np.random.default_rng(11), np.random.default_rng(11)
+    for it in range(3):
+        host = mem.sample(24, rng_a)
+        dev = dmem.sample(24, rng_b)
+        np.testing.assert_array_equal(dev["batch_idx"], host["batch_idx"])
+        for k in BATCH_KEYS:
+            np.testing.assert_array_equal(dev[k].cpu().numpy(), np.asarray(host[k], dtype=np.float32).reshape(dev[k].shape), err_msg=k)
+        np.testing.assert_array_equal(dev["mask_counts"], mask_counts(host))
+    if float(host["return_batch"].max()) > 0 and float(host["expert_flag_batch"].max()) >= 1:
+        u = np.random.default_rng(5).random((24, 6)).astype(np.float32)
+        r_host = agents[0].update_parameters(host, agents[0].update_step, 0, noise_u=u)
+        r_dev = agents[1].update_parameters(dev, agents[1].update_step, 0, noise_u=u)
+        for k in r_host:
+            assert_close(r_dev[k], r_host[k], 2e-3, 1e-6, k)       # same inputs; run-to-run atomics noise only
+    # the lazy form: one gather launch straight into the runtime's input buffers
+    lazy = dmem.sample_lazy(24, rng=np.random.default_rng(4))
+    ref = mem.sample(24, rng=np.random.default_rng(4))
+    rt = agents[1].runtime(24, ref["point_state_batch"].shape[2])
+    rt.upload(lazy)
+    torch.cuda.synchronize()
+    for k in BATCH_KEYS:
+        np.testing.assert_array_equal(rt.dbuf[k].cpu().numpy(), np.asarray(ref[k], dtype=np.float32).reshape(rt.dbuf[k].shape), err_msg="lazy " + k)
+    np.testing.assert_array_equal(rt.dbuf["time_m1"].cpu().numpy(), np.asarray(ref["time_batch"], dtype=np.float32) - 1.0)
+    # online insertion: overwrite a slice on the host, refresh it, sample it back
+    mem.action[100:110] = 0.25
+    dmem.refresh(100, 110)
+    got = dmem.sample(10, batch_idx=np.arange(100, 110))
+    assert float((got["action_batch"] - 0.25).abs().max()) == 0.0
