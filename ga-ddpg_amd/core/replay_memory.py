@@ -153,6 +153,95 @@ class BaseMemory(object):
         if self.self_supervision and self.name != "expert":
             raise NotImplementedError("set_onpolicy_goal (reference :233-249) is outside the path")
 
+    # ------------------------------------------------------------------ writer side
+    def update_reward(self, reward, test, explore, target_name):
+        """success bookkeeping of add_episode (reference :71-80)"""
+        self._TOTAL_REW += reward
+        self._TOTAL_CNT += 1
+        self._REW.append(reward)
+        if explore:
+            (self._TEST_REW if test else self._ONLINE_REW).append(reward)
+        if target_name != "noexists" and target_name not in self.object_performance:
+            self.object_performance[target_name] = [0, 0, 0]
+        self.object_performance[target_name][0] += 1
+        self.object_performance[target_name][1] += reward
+
+    def push(self, step_dict):
+        """store one transition at the write cursor (reference :178-207).  Frames whose cloud has fewer than 100
+        columns or is all zero are dropped; the cursor wraps to buffer_start_idx."""
+        cloud = step_dict["point_state"]
+        if cloud.shape[1] < 100 or cloud.sum() == 0:
+            return
+        slot = self.cur_idx % len(self.point_state)
+        for name in self.attr_names:
+            if name == "image_state":
+                if self.use_image:
+                    raise NotImplementedError("image observations are outside the path (SURVEY 2)")
+            elif name in step_dict:
+                getattr(self, name)[slot] = step_dict[name]
+        if self.cur_idx >= len(self.episode_map) - 1:
+            self.is_full = True
+        self.cur_idx += 1
+        self.total_env_step += 1
+        if self.cur_idx >= len(self.point_state) or self.cur_idx < self.buffer_start_idx:
+            self.cur_idx = self.buffer_start_idx
+
+    def add_episode(self, episode, explore=False, test=False):
+        """append a rollout, back-fill its discounted returns-to-go and point every step's episode_map entry at the
+        episode's last index (reference :209-231).  Unsuccessful rollouts are skipped outside RL mode."""
+        n = len(episode)
+        if (not self.RL) and episode[-1]["reward"] < 0.5 and not explore:
+            return
+        if n > 0:
+            self.update_reward(episode[-1]["reward"] > 0.5, test, explore, episode[-1]["target_name"])
+        for transition in episode:
+            self.push(transition)
+        if n > 0 and self.cur_idx - n >= 0:
+            go = 0
+            for i in range(n):
+                j = self.cur_idx - 1 - i
+                self.returns[j] = self.reward[j] + self.gamma ** i * go          # gamma**i, as the reference
+                go = self.returns[j]
+            self.episode_map[self.cur_idx - n:self.cur_idx] = self.cur_idx - 1
+
+    def get_expert_upper_idx(self):
+        hi = self.upper_idx()
+        if self.expert_flags is not None and np.sum(self.expert_flags[:hi]) > 0:
+            return np.where(self.expert_flags[:hi] >= 1)[0][-1]
+        return 0
+
+    # ------------------------------------------------------------------ on-disk format (SURVEY 8f N2)
+    SAVE_EXTRA = ("episode_map", "is_full", "cur_idx", "total_env_step", "target_idx")
+
+    def save(self, save_dir="."):
+        """one .npz named RL_SAVE_DATA_NAME holding every attr_names array plus the cursor fields
+        (reference :338-356): loadable by the reference's BaseMemory.load and vice versa."""
+        os.makedirs(save_dir, exist_ok=True)
+        np.savez(os.path.join(save_dir, self.save_data_name),
+                 **{name: getattr(self, name) for name in list(self.attr_names) + list(self.SAVE_EXTRA)})
+
+    def load(self, data_dir, buffer_size=100000, **kwargs):
+        """inverse of save (reference :274-336): copies the first max(episode_map) transitions of every array,
+        restores the cursor, recomputes the returns.  A missing directory / file leaves the buffer untouched."""
+        path = os.path.join(data_dir, self.save_data_name)
+        if not os.path.exists(data_dir) or not os.path.exists(path):
+            return
+        data = np.load(path, allow_pickle=True, mmap_mode="r")
+        n = int(np.amax(data["episode_map"]))
+        for name in list(self.attr_names) + ["episode_map", "target_idx"]:
+            if (name == "image_state" and not self.use_image) or name not in data:
+                continue
+            arr = data[name]
+            if not isinstance(arr, np.ndarray):
+                setattr(self, name, arr)
+            else:
+                getattr(self, name)[:n] = arr[:n]
+        self.cur_idx = n
+        self.total_env_step = int(data["total_env_step"])
+        self.is_full = bool(data["is_full"]) and self.cur_idx >= self.buffer_size - 1
+        self.cur_idx = self.upper_idx()
+        self.recompute_return_with_gamma()
+
     # ------------------------------------------------------------------ returns
     def recompute_return_with_gamma(self):
         """discounted return-to-go per episode (reference :152-164)."""

@@ -376,6 +376,58 @@ def gen_replay():
     np.savez_compressed(os.path.join(OUT, "replay_sample.npz"), **out)
 
 
+def _episodes(n_pts, seed):
+    """seeded rollouts in the reference's transition-dict format (add_episode / push input)"""
+    rng = np.random.default_rng(seed)
+    eps = []
+    for e in range(7):
+        L = int(rng.integers(3, 9))
+        success = bool(e % 3 != 1)
+        ep = []
+        for t in range(L):
+            cloud = rng.normal(size=(4, n_pts + 6)) * 0.1
+            if e == 4 and t == 2:
+                cloud[:] = 0.0                                # all-zero frame: push() drops it
+            ep.append({"point_state": cloud, "action": rng.normal(size=6).astype(np.float32),
+                       "expert_action": rng.normal(size=6).astype(np.float32), "goal": rng.normal(size=7).astype(np.float32),
+                       "reward": np.float32(1.0 if (success and t == L - 1) else 0.0), "terminal": np.float32(t == L - 1),
+                       "timestep": np.float32(t), "expert_flags": np.float32(e % 2), "perturb_flags": np.float32(t == 1),
+                       "state_pose": np.eye(4, dtype=np.float32), "target_idx": np.float32(e), "target_name": "obj%d" % (e % 3)})
+        eps.append(ep)
+    return eps
+
+
+def gen_replay_io():
+    """writer side + on-disk format through the reference's own BaseMemory: add_episode -> save -> (fresh) load -> sample.
+    The saved .npz is committed as a fixture (a data file in the reference's format); the episodes are regenerated
+    from the seed by the test."""
+    import tempfile
+    from core.replay_memory import BaseMemory as RefMemory
+    cfg = _fresh_ref_cfg("td3_critic_aux_policy_aux.yaml")
+    cfg.RL_TRAIN.uniform_num_pts = 128
+    cfg.RL_SAVE_DATA_NAME = "replay_io_saved.npz"
+    mem = RefMemory(48, cfg)
+    for ep in _episodes(128, SEED + 9):
+        mem.add_episode(ep)
+    out = {"after_add/" + k: np.asarray(getattr(mem, k)) for k in
+           ("action", "reward", "returns", "terminal", "timestep", "episode_map", "expert_flags", "perturb_flags", "goal")}
+    out["after_add/cur_idx"] = np.int64(mem.cur_idx)
+    out["after_add/total_env_step"] = np.int64(mem.total_env_step)
+    out["after_add/is_full"] = np.bool_(mem.is_full)
+    mem.save(OUT)                                             # -> tests/golden/replay_io_saved.npz
+    mem2 = RefMemory(48, cfg)
+    mem2.load(OUT)
+    out["after_load/cur_idx"] = np.int64(mem2.cur_idx)
+    out["after_load/returns"] = np.asarray(mem2.returns)
+    out["after_load/point_state_sum"] = np.float64(mem2.point_state.sum())
+    np.random.seed(SEED + 1)
+    mem2.episode_max_len = 2
+    data = mem2.sample(8)
+    for k, v in data.items():
+        out["batch/" + k] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "replay_io.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     install_shims()
@@ -384,6 +436,7 @@ def main():
     gen_losses()
     gen_heads()
     gen_replay()
+    gen_replay_io()
     gen_encoder()
     print("bc ->", gen_bc())
     print("ddpg ->", gen_ddpg())

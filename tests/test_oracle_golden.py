@@ -158,3 +158,67 @@ def test_replay_sample_matches_reference(golden_dir):
         np.testing.assert_array_equal(data[k], g["batch/" + k], err_msg=k)
     mem.recompute_return_with_gamma()
     np.testing.assert_array_equal(mem.returns, g["recomputed_returns"])
+
+
+def _replay_episodes(n_pts, seed):
+    """the seeded rollouts oracle/make_golden.py::_episodes fed to the reference's add_episode"""
+    rng = np.random.default_rng(seed)
+    eps = []
+    for e in range(7):
+        L = int(rng.integers(3, 9))
+        success = bool(e % 3 != 1)
+        ep = []
+        for t in range(L):
+            cloud = rng.normal(size=(4, n_pts + 6)) * 0.1
+            if e == 4 and t == 2:
+                cloud[:] = 0.0
+            ep.append({"point_state": cloud, "action": rng.normal(size=6).astype(np.float32),
+                       "expert_action": rng.normal(size=6).astype(np.float32), "goal": rng.normal(size=7).astype(np.float32),
+                       "reward": np.float32(1.0 if (success and t == L - 1) else 0.0), "terminal": np.float32(t == L - 1),
+                       "timestep": np.float32(t), "expert_flags": np.float32(e % 2), "perturb_flags": np.float32(t == 1),
+                       "state_pose": np.eye(4, dtype=np.float32), "target_idx": np.float32(e), "target_name": "obj%d" % (e % 3)})
+        eps.append(ep)
+    return eps
+
+
+def test_replay_writer_and_disk_format_match_reference(golden_dir, tmp_path):
+    """add_episode (return back-fill, episode_map, dropped frames), save, load and sample-after-load
+    against the reference's own BaseMemory (tests/golden/replay_io.npz; replay_io_saved.npz is the file the REFERENCE
+    wrote -- we must load it, and the file we write must hold the same arrays)."""
+    import shutil
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    g = np.load(os.path.join(golden_dir, "replay_io.npz"))
+    c = load_cfg("ddpg_td3_aux.yaml")
+    c.RL_TRAIN.uniform_num_pts = 128
+    c.RL_SAVE_DATA_NAME = "replay_io_saved.npz"
+    mem = BaseMemory(48, c)
+    for ep in _replay_episodes(128, SEED + 9):
+        mem.add_episode(ep)
+    for k in ("action", "reward", "returns", "terminal", "timestep", "episode_map", "expert_flags", "perturb_flags", "goal"):
+        np.testing.assert_array_equal(getattr(mem, k), g["after_add/" + k], err_msg=k)
+    assert (mem.cur_idx, mem.total_env_step, mem.is_full) == (int(g["after_add/cur_idx"]), int(g["after_add/total_env_step"]),
+                                                              bool(g["after_add/is_full"]))
+    # our file == the reference's file, array by array
+    mem.save(str(tmp_path))
+    ours, theirs = np.load(tmp_path / "replay_io_saved.npz", allow_pickle=True), np.load(
+        os.path.join(golden_dir, "replay_io_saved.npz"), allow_pickle=True)
+    assert sorted(ours.files) == sorted(theirs.files)
+    for k in theirs.files:
+        np.testing.assert_array_equal(ours[k], theirs[k], err_msg="saved " + k)
+    # load the reference's file into a fresh buffer, then sample like the reference did
+    d = tmp_path / "in"
+    d.mkdir()
+    shutil.copy(os.path.join(golden_dir, "replay_io_saved.npz"), d / "replay_io_saved.npz")
+    mem2 = BaseMemory(48, c)
+    mem2.load(str(d))
+    assert mem2.cur_idx == int(g["after_load/cur_idx"])
+    np.testing.assert_array_equal(mem2.returns, g["after_load/returns"])
+    assert float(mem2.point_state.sum()) == float(g["after_load/point_state_sum"])
+    np.random.seed(SEED + 1)
+    mem2.episode_max_len = 2
+    data = mem2.sample(8)
+    for k in [k[len("batch/"):] for k in g.files if k.startswith("batch/")]:
+        np.testing.assert_array_equal(data[k], g["batch/" + k], err_msg=k)
+    mem3 = BaseMemory(48, c)
+    mem3.load(str(tmp_path / "does_not_exist"))            # silently ignored, like the reference
+    assert mem3.cur_idx == 0
