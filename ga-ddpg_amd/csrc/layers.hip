@@ -107,7 +107,18 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
     const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
     float best = -1.f;
     int arg = r0;
-    for (int r = r0; r < r1; ++r) {
+    int r = r0;
+    for (; r + 4 <= r1; r += 4) {            // four independent loads in flight per thread (the loop is load-latency bound)
+        const float* p = z + (size_t)r * z_pitch + c;
+        const float z0 = p[0], z1 = p[z_pitch], z2 = p[2 * (size_t)z_pitch], z3 = p[3 * (size_t)z_pitch];
+        const float y0 = fmaxf(fmaf(z0, sc, sh), 0.f), y1 = fmaxf(fmaf(z1, sc, sh), 0.f);
+        const float y2 = fmaxf(fmaf(z2, sc, sh), 0.f), y3 = fmaxf(fmaf(z3, sc, sh), 0.f);
+        if (y0 > best) { best = y0; arg = r; }
+        if (y1 > best) { best = y1; arg = r + 1; }
+        if (y2 > best) { best = y2; arg = r + 2; }
+        if (y3 > best) { best = y3; arg = r + 3; }
+    }
+    for (; r < r1; ++r) {
         const float y = fmaxf(fmaf(z[(size_t)r * z_pitch + c], sc, sh), 0.f);
         if (y > best) { best = y; arg = r; }
     }
