@@ -747,7 +747,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     }
 }
 
-static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1;
+static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
 }
@@ -759,6 +759,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
+    if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
     GAD_REQUIRE(false, GAD_ERR_SHAPE, "set_option: unknown option '%s'", name);
     return GAD_OK;
 }
@@ -1502,6 +1503,93 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
     atomic_add_f64(gacc + gr.woff[g] + e, s);
 }
 
+// skinny dW for the small-M layers (FC head, actor / critic heads: <= 1024 rows to reduce over, outputs up to 1024 x 1032).
+// One 32x32 tile of dW per workgroup, the 8 wavefronts split the ROWS.  Both MFMA operands are indexed [row][channel]
+// in memory with the reduction index (rows) leading, so with the k = 8j+4h+i visiting order lane (channel = lane%32)
+// needs four consecutive rows of its channel: four coalesced 4-byte loads each for z, dY (-> dZ in registers, per-lane
+// BatchNorm constants) and for the layer input (-> act(scale*z+shift), or the bias / extra column).  No LDS staging,
+// all loads of a wavefront's rows in flight before its first MFMA; partial tiles summed through LDS, then f64 atomics
+// straight into the gradient arena (no split-K workspace, no reduce launch).
+__global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSrc x, Groups gr, int n_rows, int Kp,
+                                                                    int k_used, double* __restrict__ gacc) {
+    __shared__ float part[SK_NW * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int g = blockIdx.z;
+    const int doff = gr.aoff[g], zoff = gr.ooff[g], n_out = gr.nout[g];
+    const int n0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+    if (n0 >= n_out) return;
+    // A side: this lane's output channel n and its BatchNorm-backward constants
+    const int n = n0 + l31;
+    const bool n_ok = n < n_out;
+    const int ch = doff + (n_ok ? n : 0);
+    const float dsc = d.scale ? d.scale[ch] : 1.f, dsh = d.scale ? d.shift[ch] : 0.f;
+    const float dP = d.P ? d.P[ch] : 1.f, dQ = d.P ? d.Q[ch] : 0.f, dS = d.P ? d.S[ch] : 0.f;
+    // B side: this lane's input column k: 0 = activation column, 1 = extra column, 2 = bias (ones) column, 3 = padding
+    const int k = k0 + l31;
+    const int kind = k < x.c_in ? 0 : ((k == x.c_in && x.extra) ? 1 : (k == x.ones_col ? 2 : 3));
+    const int kc = zoff + (kind == 0 ? k : 0);
+    const float xs = (kind == 0 && x.scale) ? x.scale[kc] : 1.f, xt = (kind == 0 && x.shift) ? x.shift[kc] : 0.f;
+
+    const int units = (n_rows + 7) >> 3;
+    const int per = (units + SK_NW - 1) / SK_NW;
+    const int u0 = wave * per, u1 = min(units, u0 + per);
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    constexpr int CHU = 4;                                   // 8-row units per register chunk
+    for (int c0 = u0; c0 < u1; c0 += CHU) {
+        float rz[CHU][4], rg[CHU][4], rx[CHU][4], rw[CHU][4];
+#pragma unroll
+        for (int u = 0; u < CHU; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * (c0 + u) + 4 * half + i;
+                const int rr = min(r, n_rows - 1);
+                rz[u][i] = d.z ? d.z[(size_t)rr * d.z_pitch + ch] : 0.f;
+                rg[u][i] = d.G[(size_t)rr * d.g_pitch + ch];
+                rw[u][i] = d.row_w ? d.row_w[rr] : 1.f;
+                rx[u][i] = kind == 0 ? x.zin[(size_t)rr * x.zin_pitch + kc] : (kind == 1 ? x.extra[rr] : (kind == 2 ? 1.f : 0.f));
+            }
+#pragma unroll
+        for (int u = 0; u < CHU; ++u) {
+            if (c0 + u >= u1) break;                         // wave-uniform
+            float a4[4], b4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * (c0 + u) + 4 * half + i;
+                const bool live = r < n_rows;
+                const float z = rz[u][i];
+                float gq = rg[u][i];
+                if (d.relu) gq = fmaf(z, dsc, dsh) > 0.f ? gq : 0.f;
+                if (d.P) gq = dP * gq - rw[u][i] * fmaf(dS, z, dQ);
+                a4[i] = (live && n_ok) ? gq : 0.f;
+                float xv = rx[u][i];
+                if (kind == 0) { xv = fmaf(xv, xs, xt); if (x.relu) xv = fmaxf(xv, 0.f); }
+                b4[i] = live ? xv : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[i], b4[i], acc, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) part[(wave * 16 + v) * 64 + lane] = acc[v];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int w = 1; w < SK_NW; ++w)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += part[(w * 16 + v) * 64 + lane];
+    if (k >= k_used) return;
+    double* aout = gacc + gr.woff[g];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int nn = n0 + acc_row(v, half);
+        if (nn < n_out) atomic_add_f64(aout + (size_t)nn * Kp + k, (double)acc[v]);
+    }
+}
+
 extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     GAD_REQUIRE(a && a->gacc, GAD_ERR_NULL, "gemm_dw: null pointer");
     const gad_gemm_fwd_args& in = a->in;
@@ -1522,6 +1610,12 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int rows = in.n_rows;
     const bool vec = dz_vectorizable(a->dz, a->dz_off, in.n_out, in.n_groups);
+    if (g_opt_dw_skinny && in.mode == 0 && a->dz.gmode == 0 && !in.n_rows_dev && rows <= 1024) {
+        hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
+                           gr, rows, in.Kp, k_used, a->gacc);
+        GAD_CHECK_LAUNCH("gemm_dw(skinny)");
+        return GAD_OK;
+    }
     long long group_stride = 0;
 #define LAUNCH_DW3(WM, WN, TM, TN, XM, V)                                                                  \
     hipLaunchKernelGGL((gemm_dw_kernel<WM, WN, TM, TN, XM, V>), dim3(tn_ * tk_, splits, gr.n), dim3(256), 0, st, d, \

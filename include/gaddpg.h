@@ -38,8 +38,8 @@ typedef enum {
 int gad_abi_version(void);                 /* bumped on any signature change            */
 const char* gad_last_error(void);          /* thread-local description of the last <0   */
 /* Kernel-selection switches for A/B diagnostics (defaults in brackets).  "fwd_stream" [1]: route the wide and
- * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" [1]: route
- * the small-M (<= 1024 rows) forward / dX layers to the split-K kernels.  Returns GAD_ERR_SHAPE for an
+ * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route
+ * the small-M (<= 1024 rows) forward / dX / dW layers to the split-K kernels.  Returns GAD_ERR_SHAPE for an
  * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.          */
 int gad_set_option(const char* name, int value);
 
