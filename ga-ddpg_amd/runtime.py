@@ -225,15 +225,30 @@ class FusedRuntime(object):
         hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
                  d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
                  self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
+        def actor_tail(g_pi):
+            hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
+                     d["return_batch"], d["goal_batch"], B, 1.0 - ratio, int(bool(ag.policy_aux)), self.action_scale, g_pi,
+                     self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
+            P["p_bwd"].run()
+            self._reduce([self.pol.flat, self.enc.flat])
+            self._adam(self.pol.flat, ag.policy_optim)
+            if ag.train_feature:
+                self._adam(self.enc.flat, ag.state_feat_encoder_optim)
+
         if OVERLAP_PASSES:
-            # the policy forward of the actor phase needs nothing from the critic update: overlap it with the critic
-            # backward + Adam (its encoder BatchNorms come after t1's in stream order, as in the reference)
+            # The actor phase's policy forward needs nothing from the critic update: it runs beside the critic backward
+            # + Adam (its encoder BatchNorms come after t1's in stream order, as in the reference).  On steps without
+            # the actor-critic term (update_step % policy_update_gap != 0) the WHOLE actor phase -- loss, backward,
+            # Adam of policy + encoder -- is independent of the critic phase (disjoint parameters, gradient arenas and
+            # result slots) and runs there too.
             s2 = engine.side_stream(which=2)
             self._ev[2].record(main)
             s2.wait_event(self._ev[2])
             with torch.cuda.stream(s2):
                 P["p_fwd"].run()
                 hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
+                if not policy_step:
+                    actor_tail(None)
         P["c_bwd"].run()
         self._reduce([self.cr.flat, self.venc.flat])
         self.clip_sumsq.zero_()
@@ -247,21 +262,14 @@ class FusedRuntime(object):
         else:
             P["p_fwd"].run()
             hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
-        g_pi = None
         if policy_step:
             P["v_fwd"].run()
             hip.call("gad_actor_critic_loss", self.hs_cpi.out, d["expert_flag_batch"], d["return_batch"], B, ratio,
                      self.inv_n_actor_critic(), self.hs_cpi.g_out, engine._ptr(self.scal, 8))
             P["v_bwd"].run()
-            g_pi = self.slot_v.daction
-        hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
-                 d["return_batch"], d["goal_batch"], B, 1.0 - ratio, int(bool(ag.policy_aux)), self.action_scale, g_pi,
-                 self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
-        P["p_bwd"].run()
-        self._reduce([self.pol.flat, self.enc.flat])
-        self._adam(self.pol.flat, ag.policy_optim)
-        if ag.train_feature:
-            self._adam(self.enc.flat, ag.state_feat_encoder_optim)
+            actor_tail(self.slot_v.daction)
+        elif not OVERLAP_PASSES:
+            actor_tail(None)
         self._target_updates()
         self._stats()
         self.enc.bump_batches_tracked(2)
