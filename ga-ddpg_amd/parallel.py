@@ -58,15 +58,24 @@ class DataParallelContext(object):
         rt.allreduce = self.allreduce_grads
         rt.inv_n = torch.zeros(8, dtype=torch.float32, device=rt.dev)
         self._counts = torch.zeros(4, dtype=torch.float64, device=rt.dev)
+        self._counts_host = torch.zeros(4, dtype=torch.float64)
+        if torch.device(rt.dev).type == "cuda":
+            self._counts_host = self._counts_host.pin_memory()
+        # inv_n[0:5] = numer / counts[pick]   (layout: inverse_counts)
+        self._numer = torch.tensor([1.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0, 1.0], dtype=torch.float64, device=rt.dev)
+        self._pick = torch.tensor([0, 1, 2, 1, 3], dtype=torch.int64, device=rt.dev)
 
     def allreduce_grads(self, tensors):
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def set_counts(self, batch):
-        """global mask counts -> rt.inv_n (one tiny all-reduce per step)"""
-        c = self.global_counts(mask_counts(batch), self._counts.device)
-        self.rt.inv_n.copy_(torch.from_numpy(inverse_counts(c).astype(np.float32)), non_blocking=False)
+        """global mask counts -> rt.inv_n: one 4-double all-reduce per step, stream-ordered (no host sync: the
+        reciprocals are formed on the device; an empty mask gives inf -> NaN losses, like the reference)"""
+        self._counts_host.numpy()[:] = mask_counts(batch)
+        self._counts.copy_(self._counts_host, non_blocking=True)
+        dist.all_reduce(self._counts, op=dist.ReduceOp.SUM, group=self.group)
+        self.rt.inv_n[0:5] = (self._numer / self._counts.index_select(0, self._pick)).float()
 
     def global_counts(self, local, device):
         t = torch.as_tensor(local, dtype=torch.float64, device=device)
