@@ -35,7 +35,8 @@ typedef enum {
     GAD_ERR_UNSUPPORTED = -4
 } gad_status;
 
-int gad_abi_version(void);                 /* bumped on any signature change            */
+int gad_abi_version(void);                 /* bumped on any signature change or new entry point (2: gad_set_option,
+                                            * gad_bn_running_update, gad_replay_gather)  */
 const char* gad_last_error(void);          /* thread-local description of the last <0   */
 /* Kernel-selection switches for A/B diagnostics (defaults in brackets).  "fwd_stream" [1]: route the wide and
  * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route
