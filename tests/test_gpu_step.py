@@ -230,3 +230,73 @@ def test_gradient_accuracy_vs_float64(policy_step):
         # outcome depends on the batch, not on the kernel (GAD_DIAG_SEED / GAD_OPT_fwd_stream A/B)
         assert float((mine - ref).abs().max()) / scale <= max(1.5e-1, 3.0 * m_t32), (key, m_t32)
     print("worst HIP-error / allowance ratio:", worst)
+
+
+def test_bc_step_config0_batch64_vs_oracle():
+    """BASELINE configs[0]: offline BC update (bc_aux_dagger), batch 64, 1024-point clouds: one step from identical
+    parameters against the CPU oracle -- losses 1e-4, actions / aux poses 1e-4 of the tensor scale, policy and encoder
+    gradients norm-wise (helpers.check... policy: same kink caveat as the DDPG steps)."""
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    agent, nets = _filled_agent("bc_dagger_aux.yaml", 21)
+    c = load_cfg("bc_dagger_aux.yaml")
+    oracle = ref_step.OracleAgent(c.RL_TRAIN)
+    for name, net in oracle.nets().items():
+        fill_module_(net, name, 21)
+    mem = BaseMemory(1500, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 1500, seed=8)
+    batch = sample_valid_batch(mem, 64, np.random.default_rng(2))
+    got = agent.update_parameters(batch, agent.update_step, 0)
+    want = oracle.update_parameters(batch)
+    torch.cuda.synchronize()
+    assert set(got.keys()) == set(want.keys())
+    for k in ("bc_loss", "policy_grasp_aux_loss"):
+        assert_close(got[k], want[k], 1e-4, 1e-6, k)
+    for k in ("critic_loss", "critic_grasp_aux_loss", "actor_critic_loss"):
+        assert got[k] == 0.0 and want[k] == 0.0, k                      # BC has no critic
+    pi_ref, aux_ref = oracle.dbg["pi"].numpy(), oracle.dbg["aux_pred"].numpy()
+    assert_close(agent.pi.cpu().numpy(), pi_ref, 1e-4, 1e-5 * np.abs(pi_ref).max(), "pi")
+    assert_close(agent.aux_pred.cpu().numpy(), aux_ref, 1e-4, 1e-5 * np.abs(aux_ref).max(), "aux_pred")
+    on = {n + "/" + k: p.grad for n, net in oracle.nets().items() for k, p in net.named_parameters() if p.grad is not None}
+    worst = 0.0
+    for name in ("policy", "state_feature_extractor"):
+        for k, p in nets[name].named_parameters():
+            ref = on.get(name + "/" + k)
+            if ref is None or any(x in k for x in SKIP):
+                continue
+            scale = float(ref.abs().max()) + 1e-30
+            err = (p.grad.cpu() - ref).abs()
+            worst = max(worst, float(err.median()) / scale)
+            assert float(err.median()) / scale <= 5e-3 and float(err.max()) / scale <= 1.5e-1, (name, k)
+    print("worst median gradient error / scale:", worst)
+
+
+def test_ddpg_step_config4_batch512_properties():
+    """BASELINE configs[4] runs B=512 per GPU: the fused step at that size -- finite results, the 11 keys, row
+    bookkeeping, and scale consistency with the same clouds at B=256 (losses are means: same order of magnitude)."""
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle.detfill import fill_module_
+    outs = {}
+    for B in (512, 256):
+        agent, cfg = make_agent("ddpg_td3_aux.yaml")
+        for name in ("policy", "policy_target", "critic", "critic_target", "state_feature_extractor"):
+            fill_module_(getattr(agent, name), name, 5)
+        mem = BaseMemory(3000, cfg, point_dtype=np.float32)
+        fill_synthetic_buffer(mem, 3000, seed=6)
+        rng = np.random.default_rng(4)
+        r = None
+        for s in range(2):                                        # a policy step and a non-policy step
+            batch = sample_valid_batch(mem, B, rng)
+            r = agent.update_parameters(batch, agent.update_step, s, noise_u=rng.random((B, 6)).astype(np.float32))
+            assert len(r) == 11 and all(np.isfinite(v) for v in r.values()), r
+            assert r["train_batch_size"] == 0.0                    # a slot the reference zeroes and never fills (core/agent.py:213-216)
+        outs[B] = r
+        rt = agent._rt
+        assert int(rt.geo.rows[0]["n"].item()) <= B * 32 * 64 and int(rt.geo.rows[2]["n"].item()) == B * 32
+    for k in ("critic_loss", "bc_loss", "policy_grasp_aux_loss", "critic_grasp_aux_loss"):
+        assert 0.3 < outs[512][k] / outs[256][k] < 3.0, (k, outs[512][k], outs[256][k])
