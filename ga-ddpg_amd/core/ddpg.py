@@ -43,6 +43,10 @@ class DDPG(Agent):
         """One gradient step.  `noise_u` (B,6) optionally injects the uniform draw of the TD3
         target-policy noise (the reference draws it with torch.rand_like, core/utils.py:575)."""
         self.mix_value_ratio, self.mix_policy_ratio = self.get_mix_ratio(self.update_step)
+        if test:
+            # reference core/agent.py:276-280 would run the SAME update with eval-mode BatchNorm; no driver of the
+            # reference calls it that way and the fused step only implements train-mode statistics: refuse loudly
+            raise NotImplementedError("update_parameters(test=True): eval-mode update is not implemented")
         self.set_mode(test)
         ps = batch_data["point_state_batch"]
         rt = self.runtime(ps.shape[0], ps.shape[2])
