@@ -960,6 +960,8 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
             const bool stats = e.dbeta != nullptr && kok;
             if (stats) { sc = e.ps[goff + k]; sh = e.pt[goff + k]; mu = e.pm[goff + k]; is = e.pi[goff + k]; }
             float sb = 0.f, sg = 0.f;
+            int run_smp = -1;
+            double run_sum = 0.0;
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -979,11 +981,21 @@ __global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const 
                         if (k < e.feat_c) {
                             if (e.dfeat) atomic_add_f32(e.dfeat + (size_t)ptS[il] * e.feat_c + k, gv);
                         } else if (k >= e.feat_c + 3 && k < e.feat_c + 3 + e.act_c) {
-                            if (e.daction)
-                                atomic_add_f64(e.daction + (size_t)(grS[il] / e.gps) * e.act_c + (k - e.feat_c - 3), (double)gv);
+                            // per-sample action gradient: ~875 rows of a sample add into the same 6 addresses.  The rows a
+                            // lane holds are consecutive runs of a tile, almost always of ONE sample: accumulate the run
+                            // in a register and issue one f64 atomic per run instead of one per row
+                            if (e.daction) {
+                                const int smp = grS[il] / e.gps;
+                                if (smp != run_smp) {
+                                    if (run_smp >= 0) atomic_add_f64(e.daction + (size_t)run_smp * e.act_c + (k - e.feat_c - 3), run_sum);
+                                    run_smp = smp; run_sum = 0.0;
+                                }
+                                run_sum += (double)gv;
+                            }
                         }
                     }
                 }
+            if (run_smp >= 0) atomic_add_f64(e.daction + (size_t)run_smp * e.act_c + (k - e.feat_c - 3), run_sum);
             cb[tn] += sb; cg[tn] += sg;
         }
         __syncthreads();
