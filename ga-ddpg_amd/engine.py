@@ -541,10 +541,12 @@ def _bn_coef(plan, enc, slot, m, count, want_dw):
               _ptr(gacc, m.b_off, 8) if want_dw else None)
 
 
-def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False):
+def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1):
     """Backward of plan_encoder_forward.  g_fc2 (B, 512) is dLoss/d(relu(bn(Zfc[1]))) as produced by
     the consumer head's dX kernel, whose epilogue must also have filled this slot's bstats for fc[1].
-    Weight gradients accumulate (f64) into enc.flat.gacc when want_dw."""
+    Weight gradients accumulate (f64) into enc.flat.gacc when want_dw; their GEMMs are forked onto side stream
+    `dw_lane` (two backward passes that may run concurrently -- critic and actor -- get different lanes: each lane has
+    its own split-K workspace and is stream-ordered)."""
     geo = slot.geo
     plan = Plan()
     B = slot.B
@@ -592,7 +594,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **_layer_input(enc, slot, geo, s, l, action))
         a.dz = dz
         a.gacc = _ptr(enc.flat.gacc)
-        lane = 1 + (len(dw_lanes) % DW_LANES) if CONCURRENT_DW else 0       # alternate the dW side streams
+        lane = dw_lane + (len(dw_lanes) % DW_LANES) if CONCURRENT_DW else 0
         dw_lanes.append(lane)
         ws = dw_workspace(enc.flat.device, lane=lane)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()

@@ -84,7 +84,7 @@ class FusedRuntime(object):
         self.allreduce = None            # callable(list of flat grad tensors)
         self.inv_n = None
         self.resident = False            # True: the static batch buffers were filled on the device
-        self._ev = [torch.cuda.Event() for _ in range(4)]
+        self._ev = [torch.cuda.Event() for _ in range(5)]
 
     # ------------------------------------------------------------------ plans over static buffers
     def _build_plans(self):
@@ -99,7 +99,7 @@ class FusedRuntime(object):
         bw.zero(enc.flat.gacc)
         bw.zero(self.slot_p.bstats)
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
-        bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True))
+        bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True, dw_lane=2))
         bw.call("gad_grad_from_arena", pol.flat.gacc, pol.flat.m2p, pol.flat.n, pol.flat.grad, 0)
         bw.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
         P["p_bwd"] = bw
@@ -203,28 +203,6 @@ class FusedRuntime(object):
         # Both go through value_encoder's BatchNorms; the reference runs the current-state pass first
         # (core/ddpg.py:145-152, then target_value() inside compute_critic_loss), so the target chain's value-encoder
         # pass only computes batch statistics and its running-statistics momentum update is applied after the join.
-        if OVERLAP_PASSES:
-            s1 = engine.side_stream(which=1)
-            self._ev[0].record(main)
-            s1.wait_event(self._ev[0])
-            with torch.cuda.stream(s1):
-                self.geo.run(d["point_state_batch"])
-                P["c_fwd"].run()
-            self.geo_next.run(d["next_point_state_batch"])
-        else:
-            self.geo.run(d["point_state_batch"])
-            self.geo_next.run(d["next_point_state_batch"])
-            P["c_fwd"].run()
-        P["t1"].run()
-        hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), self.a_next)
-        P["t2"].run()
-        if OVERLAP_PASSES:
-            self._ev[1].record(s1)
-            main.wait_event(self._ev[1])
-            P["t2_run"].run()
-        hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
-                 d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
-                 self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
         def actor_tail(g_pi):
             hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
                      d["return_batch"], d["goal_batch"], B, 1.0 - ratio, int(bool(ag.policy_aux)), self.action_scale, g_pi,
@@ -236,19 +214,42 @@ class FusedRuntime(object):
                 self._adam(self.enc.flat, ag.state_feat_encoder_optim)
 
         if OVERLAP_PASSES:
-            # The actor phase's policy forward needs nothing from the critic update: it runs beside the critic backward
-            # + Adam (its encoder BatchNorms come after t1's in stream order, as in the reference).  On steps without
-            # the actor-critic term (update_step % policy_update_gap != 0) the WHOLE actor phase -- loss, backward,
-            # Adam of policy + encoder -- is independent of the critic phase (disjoint parameters, gradient arenas and
-            # result slots) and runs there too.
-            s2 = engine.side_stream(which=2)
+            s1, s2 = engine.side_stream(which=1), engine.side_stream(which=2)
+            self._ev[0].record(main)
+            s1.wait_event(self._ev[0])
+            with torch.cuda.stream(s1):
+                self.geo.run(d["point_state_batch"])
+                self._ev[4].record(s1)                      # geometry of the current state ready (the actor pass needs it)
+                P["c_fwd"].run()
+            self.geo_next.run(d["next_point_state_batch"])
+        else:
+            self.geo.run(d["point_state_batch"])
+            self.geo_next.run(d["next_point_state_batch"])
+            P["c_fwd"].run()
+        P["t1"].run()
+        if OVERLAP_PASSES:
+            # The actor phase's policy forward needs nothing from the critic update: it starts as soon as t1 is done (its
+            # encoder BatchNorms must come after t1's, as in the reference) and runs beside t2 and the critic backward.
+            # On steps without the actor-critic term (update_step % policy_update_gap != 0) the WHOLE actor phase --
+            # loss, backward, Adam of policy + encoder -- is independent of the critic phase (disjoint parameters,
+            # gradient arenas, dW lanes and result slots) and runs there too.
             self._ev[2].record(main)
             s2.wait_event(self._ev[2])
+            s2.wait_event(self._ev[4])
             with torch.cuda.stream(s2):
                 P["p_fwd"].run()
                 hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
                 if not policy_step:
                     actor_tail(None)
+        hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), self.a_next)
+        P["t2"].run()
+        if OVERLAP_PASSES:
+            self._ev[1].record(s1)
+            main.wait_event(self._ev[1])
+            P["t2_run"].run()
+        hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
+                 d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
+                 self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
         P["c_bwd"].run()
         self._reduce([self.cr.flat, self.venc.flat])
         self.clip_sumsq.zero_()

@@ -78,3 +78,27 @@ def gaps(path, steps):
 
 if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "gaps":
     gaps(sys.argv[1], int(sys.argv[2]))
+
+
+def by_stream(path, steps, which):
+    """per-kernel totals of ONE stream (default: the busiest = the main stream)"""
+    db = glob.glob(path + "/**/*.db", recursive=True)[0]
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
+    key = "stream_id" if "stream_id" in cols else "queue_id"
+    order = [r[0] for r in c.execute("select %s from %s group by %s order by sum(end-start) desc" % (key, kd, key))]
+    q = order[which]
+    rows = c.execute("select s.kernel_name, count(*), sum(d.end-d.start), avg(d.end-d.start) from %s d join %s s on d.kernel_id=s.id "
+                     "where d.%s=? group by s.kernel_name order by 3 desc" % (kd, ks, key), (q,)).fetchall()
+    print("stream %s: %.3f ms / step" % (q, sum(r[2] for r in rows) / 1e6 / steps))
+    for r in rows[:30]:
+        name = re.sub(r"\(.*", "", r[0])
+        name = re.sub(r"^_Z\d+", "", name)[:70]
+        print("%-72s %6.1f calls/step %8.1f us avg %8.3f ms/step" % (name, r[1] / steps, r[3] / 1e3, r[2] / 1e6 / steps))
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "stream":
+    by_stream(sys.argv[1], int(sys.argv[2]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
