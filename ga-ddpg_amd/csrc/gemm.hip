@@ -376,13 +376,54 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
     if ((int)(blockIdx.x * BM) >= n_rows) return;          // idle block (grid sized for the worst case)
     const int nk = (Kp + KT - 1) / KT;
     const int bulk = XM == 0 ? x.c_in : x.feat_c;
-    if (XM == 0 && x.scale) { stage_vec(sv, x.scale, zoff, x.c_in, 1.f); stage_vec(tv, x.shift, zoff, x.c_in, 0.f); }
 
     float csum[TN], csq[TN];
 #pragma unroll
     for (int t = 0; t < TN; ++t) { csum[t] = 0.f; csq[t] = 0.f; }
 
-    for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
+    int row0 = blockIdx.x * BM;
+    XRaw ra[UA];
+    float4 rb[UB];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * KT;
+        const bool tail = k0 + KT > bulk;
+#pragma unroll
+        for (int it = 0; it < UA; ++it) {
+            int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
+            const int r = row0 + i;
+            const bool ok = r < n_rows && (k0 + kk < Kp);
+            ra[it] = x_raw<XM>(x, r, ok, zoff, k0 + kk, tail, XM == 1 ? ptS[i] : 0);
+        }
+#pragma unroll
+        for (int it = 0; it < UB; ++it) {
+            int j, kk; unit_T<BN>(it * 256 + tid, j, kk);
+            const int n = n0 + j;
+            const bool ok = n < n_out && (k0 + kk < Kp);
+            rb[it] = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k0 + kk : 0));
+        }
+    };
+    auto store_tile = [&](int kt) {
+        const int k0 = kt * KT;
+#pragma unroll
+        for (int it = 0; it < UA; ++it) {
+            int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
+            const int r = row0 + i;
+            const bool ok = r < n_rows && (k0 + kk < Kp);
+            store_T<BM>(As, i, kk, x_finish<XM>(x, ra[it], ok, k0 + kk, sv, tv));
+        }
+#pragma unroll
+        for (int it = 0; it < UB; ++it) {
+            int j, kk; unit_T<BN>(it * 256 + tid, j, kk);
+            const bool ok = (n0 + j) < n_out && (k0 + kk < Kp);
+            store_T<BN>(Bs, j, kk, f4sel(ok, rb[it], f4zero()));
+        }
+    };
+    // ACT input: the first K-tile's loads need neither the row weights nor the BatchNorm vectors -- issue them first so
+    // the three global-load latencies of the prologue (tile, vectors, weights) overlap instead of chaining
+    bool preloaded = false;
+    if (XM == 0) { load_tile(0); preloaded = true; }
+    if (XM == 0 && x.scale) { stage_vec(sv, x.scale, zoff, x.c_in, 1.f); stage_vec(tv, x.shift, zoff, x.c_in, 0.f); }
+    for (; row0 < n_rows; row0 += gridDim.x * BM) {
         f32x16 acc[TM][TN];
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -396,44 +437,8 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             if (XM == 1) ptS[tid] = r < n_rows ? x.row_pt[r] : 0;
         }
         __syncthreads();                                   // wS / ptS / sv / tv visible
-
-        XRaw ra[UA];
-        float4 rb[UB];
-        auto load_tile = [&](int kt) {
-            const int k0 = kt * KT;
-            const bool tail = k0 + KT > bulk;
-#pragma unroll
-            for (int it = 0; it < UA; ++it) {
-                int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
-                const int r = row0 + i;
-                const bool ok = r < n_rows && (k0 + kk < Kp);
-                ra[it] = x_raw<XM>(x, r, ok, zoff, k0 + kk, tail, XM == 1 ? ptS[i] : 0);
-            }
-#pragma unroll
-            for (int it = 0; it < UB; ++it) {
-                int j, kk; unit_T<BN>(it * 256 + tid, j, kk);
-                const int n = n0 + j;
-                const bool ok = n < n_out && (k0 + kk < Kp);
-                rb[it] = ldg4(Wg + (size_t)(ok ? n : 0) * Kp + (ok ? k0 + kk : 0));
-            }
-        };
-        auto store_tile = [&](int kt) {
-            const int k0 = kt * KT;
-#pragma unroll
-            for (int it = 0; it < UA; ++it) {
-                int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
-                const int r = row0 + i;
-                const bool ok = r < n_rows && (k0 + kk < Kp);
-                store_T<BM>(As, i, kk, x_finish<XM>(x, ra[it], ok, k0 + kk, sv, tv));
-            }
-#pragma unroll
-            for (int it = 0; it < UB; ++it) {
-                int j, kk; unit_T<BN>(it * 256 + tid, j, kk);
-                const bool ok = (n0 + j) < n_out && (k0 + kk < Kp);
-                store_T<BN>(Bs, j, kk, f4sel(ok, rb[it], f4zero()));
-            }
-        };
-        load_tile(0);
+        if (!preloaded) load_tile(0);
+        preloaded = false;
         for (int kt = 0; kt < nk; ++kt) {
             store_tile(kt);
             __syncthreads();
