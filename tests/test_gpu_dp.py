@@ -1,0 +1,118 @@
+"""SURVEY 8e on real device code: the fused update step under DataParallelContext with world_size 2, both ranks on
+cuda:0 (one GPU is all a test box has; the `gloo` backend carries the CUDA tensors -- RCCL refuses two ranks on one
+device).  What bench.py --gpus N exercises, minus the transport:
+
+* identical minibatch on both ranks  ==  the single-process step on that minibatch (same per-replica BatchNorm
+  statistics, global mask counts doubled, summed gradients halved by them): losses, actions, Q-values to float32
+  rounding, post-Adam parameters to +-lr noise;
+* different minibatches: the replicas stay in lock step (bit-equal parameters on both ranks after the step), the
+  returned losses are the global ones (equal on both ranks), gradients are finite."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+B = 32
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _agent(seed=17):
+    from ga_ddpg_amd.api import make_agent
+    from oracle.detfill import fill_module_
+    agent, cfg = make_agent("ddpg_td3_aux.yaml")
+    for name in ("policy", "policy_target", "critic", "critic_target", "state_feature_extractor"):
+        fill_module_(getattr(agent, name), name, seed)
+    return agent, cfg
+
+
+def _batches(cfg, n):
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    mem = BaseMemory(1200, cfg, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 1200, seed=9)
+    rng = np.random.default_rng(3)
+    return [sample_valid_batch(mem, B, rng) for _ in range(n)], rng.random((B, 6)).astype(np.float32)
+
+
+def _state(agent):
+    return {n + "/" + k: p.detach().cpu().clone() for n in ("policy", "critic", "state_feature_extractor")
+            for k, p in getattr(agent, n).named_parameters()}
+
+
+def _worker(rank, world, port, same_batch, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ga_ddpg_amd.parallel import DataParallelContext
+    agent, cfg = _agent()
+    batches, u = _batches(cfg, 2)
+    batch = batches[0] if same_batch else batches[rank]
+    rt = agent.runtime(B, batch["point_state_batch"].shape[2])
+    dp = DataParallelContext()
+    agent._dp = dp
+    dp.attach(rt)
+    res = {}
+    for s in range(2):                                    # a policy step and a non-policy step
+        r = agent.update_parameters(batch, agent.update_step, s, noise_u=u)
+        if s == 0:
+            res = {"ret": r, "pi": agent.pi.cpu().clone(), "q1": agent.qf1.cpu().clone(), "y": agent.next_q_value.cpu().clone()}
+    torch.cuda.synchronize()
+    res["ret2"] = r
+    res["state"] = _state(agent)
+    res["finite"] = all(bool(torch.isfinite(p.grad).all()) for n in ("policy", "critic")
+                        for p in getattr(agent, n).parameters() if p.grad is not None)
+    torch.save(res, os.path.join(out_dir, "rank%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(same_batch, tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), same_batch, str(tmp_path)), nprocs=2, join=True)
+    return [torch.load(os.path.join(tmp_path, "rank%d.pt" % r), weights_only=False) for r in range(2)]
+
+
+def test_two_ranks_same_batch_equal_single_process(tmp_path):
+    from tests.helpers import assert_close
+    r0, r1 = _run(True, tmp_path)
+    agent, cfg = _agent()
+    batches, u = _batches(cfg, 2)
+    ref = agent.update_parameters(batches[0], agent.update_step, 0, noise_u=u)
+    for k, v in ref.items():
+        tol = 3e-2 if k in ("actor_critic_loss", "critic_grad") else 2e-4       # post-Adam quantities: DESIGN.md 6
+        want = 2 * v if k in ("reward_mask_num", "expert_mask_num") else v        # row counts are global sums
+        assert_close(r0["ret"][k], want, tol, 1e-6, "rank0 " + k)
+        assert_close(r1["ret"][k], want, tol, 1e-6, "rank1 " + k)
+    assert_close(r0["pi"].numpy(), agent.pi.cpu().numpy(), 1e-4, 1e-5, "pi")
+    assert_close(r0["q1"].numpy(), agent.qf1.cpu().numpy(), 1e-4, 1e-5, "q1")
+    assert_close(r0["y"].numpy(), agent.next_q_value.cpu().numpy(), 1e-4, 1e-5, "td target")
+    lr = 1e-3
+    agent.update_parameters(batches[0], agent.update_step, 1, noise_u=u)
+    st = _state(agent)
+    for k, v in st.items():                                # two Adam steps: within 2 x 2.2 lr of each other (sign-like first steps)
+        assert float((r0["state"][k] - v).abs().max()) <= 4.4 * lr + 1e-6, k
+
+
+def test_two_ranks_different_batches_stay_in_lock_step(tmp_path):
+    r0, r1 = _run(False, tmp_path)
+    assert r0["finite"] and r1["finite"]
+    for k, v in r0["state"].items():
+        if "running" in k:
+            continue
+        assert torch.equal(v, r1["state"][k]), "replicas diverged at " + k
+    for k in r0["ret2"]:
+        if k == "critic_grad":
+            continue        # the second step is a policy step: critic.grad then also holds the replica's own (unreduced,
+                            # discarded) actor-term gradient, exactly like the reference's DataParallel replica
+        assert r0["ret2"][k] == r1["ret2"][k] or abs(r0["ret2"][k] - r1["ret2"][k]) <= 1e-6 * abs(r0["ret2"][k]), k
