@@ -10,7 +10,9 @@ weights, alternating policy / non-policy steps.  A "step" = one Agent.update_par
 `value` is measured with the minibatches already resident in HBM (a ring of pre-sampled batches);
 the host-sampling + PCIe inclusive rate is reported separately as `value_host_inclusive`.
 N > 1: one process per GPU, batch rows sharded (256 per rank -> weak scaling), one RCCL all-reduce of
-the flat gradients per optimiser phase (ga_ddpg_amd.parallel).
+the flat gradients per optimiser phase (ga_ddpg_amd.parallel).  `value` is then the whole-job aggregate: B=256
+minibatch-steps per second summed over the ranks (= optimiser iterations/s x N; `config.iterations_per_s` holds the
+iteration rate), time = max over ranks between two barrier + synchronize fences.
 
 Extra objects on the JSON line:
   roofline      dominant kernel: algorithmic FLOPs of the layer as the reference computes it (dense
@@ -18,7 +20,11 @@ Extra objects on the JSON line:
                 stream), against the FP32 MFMA peak; `executed_frac` is the same with the FLOPs the
                 de-duplicated kernel really executes.
   cpu_baseline  the CPU oracle (pure-PyTorch port of the reference step) timed on this box's cores,
-                rank 0 / N=1 only, on a bounded sample (one B=256 step).
+                rank 0 / N=1 only, on a bounded sample (64 rows of one B=256 step, scaled).
+  sa_kernel_hbm BASELINE's second metric: HBM GB/s of the streaming set-abstraction kernels of this workload
+                (HIP events; algorithmic bytes and PMC traffic) and of the materialising configs[3] kernel.
+  value_host_inclusive / value_device_replay: the same loop fed by host sampling + PCIe upload / by the
+                GPU-resident replay mirror (never `value`).
 """
 import argparse
 import json
@@ -120,12 +126,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    # GAD_BENCH_BACKEND=gloo lets the N > 1 path be exercised on a box with fewer GPUs than ranks (ranks then share
+    # devices round-robin; RCCL refuses that) -- a plumbing check, not a measurement
+    backend = os.environ.get("GAD_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
     dp = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     from ga_ddpg_amd import engine
     from ga_ddpg_amd.api import make_agent
     from ga_ddpg_amd.core.replay_memory import BaseMemory
@@ -206,17 +215,20 @@ def main():
                 "executed_frac": ach / FP32_MFMA_PEAK * n_rows / dense_rows,
                 "dedup_rows": n_rows, "dense_rows": int(dense_rows)}
     steps_per_s = args.steps * 1.0 / dt
-    res = {"metric": "DDPG grad-steps/sec (B=256, N=1024 pts)", "value": steps_per_s * 1.0, "unit": "steps/s",
+    # whole-job aggregate: every rank processes one B=256 minibatch per optimiser step (weak scaling), so the job does
+    # world x (B=256 minibatch-steps) per iteration; at N=1 this is the plain step rate
+    res = {"metric": "DDPG grad-steps/sec (B=256, N=1024 pts)", "value": steps_per_s * world, "unit": "steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: DDPG/TD3 offline update (td3_critic_aux_policy_aux), "
                                   "batch=%d per GPU, 1024-pt clouds, synthetic replay buffer" % B,
                       "batch_per_gpu": B, "global_batch": B * world, "points": 1024,
-                      "parallelism": "dp%d" % world, "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
+                      "parallelism": "dp%d" % world, "iterations_per_s": steps_per_s,
+                      "value_definition": "B=256 minibatch gradient steps per second summed over ranks (= iterations/s x n_gpus)", "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
            "losses": {k: out[k] for k in ("critic_loss", "bc_loss", "actor_critic_loss")},
            "roofline": roof}
     # step-level view against the dense-FP32 roofline: mean 5.5078 GFLOP per sample and step
-    res["step_dense_tflops"] = steps_per_s * B * 5.5078e9 / 1e12
+    res["step_dense_tflops"] = steps_per_s * world * B * 5.5078e9 / 1e12
     if world == 1 and not args.no_host_rate:
         rng2 = np.random.default_rng(7)
         n = max(10, args.steps // 10)
