@@ -32,13 +32,25 @@ static inline int gad_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 __device__ __forceinline__ int gad_cdiv_dev(int a, int b) { return (a + b - 1) / b; }
 #endif
 
+void gad_geometry_set_option(const char* name, int value, int* found);
+
 #ifdef __HIPCC__
 // squared distance with the evaluation order pinned to the oracle's (oracle/pn2_ref.c sqdist):
 // every product and sum individually rounded, no FMA contraction.
 __device__ __forceinline__ float gad_sqdist(float ax, float ay, float az, float bx, float by, float bz) {
-    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
-    float xx = __fmul_rn(dx, dx), yy = __fmul_rn(dy, dy), zz = __fmul_rn(dz, dz);
-    return __fadd_rn(__fadd_rn(xx, yy), zz);
+    // hipcc contracts a*b+c into an FMA by default, and the __fmul_rn / __fadd_rn of its headers are plain operators compiled
+    // with that default: only operators written under this pragma stay individually rounded
+#pragma clang fp contract(off)
+    float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    return (xx + yy) + zz;
+}
+
+// |p|^2 with the same pinned order (FPS skip rule, oracle/pn2_ref.c: (m0 + m1) + m2)
+__device__ __forceinline__ float gad_sqnorm(float x, float y, float z) {
+#pragma clang fp contract(off)
+    float xx = x * x, yy = y * y, zz = z * z;
+    return (xx + yy) + zz;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -765,6 +765,9 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
     if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
+    int found = 0;
+    gad_geometry_set_option(name, value, &found);                                     // geometry.hip: "bq_cells"
+    if (found) return GAD_OK;
     GAD_REQUIRE(false, GAD_ERR_SHAPE, "set_option: unknown option '%s'", name);
     return GAD_OK;
 }

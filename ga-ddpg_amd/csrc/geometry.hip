@@ -9,6 +9,7 @@
 #include "common.hpp"
 
 #include <stdarg.h>
+#include <string.h>
 
 static thread_local char g_err[512] = "";
 void gad_set_error(const char* fmt, ...) {
@@ -59,8 +60,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             px[s] = sp[k * 3 + 0];
             py[s] = sp[k * 3 + 1];
             pz[s] = sp[k * 3 + 2];
-            const float mag = __fadd_rn(__fadd_rn(__fmul_rn(px[s], px[s]), __fmul_rn(py[s], py[s])),
-                                        __fmul_rn(pz[s], pz[s]));
+            const float mag = gad_sqnorm(px[s], py[s], pz[s]);
             if (mag > 1e-3f) valid |= 1u << s;
             const unsigned t = (unsigned)k & ((1u << tie_bits) - 1u);          // k mod tie_bs
             const unsigned rev = tie_bits ? (__brev(t) >> (32 - tie_bits)) : 0u;
@@ -277,6 +277,387 @@ __global__ __launch_bounds__(256) void ball_query_tiled_kernel(const float* __re
     }
 }
 
+// ---- cell-list radius search (configs[3] regime: thousands of points, a radius that is a small fraction of the cloud) ----
+// The brute-force tile scan above tests every (centroid, point) pair: 4096 tests per centroid at configs[3] for ~17 hits.
+// Here one 1024-thread workgroup sorts its cloud ONCE into a uniform grid held in LDS (cell edge >= 1.001 x radius, so
+// every in-radius point lies in the 3x3x3 cells around the centroid's cell: ~110 candidates), then each wavefront takes
+// four centroids at a time (16 lanes each): the candidates of the nine (y,z) cell rows -- three x-adjacent cells are one
+// contiguous run of the sorted cloud -- get the exact pinned-order distance test, and hits set bit k of the centroid's
+// N-bit LDS bitmap.  The bitmap is then read back in ASCENDING point order (one 64-bit word per lane, popcount prefix
+// scan), which is the reference's result order (first nsample hits by index) whatever order the cells were visited in:
+// indices, counts and the grouped tensor are bit-identical to the scans above.  Cells are only an acceleration
+// structure: a centroid outside the cloud's bounding box is clamped to the border cell, which still covers every
+// candidate it can have, and the exact predicate d2 < r2 decides.
+#define BQC_THREADS 1024
+#define BQC_WAVES 16
+#define BQC_GMAX 12                                // cells per axis; 12^3 = 1728
+#define BQC_MAXCELLS 1728
+#define BQC_MB 256                                 // centroids per workgroup
+
+struct BqcGrid { float lox, loy, loz, ivx, ivy, ivz; int nx, ny, nz; };
+
+__device__ __forceinline__ int bqc_axis(float lo, float hi, float h, float& inv) {
+    const float ext = hi - lo;
+    int n = (int)floorf(ext / h) + 1;
+    float hc = h;
+    if (!(n <= BQC_GMAX)) { n = BQC_GMAX; hc = ext / (float)BQC_GMAX * 1.0001f; }   // coarser cells: still >= h
+    if (n < 1) n = 1;
+    inv = 1.0f / hc;
+    return n;
+}
+__device__ __forceinline__ int bqc_cell1(float p, float lo, float inv, int n) {
+    const int c = (int)floorf((p - lo) * inv);
+    return c < 0 ? 0 : (c >= n ? n - 1 : c);
+}
+
+// DPP cross-lane helpers (row = 16 lanes): no LDS traffic, unlike __shfl (ds_bpermute)
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int row_incl_scan(int x) {             // inclusive prefix sum inside each 16-lane row
+    x += dpp_i<0x111>(0, x); x += dpp_i<0x112>(0, x); x += dpp_i<0x114>(0, x); x += dpp_i<0x118>(0, x);   // row_shr:1,2,4,8
+    return x;
+}
+__device__ __forceinline__ int wave_incl_scan(int x) {            // inclusive prefix sum over the wavefront
+    x = row_incl_scan(x);
+    x += dpp_i<0x142, 0xa>(0, x);                                  // row_bcast:15 -> rows 1, 3
+    x += dpp_i<0x143, 0xc>(0, x);                                  // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ float wave_max_f(float v) {            // every lane gets the wavefront maximum
+    v = fmaxf(v, __int_as_float(dpp_i<0x111>(__float_as_int(v), __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x112>(__float_as_int(v), __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x114>(__float_as_int(v), __float_as_int(v))));
+    v = fmaxf(v, __int_as_float(dpp_i<0x118>(__float_as_int(v), __float_as_int(v))));   // lane 15 of each row: row maximum
+    const int i = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 15)), __int_as_float(__builtin_amdgcn_readlane(i, 31))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 47)), __int_as_float(__builtin_amdgcn_readlane(i, 63))));
+}
+
+#define BQC_QUADS (BQC_MB / (4 * BQC_WAVES))       // passes of four centroids per wavefront
+#define BQC_CPIPE 4                                // feature channels the grouped-output phase keeps in flight per lane
+
+__global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const float* __restrict__ new_xyz,
+                                                                       const float* __restrict__ xyz,
+                                                                       const float* __restrict__ feat, int C, int N, int M,
+                                                                       float radius, int S, int32_t* __restrict__ idx,
+                                                                       int32_t* __restrict__ cnt_out, float* __restrict__ out, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float bq_lds[];
+    unsigned long long* bm = reinterpret_cast<unsigned long long*>(bq_lds);                      // [waves][4][64] bitmaps
+    int32_t* cstart = reinterpret_cast<int32_t*>(bm + BQC_WAVES * 4 * 64);                       // BQC_MAXCELLS + 1 (+ pad)
+    int32_t* cursor = cstart + BQC_MAXCELLS + 4;                                                 // build phase only
+    int32_t* lists = cursor + BQC_MAXCELLS + 4;                                                  // [waves][4][S]
+    float* red = reinterpret_cast<float*>(lists + BQC_WAVES * 4 * S);                            // 6 x waves + waves
+    float* sx = red + 8 * BQC_WAVES;                               // cloud sorted by cell
+    float* sy = sx + N;
+    float* sz = sy + N;
+    unsigned short* sidx = reinterpret_cast<unsigned short*>(sz + N);    // sorted slot -> point index
+    unsigned short* spos = sidx + N;                                     // point index -> sorted slot
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
+    const int sub = lane >> 4, l16 = lane & 15;
+    const int b = blockIdx.y, m0 = blockIdx.x * BQC_MB;
+    const int m_end = min(M, m0 + BQC_MB);
+    const float* p = xyz + (size_t)b * N * 3;
+
+    // this wavefront's centroids, fetched before the build so that their latency hides behind it
+    float qx[BQC_QUADS], qy[BQC_QUADS], qz[BQC_QUADS];
+#pragma unroll
+    for (int qi = 0; qi < BQC_QUADS; ++qi) {
+        const int m = min(m0 + 4 * (wave + qi * BQC_WAVES) + sub, M - 1);
+        const float* c = new_xyz + ((size_t)b * M + m) * 3;
+        qx[qi] = c[0]; qy[qi] = c[1]; qz[qi] = c[2];
+    }
+
+    if (dbg & 8) return;
+    // ---- build: bounding box -> grid -> counting sort -------------------------------------------------------------
+    float px[4], py[4], pz[4];
+    float hi[6] = {-3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f, -3.0e38f};          // max of (x, y, z, -x, -y, -z)
+    // thread t owns points 4t .. 4t+3: three 16-byte loads when the cloud is 16-byte aligned (N % 4 == 0)
+    const bool vec = (N & 3) == 0 && (reinterpret_cast<size_t>(xyz) & 15) == 0;
+    if (vec) {
+        if (4 * tid < N) {
+            const float4* p4 = reinterpret_cast<const float4*>(p) + 3 * tid;
+            const float4 a = p4[0], bq = p4[1], cq = p4[2];
+            px[0] = a.x; py[0] = a.y; pz[0] = a.z; px[1] = a.w; py[1] = bq.x; pz[1] = bq.y;
+            px[2] = bq.z; py[2] = bq.w; pz[2] = cq.x; px[3] = cq.y; py[3] = cq.z; pz[3] = cq.w;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = 4 * tid + u;
+            if (k < N) { px[u] = p[k * 3 + 0]; py[u] = p[k * 3 + 1]; pz[u] = p[k * 3 + 2]; }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (4 * tid + u < N) {
+            hi[0] = fmaxf(hi[0], px[u]); hi[1] = fmaxf(hi[1], py[u]); hi[2] = fmaxf(hi[2], pz[u]);
+            hi[3] = fmaxf(hi[3], -px[u]); hi[4] = fmaxf(hi[4], -py[u]); hi[5] = fmaxf(hi[5], -pz[u]);
+        }
+    }
+    for (int c = tid; c < BQC_MAXCELLS + 4; c += BQC_THREADS) cstart[c] = 0;
+    for (int i = tid; i < BQC_WAVES * 4 * 64; i += BQC_THREADS) bm[i] = 0ull;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        hi[a] = wave_max_f(hi[a]);
+        if (lane == 0) red[a * BQC_WAVES + wave] = hi[a];
+    }
+    __syncthreads();
+    if (dbg & 16) return;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        float v = red[a * BQC_WAVES + (lane & (BQC_WAVES - 1))];
+        hi[a] = wave_max_f(v);
+    }
+    BqcGrid g;
+    const float h = radius * 1.001f;
+    g.lox = -hi[3]; g.loy = -hi[4]; g.loz = -hi[5];
+    g.nx = bqc_axis(g.lox, hi[0], h, g.ivx);
+    g.ny = bqc_axis(g.loy, hi[1], h, g.ivy);
+    g.nz = bqc_axis(g.loz, hi[2], h, g.ivz);
+    const int ncell = g.nx * g.ny * g.nz;
+
+    int cell[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = 4 * tid + u;
+        cell[u] = 0;
+        if (k < N) {
+            cell[u] = (bqc_cell1(pz[u], g.loz, g.ivz, g.nz) * g.ny + bqc_cell1(py[u], g.loy, g.ivy, g.ny)) * g.nx +
+                      bqc_cell1(px[u], g.lox, g.ivx, g.nx);
+            atomicAdd(&cstart[cell[u] + 1], 1);
+        }
+    }
+    __syncthreads();
+    if (dbg & 32) return;
+    {   // inclusive scan of cstart[0 .. ncell] in place: two entries per thread (2048 >= BQC_MAXCELLS + 1)
+        int32_t* wtot = reinterpret_cast<int32_t*>(red) + 6 * BQC_WAVES;
+        const int e0 = 2 * tid;
+        const int2 a = *reinterpret_cast<const int2*>(cstart + min(e0, BQC_MAXCELLS + 2));
+        const int a0 = e0 <= ncell ? a.x : 0, a1 = e0 + 1 <= ncell ? a.y : 0;
+        const int incl = wave_incl_scan(a0 + a1);
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        const int wt = wtot[lane & (BQC_WAVES - 1)];
+        const int winc = wave_incl_scan(lane < BQC_WAVES ? wt : 0);
+        const int base = wave == 0 ? 0 : __shfl(winc, wave - 1, 64);
+        const int excl = base + incl - (a0 + a1);
+        if (e0 <= ncell) { cstart[e0] = excl + a0; cursor[e0] = excl + a0; }
+        if (e0 + 1 <= ncell) { cstart[e0 + 1] = excl + a0 + a1; cursor[e0 + 1] = excl + a0 + a1; }
+    }
+    __syncthreads();
+    if (dbg & 64) return;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = 4 * tid + u;
+        if (k < N) {
+            const int t = atomicAdd(&cursor[cell[u]], 1);
+            sx[t] = px[u]; sy[t] = py[u]; sz[t] = pz[u];
+            sidx[t] = (unsigned short)k; spos[k] = (unsigned short)t;
+        }
+    }
+    __syncthreads();
+
+    // ---- query: four centroids per wavefront pass, 16 lanes each ----------------------------------------------------
+    const float r2 = radius * radius;
+    unsigned long long* bw = bm + (size_t)(wave * 4 + sub) * 64;  // this row's centroid
+    unsigned* bm32 = reinterpret_cast<unsigned*>(bw);
+    int32_t* mylist = lists + (size_t)(wave * 4 + sub) * S;
+    const size_t plane = (size_t)M * S;
+    const bool pipe = S <= 64 && C <= BQC_CPIPE;
+    float pf[4][BQC_CPIPE];
+    int pend_q = -1;
+#pragma unroll
+    for (int qi = 0; qi < BQC_QUADS; ++qi) {
+        const int q = wave + qi * BQC_WAVES;
+        if (m0 + 4 * q >= m_end) break;                            // wave-uniform
+        const int m = m0 + 4 * q + sub;
+        const bool live = m < m_end;
+        const float ccx = qx[qi], ccy = qy[qi], ccz = qz[qi];
+        const int cx = bqc_cell1(ccx, g.lox, g.ivx, g.nx), cy = bqc_cell1(ccy, g.loy, g.ivy, g.ny),
+                  cz = bqc_cell1(ccz, g.loz, g.ivz, g.nz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        int beg[9], end[9];
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const int yy = cy + (rr % 3) - 1, zz = cz + (rr / 3) - 1;
+            const bool ok = live && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz;
+            const int rb = ok ? (zz * g.ny + yy) * g.nx : 0;
+            beg[rr] = ok ? cstart[rb + x0] : 0;
+            end[rr] = ok ? cstart[rb + x1 + 1] : 0;
+        }
+        if (!(dbg & 2)) {
+            // first 16 candidates of all nine rows in one batch of LDS reads (a row holds ~12 at configs[3]), leftovers after
+            float tx[9], ty[9], tz[9];
+            unsigned tk[9];
+#pragma unroll
+            for (int rr = 0; rr < 9; ++rr) {
+                const int t = beg[rr] + l16;
+                const int tc = t < end[rr] ? t : 0;
+                tx[rr] = sx[tc]; ty[rr] = sy[tc]; tz[rr] = sz[tc]; tk[rr] = sidx[tc];
+            }
+#pragma unroll
+            for (int rr = 0; rr < 9; ++rr) {
+                const float d2 = gad_sqdist(ccx, ccy, ccz, tx[rr], ty[rr], tz[rr]);
+                if (beg[rr] + l16 < end[rr] && d2 < r2) atomicOr(&bm32[tk[rr] >> 5], 1u << (tk[rr] & 31));
+            }
+#pragma unroll
+            for (int rr = 0; rr < 9; ++rr) {
+                for (int t = beg[rr] + 16 + l16; t < end[rr]; t += 16) {
+                    const float d2 = gad_sqdist(ccx, ccy, ccz, sx[t], sy[t], sz[t]);
+                    const unsigned k = sidx[t];
+                    if (d2 < r2) atomicOr(&bm32[k >> 5], 1u << (k & 31));
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // a wavefront touches only its own bitmaps and lists
+        __builtin_amdgcn_wave_barrier();
+        if (dbg & 4) continue;
+
+        // ---- bitmaps -> ascending index lists, the four centroids side by side: lane l16 owns bits [256 l16, 256 l16 + 256)
+        unsigned long long w[4];
+        {
+            const ulonglong2 w01 = *reinterpret_cast<const ulonglong2*>(bw + 4 * l16);
+            const ulonglong2 w23 = *reinterpret_cast<const ulonglong2*>(bw + 4 * l16 + 2);
+            w[0] = w01.x; w[1] = w01.y; w[2] = w23.x; w[3] = w23.y;
+            *reinterpret_cast<ulonglong2*>(bw + 4 * l16) = ulonglong2{0ull, 0ull};
+            *reinterpret_cast<ulonglong2*>(bw + 4 * l16 + 2) = ulonglong2{0ull, 0ull};
+        }
+        const int nb = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
+        const int incl = row_incl_scan(nb);
+        const int total = __shfl(incl, lane | 15, 64);
+        int lowbit = 0;                                            // lowest set bit of this lane's 256
+#pragma unroll
+        for (int i = 3; i >= 0; --i) lowbit = w[i] ? 64 * i + (__ffsll((long long)w[i]) - 1) : lowbit;
+        const unsigned have = (unsigned)(__ballot(nb > 0) >> (16 * sub)) & 0xffffu;
+        const int firstv = __shfl(256 * l16 + lowbit, (lane & 48) | (have ? __ffs((int)have) - 1 : 0), 64);
+        const int first = have ? firstv : 0;
+        int pos = incl - nb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long ww = w[i];
+            while (ww != 0ull && pos < S) {
+                mylist[pos++] = 256 * l16 + 64 * i + (__ffsll((long long)ww) - 1);
+                ww &= ww - 1ull;
+            }
+        }
+        const int cnt = total < S ? total : S;
+        for (int s2 = cnt + l16; s2 < S; s2 += 16) mylist[s2] = first;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+
+        // ---- write-out: one centroid per 64-lane sweep.  Fast path (nsample <= 64, <= BQC_CPIPE feature channels): the
+        // feature loads of this pass stay in flight across the NEXT pass's scan and are stored after it
+        if (cnt_out && l16 == 0 && live) cnt_out[(size_t)b * M + m] = cnt;
+        if (pipe) {
+            const bool act = lane < S;
+            if (out && pend_q >= 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                      // phase C of the previous pass
+                    const int mj = m0 + 4 * pend_q + j;
+                    if (mj < m_end && act) {
+                        float* o = out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S + lane;
+#pragma unroll
+                        for (int ch = 0; ch < BQC_CPIPE; ++ch)
+                            if (ch < C) o[(3 + ch) * plane] = pf[j][ch];
+                    }
+                }
+            }
+            int kk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                          // phase A: indices and the feature loads of all four
+                const bool okj = act && (m0 + 4 * q + j < m_end);
+                kk[j] = okj ? lists[(size_t)(wave * 4 + j) * S + lane] : 0;
+                if (out) {
+                    const float* f = feat + (size_t)b * C * N + kk[j];
+#pragma unroll
+                    for (int ch = 0; ch < BQC_CPIPE; ++ch) pf[j][ch] = ch < C ? f[(size_t)ch * N] : 0.f;
+                }
+            }
+            pend_q = q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                          // phase B: indices + recentred coordinates (LDS only)
+                const int mj = m0 + 4 * q + j;
+                if (mj >= m_end) break;
+                const size_t gi = (size_t)b * M + mj;
+                if (act) {
+                    idx[gi * S + lane] = kk[j];
+                    if (out) {
+                        const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccx), 16 * j));
+                        const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccy), 16 * j));
+                        const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccz), 16 * j));
+                        float* o = out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S + lane;
+                        const int t = spos[kk[j]];
+                        o[0 * plane] = __fsub_rn(sx[t], jx);
+                        o[1 * plane] = __fsub_rn(sy[t], jy);
+                        o[2 * plane] = __fsub_rn(sz[t], jz);
+                    }
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int mj = m0 + 4 * q + j;
+                if (mj >= m_end) break;
+                const size_t gi = (size_t)b * M + mj;
+                const int32_t* my = lists + (size_t)(wave * 4 + j) * S;
+                const float jx = __shfl(ccx, 16 * j, 64), jy = __shfl(ccy, 16 * j, 64), jz = __shfl(ccz, 16 * j, 64);
+                float* o = out ? out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S : nullptr;
+                for (int s2 = lane; s2 < S; s2 += 64) {
+                    const int k = my[s2];
+                    idx[gi * S + s2] = k;
+                    if (o) {
+                        const int t = spos[k];
+                        o[0 * plane + s2] = __fsub_rn(sx[t], jx);
+                        o[1 * plane + s2] = __fsub_rn(sy[t], jy);
+                        o[2 * plane + s2] = __fsub_rn(sz[t], jz);
+                        const float* f = feat + (size_t)b * C * N + k;
+                        for (int ch = 0; ch < C; ++ch) o[(3 + ch) * plane + s2] = f[(size_t)ch * N];
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                           // the lists are rewritten by the next pass
+    }
+    if (pipe && out && pend_q >= 0 && lane < S) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int mj = m0 + 4 * pend_q + j;
+            if (mj < m_end) {
+                float* o = out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S + lane;
+#pragma unroll
+                for (int ch = 0; ch < BQC_CPIPE; ++ch)
+                    if (ch < C) o[(3 + ch) * plane] = pf[j][ch];
+            }
+        }
+    }
+}
+
+static int g_opt_bq_cells = 1;
+void gad_geometry_set_option(const char* name, int value, int* found) {
+    if (!strcmp(name, "bq_cells")) { g_opt_bq_cells = value; *found = 1; }
+}
+static size_t bqc_lds_bytes(int N, int S) {
+    return (size_t)BQC_WAVES * 4 * 64 * 8 + (size_t)2 * (BQC_MAXCELLS + 4) * 4 + (size_t)BQC_WAVES * 4 * S * 4 + (size_t)8 * BQC_WAVES * 4 +
+           (size_t)3 * N * 4 + (size_t)2 * N * 2;
+}
+static bool bq_use_cells(int N, int nsample, float radius) {
+    return g_opt_bq_cells && N > 1024 && N <= BQ_MAXN && radius > 0.f && radius < 1.0e18f && nsample <= 128;
+}
+static int bq_launch_cells(const float* new_xyz, const float* xyz, const float* feat, int B, int C, int N, int M, float radius,
+                           int nsample, int32_t* idx, int32_t* cnt, float* out, hipStream_t st) {
+    const size_t lds = bqc_lds_bytes(N, nsample);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ball_query_cells_kernel, dim3(gad_cdiv(M, BQC_MB), B), dim3(BQC_THREADS), lds, st, new_xyz, xyz, feat, C, N,
+                       M, radius, nsample, idx, cnt, out, g_opt_bq_cells);
+    return 0;
+}
+
 static bool bq_use_tiled(int N, int nsample) { return N > 1024 && N <= BQ_MAXN && nsample <= 256; }
 static int bq_launch_tiled(const float* new_xyz, const float* xyz, const float* feat, int B, int C, int N, int M, float radius,
                            int nsample, int32_t* idx, int32_t* cnt, float* out, hipStream_t st) {
@@ -307,6 +688,11 @@ extern "C" int gad_ball_query(const float* new_xyz, const float* xyz, int B, int
     GAD_REQUIRE(B >= 0 && N >= 1 && M >= 0 && nsample >= 1, GAD_ERR_SHAPE, "ball_query: bad shape");
     const int G = B * M;
     if (G == 0) return GAD_OK;
+    if (bq_use_cells(N, nsample, radius)) {
+        bq_launch_cells(new_xyz, xyz, nullptr, B, 0, N, M, radius, nsample, idx, cnt, nullptr, (hipStream_t)stream);
+        GAD_CHECK_LAUNCH("ball_query(cells)");
+        return GAD_OK;
+    }
     if (bq_use_tiled(N, nsample)) {
         bq_launch_tiled(new_xyz, xyz, nullptr, B, 0, N, M, radius, nsample, idx, cnt, nullptr, (hipStream_t)stream);
         GAD_CHECK_LAUNCH("ball_query(tiled)");
@@ -443,6 +829,11 @@ extern "C" int gad_query_and_group(const float* new_xyz, const float* xyz, const
     GAD_REQUIRE(nsample >= 1 && nsample <= 4096, GAD_ERR_SHAPE, "query_and_group: nsample out of range");
     const int G = B * M;
     if (G == 0) return GAD_OK;
+    if (bq_use_cells(N, nsample, radius)) {
+        bq_launch_cells(new_xyz, xyz, features, B, C, N, M, radius, nsample, idx, nullptr, out, (hipStream_t)stream);
+        GAD_CHECK_LAUNCH("query_and_group(cells)");
+        return GAD_OK;
+    }
     if (bq_use_tiled(N, nsample)) {
         bq_launch_tiled(new_xyz, xyz, features, B, C, N, M, radius, nsample, idx, nullptr, out, (hipStream_t)stream);
         GAD_CHECK_LAUNCH("query_and_group(tiled)");

@@ -132,3 +132,116 @@ def test_rows_compaction():
         assert (grp[lo:hi] == g).all()
         assert w[lo] == S - (hi - lo) + 1 and (w[lo + 1:hi] == 1).all()
         assert w[lo:hi].sum() == S           # multiplicities reproduce the padded neighbourhood
+
+
+def _bq(new_xyz, xyz, r, S):
+    from ga_ddpg_amd import hip
+    B, N, _ = xyz.shape
+    M = new_xyz.shape[1]
+    idx = torch.full((B, M, S), -1, dtype=torch.int32, device="cuda")
+    cnt = torch.full((B, M), -1, dtype=torch.int32, device="cuda")
+    hip.call("gad_ball_query", new_xyz, xyz, B, N, M, float(r), S, idx, cnt)
+    return idx, cnt
+
+
+@pytest.mark.parametrize("case", ["uniform", "ragged_n", "clustered", "tiny_radius", "huge_radius", "degenerate", "outside",
+                                  "planar", "one_centroid"])
+def test_cell_list_ball_query_matches_oracle(case):
+    """the large-cloud radius search (1024 < N <= 4096: uniform grid in LDS + per-centroid bitmap, geometry.hip
+    ball_query_cells_kernel) against the C oracle on the cases that stress the grid: ragged N, clusters that overflow
+    single cells, a radius so small the grid resolution is capped, a radius larger than the cloud (every point a hit,
+    truncation to the first nsample by index), zero-extent clouds, centroids outside the bounding box, M % 4 != 0."""
+    from ga_ddpg_amd import hip
+    from oracle import cref
+    rng = np.random.default_rng(sum(map(ord, case)))
+    B, N, M, r, S = 2, 4096, 67, 0.1, 64
+    xyz = rng.random((B, N, 3)).astype(np.float32)
+    if case == "ragged_n":
+        N = 2501; xyz = xyz[:, :N].copy(); S = 17
+    elif case == "clustered":
+        xyz[:, : N // 2] = (0.5 + 0.01 * rng.normal(size=(B, N // 2, 3))).astype(np.float32); S = 128
+    elif case == "tiny_radius":
+        r = 1e-3; xyz[:, 1::2] = xyz[:, ::2] + np.float32(4e-4)
+    elif case == "huge_radius":
+        r = 5.0; S = 32
+    elif case == "degenerate":
+        xyz[:] = np.float32(0.25); xyz[1, 7] = 0.2501
+    elif case == "planar":
+        xyz[..., 2] = np.float32(-3.0); r = 0.05
+    elif case == "one_centroid":
+        M = 1
+    pick = rng.integers(0, N, size=(B, M))
+    new_xyz = np.take_along_axis(xyz, pick[..., None], 1).copy()
+    if case == "outside":
+        new_xyz[:, ::3] += np.float32(0.07) * rng.normal(size=new_xyz[:, ::3].shape).astype(np.float32)
+        new_xyz[0, 0] = (-0.05, 0.5, 0.5); new_xyz[0, 1] = (1.5, 1.5, 1.5); new_xyz[1, 2] = (0.5, 1.09, -0.09)
+    want, wcnt = cref.ball_query(new_xyz, xyz, r, S, return_count=True)
+    idx, cnt = _bq(torch.from_numpy(new_xyz).cuda(), torch.from_numpy(xyz).cuda(), r, S)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
+
+
+def test_cell_list_equals_brute_force_at_full_size():
+    """configs[3] size: the cell-list kernel and the brute-force tile scan (option bq_cells = 0) agree bit for bit on
+    indices, counts and the grouped tensor."""
+    from ga_ddpg_amd import hip
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
+    B, N, M, S = 128, 4096, 512, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xyz = torch.rand(B, N, 3, device="cuda", generator=g)
+    feats = torch.randn(B, 4, N, device="cuda", generator=g)
+    new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), pu.furthest_point_sample(xyz, M)).transpose(1, 2).contiguous()
+    try:
+        hip.set_option("bq_cells", 0)
+        i0, c0 = _bq(new_xyz, xyz, 0.1, S)
+        q0, o0 = pu.query_and_group(0.1, S, xyz, new_xyz, feats)
+    finally:
+        hip.set_option("bq_cells", 1)
+    i1, c1 = _bq(new_xyz, xyz, 0.1, S)
+    q1, o1 = pu.query_and_group(0.1, S, xyz, new_xyz, feats)
+    assert torch.equal(i0, i1) and torch.equal(c0, c1) and torch.equal(q0, q1) and torch.equal(q1, i1)
+    assert torch.equal(o0, o1)
+    assert 5 < float(c1.float().mean()) < 40                      # ~17 neighbours expected: the test is not vacuous
+
+
+def _contraction_sensitive_case(rng, N):
+    """a cloud, one centroid and a radius for which the squared distance of one point lies on different sides of r^2
+    depending on whether dy*dy + dx*dx is fused into an FMA or rounded twice (the oracle: every operation rounded)"""
+    f32 = np.float32
+    while True:
+        c = rng.random(3).astype(f32)
+        pts = (c + (rng.random((4096, 3)).astype(f32) - f32(0.5)) * f32(0.2)).astype(f32)
+        d = (c[None] - pts).astype(f32)
+        xx, yy, zz = (d[:, 0] * d[:, 0]).astype(f32), (d[:, 1] * d[:, 1]).astype(f32), (d[:, 2] * d[:, 2]).astype(f32)
+        pinned = ((xx + yy).astype(f32) + zz).astype(f32)
+        fused = ((d[:, 1].astype(np.float64) ** 2 + xx.astype(np.float64)).astype(f32) + zz).astype(f32)
+        for i in np.nonzero(pinned != fused)[0]:
+            lo, hi = min(pinned[i], fused[i]), max(pinned[i], fused[i])
+            r = f32(np.sqrt(np.float64(hi)))
+            for _ in range(8):                                     # a float32 radius whose float32 square is in (lo, hi]
+                r2 = f32(r * r)
+                if lo < r2 <= hi:
+                    xyz = (rng.random((1, N, 3)) * 2.0 - 0.5).astype(f32)          # mostly far away
+                    xyz[0, :32] = pts[:32]
+                    xyz[0, 5] = pts[i]
+                    return xyz, c.reshape(1, 1, 3), float(r)
+                r = np.nextafter(r, f32(0) if r2 > hi else f32(4), dtype=f32)
+
+
+@pytest.mark.parametrize("N,cells", [(512, 1), (2048, 1), (2048, 0)])
+def test_ball_query_distance_is_not_fma_contracted(N, cells):
+    """d^2 < r^2 is evaluated as ((dx*dx) + (dy*dy)) + (dz*dz) with every operation rounded (oracle/pn2_ref.c sqdist);
+    radii chosen so that a fused multiply-add anywhere in that expression flips a neighbour"""
+    from ga_ddpg_amd import hip
+    from oracle import cref
+    rng = np.random.default_rng(77 + N + cells)
+    try:
+        hip.set_option("bq_cells", cells)
+        for _ in range(6):
+            xyz, ctr, r = _contraction_sensitive_case(rng, N)
+            want, wcnt = cref.ball_query(ctr, xyz, r, 64, return_count=True)
+            idx, cnt = _bq(torch.from_numpy(ctr).cuda(), torch.from_numpy(xyz).cuda(), r, 64)
+            np.testing.assert_array_equal(idx.cpu().numpy(), want)
+            np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
+    finally:
+        hip.set_option("bq_cells", 1)
