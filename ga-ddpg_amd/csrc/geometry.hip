@@ -296,14 +296,14 @@ __global__ __launch_bounds__(256) void ball_query_tiled_kernel(const float* __re
 
 struct BqcGrid { float lox, loy, loz, ivx, ivy, ivz; int nx, ny, nz; };
 
-__device__ __forceinline__ int bqc_axis(float lo, float hi, float h, float& inv) {
+// cells along one axis: edge >= h (= 1.001 r).  Only an acceleration structure, so approximate arithmetic is fine as
+// long as the edge never drops below the radius: the 1e-3 (1e-4) slack covers the ~1e-7 error of v_rcp_f32
+__device__ __forceinline__ int bqc_axis(float lo, float hi, float inv_h, float& inv) {
     const float ext = hi - lo;
-    int n = (int)floorf(ext / h) + 1;
-    float hc = h;
-    if (!(n <= BQC_GMAX)) { n = BQC_GMAX; hc = ext / (float)BQC_GMAX * 1.0001f; }   // coarser cells: still >= h
-    if (n < 1) n = 1;
-    inv = 1.0f / hc;
-    return n;
+    int n = (int)(ext * inv_h) + 1;
+    inv = inv_h;
+    if (!(n <= BQC_GMAX)) { n = BQC_GMAX; inv = (float)BQC_GMAX * __builtin_amdgcn_rcpf(ext * 1.0001f); }   // coarser cells
+    return n < 1 ? 1 : n;
 }
 __device__ __forceinline__ int bqc_cell1(float p, float lo, float inv, int n) {
     const int c = (int)floorf((p - lo) * inv);
@@ -323,35 +323,53 @@ __device__ __forceinline__ int wave_incl_scan(int x) {            // inclusive p
     x += dpp_i<0x143, 0xc>(0, x);                                  // row_bcast:31 -> rows 2, 3
     return x;
 }
-__device__ __forceinline__ float wave_max_f(float v) {            // every lane gets the wavefront maximum
+__device__ __forceinline__ float row_max_f(float v) {             // lane 15 of each row: the row maximum
     v = fmaxf(v, __int_as_float(dpp_i<0x111>(__float_as_int(v), __float_as_int(v))));
     v = fmaxf(v, __int_as_float(dpp_i<0x112>(__float_as_int(v), __float_as_int(v))));
     v = fmaxf(v, __int_as_float(dpp_i<0x114>(__float_as_int(v), __float_as_int(v))));
-    v = fmaxf(v, __int_as_float(dpp_i<0x118>(__float_as_int(v), __float_as_int(v))));   // lane 15 of each row: row maximum
-    const int i = __float_as_int(v);
+    v = fmaxf(v, __int_as_float(dpp_i<0x118>(__float_as_int(v), __float_as_int(v))));
+    return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {            // every lane gets the wavefront maximum
+    const int i = __float_as_int(row_max_f(v));
     return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 15)), __int_as_float(__builtin_amdgcn_readlane(i, 31))),
                  fmaxf(__int_as_float(__builtin_amdgcn_readlane(i, 47)), __int_as_float(__builtin_amdgcn_readlane(i, 63))));
 }
 
 #define BQC_QUADS (BQC_MB / (4 * BQC_WAVES))       // passes of four centroids per wavefront
 #define BQC_CPIPE 4                                // feature channels the grouped-output phase keeps in flight per lane
+// LDS map (bytes; the cloud arrays are sized for BQ_MAXN so that every offset is an instruction immediate)
+#define BQC_L_SY 16384
+#define BQC_L_SZ 32768
+#define BQC_L_SIDX 49152                           // u16[4096]  sorted slot -> point index
+#define BQC_L_SPOS 57344                           // u16[4096]  point index -> sorted slot
+#define BQC_L_BM 65536                             // u64[waves][4][64]  per-centroid bitmaps
+#define BQC_L_TAB 98304                            // u32[waves][16][9]  (candidate run: first sorted slot | length << 16)
+#define BQC_L_CSTART 107520                        // i32[BQC_MAXCELLS + 4]
+#define BQC_L_RED 114448                           // f32[128]
+#define BQC_L_LISTS 114960                         // i32[waves][4][SP]; the build's scatter cursors live here first
 
+// SP: list stride (nsample <= SP).  The workgroup's 256 centroids: wavefront w takes quads q = w + 16 qi (qi < 4) of
+// four consecutive centroids; lane group sub = lane / 16 works on centroid 4q + sub.
+template <int SP>
 __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const float* __restrict__ new_xyz,
                                                                        const float* __restrict__ xyz,
                                                                        const float* __restrict__ feat, int C, int N, int M,
                                                                        float radius, int S, int32_t* __restrict__ idx,
                                                                        int32_t* __restrict__ cnt_out, float* __restrict__ out, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float bq_lds[];
-    unsigned long long* bm = reinterpret_cast<unsigned long long*>(bq_lds);                      // [waves][4][64] bitmaps
-    int32_t* cstart = reinterpret_cast<int32_t*>(bm + BQC_WAVES * 4 * 64);                       // BQC_MAXCELLS + 1 (+ pad)
-    int32_t* cursor = cstart + BQC_MAXCELLS + 4;                                                 // build phase only
-    int32_t* lists = cursor + BQC_MAXCELLS + 4;                                                  // [waves][4][S]
-    float* red = reinterpret_cast<float*>(lists + BQC_WAVES * 4 * S);                            // 6 x waves + waves
-    float* sx = red + 8 * BQC_WAVES;                               // cloud sorted by cell
-    float* sy = sx + N;
-    float* sz = sy + N;
-    unsigned short* sidx = reinterpret_cast<unsigned short*>(sz + N);    // sorted slot -> point index
-    unsigned short* spos = sidx + N;                                     // point index -> sorted slot
+    char* const L = reinterpret_cast<char*>(bq_lds);
+    float* const sx = reinterpret_cast<float*>(L);
+    float* const sy = reinterpret_cast<float*>(L + BQC_L_SY);
+    float* const sz = reinterpret_cast<float*>(L + BQC_L_SZ);
+    unsigned short* const sidx = reinterpret_cast<unsigned short*>(L + BQC_L_SIDX);
+    unsigned short* const spos = reinterpret_cast<unsigned short*>(L + BQC_L_SPOS);
+    unsigned long long* const bm = reinterpret_cast<unsigned long long*>(L + BQC_L_BM);
+    unsigned* const tab = reinterpret_cast<unsigned*>(L + BQC_L_TAB);
+    int32_t* const cstart = reinterpret_cast<int32_t*>(L + BQC_L_CSTART);
+    float* const red = reinterpret_cast<float*>(L + BQC_L_RED);
+    int32_t* const lists = reinterpret_cast<int32_t*>(L + BQC_L_LISTS);
+    int32_t* const cursor = lists;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave: an SGPR
     const int sub = lane >> 4, l16 = lane & 15;
@@ -359,15 +377,14 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
     const int m_end = min(M, m0 + BQC_MB);
     const float* p = xyz + (size_t)b * N * 3;
 
-    // this wavefront's centroids, fetched before the build so that their latency hides behind it
-    float qx[BQC_QUADS], qy[BQC_QUADS], qz[BQC_QUADS];
-#pragma unroll
-    for (int qi = 0; qi < BQC_QUADS; ++qi) {
-        const int m = min(m0 + 4 * (wave + qi * BQC_WAVES) + sub, M - 1);
-        const float* c = new_xyz + ((size_t)b * M + m) * 3;
-        qx[qi] = c[0]; qy[qi] = c[1]; qz[qi] = c[2];
+    // lane c16 = lane % 16 prepares centroid 4 * (wave + 16 * (c16 / 4)) + c16 % 4 (the four lane rows in unison); its
+    // coordinates are fetched now so that the latency hides behind the build
+    const int pm = m0 + 4 * (wave + BQC_WAVES * (l16 >> 2)) + (l16 & 3);
+    float pcx, pcy, pcz;
+    {
+        const float* c = new_xyz + ((size_t)b * M + min(pm, M - 1)) * 3;
+        pcx = c[0]; pcy = c[1]; pcz = c[2];
     }
-
     if (dbg & 8) return;
     // ---- build: bounding box -> grid -> counting sort -------------------------------------------------------------
     float px[4], py[4], pz[4];
@@ -405,16 +422,14 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
     __syncthreads();
     if (dbg & 16) return;
 #pragma unroll
-    for (int a = 0; a < 6; ++a) {
-        float v = red[a * BQC_WAVES + (lane & (BQC_WAVES - 1))];
-        hi[a] = wave_max_f(v);
-    }
+    for (int a = 0; a < 6; ++a)                                    // 16 per-wavefront values = one lane row
+        hi[a] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(row_max_f(red[a * BQC_WAVES + l16])), 15));
     BqcGrid g;
-    const float h = radius * 1.001f;
+    const float inv_h = __builtin_amdgcn_rcpf(radius * 1.001f);
     g.lox = -hi[3]; g.loy = -hi[4]; g.loz = -hi[5];
-    g.nx = bqc_axis(g.lox, hi[0], h, g.ivx);
-    g.ny = bqc_axis(g.loy, hi[1], h, g.ivy);
-    g.nz = bqc_axis(g.loz, hi[2], h, g.ivz);
+    g.nx = bqc_axis(g.lox, hi[0], inv_h, g.ivx);
+    g.ny = bqc_axis(g.loy, hi[1], inv_h, g.ivy);
+    g.nz = bqc_axis(g.loz, hi[2], inv_h, g.ivz);
     const int ncell = g.nx * g.ny * g.nz;
 
     int cell[4];
@@ -438,8 +453,7 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
         const int incl = wave_incl_scan(a0 + a1);
         if (lane == 63) wtot[wave] = incl;
         __syncthreads();
-        const int wt = wtot[lane & (BQC_WAVES - 1)];
-        const int winc = wave_incl_scan(lane < BQC_WAVES ? wt : 0);
+        const int winc = row_incl_scan(wtot[l16]);                 // 16 wavefront totals = one lane row
         const int base = wave == 0 ? 0 : __shfl(winc, wave - 1, 64);
         const int excl = base + incl - (a0 + a1);
         if (e0 <= ncell) { cstart[e0] = excl + a0; cursor[e0] = excl + a0; }
@@ -458,59 +472,81 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
     }
     __syncthreads();
 
+    // ---- candidate runs of this wavefront's 16 centroids: nine (y, z) cell rows, three x-adjacent cells = one run ----
+    {
+        const int cx = bqc_cell1(pcx, g.lox, g.ivx, g.nx), cy = bqc_cell1(pcy, g.loy, g.ivy, g.ny),
+                  cz = bqc_cell1(pcz, g.loz, g.ivz, g.nz);
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1) + 1;
+        const int nyx = g.ny * g.nx, rb0 = (cz * g.ny + cy) * g.nx;
+        unsigned* te = tab + (wave * 16 + l16) * 9;
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+            const int dy = (rr % 3) - 1, dz = (rr / 3) - 1;
+            const bool ok = pm < m_end && (unsigned)(cy + dy) < (unsigned)g.ny && (unsigned)(cz + dz) < (unsigned)g.nz;
+            const int rb = ok ? rb0 + dz * nyx + dy * g.nx : 0;
+            const int beg = cstart[rb + x0], end = cstart[rb + x1];
+            if (sub == 0) te[rr] = ok ? (unsigned)beg | ((unsigned)(end - beg) << 16) : 0u;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");         // from here on a wavefront touches only its own LDS rows
+    __builtin_amdgcn_wave_barrier();
+
     // ---- query: four centroids per wavefront pass, 16 lanes each ----------------------------------------------------
     const float r2 = radius * radius;
-    unsigned long long* bw = bm + (size_t)(wave * 4 + sub) * 64;  // this row's centroid
-    unsigned* bm32 = reinterpret_cast<unsigned*>(bw);
-    int32_t* mylist = lists + (size_t)(wave * 4 + sub) * S;
+    // the centroid of (pass qi, lane group sub) was prepared by lane 4 qi + sub
+    float qx[BQC_QUADS], qy[BQC_QUADS], qz[BQC_QUADS];
+#pragma unroll
+    for (int qi = 0; qi < BQC_QUADS; ++qi) {
+        qx[qi] = __shfl(pcx, 4 * qi + sub, 64); qy[qi] = __shfl(pcy, 4 * qi + sub, 64); qz[qi] = __shfl(pcz, 4 * qi + sub, 64);
+    }
+    const unsigned bmrow = BQC_L_BM + (unsigned)(wave * 4 + sub) * 512u;        // LDS byte address of this lane group's bitmap
+    unsigned long long* const bw = bm + (size_t)(wave * 4 + sub) * 64;
+    int32_t* const mylist = lists + (size_t)(wave * 4 + sub) * SP;
     const size_t plane = (size_t)M * S;
-    const bool pipe = S <= 64 && C <= BQC_CPIPE;
+    const bool pipe = SP == 64 && C <= BQC_CPIPE;
     float pf[4][BQC_CPIPE];
     int pend_q = -1;
+    // candidate slot t of the sorted cloud: exact test, hit -> bit k of the bitmap (a miss ORs in 0; slots past the end of a
+    // run read whatever follows -- in bounds of the LDS allocation -- and are masked by `valid`)
+    auto mark = [&](unsigned k, bool hit) {
+        atomicOr(reinterpret_cast<unsigned*>(L + (bmrow | ((k >> 3) & 0x1fcu))), hit ? 1u << (k & 31) : 0u);
+    };
+    auto probe = [&](unsigned t, bool valid, float ccx, float ccy, float ccz) {
+        const float x = sx[t], y = sy[t], z = sz[t];
+        const unsigned k = sidx[t];
+        mark(k, valid & (gad_sqdist(ccx, ccy, ccz, x, y, z) < r2));
+    };
 #pragma unroll
     for (int qi = 0; qi < BQC_QUADS; ++qi) {
         const int q = wave + qi * BQC_WAVES;
         if (m0 + 4 * q >= m_end) break;                            // wave-uniform
-        const int m = m0 + 4 * q + sub;
-        const bool live = m < m_end;
         const float ccx = qx[qi], ccy = qy[qi], ccz = qz[qi];
-        const int cx = bqc_cell1(ccx, g.lox, g.ivx, g.nx), cy = bqc_cell1(ccy, g.loy, g.ivy, g.ny),
-                  cz = bqc_cell1(ccz, g.loz, g.ivz, g.nz);
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-        int beg[9], end[9];
-#pragma unroll
-        for (int rr = 0; rr < 9; ++rr) {
-            const int yy = cy + (rr % 3) - 1, zz = cz + (rr / 3) - 1;
-            const bool ok = live && yy >= 0 && yy < g.ny && zz >= 0 && zz < g.nz;
-            const int rb = ok ? (zz * g.ny + yy) * g.nx : 0;
-            beg[rr] = ok ? cstart[rb + x0] : 0;
-            end[rr] = ok ? cstart[rb + x1 + 1] : 0;
-        }
         if (!(dbg & 2)) {
-            // first 16 candidates of all nine rows in one batch of LDS reads (a row holds ~12 at configs[3]), leftovers after
+            const unsigned* te = tab + (wave * 16 + qi * 4 + sub) * 9;
+            const unsigned short* te16 = reinterpret_cast<const unsigned short*>(te);
+            unsigned beg[9], len[9];
+#pragma unroll
+            for (int rr = 0; rr < 9; ++rr) { beg[rr] = te16[2 * rr]; len[rr] = te16[2 * rr + 1]; }
+            // the first 16 slots of all nine runs (a run holds ~12 candidates at configs[3]): every LDS read is issued
+            // before the first bitmap atomic, which the compiler will not move loads across
             float tx[9], ty[9], tz[9];
             unsigned tk[9];
 #pragma unroll
             for (int rr = 0; rr < 9; ++rr) {
-                const int t = beg[rr] + l16;
-                const int tc = t < end[rr] ? t : 0;
-                tx[rr] = sx[tc]; ty[rr] = sy[tc]; tz[rr] = sz[tc]; tk[rr] = sidx[tc];
+                const unsigned t = beg[rr] + (unsigned)l16;
+                tx[rr] = sx[t]; ty[rr] = sy[t]; tz[rr] = sz[t]; tk[rr] = sidx[t];
             }
 #pragma unroll
-            for (int rr = 0; rr < 9; ++rr) {
-                const float d2 = gad_sqdist(ccx, ccy, ccz, tx[rr], ty[rr], tz[rr]);
-                if (beg[rr] + l16 < end[rr] && d2 < r2) atomicOr(&bm32[tk[rr] >> 5], 1u << (tk[rr] & 31));
-            }
+            for (int rr = 0; rr < 9; ++rr)
+                mark(tk[rr], ((unsigned)l16 < len[rr]) & (gad_sqdist(ccx, ccy, ccz, tx[rr], ty[rr], tz[rr]) < r2));
 #pragma unroll
             for (int rr = 0; rr < 9; ++rr) {
-                for (int t = beg[rr] + 16 + l16; t < end[rr]; t += 16) {
-                    const float d2 = gad_sqdist(ccx, ccy, ccz, sx[t], sy[t], sz[t]);
-                    const unsigned k = sidx[t];
-                    if (d2 < r2) atomicOr(&bm32[k >> 5], 1u << (k & 31));
-                }
+                if (__builtin_amdgcn_ballot_w64(len[rr] > 16u) != 0ull)                // wave-uniform
+                    for (unsigned off = 16; __builtin_amdgcn_ballot_w64(off < len[rr]) != 0ull; off += 16)
+                        probe(beg[rr] + (unsigned)l16 + off, off + (unsigned)l16 < len[rr], ccx, ccy, ccz);
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // a wavefront touches only its own bitmaps and lists
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (dbg & 4) continue;
 
@@ -526,12 +562,6 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
         const int nb = __popcll(w[0]) + __popcll(w[1]) + __popcll(w[2]) + __popcll(w[3]);
         const int incl = row_incl_scan(nb);
         const int total = __shfl(incl, lane | 15, 64);
-        int lowbit = 0;                                            // lowest set bit of this lane's 256
-#pragma unroll
-        for (int i = 3; i >= 0; --i) lowbit = w[i] ? 64 * i + (__ffsll((long long)w[i]) - 1) : lowbit;
-        const unsigned have = (unsigned)(__ballot(nb > 0) >> (16 * sub)) & 0xffffu;
-        const int firstv = __shfl(256 * l16 + lowbit, (lane & 48) | (have ? __ffs((int)have) - 1 : 0), 64);
-        const int first = have ? firstv : 0;
         int pos = incl - nb;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -542,36 +572,45 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
             }
         }
         const int cnt = total < S ? total : S;
-        for (int s2 = cnt + l16; s2 < S; s2 += 16) mylist[s2] = first;
+        if (cnt < S) {                                             // pad with the first hit (0 if the ball is empty)
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int first = total > 0 ? mylist[0] : 0;
+            for (int s2 = cnt + l16; s2 < S; s2 += 16) mylist[s2] = first;
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
 
         // ---- write-out: one centroid per 64-lane sweep.  Fast path (nsample <= 64, <= BQC_CPIPE feature channels): the
         // feature loads of this pass stay in flight across the NEXT pass's scan and are stored after it
-        if (cnt_out && l16 == 0 && live) cnt_out[(size_t)b * M + m] = cnt;
+        if (cnt_out && l16 == 0 && m0 + 4 * q + sub < m_end) cnt_out[(size_t)b * M + m0 + 4 * q + sub] = cnt;
         if (pipe) {
             const bool act = lane < S;
             if (out && pend_q >= 0) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {                      // phase C of the previous pass
-                    const int mj = m0 + 4 * pend_q + j;
-                    if (mj < m_end && act) {
-                        float* o = out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S + lane;
+                    const int mj = m0 + 4 * pend_q + j;            // uniform
+                    float* oc = out + ((size_t)b * (3 + C) + 3) * plane + (size_t)mj * S;
+                    if (mj < m_end) {
 #pragma unroll
-                        for (int ch = 0; ch < BQC_CPIPE; ++ch)
-                            if (ch < C) o[(3 + ch) * plane] = pf[j][ch];
+                        for (int ch = 0; ch < BQC_CPIPE; ++ch) {
+                            if (ch < C && act) oc[lane] = pf[j][ch];
+                            oc += plane;
+                        }
                     }
                 }
             }
-            int kk[4];
+            unsigned kk[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {                          // phase A: indices and the feature loads of all four
                 const bool okj = act && (m0 + 4 * q + j < m_end);
-                kk[j] = okj ? lists[(size_t)(wave * 4 + j) * S + lane] : 0;
+                kk[j] = okj ? (unsigned)(lists + (size_t)(wave * 4 + j) * SP)[lane] : 0u;
                 if (out) {
-                    const float* f = feat + (size_t)b * C * N + kk[j];
+                    const float* fc = feat + (size_t)b * C * N;
 #pragma unroll
-                    for (int ch = 0; ch < BQC_CPIPE; ++ch) pf[j][ch] = ch < C ? f[(size_t)ch * N] : 0.f;
+                    for (int ch = 0; ch < BQC_CPIPE; ++ch) {
+                        if (ch < C) pf[j][ch] = fc[kk[j]];
+                        fc += N;
+                    }
                 }
             }
             pend_q = q;
@@ -581,16 +620,16 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
                 if (mj >= m_end) break;
                 const size_t gi = (size_t)b * M + mj;
                 if (act) {
-                    idx[gi * S + lane] = kk[j];
+                    (idx + gi * S)[lane] = (int)kk[j];
                     if (out) {
                         const float jx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccx), 16 * j));
                         const float jy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccy), 16 * j));
                         const float jz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ccz), 16 * j));
-                        float* o = out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S + lane;
-                        const int t = spos[kk[j]];
-                        o[0 * plane] = __fsub_rn(sx[t], jx);
-                        o[1 * plane] = __fsub_rn(sy[t], jy);
-                        o[2 * plane] = __fsub_rn(sz[t], jz);
+                        float* orow = out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S;
+                        const unsigned t = spos[kk[j]];
+                        orow[lane] = __fsub_rn(sx[t], jx);
+                        (orow + plane)[lane] = __fsub_rn(sy[t], jy);
+                        (orow + 2 * plane)[lane] = __fsub_rn(sz[t], jz);
                     }
                 }
             }
@@ -600,7 +639,7 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
                 const int mj = m0 + 4 * q + j;
                 if (mj >= m_end) break;
                 const size_t gi = (size_t)b * M + mj;
-                const int32_t* my = lists + (size_t)(wave * 4 + j) * S;
+                const int32_t* my = lists + (size_t)(wave * 4 + j) * SP;
                 const float jx = __shfl(ccx, 16 * j, 64), jy = __shfl(ccy, 16 * j, 64), jz = __shfl(ccz, 16 * j, 64);
                 float* o = out ? out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S : nullptr;
                 for (int s2 = lane; s2 < S; s2 += 64) {
@@ -619,15 +658,17 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
         }
         __builtin_amdgcn_wave_barrier();                           // the lists are rewritten by the next pass
     }
-    if (pipe && out && pend_q >= 0 && lane < S) {
+    if (pipe && out && pend_q >= 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int mj = m0 + 4 * pend_q + j;
+            float* oc = out + ((size_t)b * (3 + C) + 3) * plane + (size_t)mj * S;
             if (mj < m_end) {
-                float* o = out + ((size_t)b * (3 + C)) * plane + (size_t)mj * S + lane;
 #pragma unroll
-                for (int ch = 0; ch < BQC_CPIPE; ++ch)
-                    if (ch < C) o[(3 + ch) * plane] = pf[j][ch];
+                for (int ch = 0; ch < BQC_CPIPE; ++ch) {
+                    if (ch < C && lane < S) oc[lane] = pf[j][ch];
+                    oc += plane;
+                }
             }
         }
     }
@@ -637,24 +678,26 @@ static int g_opt_bq_cells = 1;
 void gad_geometry_set_option(const char* name, int value, int* found) {
     if (!strcmp(name, "bq_cells")) { g_opt_bq_cells = value; *found = 1; }
 }
-static size_t bqc_lds_bytes(int N, int S) {
-    return (size_t)BQC_WAVES * 4 * 64 * 8 + (size_t)2 * (BQC_MAXCELLS + 4) * 4 + (size_t)BQC_WAVES * 4 * S * 4 + (size_t)8 * BQC_WAVES * 4 +
-           (size_t)3 * N * 4 + (size_t)2 * N * 2;
-}
 static bool bq_use_cells(int N, int nsample, float radius) {
     return g_opt_bq_cells && N > 1024 && N <= BQ_MAXN && radius > 0.f && radius < 1.0e18f && nsample <= 128;
 }
 static int bq_launch_cells(const float* new_xyz, const float* xyz, const float* feat, int B, int C, int N, int M, float radius,
                            int nsample, int32_t* idx, int32_t* cnt, float* out, hipStream_t st) {
-    const size_t lds = bqc_lds_bytes(N, nsample);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_cells_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_cells_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(ball_query_cells_kernel<128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(ball_query_cells_kernel, dim3(gad_cdiv(M, BQC_MB), B), dim3(BQC_THREADS), lds, st, new_xyz, xyz, feat, C, N,
-                       M, radius, nsample, idx, cnt, out, g_opt_bq_cells);
+    const dim3 grid(gad_cdiv(M, BQC_MB), B);
+    if (nsample <= 64)
+        hipLaunchKernelGGL(ball_query_cells_kernel<64>, grid, dim3(BQC_THREADS), BQC_L_LISTS + BQC_WAVES * 4 * 64 * 4, st, new_xyz,
+                           xyz, feat, C, N, M, radius, nsample, idx, cnt, out, g_opt_bq_cells);
+    else
+        hipLaunchKernelGGL(ball_query_cells_kernel<128>, grid, dim3(BQC_THREADS), BQC_L_LISTS + BQC_WAVES * 4 * 128 * 4, st, new_xyz,
+                           xyz, feat, C, N, M, radius, nsample, idx, cnt, out, g_opt_bq_cells);
     return 0;
 }
 
