@@ -24,8 +24,27 @@ extern "C" int gad_abi_version(void) { return 2; }
 // ------------------------------------------------------------------------------------------------
 // furthest point sampling
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool fps_better(float v, unsigned key, float bv, unsigned bkey) {
-    return v > bv || (v == bv && key < bkey);
+// Arg-max candidates are packed as (float bits of the distance) << 32 | ~key: distances are >= +0, so their bit patterns
+// order like the values, and among equal distances the SMALLER key must win (see the tie rule below); 0 = "no candidate".
+// pack(a) > pack(b)  <=>  a.v > b.v || (a.v == b.v && a.key < b.key), the upstream comparison.
+__device__ __forceinline__ unsigned long long fps_pack(float v, unsigned key) {
+    return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned long long)(unsigned)(~key);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long fps_dpp_max(unsigned long long v) {      // lanes without a source keep v
+    const int lo = __builtin_amdgcn_update_dpp((int)(unsigned)v, (int)(unsigned)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp((int)(unsigned)(v >> 32), (int)(unsigned)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo;
+    return o > v ? o : v;
+}
+// wavefront maximum (uniform result): DPP row shifts / row broadcasts instead of six ds_bpermute round trips
+__device__ __forceinline__ unsigned long long fps_wave_max(unsigned long long v) {
+    v = fps_dpp_max<0x111, 0xf>(v); v = fps_dpp_max<0x112, 0xf>(v); v = fps_dpp_max<0x114, 0xf>(v); v = fps_dpp_max<0x118, 0xf>(v);
+    v = fps_dpp_max<0x142, 0xa>(v);                                // row_bcast:15 -> rows 1, 3
+    v = fps_dpp_max<0x143, 0xc>(v);                                // row_bcast:31 -> rows 2, 3: lane 63 holds the maximum
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 // One workgroup (WAVES wavefronts) per cloud; thread t keeps points k = s*T + t (s < NPL) in
@@ -40,8 +59,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
     constexpr int T = 64 * WAVES;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sp = lds;                                   // N*3 coordinates
-    float* red_v = lds + ((N * 3 + 3) & ~3);           // WAVES values
-    unsigned* red_k = (unsigned*)(red_v + WAVES);      // WAVES keys
+    unsigned long long* red = reinterpret_cast<unsigned long long*>(lds + ((N * 3 + 3) & ~3));   // 2 x WAVES packed maxima
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = xyz + (size_t)b * N * 3;
     for (int i = tid; i < N * 3; i += T) sp[i] = p[i];
@@ -77,32 +95,27 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
     }
     for (int j = 1; j < M; ++j) {
         const float x1 = sp[old * 3 + 0], y1 = sp[old * 3 + 1], z1 = sp[old * 3 + 2];
-        float best = -1.f;
-        unsigned bkey = 0;
+        unsigned long long best = 0ull;
 #pragma unroll
         for (int s = 0; s < NPL; ++s) {
             if (valid & (1u << s)) {
                 const float d = gad_sqdist(px[s], py[s], pz[s], x1, y1, z1);
                 const float d2 = d < tmp[s] ? d : tmp[s];
                 tmp[s] = d2;
-                if (fps_better(d2, key[s], best, bkey)) { best = d2; bkey = key[s]; }
+                const unsigned long long c = fps_pack(d2, key[s]);
+                best = c > best ? c : best;
             }
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const float ov = __shfl_xor(best, o, 64);
-            const unsigned ok = __shfl_xor(bkey, o, 64);
-            if (fps_better(ov, ok, best, bkey)) { best = ov; bkey = ok; }
-        }
-        if (WAVES > 1) {
-            if ((tid & 63) == 0) { red_v[tid >> 6] = best; red_k[tid >> 6] = bkey; }
+        best = fps_wave_max(best);
+        if (WAVES > 1) {                                           // one barrier per pick: the exchange buffer alternates
+            unsigned long long* r = red + (j & 1) * WAVES;
+            if ((tid & 63) == 0) r[tid >> 6] = best;
             __syncthreads();
-            best = red_v[0]; bkey = red_k[0];
+            best = r[0];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w)
-                if (fps_better(red_v[w], red_k[w], best, bkey)) { best = red_v[w]; bkey = red_k[w]; }
-            __syncthreads();
+            for (int w = 1; w < WAVES; ++w) best = r[w] > best ? r[w] : best;
         }
+        const unsigned bkey = best ? ~(unsigned)best : 0u;         // no candidate at all (every point skipped): index 0
         old = (int)(bkey & 0xFFFFu);
         if (tid == 0) {
             idx[(size_t)b * M + j] = old;
