@@ -85,7 +85,8 @@ class Agent(object):
         self.test_mode = test
         nets = [self.state_feature_extractor, self.policy] + ([self.critic] if hasattr(self, "critic") else [])
         for n in nets:
-            n.train(not test)
+            if n.training == bool(test):             # nn.Module.train() walks the whole module tree: only on a real change
+                n.train(not test)
 
     def update_parameters(self, batch_data, updates, k):
         return {}

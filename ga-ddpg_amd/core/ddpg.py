@@ -34,7 +34,7 @@ class DDPG(Agent):
 
     def get_mix_ratio(self, update_step):
         """reference ddpg.py:108-117"""
-        idx = int((self.update_step > np.array(self.mix_milestones)).sum())
+        idx = sum(1 for m in self.mix_milestones if self.update_step > m)
         mix_policy_ratio = min(get_valid_index(self.mix_policy_ratio_list, idx), self.ddpg_coefficients[4])
         mix_value_ratio = min(get_valid_index(self.mix_value_ratio_list, idx), self.ddpg_coefficients[3])
         return mix_value_ratio, mix_policy_ratio

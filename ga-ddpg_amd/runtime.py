@@ -139,16 +139,19 @@ class FusedRuntime(object):
         P["v_bwd"] = vb
 
     # ------------------------------------------------------------------ host -> device
-    def load_device_batch(self, dbatch):
+    def load_device_batch(self, dbatch, keys=None):
         """device-resident minibatch (dict of CUDA float32 tensors with the BATCH_KEYS layout):
-        device-to-device copies into the static buffers, no host traffic."""
-        for k in BATCH_KEYS:
+        device-to-device copies into the static buffers, no host traffic.  `keys`: only these (staged upload)."""
+        for k in (BATCH_KEYS if keys is None else keys):
             if k in dbatch:
                 self.dbuf[k].copy_(dbatch[k], non_blocking=True)
-        hip.call("gad_affine_act", self.dbuf["time_batch"], 1, self.B, 1, self._one, self._minus_one, 0,
-                 self.dbuf["time_m1"], 1)
+                if k == "time_batch":
+                    hip.call("gad_affine_act", self.dbuf["time_batch"], 1, self.B, 1, self._one, self._minus_one, 0,
+                             self.dbuf["time_m1"], 1)
 
-    def upload(self, batch):
+    def upload(self, batch, keys=None):
+        """minibatch -> the static device buffers.  `keys` restricts the call to some of BATCH_KEYS: ddpg_step uploads
+        in stages so that the first kernels of the critical chain are enqueued before the remaining copies."""
         if batch is None:
             return
         if "replay_gather" in batch:             # DeviceReplay.sample_lazy(): one gather launch into the static buffers
@@ -156,9 +159,9 @@ class FusedRuntime(object):
                 raise RuntimeError("batch size changed: runtime was built for B=%d" % self.B)
             return batch["replay_gather"].gather_into(batch, self.dbuf)
         if torch.is_tensor(batch["point_state_batch"]):
-            return self.load_device_batch(batch)
+            return self.load_device_batch(batch, keys)
         B = self.B
-        for k in BATCH_KEYS:
+        for k in (BATCH_KEYS if keys is None else keys):
             if k not in batch or (not self.has_critic and k in ("next_point_state_batch",)):
                 continue
             a = np.asarray(batch[k])
@@ -167,9 +170,10 @@ class FusedRuntime(object):
             h = self.hbuf[k]
             np.copyto(h.numpy(), a.reshape(h.shape), casting="same_kind")
             self.dbuf[k].copy_(h, non_blocking=True)
-        h = self.hbuf["time_m1"]
-        np.subtract(self.hbuf["time_batch"].numpy(), 1.0, out=h.numpy())
-        self.dbuf["time_m1"].copy_(h, non_blocking=True)
+            if k == "time_batch":
+                h = self.hbuf["time_m1"]
+                np.subtract(self.hbuf["time_batch"].numpy(), 1.0, out=h.numpy())
+                self.dbuf["time_m1"].copy_(h, non_blocking=True)
 
     def _adam(self, flat, optim, clip=None):
         g = optim.param_groups[0]
@@ -187,17 +191,23 @@ class FusedRuntime(object):
         B = self.B
         ratio = float(ag.mix_policy_ratio)
         policy_step = ag.update_step % ag.policy_update_gap == 0
-        self.upload(batch)
-        if self.dp is not None:
-            self.dp.set_counts(batch if batch is not None else self._host_flags())
-        if noise_u is None:
-            self.noise_u.uniform_(0.0, 1.0)                         # torch.rand_like in the reference
-        else:
-            self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
-        self.scal.zero_()
+        # staged upload (dict batches): the target chain on the main stream is the critical path of the step, so its
+        # inputs go first and its geometry is enqueued before anything else
+        staged = OVERLAP_PASSES and batch is not None and "replay_gather" not in batch
+        first = ("next_point_state_batch", "time_batch")
+        second = ("point_state_batch", "action_batch")
+        self.upload(batch, first if staged else None)
         main = torch.cuda.current_stream()
-        idx = int((ag.update_step > np.array(ag.mix_milestones)).sum())
+        idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
+
+        def small_inits():
+            # not needed by the geometry / first passes: enqueued after them so that the GPU starts the step earlier
+            if noise_u is None:
+                self.noise_u.uniform_(0.0, 1.0)                     # torch.rand_like in the reference
+            else:
+                self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
+            self.scal.zero_()
         # ---- critic phase.  The TD target chain (encoder(next) -> target policy -> value encoder(next, a') -> target
         # critic) and the value pass on the current state are independent: the latter runs on a second stream.
         # Both go through value_encoder's BatchNorms; the reference runs the current-state pass first
@@ -215,18 +225,30 @@ class FusedRuntime(object):
 
         if OVERLAP_PASSES:
             s1, s2 = engine.side_stream(which=1), engine.side_stream(which=2)
+            self.geo_next.run(d["next_point_state_batch"])
+            if staged:
+                self.upload(batch, second)
             self._ev[0].record(main)
             s1.wait_event(self._ev[0])
             with torch.cuda.stream(s1):
                 self.geo.run(d["point_state_batch"])
                 self._ev[4].record(s1)                      # geometry of the current state ready (the actor pass needs it)
+            if staged:
+                self.upload(batch, tuple(k for k in BATCH_KEYS if k not in first + second))
+            if self.dp is not None:
+                self.dp.set_counts(batch if batch is not None else self._host_flags())
+            small_inits()                                           # main stream, before t1 (and before the fork of s2)
+            P["t1"].run()
+            with torch.cuda.stream(s1):
                 P["c_fwd"].run()
-            self.geo_next.run(d["next_point_state_batch"])
         else:
+            if self.dp is not None:
+                self.dp.set_counts(batch if batch is not None else self._host_flags())
             self.geo.run(d["point_state_batch"])
             self.geo_next.run(d["next_point_state_batch"])
             P["c_fwd"].run()
-        P["t1"].run()
+            small_inits()
+            P["t1"].run()
         if OVERLAP_PASSES:
             # The actor phase's policy forward needs nothing from the critic update: it starts as soon as t1 is done (its
             # encoder BatchNorms must come after t1's, as in the reference) and runs beside t2 and the critic backward.
@@ -234,6 +256,11 @@ class FusedRuntime(object):
             # loss, backward, Adam of policy + encoder -- is independent of the critic phase (disjoint parameters,
             # gradient arenas, dW lanes and result slots) and runs there too.
             self._ev[2].record(main)
+        # the rest of the target chain is enqueued BEFORE the actor pass: the host needs ~0.4 ms for the actor pass's
+        # launches, and the main stream (the critical path) would sit idle behind them
+        hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), self.a_next)
+        P["t2"].run()
+        if OVERLAP_PASSES:
             s2.wait_event(self._ev[2])
             s2.wait_event(self._ev[4])
             with torch.cuda.stream(s2):
@@ -241,8 +268,6 @@ class FusedRuntime(object):
                 hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
                 if not policy_step:
                     actor_tail(None)
-        hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), self.a_next)
-        P["t2"].run()
         if OVERLAP_PASSES:
             self._ev[1].record(s1)
             main.wait_event(self._ev[1])

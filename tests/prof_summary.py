@@ -102,3 +102,42 @@ def by_stream(path, steps, which):
 
 if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "stream":
     by_stream(sys.argv[1], int(sys.argv[2]), int(sys.argv[4]) if len(sys.argv) > 4 else 0)
+
+
+def timeline(path, step_no, min_us=6.0):
+    """kernels of ONE steady-state step in start order: offset, duration, stream, name (kernels shorter than min_us are
+    folded into a count) -- for reading the critical path across streams.  Steps are delimited by actor_loss/adam pairs:
+    the step starts at the first prep_points_kernel after the previous step's last adam_kernel."""
+    db = glob.glob(path + "/**/*.db", recursive=True)[0]
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table'")]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    cols = [r[1] for r in c.execute("pragma table_info(%s)" % kd)]
+    key = "stream_id" if "stream_id" in cols else "queue_id"
+    rows = c.execute("select d.start, d.end, d.%s, s.kernel_name from %s d join %s s on d.kernel_id=s.id order by d.start"
+                     % (key, kd, ks)).fetchall()
+    starts = [i for i, r in enumerate(rows) if "prep_points" in r[3]]
+    starts = starts[::2]                                           # two per step (current / next clouds)
+    a, b = starts[step_no], starts[step_no + 1]
+    t0 = rows[a][0]
+    sid = {}
+    small = 0
+    print("step %d: %.3f ms, %d kernels" % (step_no, (rows[b][0] - t0) / 1e6, b - a))
+    last_end = {}
+    for s, e, q, name in rows[a:b]:
+        q = sid.setdefault(q, len(sid))
+        name = re.sub(r"\(.*", "", name)
+        name = re.sub(r"^_Z\d+", "", name)[:46]
+        gap = (s - last_end[q]) / 1e3 if q in last_end else 0.0
+        last_end[q] = e
+        if (e - s) / 1e3 < min_us and gap < 10:
+            small += 1
+            continue
+        print("%8.1f us  +%6.1f  s%d %s%-46s %s" % ((s - t0) / 1e3, (e - s) / 1e3, q, "   " * q, name,
+                                                   ("(idle %.0f us before)" % gap) if gap >= 10 else ""))
+    print("(%d kernels under %.0f us not shown)" % (small, min_us))
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "timeline":
+    timeline(sys.argv[1], int(sys.argv[2]), float(sys.argv[4]) if len(sys.argv) > 4 else 6.0)
