@@ -271,6 +271,18 @@ def main():
         by_tag = {}
         for e0, e1, tag in engine.TIMING["events"]:
             by_tag.setdefault(tag, []).append(e0.elapsed_time(e1))
+        # the same launches with the whole step on ONE stream: the kernel by itself, without the other passes of the
+        # step competing for CUs and HBM (in the overlapped step two or three encoder passes run side by side)
+        engine.SERIAL = True
+        engine.TIMING.update(enabled=True, tag="*", events=[])
+        for i in range(6):
+            step(args.warmup + args.steps + 10 + i)
+        torch.cuda.synchronize()
+        engine.TIMING["enabled"] = False
+        engine.SERIAL = False
+        alone = {}
+        for e0, e1, tag in engine.TIMING["events"]:
+            alone.setdefault(tag, []).append(e0.elapsed_time(e1))
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
         tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
         n1 = int(rt.geo.rows[0]["n"].item())
@@ -278,11 +290,19 @@ def main():
         for tag, cin, cout in (("fwd.sa1.l2", 64, 64), ("fwd.sa1.l3", 64, 128)):
             if tag in by_tag:
                 ms = float(np.mean(by_tag[tag]))
+                ms1 = float(np.mean(alone[tag])) if tag in alone else None
                 alg = n1 * (cin + cout) * 4.0
                 pmc = tj.get(tag, {}).get("bytes_per_launch")
                 sa[tag] = {"kernel": "gemm_fwd_stream_kernel", "bound": "hbm", "launch_ms": ms, "rows": n1,
                            "algorithmic_bytes": alg, "traffic": pmc, "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0,
-                           "unit": "GB/s", "frac": alg / (ms * 1e-3) / 8e12}
+                           "unit": "GB/s", "frac": alg / (ms * 1e-3) / 8e12,
+                           "launch_ms_alone": ms1, "frac_alone": None if ms1 is None else alg / (ms1 * 1e-3) / 8e12,
+                           "note": "launch_ms / frac: inside the overlapped step (other encoder passes run beside it); "
+                                   "*_alone: the same launch with the step serialised on one stream"}
+        if args.roofline_tag in alone and res.get("roofline"):
+            ms1 = float(np.mean(alone[args.roofline_tag]))
+            res["roofline"]["launch_ms_alone"] = ms1
+            res["roofline"]["frac_alone"] = res["roofline"]["algorithmic_flops_per_launch"] / (ms1 * 1e-3) / 1e12 / res["roofline"]["peak"]
         sa["query_and_group"] = sa_kernel_hbm()
         sa["query_and_group"]["traffic"] = (json.load(open(tpath)).get("query_and_group", {}).get("bytes_per_launch")
                                             if os.path.exists(tpath) else None)

@@ -322,12 +322,15 @@ def dw_workspace(device, elems=48 * 1024 * 1024, lane=0):
 
 
 _SIDE = {}
+SERIAL = False            # bench.py / diagnostics: run the whole step on ONE stream (per-kernel durations without contention)
 
 
 def side_stream(device=None, which=0):
     """auxiliary HIP streams (per device, created lazily): 0 = weight-gradient GEMMs forked off the dX chain,
     1 / 2 = whole encoder passes overlapped by runtime.FusedRuntime"""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if SERIAL:                                   # diagnostics: every fork / join degenerates to the caller's stream
+        return torch.cuda.current_stream(dev)
     if (dev, which) not in _SIDE:
         _SIDE[(dev, which)] = torch.cuda.Stream(device=dev)
     return _SIDE[(dev, which)]
