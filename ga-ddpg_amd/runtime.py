@@ -85,6 +85,7 @@ class FusedRuntime(object):
         self.inv_n = None
         self.resident = False            # True: the static batch buffers were filled on the device
         self._ev = [torch.cuda.Event() for _ in range(5)]
+        self._ev_counts = torch.cuda.Event()
 
     # ------------------------------------------------------------------ plans over static buffers
     def _build_plans(self):
@@ -236,9 +237,16 @@ class FusedRuntime(object):
             if staged:
                 self.upload(batch, tuple(k for k in BATCH_KEYS if k not in first + second))
             if self.dp is not None:
-                self.dp.set_counts(batch if batch is not None else self._host_flags())
+                # global mask counts: a 4-double all-reduce whose latency would sit at the head of the critical chain;
+                # on its own stream it overlaps the geometry and t1, the loss kernels' streams wait for it below
+                sc = engine.side_stream(which=3)
+                with torch.cuda.stream(sc):
+                    self.dp.set_counts(batch if batch is not None else self._host_flags())
+                    self._ev_counts.record(sc)
             small_inits()                                           # main stream, before t1 (and before the fork of s2)
             P["t1"].run()
+            if self.dp is not None:
+                main.wait_event(self._ev_counts)
             with torch.cuda.stream(s1):
                 P["c_fwd"].run()
         else:
