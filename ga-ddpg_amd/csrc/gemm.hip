@@ -17,6 +17,7 @@
 // BatchNorm statistics: registers -> __shfl_xor -> LDS across wavefronts -> f64 device atomics
 // into one of GAD_STAT_REPLICAS accumulators (blockIdx % replicas) to bound same-address contention.
 #include "common.hpp"
+#include <type_traits>
 #include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -752,7 +753,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     }
 }
 
-static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1;
+static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
 }
@@ -765,6 +766,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
     if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
+    if (!strcmp(name, "dw_stream")) { g_opt_dw_stream = value; return GAD_OK; }
     int found = 0;
     gad_geometry_set_option(name, value, &found);                                     // geometry.hip: "bq_cells"
     if (found) return GAD_OK;
@@ -1610,6 +1612,168 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSr
     }
 }
 
+// Streaming dW for the SA1 layers (>= 32k de-duplicated rows, 64 input channels, 64 or 128 output channels).
+// dW[n][k] = sum_r dZ[r][n] * X[r][k]: the reduction index is the leading index of both operands in memory, so a lane that
+// owns output channel n (A side) / input channel k (B side) feeds the MFMA straight from coalesced 4-byte global loads --
+// no LDS tiles, no barriers in the loop, BatchNorm constants per lane in registers (as in the skinny kernel above).
+// Work split: a workgroup of 8 wavefronts owns one split of the rows (the dw_reduce geometry: blockIdx.x = split);
+// for 128 output channels wavefronts 0-3 take output channels 0-63 and 4-7 take 64-127, each set dealing the split's
+// 8-row units among its four members.  Every wavefront keeps a 64 x 64 block of dW in 64 accumulator registers
+// (2 x 2 MFMA tiles: each loaded operand is used twice), loads unit u+1 while computing unit u, and the four partial
+// blocks are summed through LDS into the split's partial tile.
+template <int NG, int GM>
+__global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                             int n_rows_static, int splits, float* __restrict__ partial) {
+    constexpr int NO = 64 * NG, KP = 64, RW = 8 / NG;              // RW: wavefronts that share the rows of one column set
+    __shared__ float red[8 * 16 * 64];                             // one accumulator tile of every wavefront
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int cset = wave / RW, wr = wave % RW;                    // column set, rank among the wavefronts of that set
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    int chunk = (n_rows + splits - 1) / splits;
+    chunk = (chunk + KT - 1) / KT * KT;                            // == dw_reduce_kernel's split geometry
+    const int r_begin = blockIdx.x * chunk, r_end = min(n_rows, r_begin + chunk);
+    if (r_begin >= n_rows) return;                                 // inactive split: dw_reduce does not read it
+
+    // per-lane constants: A side (dZ) output channels n = 64 cset + 32 j + l31, B side (X) input channels k = 32 b + l31
+    float dsc[2], dsh[2], dP[2], dQ[2], dS[2], xs[2], xt[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = 64 * cset + 32 * j + l31;
+        dsc[j] = d.scale[ch]; dsh[j] = d.shift[ch]; dP[j] = d.P[ch]; dQ[j] = d.Q[ch]; dS[j] = d.S[ch];
+        xs[j] = x.scale[32 * j + l31]; xt[j] = x.shift[32 * j + l31];
+    }
+    // Addressing of the main loop: raw buffer loads whose per-lane byte offset is a CONSTANT (channel block + the
+    // half-wave's 4-row stagger) and whose row position lives in the scalar offset -- no vector ALU work per load.
+    const unsigned lane_n = 64u * cset + l31;
+    const int zpitch4 = d.z_pitch * 4, xpitch4 = x.zin_pitch * 4, gpitch4 = (GM == 0 ? d.g_pitch : d.c) * 4;
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x.zin), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.row_w ? d.row_w : d.z), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.argmax : d.row_grp), 0, 0x7ffffffc, 0x00020000);
+    const int vl_z = 4 * half * zpitch4 + (int)lane_n * 4, vl_x = 4 * half * xpitch4 + l31 * 4;
+    const int vl_g = (GM == 0 ? 4 * half * gpitch4 : 0) + (int)lane_n * 4, vl_r = 4 * half * 4;
+
+    struct Unit { float z[4][2], g[4][2], xv[4][2], w[4]; int a[4][2]; };
+    auto ldf = [](__amdgpu_buffer_rsrc_t r, int vo, int so) { return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0)); };
+    auto load = [&](Unit& u, int unit) {                           // a unit with all eight rows inside the split
+        const int rs = r_begin + 8 * unit;                         // scalar
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u.w[i] = d.row_w ? ldf(wr_, vl_r, (rs + i) * 4) : 1.f;
+            int vg = vl_g;
+            if (GM == 1) vg = (int)__builtin_amdgcn_raw_buffer_load_b32(pr, vl_r, (rs + i) * 4, 0) * gpitch4 + vl_g;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u.z[i][j] = ldf(zr, vl_z + 128 * j, (rs + i) * zpitch4);
+                u.g[i][j] = ldf(gr_, vg + 128 * j, GM == 0 ? (rs + i) * gpitch4 : 0);
+                if (GM == 1) u.a[i][j] = (int)__builtin_amdgcn_raw_buffer_load_b32(ar, vg + 128 * j, 0, 0);
+                u.xv[i][j] = ldf(xr, vl_x + 128 * j, (rs + i) * xpitch4);
+            }
+        }
+    };
+    auto load_tail = [&](Unit& u, int unit) {                      // the ragged last unit: clamped rows, plain loads
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(r_begin + 8 * unit + 4 * half + i, r_end - 1);
+            u.w[i] = d.row_w ? d.row_w[r] : 1.f;
+            const size_t go = (GM == 0 ? (size_t)r * d.g_pitch : (size_t)d.row_grp[r] * d.c) + lane_n;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u.z[i][j] = d.z[(size_t)r * d.z_pitch + lane_n + 32 * j];
+                u.g[i][j] = (GM == 0 ? d.G : d.dout)[go + 32 * j];
+                if (GM == 1) u.a[i][j] = d.argmax[go + 32 * j];
+                u.xv[i][j] = x.zin[(size_t)r * x.zin_pitch + l31 + 32 * j];
+            }
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][b][v] = 0.f;
+    auto compute = [&](const Unit& u, int unit, auto tail) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r_begin + 8 * unit + 4 * half + i;
+            const bool live = !decltype(tail)::value || r < r_end;
+            float a2[2], b2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float z = u.z[i][j];
+                float gq = u.g[i][j];
+                if (GM == 1) gq = u.a[i][j] == r ? gq : 0.f;
+                gq = fmaf(z, dsc[j], dsh[j]) > 0.f ? gq : 0.f;
+                gq = dP[j] * gq - u.w[i] * fmaf(dS[j], z, dQ[j]);
+                a2[j] = live ? gq : 0.f;
+                const float xv = fmaxf(fmaf(u.xv[i][j], xs[j], xt[j]), 0.f);
+                b2[j] = live ? xv : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[j][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[j], b2[b], acc[j][b], 0, 0, 0);
+        }
+    };
+    const std::integral_constant<bool, false> full;
+    const std::integral_constant<bool, true> part;
+    const int nfull = (r_end - r_begin) >> 3;                      // units with all eight rows inside the split
+    Unit u0, u1;
+    int un = wr;                                                   // units are dealt round-robin to the set's wavefronts
+    if (un < nfull) load(u0, un);
+    while (un < nfull) {
+        if (un + RW < nfull) load(u1, un + RW);
+        compute(u0, un, full);
+        un += RW;
+        if (un >= nfull) break;
+        if (un + RW < nfull) load(u0, un + RW);
+        compute(u1, un, full);
+        un += RW;
+    }
+    if (((r_end - r_begin) & 7) != 0 && wr == nfull % RW) {        // the ragged last unit of the last split
+        load_tail(u0, nfull);
+        compute(u0, nfull, part);
+    }
+    // the set's RW partial 64 x 64 blocks -> one: tile (j, b) of every wavefront through LDS, summed by wavefront (j, b) of the set
+    float* pout = partial + (size_t)blockIdx.x * NO * KP;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = t >> 1, b = t & 1;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) red[(wave * 16 + v) * 64 + lane] = acc[j][b][v];
+        __syncthreads();
+        if (wr == t % RW) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < RW; ++w) sum += red[((cset * RW + w) * 16 + v) * 64 + lane];
+                const int n = 64 * cset + 32 * j + acc_row(v, half), k = 32 * b + l31;
+                pout[(size_t)n * KP + k] = sum;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+#define DW_STREAM_SPLITS 256
+static bool dw_streamable(const gad_gemm_dw_args& a, int k_used) {
+    const gad_gemm_fwd_args& in = a.in;
+    const gad_dz_src& d = a.dz;
+    if (!g_opt_dw_stream || in.mode != 0 || in.n_groups != 1 || in.Kp != 64 || in.c_in != 64 || k_used != 64) return false;
+    if (in.zin_off[0] != 0 || a.dz_off[0] != 0 || (in.n_out[0] != 64 && in.n_out[0] != 128)) return false;   // w_off: arena offset, dw_reduce applies it
+    if (in.n_rows < 32768 || !in.scale || !in.shift || !in.relu || in.extra || in.ones_col >= 0) return false;
+    if (!d.z || !d.scale || !d.shift || !d.relu || !d.coefP || !d.coefQ || !d.coefS) return false;
+    if (d.gmode != 0 && d.c != in.n_out[0]) return false;
+    if (!a.partial || (long long)DW_STREAM_SPLITS * in.n_out[0] * 64 > a.partial_elems) return false;
+    return a.row_splits <= 0;
+}
+
 extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     GAD_REQUIRE(a && a->gacc, GAD_ERR_NULL, "gemm_dw: null pointer");
     const gad_gemm_fwd_args& in = a->in;
@@ -1634,6 +1798,22 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
                            gr, rows, in.Kp, k_used, a->gacc);
         GAD_CHECK_LAUNCH("gemm_dw(skinny)");
+        return GAD_OK;
+    }
+    if (dw_streamable(*a, k_used)) {
+        const int splits = DW_STREAM_SPLITS;
+        float* part = a->partial;
+        if (in.n_out[0] == 64) {
+            if (a->dz.gmode == 0) hipLaunchKernelGGL((gemm_dw_stream_kernel<1, 0>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
+            else                  hipLaunchKernelGGL((gemm_dw_stream_kernel<1, 1>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
+        } else {
+            if (a->dz.gmode == 0) hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 0>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
+            else                  hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 1>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
+        }
+        GAD_CHECK_LAUNCH("gemm_dw(stream)");
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256), 0,
+                           st, part, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
+        GAD_CHECK_LAUNCH("dw_reduce");
         return GAD_OK;
     }
     long long group_stride = 0;

@@ -300,7 +300,7 @@ def test_target_noise_and_optimizer_kernels():
 
 
 def test_stream_forward_matches_tiled_forward():
-    """The streaming SA1 forward / dX kernels and the tiled kernels are two schedules of the same arithmetic: every SA
+    """The streaming SA1 forward / dX / dW kernels and the tiled kernels are two schedules of the same arithmetic: every SA
     output of both encoders (with / without action columns) agrees to float32 rounding on the same geometry, the
     parameter gradients norm-wise."""
     from ga_ddpg_amd import engine, hip
@@ -323,6 +323,7 @@ def test_stream_forward_matches_tiled_forward():
         for mode in (1, 0):
             hip.set_option("fwd_stream", mode)
             hip.set_option("dx_stream", mode)
+            hip.set_option("dw_stream", mode)
             for value in (False, True):
                 torch.manual_seed(0)
                 enc = engine.EncoderNet(net.value_encoder if value else net.encoder, dev)
@@ -333,6 +334,7 @@ def test_stream_forward_matches_tiled_forward():
     finally:
         hip.set_option("fwd_stream", 1)
         hip.set_option("dx_stream", 1)
+        hip.set_option("dw_stream", 1)
     for value in (False, True):
         for i, (a, b) in enumerate(zip(outs[(1, value)], outs[(0, value)])):
             # last tensor: the flat parameter gradient (norm-wise: ReLU flips between the two roundings, helpers.py)
