@@ -1761,6 +1761,160 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
     }
 }
 
+// Streaming dW for SA1 layer 1, whose input rows are GATHERED: [feat[pt] | src_xyz[pt] - ctr_xyz[grp] | action[sample] | 0]
+// (<= 32 columns, no BatchNorm in front).  Same scheme as above with one B tile: lane c of the B side produces input column
+// c of its rows from per-lane constants (which array, which stride, which component), the A side is the adjacent-pair
+// mapping (accumulator row i of tile j = output channel 2 i + j, one 8-byte load per row for z and for dY).
+__global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                                    int n_rows_static, int splits, int Kp, int k_used,
+                                                                    float inv_gps, float* __restrict__ partial) {
+    constexpr int RW = 8;
+    typedef unsigned gad_u32x2 __attribute__((ext_vector_type(2)));
+    __shared__ float red[8 * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    int chunk = (n_rows + splits - 1) / splits;
+    chunk = (chunk + KT - 1) / KT * KT;
+    const int r_begin = blockIdx.x * chunk, r_end = min(n_rows, r_begin + chunk);
+    if (r_begin >= n_rows) return;
+
+    const unsigned lane_n = 2u * l31;
+    float dsc[2], dsh[2], dP[2], dQ[2], dS[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ch = lane_n + j;
+        dsc[j] = d.scale[ch]; dsh[j] = d.shift[ch]; dP[j] = d.P[ch]; dQ[j] = d.Q[ch]; dS[j] = d.S[ch];
+    }
+    // B side: what input column k = l31 is made of
+    const int k = l31, fc = x.feat_c;
+    const int kind = k < fc ? 0 : (k < fc + 3 ? 1 : ((x.action && k < fc + 3 + x.act_c) ? 2 : 3));
+    const float* base1 = kind == 0 ? x.feat : (kind == 1 ? x.src_xyz : (kind == 2 ? x.action : x.feat));
+    const int stride1 = kind == 0 ? fc : (kind == 1 ? 3 : (kind == 2 ? x.act_c : 0));
+    const int off1 = kind == 0 ? k : (kind == 1 ? k - fc : (kind == 2 ? k - fc - 3 : 0));
+    const bool sub_ctr = kind == 1 && x.ctr_xyz != nullptr;
+    const float* base2 = sub_ctr ? x.ctr_xyz + off1 : x.src_xyz;   // lanes without a centre read a valid address, unused
+
+    const int zpitch4 = d.z_pitch * 4, gpitch4 = d.g_pitch * 4;
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.G), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.row_w ? d.row_w : d.z), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ptr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(x.row_pt), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grpr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(x.row_grp), 0, 0x7ffffffc, 0x00020000);
+    const int vl_z = 4 * half * zpitch4 + (int)lane_n * 4, vl_g = 4 * half * gpitch4 + (int)lane_n * 4, vl_r = 4 * half * 4;
+
+    struct Unit { float z[4][2], g[4][2], w[4], x1[4], x2[4]; };
+    auto gather = [&](Unit& u, int i, int pt, int grp) {
+        int idx = pt;
+        if (kind == 2) {                                           // sample = grp / gps (gps need not be a power of two)
+            int q = (int)((float)grp * inv_gps);
+            const int rem = grp - q * x.gps;
+            q += rem >= x.gps ? 1 : (rem < 0 ? -1 : 0);
+            idx = q;
+        }
+        u.x1[i] = base1[(size_t)idx * stride1 + off1];
+        u.x2[i] = base2[sub_ctr ? (size_t)grp * 3 : 0];
+    };
+    auto load = [&](Unit& u, int unit) {
+        const int rs = r_begin + 8 * unit;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pt = (int)__builtin_amdgcn_raw_buffer_load_b32(ptr_, vl_r, (rs + i) * 4, 0);
+            const int grp = (int)__builtin_amdgcn_raw_buffer_load_b32(grpr, vl_r, (rs + i) * 4, 0);
+            u.w[i] = d.row_w ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(wr_, vl_r, (rs + i) * 4, 0)) : 1.f;
+            const gad_u32x2 zz = __builtin_amdgcn_raw_buffer_load_b64(zr, vl_z, (rs + i) * zpitch4, 0);
+            const gad_u32x2 gg = __builtin_amdgcn_raw_buffer_load_b64(gr_, vl_g, (rs + i) * gpitch4, 0);
+            u.z[i][0] = __uint_as_float(zz.x); u.z[i][1] = __uint_as_float(zz.y);
+            u.g[i][0] = __uint_as_float(gg.x); u.g[i][1] = __uint_as_float(gg.y);
+            gather(u, i, pt, grp);
+        }
+    };
+    auto load_tail = [&](Unit& u, int unit) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = min(r_begin + 8 * unit + 4 * half + i, r_end - 1);
+            u.w[i] = d.row_w ? d.row_w[r] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                u.z[i][j] = d.z[(size_t)r * d.z_pitch + lane_n + j];
+                u.g[i][j] = d.G[(size_t)r * d.g_pitch + lane_n + j];
+            }
+            gather(u, i, x.row_pt[r], x.row_grp[r]);
+        }
+    };
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[j][v] = 0.f;
+    auto compute = [&](const Unit& u, int unit, auto tail) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r_begin + 8 * unit + 4 * half + i;
+            const bool live = !decltype(tail)::value || r < r_end;
+            float xv = sub_ctr ? __fsub_rn(u.x1[i], u.x2[i]) : u.x1[i];
+            xv = (kind != 3 && live) ? xv : 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float z = u.z[i][j];
+                float gq = fmaf(z, dsc[j], dsh[j]) > 0.f ? u.g[i][j] : 0.f;
+                gq = dP[j] * gq - u.w[i] * fmaf(dS[j], z, dQ[j]);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? gq : 0.f, xv, acc[j], 0, 0, 0);
+            }
+        }
+    };
+    const std::integral_constant<bool, false> full;
+    const std::integral_constant<bool, true> part;
+    const int nfull = (r_end - r_begin) >> 3;
+    Unit u0, u1;
+    int un = wave;
+    if (un < nfull) load(u0, un);
+    while (un < nfull) {
+        if (un + RW < nfull) load(u1, un + RW);
+        compute(u0, un, full);
+        un += RW;
+        if (un >= nfull) break;
+        if (un + RW < nfull) load(u0, un + RW);
+        compute(u1, un, full);
+        un += RW;
+    }
+    if (((r_end - r_begin) & 7) != 0 && wave == nfull % RW) {
+        load_tail(u0, nfull);
+        compute(u0, nfull, part);
+    }
+    float* pout = partial + (size_t)blockIdx.x * 64 * Kp;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) red[(wave * 16 + v) * 64 + lane] = acc[j][v];
+        __syncthreads();
+        if ((wave >> 2) == j) {                                    // four wavefronts per tile, four accumulator rows each
+#pragma unroll
+            for (int vv = 0; vv < 4; ++vv) {
+                const int v = 4 * (wave & 3) + vv;
+                float sum = 0.f;
+#pragma unroll
+                for (int w = 0; w < RW; ++w) sum += red[(w * 16 + v) * 64 + lane];
+                const int n = 2 * acc_row(v, half) + j;
+                if (l31 < Kp) pout[(size_t)n * Kp + l31] = l31 < k_used ? sum : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+static bool dw_gather_streamable(const gad_gemm_dw_args& a, int k_used) {
+    const gad_gemm_fwd_args& in = a.in;
+    const gad_dz_src& d = a.dz;
+    if (!g_opt_dw_stream || in.mode != 1 || in.n_groups != 1 || in.Kp > 32 || in.n_out[0] != 64 || k_used > in.Kp) return false;
+    if (in.zin_off[0] != 0 || a.dz_off[0] != 0 || in.n_rows < 32768 || d.gmode != 0 || !d.G) return false;
+    if (!d.z || !d.scale || !d.shift || !d.relu || !d.coefP || !d.coefQ || !d.coefS) return false;
+    if (in.feat_c + 3 + (in.action ? in.act_c : 0) > in.Kp) return false;
+    if (!a.partial || 256ll * 64 * in.Kp > a.partial_elems) return false;
+    return a.row_splits <= 0;
+}
+
 #define DW_STREAM_SPLITS 256
 static bool dw_streamable(const gad_gemm_dw_args& a, int k_used) {
     const gad_gemm_fwd_args& in = a.in;
@@ -1798,6 +1952,17 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
                            gr, rows, in.Kp, k_used, a->gacc);
         GAD_CHECK_LAUNCH("gemm_dw(skinny)");
+        return GAD_OK;
+    }
+    if (dw_gather_streamable(*a, k_used)) {
+        const int splits = 256;
+        const int gps = in.grp_per_sample > 0 ? in.grp_per_sample : 1;
+        hipLaunchKernelGGL(gemm_dw_gather_stream_kernel, dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, in.Kp, k_used,
+                           1.0f / (float)gps, a->partial);
+        GAD_CHECK_LAUNCH("gemm_dw(gather stream)");
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256), 0,
+                           st, a->partial, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
+        GAD_CHECK_LAUNCH("dw_reduce");
         return GAD_OK;
     }
     if (dw_streamable(*a, k_used)) {
