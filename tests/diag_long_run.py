@@ -1,6 +1,6 @@
 """Diagnostic (not a test): 3000 DDPG update steps at B=256 fed by the GPU-resident replay mirror -- finite losses,
-learning curves, device memory.  Round-1 run: 236 steps/s including sampling; critic_loss 0.094 -> 0.021, aux losses
-0.37 -> 0.25, bc_loss flat (the synthetic expert actions are noise).
+learning curves, device memory.  Round-1 run: 265 steps/s including sampling; critic_loss 0.072 -> 0.011, aux losses
+0.36 -> 0.25, bc_loss flat (the synthetic expert actions are noise).
     python tests/diag_long_run.py"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
