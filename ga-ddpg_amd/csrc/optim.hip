@@ -199,3 +199,47 @@ extern "C" int gad_replay_gather(const gad_replay_gather_args* a, void* stream) 
     GAD_CHECK_LAUNCH("replay_gather");
     return GAD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// one launch clears up to six buffers (statistics, gradient arenas, scatter targets of a backward pass): each of
+// them used to be its own fill kernel at the head / in the middle of the pass's dependency chain
+// ------------------------------------------------------------------------------------------------
+struct ZeroSegs { void* p[6]; long long n[6]; };   // n: bytes (multiples of 4)
+
+__global__ __launch_bounds__(256) void zero_buffers_kernel(ZeroSegs z) {
+    const int sgm = blockIdx.y;
+    char* base = static_cast<char*>(z.p[sgm]);
+    const long long bytes = z.n[sgm];
+    if (!base || bytes <= 0) return;
+    const long long head = ((16 - (reinterpret_cast<size_t>(base) & 15)) & 15);          // bytes up to 16-byte alignment
+    const long long h = head < bytes ? head : bytes;
+    const long long body = (bytes - h) / 16;
+    const long long stride = (long long)gridDim.x * 256;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    float4* b16 = reinterpret_cast<float4*>(base + h);
+    for (long long i = t; i < body; i += stride) b16[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < h / 4) reinterpret_cast<float*>(base)[t] = 0.f;
+    const long long tail0 = h + body * 16;
+    if (t < (bytes - tail0) / 4) reinterpret_cast<float*>(base + tail0)[t] = 0.f;
+}
+
+extern "C" int gad_zero_buffers(void* p0, long long n0, void* p1, long long n1, void* p2, long long n2, void* p3,
+                                long long n3, void* p4, long long n4, void* p5, long long n5, void* stream) {
+    ZeroSegs z;
+    void* ps[6] = {p0, p1, p2, p3, p4, p5};
+    const long long ns[6] = {n0, n1, n2, n3, n4, n5};
+    int last = -1;
+    long long nmax = 0;
+    for (int i = 0; i < 6; ++i) {
+        GAD_REQUIRE(ns[i] >= 0 && ns[i] % 4 == 0, GAD_ERR_SHAPE, "zero_buffers: byte count %d must be a non-negative multiple of 4", i);
+        GAD_REQUIRE((reinterpret_cast<size_t>(ps[i]) & 3) == 0, GAD_ERR_SHAPE, "zero_buffers: buffer %d is not 4-byte aligned", i);
+        z.p[i] = ps[i]; z.n[i] = ps[i] ? ns[i] : 0;
+        if (z.n[i] > 0) { last = i; nmax = z.n[i] > nmax ? z.n[i] : nmax; }
+    }
+    if (last < 0) return GAD_OK;
+    long long blocks = (nmax / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(zero_buffers_kernel, dim3((unsigned)blocks, last + 1), dim3(256), 0, (hipStream_t)stream, z);
+    GAD_CHECK_LAUNCH("zero_buffers");
+    return GAD_OK;
+}

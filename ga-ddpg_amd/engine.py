@@ -368,6 +368,18 @@ class Plan(object):
         self.keep.append(t)
         self.calls.append(("zero", None, t, None, False))
 
+    def zero_multi(self, tensors):
+        """clear several buffers with ONE launch per six of them (gad_zero_buffers) instead of a fill kernel each"""
+        import ctypes as C
+        ts = [t for t in tensors if t is not None]
+        for i in range(0, len(ts), 6):
+            grp = ts[i:i + 6]
+            a = []
+            for t in grp:
+                a += [t, C.c_longlong(t.numel() * t.element_size())]
+            a += [None, C.c_longlong(0)] * (6 - len(grp))
+            self.call("gad_zero_buffers", *a)
+
     def fn(self, f):
         self.calls.append(("py", f, None, None, False))
 
@@ -544,7 +556,8 @@ def _bn_coef(plan, enc, slot, m, count, want_dw):
               _ptr(gacc, m.b_off, 8) if want_dw else None)
 
 
-def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1):
+def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1, zero_scatter=True):
+    # zero_scatter=False: the caller has cleared slot.dF[0], slot.dF[1] (and slot.daction) at the head of its plan
     """Backward of plan_encoder_forward.  g_fc2 (B, 512) is dLoss/d(relu(bn(Zfc[1]))) as produced by
     the consumer head's dX kernel, whose epilogue must also have filled this slot's bstats for fc[1].
     Weight gradients accumulate (f64) into enc.flat.gacc when want_dw; their GEMMs are forked onto side stream
@@ -640,11 +653,13 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         dw(s, 0, d, m1, action)
         if s > 0:
             fc = slot.F[s - 1].shape[1]
-            plan.zero(slot.dF[s - 1])
+            if zero_scatter:
+                plan.zero(slot.dF[s - 1])
             dx(rows_kw, d, m1, fc, epilogue=1, dfeat=_ptr(slot.dF[s - 1]), feat_c=fc, row_pt=_ptr(r["pt"]),
                row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
         elif want_daction and action is not None:
-            plan.zero(slot.daction)
+            if zero_scatter:
+                plan.zero(slot.daction)
             dx(rows_kw, d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),
                daction=_ptr(slot.daction), act_c=6, grp_per_sample=geo.M1)
     for lane in sorted(set(dw_lanes) - {0}):

@@ -96,11 +96,10 @@ class FusedRuntime(object):
         P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None)
         P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
         bw = Plan()
-        bw.zero(pol.flat.gacc)
-        bw.zero(enc.flat.gacc)
-        bw.zero(self.slot_p.bstats)
+        bw.zero_multi([pol.flat.gacc, enc.flat.gacc, self.slot_p.bstats, self.slot_p.dF[0], self.slot_p.dF[1]])
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
-        bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True, dw_lane=2))
+        bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True, dw_lane=2,
+                                               zero_scatter=False))
         bw.call("gad_grad_from_arena", pol.flat.gacc, pol.flat.m2p, pol.flat.n, pol.flat.grad, 0)
         bw.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
         P["p_bwd"] = bw
@@ -117,11 +116,10 @@ class FusedRuntime(object):
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
         P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
         cb = Plan()
-        cb.zero(cr.flat.gacc)
-        cb.zero(venc.flat.gacc)
-        cb.zero(self.slot_v.bstats)
+        cb.zero_multi([cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1]])
         cb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
-        cb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=d["action_batch"], want_dw=True))
+        cb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=d["action_batch"], want_dw=True,
+                                               zero_scatter=False))
         cb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 0)
         cb.call("gad_grad_from_arena", venc.flat.gacc, venc.flat.m2p, venc.flat.n, venc.flat.grad, 0)
         P["c_bwd"] = cb
@@ -130,13 +128,12 @@ class FusedRuntime(object):
         v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
         P["v_fwd"] = v
         vb = Plan()
-        vb.zero(cr.flat.gacc)
-        vb.zero(self.slot_v.bstats)
+        vb.zero_multi([cr.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.slot_v.daction])
         vb.extend(heads.plan_critic_backward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
         # the reference's backward also leaves the actor-loss gradient in critic.grad (logged as critic_grad)
         vb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 1)
         vb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_cpi.g_feat, action=self.pi, want_dw=False,
-                                               want_daction=True))
+                                               want_daction=True, zero_scatter=False))
         P["v_bwd"] = vb
 
     # ------------------------------------------------------------------ host -> device

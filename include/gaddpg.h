@@ -350,6 +350,17 @@ typedef struct {
 
 int gad_replay_gather(const gad_replay_gather_args* host_args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * G. housekeeping
+ * ------------------------------------------------------------------------------------------- */
+
+/* Clears up to six device buffers in one launch (pN may be NULL; nN = bytes, multiples of 4).  Replaces the
+ * tensor.zero_() calls the reference's autograd does implicitly (fresh .grad / statistics buffers every backward,
+ * core/agent.py:261-280 set_mode -> zero_grad): gradient arenas, BatchNorm-backward statistics and the scatter
+ * targets of one backward pass. */
+int gad_zero_buffers(void* p0, long long n0, void* p1, long long n1, void* p2, long long n2, void* p3,
+                     long long n3, void* p4, long long n4, void* p5, long long n5, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
