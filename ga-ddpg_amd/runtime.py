@@ -86,6 +86,7 @@ class FusedRuntime(object):
         self.resident = False            # True: the static batch buffers were filled on the device
         self._ev = [torch.cuda.Event() for _ in range(5)]
         self._ev_counts = torch.cuda.Event()
+        self._ev_in = torch.cuda.Event()
 
     # ------------------------------------------------------------------ plans over static buffers
     def _build_plans(self):
@@ -233,17 +234,19 @@ class FusedRuntime(object):
                 self._ev[4].record(s1)                      # geometry of the current state ready (the actor pass needs it)
             if staged:
                 self.upload(batch, tuple(k for k in BATCH_KEYS if k not in first + second))
-            if self.dp is not None:
-                # global mask counts: a 4-double all-reduce whose latency would sit at the head of the critical chain;
-                # on its own stream it overlaps the geometry and t1, the loss kernels' streams wait for it below
-                sc = engine.side_stream(which=3)
-                with torch.cuda.stream(sc):
+            # small independent launches (noise draw, result-slot clear, and for data-parallel runs the global mask counts: a
+            # 4-double all-reduce) would sit on the critical chain in front of t1: on their own stream they overlap the
+            # geometry and t1; the main stream -- and through _ev[2] the actor stream -- waits for them after t1
+            sc = engine.side_stream(which=3)
+            self._ev_in.record(main)                                # after the uploads (noise_u may be copied from the host)
+            sc.wait_event(self._ev_in)
+            with torch.cuda.stream(sc):
+                small_inits()
+                if self.dp is not None:
                     self.dp.set_counts(batch if batch is not None else self._host_flags())
-                    self._ev_counts.record(sc)
-            small_inits()                                           # main stream, before t1 (and before the fork of s2)
+                self._ev_counts.record(sc)
             P["t1"].run()
-            if self.dp is not None:
-                main.wait_event(self._ev_counts)
+            main.wait_event(self._ev_counts)
             with torch.cuda.stream(s1):
                 P["c_fwd"].run()
         else:
