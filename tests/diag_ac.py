@@ -1,4 +1,6 @@
 """Diagnostic: gradient of the actor-critic term wrt pi (value-encoder dX path) in full-step context."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 import numpy as np
 import torch

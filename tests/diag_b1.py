@@ -1,4 +1,6 @@
 """Diagnostic (not a test): golden DDPG run b (steps b0,b1): HIP vs CPU oracle vs golden, per-sample TD target."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import os
 
 import numpy as np

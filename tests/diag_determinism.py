@@ -1,4 +1,6 @@
 """Diagnostic: run-to-run reproducibility of one DDPG update step (same init, same batch), per kernel option."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 import numpy as np
 import torch

@@ -1,5 +1,7 @@
 """Diagnostic: encoder backward vs golden for both encoders in either order; saves grads."""
 import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys
 import numpy as np
 import torch
 from tests.test_gpu_encoder import _feature_net, _geometry, _run_encoder
@@ -32,4 +34,4 @@ def main(order):
 
 if __name__ == "__main__":
     os.makedirs("gpurun_out", exist_ok=True)
-    main(sys.argv[1])
+    main(sys.argv[1] if len(sys.argv) > 1 else "pv")

@@ -1,4 +1,6 @@
 """Diagnostic: host enqueue time vs GPU time of one update step (B=256)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import time
 import numpy as np
 import torch

@@ -1,4 +1,6 @@
 """Diagnostic: per-launch-tag durations of the DDPG step (HIP events around every tagged GEMM)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
 from collections import defaultdict
 

@@ -1,5 +1,7 @@
 """Diagnostic: streaming vs tiled SA1 forward on one batch: per-tensor differences, and both against a float64
 evaluation of the first SA1 layer computed with torch from the same gathered rows."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch
 
