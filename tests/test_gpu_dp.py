@@ -116,3 +116,41 @@ def test_two_ranks_different_batches_stay_in_lock_step(tmp_path):
             continue        # the second step is a policy step: critic.grad then also holds the replica's own (unreduced,
                             # discarded) actor-term gradient, exactly like the reference's DataParallel replica
         assert r0["ret2"][k] == r1["ret2"][k] or abs(r0["ret2"][k] - r1["ret2"][k]) <= 1e-6 * abs(r0["ret2"][k]), k
+
+
+def _worker_nccl1(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from ga_ddpg_amd.parallel import DataParallelContext
+    res = {}
+    for use_dp in (False, True):
+        agent, cfg = _agent()
+        batches, u = _batches(cfg, 1)
+        rt = agent.runtime(B, batches[0]["point_state_batch"].shape[2])
+        if use_dp:
+            dp = DataParallelContext()
+            agent._dp = dp
+            dp.attach(rt)
+        rets = [agent.update_parameters(batches[0], agent.update_step, s, noise_u=u) for s in range(2)]
+        torch.cuda.synchronize()
+        res[use_dp] = {"rets": rets, "pi": agent.pi.cpu().clone(), "state": _state(agent)}
+    torch.save(res, os.path.join(out_dir, "nccl1.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_single_rank_rccl_equals_plain_step(tmp_path):
+    """the data-parallel hooks over the REAL transport (backend "nccl" = RCCL) with one rank: the count exchange on its own
+    stream, the two gradient all-reduces (one of them issued from the actor stream) and the scalar reduction must leave
+    the step unchanged -- this is the stream-ordering contract of RCCL collectives that the gloo tests cannot exercise."""
+    mp.spawn(_worker_nccl1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "nccl1.pt"), weights_only=False)
+    a, b = res[False], res[True]
+    for k in a["rets"][0]:
+        tol = 2e-2 if k == "actor_critic_loss" else 1e-5
+        assert abs(a["rets"][0][k] - b["rets"][0][k]) <= tol * abs(a["rets"][0][k]) + 1e-7, (k, a["rets"][0][k], b["rets"][0][k])
+        assert np.isfinite(b["rets"][1][k])
+    assert float((a["pi"] - b["pi"]).abs().max()) <= 5e-2 * float(a["pi"].abs().max())   # after two Adam steps: sanity bound
+    for n in a["state"]:
+        assert bool(torch.isfinite(b["state"][n]).all()), n
