@@ -140,9 +140,13 @@ def main():
     backend = os.environ.get("GAD_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
     dp = None
-    if world > 1:
+    # GAD_BENCH_FORCE_DP=1: run the data-parallel hooks (count exchange, gradient all-reduces, scalar reduction) over a
+    # ONE-rank RCCL group -- what they cost per step without any transport, the floor under the N > 1 numbers
+    force_dp = world == 1 and os.environ.get("GAD_BENCH_FORCE_DP", "0") == "1"
+    if world > 1 or force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
         dist.init_process_group(backend, rank=rank, world_size=world)
     from ga_ddpg_amd import engine
     from ga_ddpg_amd.api import make_agent
@@ -158,7 +162,7 @@ def main():
     rng = np.random.default_rng(SEED + 1000 + rank)
     host_batches = [sample_valid_batch(mem, B, rng) for _ in range(args.ring)]
     rt = agent.runtime(B, host_batches[0]["point_state_batch"].shape[2])
-    if world > 1:
+    if world > 1 or force_dp:
         dp = DataParallelContext()
         agent._dp = dp
         dp.attach(rt)
@@ -315,4 +319,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        import torch.distributed as _dist
+        if _dist.is_available() and _dist.is_initialized():
+            _dist.destroy_process_group()

@@ -35,6 +35,9 @@ class FusedRuntime(object):
         if self.has_critic:
             self.cr = _head_net(agent.critic, "critic", dev)
             self.cr_t = _head_net(agent.critic_target, "critic", dev)
+        # one gradient buffer per optimiser phase (a data-parallel run all-reduces it in one call); before any plan exists
+        self.bucket_a = engine.coalesce_grads([self.pol.flat, self.enc.flat])
+        self.bucket_c = engine.coalesce_grads([self.cr.flat, self.venc.flat]) if self.has_critic else None
         sa1 = engine.SAConfig(fe.pointnet_nclusters, fe.pointnet_radius, 64)
         sa2 = engine.SAConfig(32, 0.04, 128)
         self.geo = engine.Geometry(B, self.N, sa1, sa2, dev)
@@ -182,7 +185,9 @@ class FusedRuntime(object):
 
     def _reduce(self, flats):
         if self.allreduce is not None:
-            self.allreduce([f.grad for f in flats])
+            b = getattr(flats[0], "_grad_bucket", None)
+            whole = b is not None and b[0] == tuple(id(f) for f in flats)
+            self.allreduce([b[1]] if whole else [f.grad for f in flats])
 
     # ------------------------------------------------------------------ the update steps
     def ddpg_step(self, batch, noise_u=None):
@@ -239,13 +244,13 @@ class FusedRuntime(object):
             # geometry and t1; the main stream -- and through _ev[2] the actor stream -- waits for them after t1
             sc = engine.side_stream(which=3)
             self._ev_in.record(main)                                # after the uploads (noise_u may be copied from the host)
+            P["t1"].run()                                           # enqueued FIRST: the host needs ~0.1 ms for the launches below
             sc.wait_event(self._ev_in)
             with torch.cuda.stream(sc):
                 small_inits()
                 if self.dp is not None:
                     self.dp.set_counts(batch if batch is not None else self._host_flags())
                 self._ev_counts.record(sc)
-            P["t1"].run()
             main.wait_event(self._ev_counts)
             with torch.cuda.stream(s1):
                 P["c_fwd"].run()

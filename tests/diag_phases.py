@@ -23,6 +23,16 @@ def main():
     d = {k: torch.as_tensor(np.ascontiguousarray(hb[k], dtype=np.float32)).cuda() for k in BATCH_KEYS}
     d["mask_counts"] = mask_counts(hb)
     rt = agent.runtime(B, hb["point_state_batch"].shape[2])
+    if os.environ.get("GAD_DIAG_DP", "0") == "1":                    # the data-parallel hooks over a one-rank RCCL group
+        import torch.distributed as dist
+        from ga_ddpg_amd.parallel import DataParallelContext
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+        dp = DataParallelContext()
+        agent._dp = dp
+        dp.attach(rt)
+        for a in ("set_counts", "reduce_scalars"):
+            pass
     log = []
     on = [False]
 
@@ -49,6 +59,9 @@ def main():
     wrap(rt.geo_next, "run", "geo(next)")
     for a in ("_adam", "_stats", "_target_updates", "_download", "upload", "_reduce"):
         wrap(rt, a, a)
+    if rt.dp is not None:
+        wrap(rt.dp, "set_counts", "dp.set_counts")
+        wrap(rt.dp, "reduce_scalars", "dp.reduce_scalars")
     for i in range(12):
         agent.update_parameters(d, agent.update_step, i)
     torch.cuda.synchronize()
