@@ -207,8 +207,8 @@ __device__ __forceinline__ DzRaw dz_raw(const DzSrc& d, int r, bool valid, int o
     return o;
 }
 
-// vec: LDS copies of {scale, shift, P, Q, S} of this group's channels (VMAX floats each)
-template <bool VEC>
+// vec: LDS copies of {scale, shift, P, Q, S} of this group's channels (VM floats each; VM = VMAX unless the kernel sizes its LDS for narrower layers)
+template <bool VEC, int VM = VMAX>
 __device__ __forceinline__ float4 dz_finish(const DzSrc& d, const DzRaw& raw, int r, bool valid, int n, int nmax, float w,
                                             const float* vec) {
     if (!VEC) return raw.g;
@@ -223,28 +223,29 @@ __device__ __forceinline__ float4 dz_finish(const DzSrc& d, const DzRaw& raw, in
     if (d.relu) {
         float4 y = z;
         if (d.scale) {
-            const float4 s = *reinterpret_cast<const float4*>(vec + nn), t = *reinterpret_cast<const float4*>(vec + VMAX + nn);
+            const float4 s = *reinterpret_cast<const float4*>(vec + nn), t = *reinterpret_cast<const float4*>(vec + VM + nn);
             y.x = fmaf(z.x, s.x, t.x); y.y = fmaf(z.y, s.y, t.y); y.z = fmaf(z.z, s.z, t.z); y.w = fmaf(z.w, s.w, t.w);
         }
         g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
         g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
     }
     if (d.P) {
-        const float4 P = *reinterpret_cast<const float4*>(vec + 2 * VMAX + nn);
-        const float4 Q = *reinterpret_cast<const float4*>(vec + 3 * VMAX + nn);
-        const float4 S = *reinterpret_cast<const float4*>(vec + 4 * VMAX + nn);
+        const float4 P = *reinterpret_cast<const float4*>(vec + 2 * VM + nn);
+        const float4 Q = *reinterpret_cast<const float4*>(vec + 3 * VM + nn);
+        const float4 S = *reinterpret_cast<const float4*>(vec + 4 * VM + nn);
         g.x = P.x * g.x - w * fmaf(S.x, z.x, Q.x); g.y = P.y * g.y - w * fmaf(S.y, z.y, Q.y);
         g.z = P.z * g.z - w * fmaf(S.z, z.z, Q.z); g.w = P.w * g.w - w * fmaf(S.w, z.w, Q.w);
     }
     return f4sel(valid && inside, g, f4zero());
 }
 
+template <int VM = VMAX>
 __device__ __forceinline__ void stage_dz_vecs(float* vec, const DzSrc& d, int off, int n) {
     stage_vec(vec, d.scale, off, n, 1.f);
-    stage_vec(vec + VMAX, d.shift, off, n, 0.f);
-    stage_vec(vec + 2 * VMAX, d.P, off, n, 1.f);
-    stage_vec(vec + 3 * VMAX, d.Q, off, n, 0.f);
-    stage_vec(vec + 4 * VMAX, d.S, off, n, 0.f);
+    stage_vec(vec + VM, d.shift, off, n, 0.f);
+    stage_vec(vec + 2 * VM, d.P, off, n, 1.f);
+    stage_vec(vec + 3 * VM, d.Q, off, n, 0.f);
+    stage_vec(vec + 4 * VM, d.S, off, n, 0.f);
 }
 
 static bool dz_vectorizable(const gad_dz_src& d, const int32_t* off, const int32_t* n_out, int ng) {
@@ -868,7 +869,7 @@ struct DxEpi {
 };
 
 template <int WM, int WN, int TM, int TN, bool VEC>
-__global__ __launch_bounds__(256) void gemm_dx_kernel(DzSrc d, Groups gr, const int32_t* __restrict__ n_rows_dev,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_dx_kernel(DzSrc d, Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                        int n_rows_static, const float* __restrict__ W, int Kp,
                                                        DxEpi e) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -1373,7 +1374,9 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
 // split over rows: every (tile, split) block writes its partial tile to the caller's workspace, a
 // second kernel sums the splits in f64.  Without a workspace: f64 atomics.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int XM, bool VEC>
+// VM: stride of the per-channel vectors in LDS (>= the widest layer side).  512 instead of VMAX = 1024 brings the
+// workgroup from 46 KB to 32 KB of LDS: four instead of three resident workgroups per CU (the register budget allows four).
+template <int WM, int WN, int TM, int TN, int XM, bool VEC, int VM>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr,
                                                        const int32_t* __restrict__ n_rows_dev, int n_rows_static,
                                                        int Kp, int k_used, int n_ktiles, double* __restrict__ gacc,
@@ -1382,13 +1385,13 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     constexpr int PA = PitchD<BM>::v, PB = PitchD<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
     constexpr int TILE = KT * PA + KT * PB;
-    constexpr int SM = TILE + (VEC ? 5 * VMAX : 4) + 2 * VMAX;
+    constexpr int SM = TILE + (VEC ? 5 * VM : 4) + 2 * VM;
     __shared__ __attribute__((aligned(16))) float smem[SM];
     float* As = smem;
     float* Bs = smem + KT * PA;
     float* vec = smem + TILE;
-    float* sv = vec + (VEC ? 5 * VMAX : 4);
-    float* tv = sv + VMAX;
+    float* sv = vec + (VEC ? 5 * VM : 4);
+    float* tv = sv + VM;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -1403,7 +1406,7 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     const int r_begin = blockIdx.y * chunk;
     const int r_end = min(r_begin + chunk, n_rows);
     if (r_begin >= r_end) return;     // the reducer skips the same splits (same chunk arithmetic)
-    if (VEC) stage_dz_vecs(vec, d, doff, n_out);
+    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out);
     if (XM == 0 && x.scale) { stage_vec(sv, x.scale, zoff, x.c_in, 1.f); stage_vec(tv, x.shift, zoff, x.c_in, 0.f); }
     __syncthreads();
 
@@ -1462,7 +1465,7 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
         for (int it = 0; it < UA; ++it) {
             int kk, i; unit_D<BM>(it * 256 + tid, kk, i);
             const int r = rb0 + kk;
-            store_D<BM>(As, kk, i, dz_finish<VEC>(d, ra[it], r, r < r_end, n0 + i, n_out, wa[it], vec));
+            store_D<BM>(As, kk, i, dz_finish<VEC, VM>(d, ra[it], r, r < r_end, n0 + i, n_out, wa[it], vec));
         }
 #pragma unroll
         for (int it = 0; it < UB; ++it) {
@@ -1982,9 +1985,11 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         return GAD_OK;
     }
     long long group_stride = 0;
-#define LAUNCH_DW3(WM, WN, TM, TN, XM, V)                                                                  \
-    hipLaunchKernelGGL((gemm_dw_kernel<WM, WN, TM, TN, XM, V>), dim3(tn_ * tk_, splits, gr.n), dim3(256), 0, st, d, \
+#define LAUNCH_DW4(WM, WN, TM, TN, XM, V, VM)                                                              \
+    hipLaunchKernelGGL((gemm_dw_kernel<WM, WN, TM, TN, XM, V, VM>), dim3(tn_ * tk_, splits, gr.n), dim3(256), 0, st, d, \
                        x, gr, in.n_rows_dev, rows, in.Kp, k_used, tk_, a->gacc, part, group_stride)
+#define LAUNCH_DW3(WM, WN, TM, TN, XM, V)                                                                  \
+    do { if (narrow) LAUNCH_DW4(WM, WN, TM, TN, XM, V, 512); else LAUNCH_DW4(WM, WN, TM, TN, XM, V, VMAX); } while (0)
 #define LAUNCH_DW(WM, WN, TM, TN)                                                                          \
     do {                                                                                                   \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                                \
@@ -2003,6 +2008,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     } while (0)
     int splits = 1;
     float* part = a->partial;
+    const bool narrow = nmax <= 512 && (in.mode != 0 || in.c_in <= 512);   // per-channel vectors fit a 512-float stride
     if (nmax <= 32) {
         LAUNCH_DW(1, 4, 1, 1);      // 32 x 128
     } else if (k_used <= 32) {
@@ -2012,6 +2018,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     }
 #undef LAUNCH_DW
 #undef LAUNCH_DW3
+#undef LAUNCH_DW4
     GAD_CHECK_LAUNCH("gemm_dw");
     if (part) {
         hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n),
