@@ -868,7 +868,7 @@ struct DxEpi {
     float* dfeat; int feat_c; const int32_t* row_pt; const int32_t* row_grp; double* daction; int act_c; int gps;
 };
 
-template <int WM, int WN, int TM, int TN, bool VEC>
+template <int WM, int WN, int TM, int TN, bool VEC, int VM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_dx_kernel(DzSrc d, Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                        int n_rows_static, const float* __restrict__ W, int Kp,
                                                        DxEpi e) {
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
     constexpr int OFFB = (KT * PA + 3) & ~3;
     constexpr int TILE = OFFB + KT * PB;
-    constexpr int SM = TILE + 3 * BM + (VEC ? 5 * VMAX : 4);
+    constexpr int SM = TILE + 3 * BM + (VEC ? 5 * VM : 4);
     static_assert(TILE >= 2 * WM * BN, "reduction scratch must fit in the tile LDS");
     __shared__ __attribute__((aligned(16))) float smem[SM];
     float* As = smem;
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     if ((int)(blockIdx.x * BM) >= n_rows) return;
     const int nk = gad_cdiv_dev(n_out, KT);
-    if (VEC) stage_dz_vecs(vec, d, doff, n_out);
+    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out);
     const bool need_grp = e.mode == 1 || d.gmode != 0;
 
     float cb[TN], cg[TN];
@@ -945,7 +945,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int it = 0; it < UA; ++it) {
                 int i, kk; unit_T<BM>(it * 256 + tid, i, kk);
                 const int r = row0 + i;
-                store_T<BM>(As, i, kk, dz_finish<VEC>(d, ra[it], r, r < n_rows, nb + kk, n_out, wS[i], vec));
+                store_T<BM>(As, i, kk, dz_finish<VEC, VM>(d, ra[it], r, r < n_rows, nb + kk, n_out, wS[i], vec));
             }
 #pragma unroll
             for (int it = 0; it < UB; ++it) {
@@ -1356,8 +1356,12 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     do {                                                                                                 \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                              \
         int gx = gad_cdiv(rows, BM); if (gx > 2048) gx = 2048;                                           \
-        hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
-                           st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                              \
+        if (nmax_dx <= 512)                                                                              \
+            hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V, 512>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
+                               st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                          \
+        else                                                                                             \
+            hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V, VMAX>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
+                               st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                          \
     } while (0)
 #define LAUNCH_DX(WM, WN, TM, TN) do { if (vec) LAUNCH_DX2(WM, WN, TM, TN, true); else LAUNCH_DX2(WM, WN, TM, TN, false); } while (0)
     // 64 x 64 tiles (or 128 x 32 for narrow outputs): measured best on the whole step, also for the 2e5-row SA1
