@@ -230,14 +230,14 @@ def main():
     steps_per_s = args.steps * 1.0 / dt
     # whole-job aggregate: every rank processes one B=256 minibatch per optimiser step (weak scaling), so the job does
     # world x (B=256 minibatch-steps) per iteration; at N=1 this is the plain step rate
-    res = {"metric": "DDPG grad-steps/sec (B=256, N=1024 pts)", "value": steps_per_s * world, "unit": "steps/s",
+    res = {"metric": "DDPG grad-steps/sec (B=%d, N=1024 pts)" % B, "value": steps_per_s * world, "unit": "steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: DDPG/TD3 offline update (td3_critic_aux_policy_aux), "
                                   "batch=%d per GPU, 1024-pt clouds, synthetic replay buffer" % B,
                       "batch_per_gpu": B, "global_batch": B * world, "points": 1024,
                       "parallelism": "dp%d" % world, "iterations_per_s": steps_per_s,
-                      "value_definition": "B=256 minibatch gradient steps per second summed over ranks (= iterations/s x n_gpus)", "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
+                      "value_definition": "B=%d minibatch gradient steps per second summed over ranks (= iterations/s x n_gpus)" % B, "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
            "losses": {k: out[k] for k in ("critic_loss", "bc_loss", "actor_critic_loss")},
            "roofline": roof}
     # step-level view against the dense-FP32 roofline: mean 5.5078 GFLOP per sample and step
