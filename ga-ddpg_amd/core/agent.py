@@ -62,6 +62,9 @@ class Agent(object):
                 raise RuntimeError("the fused runtime is specialised to one batch shape (B=%d, NP=%d)"
                                    % (self._rt.B, self._rt.NP))
             self._rt = FusedRuntime(self, batch_size, n_cols)
+            # a checkpoint loaded BEFORE the first update left its Adam moments / step counts in the torch optimizers only
+            # (load_model on a fresh process): the flat optimiser state starts from them, not from zero
+            self._optim_states_in()
             if self._dp is not None:
                 self._dp.attach(self._rt)
         return self._rt
@@ -93,23 +96,28 @@ class Agent(object):
 
     @torch.no_grad()
     def select_action(self, state, actions=None, goal_state=None, vis=False, remain_timestep=0, grasp_set=None,
-                      gt_goal_rollout=False, repeat=False):
-        """Rollout-side inference (reference core/agent.py:82-125): eval-mode BatchNorm (running statistics),
-        batch of one.  Returns (action = squashed mean, log-prob placeholder 0.0, action sample, aux pose).
-        The reparameterised draw of the reference is not evaluated: `action sample` is the mean."""
-        from ..runtime import feature_forward, policy_forward
+                      gt_goal_rollout=False, repeat=False, eps=None):
+        """Rollout-side inference (reference core/agent.py:82-125): eval-mode BatchNorm (running statistics), batch of
+        one, policy.sample on the feature.  Returns the reference's tuple (action = squashed mean (6,), log-prob of the
+        sample (scalar), action_sample = tanh(mean + std * eps) * scale (6,), aux pose (7,) or the goal state).
+        `eps` (6,) injects the N(0,1) draw of the reparameterised sample (default: drawn on the device)."""
+        from ..runtime import feature_forward
         self.state_feature_extractor.eval()
         self.policy.eval()
         pc = torch.as_tensor(np.asarray(state[0][0], dtype=np.float32)[None]).cuda()
         z = feature_forward(self.state_feature_extractor.module, pc, value=False)
         feat = torch.cat((z, torch.full((1, 1), float(remain_timestep), device=z.device)), dim=1)
-        pi, aux = policy_forward(self.policy, feat)
-        action = pi[0].cpu().numpy()
+        if eps is not None:
+            eps = np.asarray(eps, dtype=np.float32).reshape(1, 6)
+        mean_sq, log_prob, sample, aux = self.policy.sample(feat, eps=eps)
+        action = mean_sq[0].cpu().numpy()
+        extra_pred = float(log_prob[0, 0])
+        action_sample = sample[0].cpu().numpy()
         if self.policy_aux:
             aux_pred = aux[0].cpu().numpy()
         else:
             aux_pred = np.asarray(goal_state, dtype=np.float32).reshape(-1) if goal_state is not None else None
-        return action, 0.0, action.copy(), aux_pred
+        return action, extra_pred, action_sample, aux_pred
 
     def _result(self, s, has_critic):
         """map the runtime's scalar block to the reference's 11-key dict (core/utils.py:1008-1020)"""
@@ -217,19 +225,34 @@ class Agent(object):
                         "val_encoder_sch": self.state_feat_val_encoder_scheduler.state_dict(),
                         "step": step}, state_feat_path)
 
+    def _reinit_lr(self, optim, milestones):
+        """fine-tuning restart of an optimiser's learning-rate schedule (reference core/agent.py:375-383): lr back to
+        `reinit_lr`, a fresh MultiStepLR over the configured milestones"""
+        for g in optim.param_groups:
+            g["lr"] = self.reinit_lr
+        sch = torch.optim.lr_scheduler.MultiStepLR(optim, milestones=list(milestones), gamma=0.5)
+        sch.initial_lr = self.reinit_lr
+        sch.base_lrs[0] = self.reinit_lr
+        return sch
+
     def load_model(self, output_dir, surfix="latest", set_init_step=False, reinit_value_feat=False):
+        """reference core/agent.py:348-431 (`reinit_value_feat` is accepted and unused there as well)"""
         paths = self._paths(output_dir, surfix)
         if os.path.exists(paths["actor"]):
             d = torch.load(paths["actor"], weights_only=False)
             self.policy.load_state_dict(d["net"])
             self.policy_optim.load_state_dict(d["opt"])
             self.policy_scheduler.load_state_dict(d["sch"])
+            if self.reinit_optim and set_init_step:                  # reference core/agent.py:375-383
+                self.policy_scheduler = self._reinit_lr(self.policy_optim, self.policy_milestones)
             hard_update(self.policy_target, self.policy, self.tau)
         if hasattr(self, "critic") and os.path.exists(paths["critic"]):
             d = torch.load(paths["critic"], weights_only=False)
             self.critic.load_state_dict(d["net"])
             self.critic_optim.load_state_dict(d["opt"])
             self.critic_scheduler.load_state_dict(d["sch"])
+            if self.reinit_optim and set_init_step:                  # reference core/agent.py:394-401
+                self.critic_scheduler = self._reinit_lr(self.critic_optim, self.value_milestones)
             hard_update(self.critic_target, self.critic, self.tau)
         step = 0
         if os.path.exists(paths["state_feat"]):

@@ -132,18 +132,24 @@ class GaussianPolicy(nn.Module):
             self.action_scale = torch.FloatTensor((action_space.high - action_space.low) / 2.0)
             self.action_bias = torch.FloatTensor((action_space.high + action_space.low) / 2.0)
             if np.abs(np.asarray(self.action_bias)).max() != 0:
-                raise NotImplementedError("asymmetric action bounds")
+                raise NotImplementedError("asymmetric action bounds (the fused update step assumes action_bias == 0, "
+                                          "which PandaTaskSpace6D satisfies)")
 
-    def sample(self, state):
-        """-> (squashed mean, log_prob, action, extra_pred).  On the update path only the squashed mean
-        and the aux head are consumed (reference ddpg.py:77,169); the reparameterised draw is not
-        evaluated, so `action` is the mean and log_prob is None."""
-        from ..runtime import policy_forward
-        pi, aux = policy_forward(self, state)
-        return pi, None, pi, aux
+    def sample(self, state, eps=None):
+        """-> (squashed mean, log_prob (B,1), action, extra_pred) as reference core/networks.py:353-371:
+        x = mean + exp(log_std) * eps with eps ~ N(0,1) (`eps` (B,6) injects the draw of Normal.rsample),
+        action = tanh(x) * scale + bias, log_prob with the tanh correction.  Inference-side evaluation through the
+        HIP head kernels (no autograd graph: the update step differentiates the heads inside the fused path)."""
+        from ..runtime import policy_sample
+        r = policy_sample(self, state, eps=eps)
+        return r["mean_sq"], r["log_prob"], r["action"], r["extra"]
 
     def forward(self, state):
-        raise NotImplementedError("use sample(); the log-std branch is not evaluated on the update path")
+        """-> (mean (raw), log_std clamped to [LOG_SIG_MIN, LOG_SIG_MAX], extra_pred with a unit quaternion when
+        extra_pred_dim == 7) as reference core/networks.py:339-351."""
+        from ..runtime import policy_sample
+        r = policy_sample(self, state, draw=False)
+        return r["mean"], r["log_std"], r["extra"]
 
     def to(self, device):
         self.action_scale = self.action_scale.to(device)

@@ -1,0 +1,128 @@
+"""Offline training driver: the caller loop of the update-step path (reference
+core/train_test_offline.py: setup() :60-104, train_off_policy() :107-161, the __main__ wiring :325-360).
+
+    python -m ga_ddpg_amd.core.train_test_offline --config_file ddpg_td3_aux.yaml --data path/to/buffer_dir \
+        --save_model --max_epoch 2000 --output_dir output/run0
+
+Kept from the reference: `updates_per_step` updates per epoch, each = memory.sample(batch_size) ->
+agent.update_parameters(batch, agent.update_step, i) -> agent.step_scheduler(agent.update_step); `save_model` every
+100 epochs (first inner iteration) and at every `save_epoch` step (surfix `epoch_<step>`); stop once
+update_step >= max_epoch; batch size = cfg.OFFLINE_BATCH_SIZE (:351); a loss table per epoch.  Not kept (out of scope,
+SURVEY section 2): the Ray harness, tensorboard writer, the test()/rollout branch and the PyBullet environment.
+The replay buffer can be mirrored in HBM (`device_replay=True`): sampling then costs one gather launch
+instead of a 17 MB host gather + PCIe upload per step."""
+import argparse
+import itertools
+import os
+import time
+
+import numpy as np
+
+from .replay_memory import BaseMemory
+from .utils import get_loss_info_dict, migrate_model
+
+LOG_INTERVAL = 4
+
+
+def setup(config_file="ddpg_td3_aux.yaml", policy=None, pretrained=None, model_surfix="latest", batch_size=None,
+          output_dir=None):
+    """-> (agent, cfg): config merged as the reference does, networks / optimisers / schedulers built by
+    make_nets_opts_schedulers, agent wired with setup_feature_extractor; an optional pretrained directory is migrated
+    (BC -> DDPG file names) into output_dir and loaded with set_init_step=True (reference :347-349, utils.py:319-334)."""
+    from ..api import make_agent
+    agent, cfg = make_agent(config_file, kind=policy)
+    cfg.RL_TRAIN.batch_size = int(batch_size if batch_size is not None else cfg.OFFLINE_BATCH_SIZE)   # reference :351
+    if pretrained:
+        src = pretrained
+        if output_dir and os.path.abspath(output_dir) != os.path.abspath(pretrained):
+            migrate_model(pretrained, output_dir, model_surfix)
+            src = output_dir
+        agent.load_model(src, surfix=model_surfix, set_init_step=True)
+    return agent, cfg
+
+
+def train_off_policy(agent, memory, config, model_output_dir=None, save_model=False, log=None, max_epochs=None,
+                     sample=None):
+    """The reference's train_off_policy() (:107-161) over an agent and a filled replay memory.
+    config = cfg.RL_TRAIN (updates_per_step, batch_size, save_epoch, max_epoch).  `sample(batch_size)` overrides
+    memory.sample (device-resident replay, prefetching samplers).  Returns the per-key loss history (deques, as the
+    reference keeps them) and the number of epochs run."""
+    losses = get_loss_info_dict()
+    sample = sample or memory.sample
+    epochs = 0
+    for epoch in itertools.count(1):
+        start_time = time.time()
+        lrs = agent.get_lr()
+        data_time, network_time = 0.0, 0.0
+        for i in range(config.updates_per_step):
+            batch_data = sample(batch_size=config.batch_size)
+            data_time += time.time() - start_time
+            start_time = time.time()
+            loss = agent.update_parameters(batch_data, agent.update_step, i)
+            network_time += time.time() - start_time
+            for k, v in loss.items():
+                if k in losses:
+                    losses[k].append(v)
+            agent.step_scheduler(agent.update_step)
+            start_time = time.time()
+            if save_model and epoch % 100 == 0 and i == 0:
+                agent.save_model(agent.update_step, output_dir=model_output_dir)
+            if save_model and agent.update_step in config.save_epoch:
+                agent.save_model(agent.update_step, output_dir=model_output_dir,
+                                 surfix="epoch_{}".format(agent.update_step))
+        epochs = epoch
+        if log is not None:
+            log("epoch: {} updates: {} lr: {:.6f} network time: {:.2f} data time: {:.2f} batch size: {}".format(
+                epoch, agent.update_step, lrs["policy_lr"], network_time, data_time, config.batch_size))
+            rows = [(name, float(np.mean(list(h)))) for name, h in losses.items() if np.mean(list(h)) != 0]
+            try:
+                import tabulate
+                log(tabulate.tabulate(rows, ["loss name", "loss val"], tablefmt="psql"))
+            except ImportError:
+                for r in rows:
+                    log("  %-28s %.6f" % r)
+        if agent.update_step >= config.max_epoch or (max_epochs is not None and epoch >= max_epochs):
+            break
+    return losses, epochs
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--config_file", default="ddpg_td3_aux.yaml")
+    ap.add_argument("--policy", default=None, help="DDPG | BC (default: from cfg.RL_TRAIN.RL)")
+    ap.add_argument("--data", default=None, help="directory holding the replay .npz written by BaseMemory.save (reference "
+                                                 "format, file name = cfg RL_SAVE_DATA_NAME); default: a seeded synthetic buffer")
+    ap.add_argument("--buffer", type=int, default=20000, help="transitions of the synthetic buffer")
+    ap.add_argument("--pretrained", default=None)
+    ap.add_argument("--model_surfix", default="latest")
+    ap.add_argument("--output_dir", default="output/offline")
+    ap.add_argument("--save_model", action="store_true")
+    ap.add_argument("--batch_size", type=int, default=None)
+    ap.add_argument("--max_epoch", type=int, default=None, help="overrides RL_TRAIN.max_epoch (update steps)")
+    ap.add_argument("--device_replay", action="store_true", help="mirror the buffer in HBM (one gather launch per sample)")
+    args = ap.parse_args(argv)
+    agent, cfg = setup(args.config_file, args.policy, args.pretrained, args.model_surfix, args.batch_size, args.output_dir)
+    config = cfg.RL_TRAIN
+    if args.max_epoch is not None:
+        config.max_epoch = args.max_epoch
+    if args.data:
+        memory = BaseMemory(int(cfg.OFFLINE_RL_MEMORY_SIZE) + 1, config)
+        memory.load(args.data, int(cfg.OFFLINE_RL_MEMORY_SIZE))
+    else:
+        from ..synth_data import fill_synthetic_buffer
+        memory = BaseMemory(args.buffer, config, point_dtype=np.float32)
+        fill_synthetic_buffer(memory, args.buffer, seed=20260928)
+    sample = None
+    if args.device_replay:
+        from .device_replay import DeviceReplay
+        dmem = DeviceReplay(memory)
+        rng = np.random.default_rng(0)
+        sample = lambda batch_size: dmem.sample_lazy(batch_size, rng)       # noqa: E731
+    losses, epochs = train_off_policy(agent, memory, config, args.output_dir, args.save_model, log=print, sample=sample)
+    if args.save_model:
+        agent.save_model(agent.update_step, output_dir=args.output_dir)
+    return losses, epochs
+
+
+if __name__ == "__main__":
+    main()

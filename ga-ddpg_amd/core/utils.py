@@ -146,3 +146,24 @@ def get_noise_delta(action, noise_level, noise_type="uniform"):
         d = np.random.uniform(-3, 3, size=(6,)) * noise_level
     d[3:] *= 5
     return d
+
+
+def migrate_model(in_model, out_model, surfix="latest", grasp_model=None):
+    """Copy a pretrained checkpoint set into a new run directory under the DDPG file names (reference
+    core/utils.py:319-334): the BC_* files of `in_model` when they exist, else its DDPG_* files; missing files are
+    skipped.  Returns the list of (source, destination) pairs copied."""
+    import os
+    import shutil
+    in_policy_name, out_policy_name = "BC", "DDPG"
+    copied = []
+    for name in ("actor", "state_feat", "goal_feat", "critic"):
+        fname = "{}_PandaYCBEnv_{}".format(name, surfix)
+        if not os.path.exists("{}/{}_{}".format(in_model, in_policy_name, fname)):
+            in_policy_name = "DDPG"              # sticky, as in the reference: later files are looked up as DDPG_*
+        src = "{}/{}_{}".format(in_model, in_policy_name, fname)
+        dst = "{}/{}_{}".format(out_model, out_policy_name, fname)
+        if os.path.exists(src):
+            os.makedirs(out_model, exist_ok=True)
+            shutil.copyfile(src, dst)
+            copied.append((src, dst))
+    return copied

@@ -145,12 +145,12 @@ extern "C" int gad_critic_loss(const float* out9, const float* tgt_out9, const f
 }
 
 // pi = tanh(mean)*scale, aux = [normalize(extra[:4]), extra[4:]]
-__global__ __launch_bounds__(256) void policy_outputs_kernel(const float* __restrict__ pol13, int B,
+__global__ __launch_bounds__(256) void policy_outputs_kernel(const float* __restrict__ pol13, int B, int pitch,
                                                              const float* __restrict__ ascale,
                                                              float* __restrict__ pi, float* __restrict__ aux) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
-    const float* o = pol13 + (size_t)i * 13;
+    const float* o = pol13 + (size_t)i * pitch;
     for (int c = 0; c < 6; ++c) pi[(size_t)i * 6 + c] = tanhf(o[c]) * ascale[c];
     if (aux) {
         float q[4];
@@ -160,13 +160,70 @@ __global__ __launch_bounds__(256) void policy_outputs_kernel(const float* __rest
     }
 }
 
-extern "C" int gad_policy_outputs(const float* pol13, int B, const float* action_scale, float* pi, float* aux_norm,
-                                  void* stream) {
+extern "C" int gad_policy_outputs(const float* pol13, int B, int pitch, const float* action_scale, float* pi,
+                                  float* aux_norm, void* stream) {
     GAD_REQUIRE(pol13 && action_scale && pi, GAD_ERR_NULL, "policy_outputs: null pointer");
+    GAD_REQUIRE(pitch >= 6 && (!aux_norm || pitch >= 13), GAD_ERR_SHAPE,
+                "policy_outputs: head pitch %d (6 mean columns, + 7 aux columns when aux_norm is requested)", pitch);
     if (B <= 0) return GAD_OK;
-    hipLaunchKernelGGL(policy_outputs_kernel, dim3(gad_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, pol13, B,
+    hipLaunchKernelGGL(policy_outputs_kernel, dim3(gad_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, pol13, B, pitch,
                        action_scale, pi, aux_norm);
     GAD_CHECK_LAUNCH("policy_outputs");
+    return GAD_OK;
+}
+
+// GaussianPolicy.forward + sample (reference core/networks.py:339-371) from the raw head outputs
+// head (B, pitch) = [mean (6) | extra (extra_dim) | log_std (6)]:
+//   log_std = clamp(log_std, -10, 2);  x = mean + exp(log_std) * eps;  y = squash ? tanh(x) : x;
+//   action = y * scale + bias;  mean_sq = squash ? tanh(mean) * scale + bias : mean;
+//   log_prob = sum_c [ -eps^2/2 - log_std - log(sqrt(2 pi)) - log(scale * (1 - y^2) + 1e-6) ]
+//   extra = extra_dim == 7 ? [normalize(extra[:4]), extra[4:]] : extra
+__global__ __launch_bounds__(256) void policy_sample_kernel(const float* __restrict__ head, int B, int pitch, int extra_dim,
+                                                            const float* __restrict__ eps,
+                                                            const float* __restrict__ ascale,
+                                                            const float* __restrict__ abias, int squash,
+                                                            float* __restrict__ mean_sq, float* __restrict__ log_std,
+                                                            float* __restrict__ log_prob, float* __restrict__ action,
+                                                            float* __restrict__ extra) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const float* o = head + (size_t)i * pitch;
+    const float* ls = o + 6 + extra_dim;
+    float lp = 0.f;
+    for (int c = 0; c < 6; ++c) {
+        const float l = fminf(fmaxf(ls[c], -10.f), 2.f);
+        const float e = eps ? eps[(size_t)i * 6 + c] : 0.f;
+        const float x = o[c] + expf(l) * e;
+        const float sc = ascale ? ascale[c] : 1.f, bi = abias ? abias[c] : 0.f;
+        const float y = squash ? tanhf(x) : x;
+        if (log_std) log_std[(size_t)i * 6 + c] = l;
+        if (action) action[(size_t)i * 6 + c] = squash ? y * sc + bi : x;
+        if (mean_sq) mean_sq[(size_t)i * 6 + c] = squash ? tanhf(o[c]) * sc + bi : o[c];
+        lp += -0.5f * e * e - l - 0.91893853320467274f - logf(sc * (1.f - y * y) + 1e-6f);
+    }
+    if (log_prob) log_prob[i] = lp;
+    if (extra) {
+        if (extra_dim == 7) {
+            float q[4];
+            unit_quat(o + 6, q);
+            for (int c = 0; c < 4; ++c) extra[(size_t)i * 7 + c] = q[c];
+            for (int c = 0; c < 3; ++c) extra[(size_t)i * 7 + 4 + c] = o[10 + c];
+        } else {
+            for (int c = 0; c < extra_dim; ++c) extra[(size_t)i * extra_dim + c] = o[6 + c];
+        }
+    }
+}
+
+extern "C" int gad_policy_sample(const float* head, int B, int pitch, int extra_dim, const float* eps,
+                                 const float* action_scale, const float* action_bias, int squash, float* mean_sq,
+                                 float* log_std, float* log_prob, float* action, float* extra, void* stream) {
+    GAD_REQUIRE(head, GAD_ERR_NULL, "policy_sample: null pointer");
+    GAD_REQUIRE(extra_dim >= 0 && pitch >= 12 + extra_dim, GAD_ERR_SHAPE,
+                "policy_sample: pitch %d < 6 + extra_dim (%d) + 6", pitch, extra_dim);
+    if (B <= 0) return GAD_OK;
+    hipLaunchKernelGGL(policy_sample_kernel, dim3(gad_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, head, B, pitch,
+                       extra_dim, eps, action_scale, action_bias, squash, mean_sq, log_std, log_prob, action, extra);
+    GAD_CHECK_LAUNCH("policy_sample");
     return GAD_OK;
 }
 
@@ -220,7 +277,7 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
                                                          const float* __restrict__ expert_action,
                                                          const float* __restrict__ expert_flag,
                                                          const float* __restrict__ ret, const float* __restrict__ goal,
-                                                         int B, float bc_scale, int policy_aux,
+                                                         int B, int pitch, float bc_scale, int policy_aux,
                                                          const float* __restrict__ ascale,
                                                          const double* __restrict__ g_pi_critic,
                                                          const float* __restrict__ inv_n, float* __restrict__ g13,
@@ -235,8 +292,8 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
     const float inv_g = inv_n ? inv_n[1] : 1.f / (ng * 6.f);
     float lb = 0.f, la = 0.f;
     for (int i = tid; i < B; i += 256) {
-        const float* o = pol13 + (size_t)i * 13;
-        float* g = g13 + (size_t)i * 13;
+        const float* o = pol13 + (size_t)i * pitch;
+        float* g = g13 + (size_t)i * pitch;
         const float* p = pi + (size_t)i * 6;
         float gpi[6];
         for (int c = 0; c < 6; ++c) gpi[c] = g_pi_critic ? (float)g_pi_critic[(size_t)i * 6 + c] : 0.f;
@@ -249,15 +306,15 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
             const float th = p[c] / ascale[c];
             g[c] = gpi[c] * ascale[c] * (1.f - th * th);
         }
-        float q[4], gq[4], gt[3], gx[4];
-        const float n = unit_quat(o + 6, q);
-        if (policy_aux && ret[i] > 0.f) {
+        if (policy_aux && ret[i] > 0.f) {                  // policy_aux implies pitch >= 13 (checked by the host entry)
+            float q[4], gq[4], gt[3], gx[4];
+            const float n = unit_quat(o + 6, q);
             la += goal_point_loss(q, o + 10, goal + (size_t)i * 7, goal + (size_t)i * 7 + 4, gq, gt);
             unit_quat_bwd(q, n, gq, gx);
             for (int c = 0; c < 4; ++c) g[6 + c] = gx[c] * inv_g;
             for (int c = 0; c < 3; ++c) g[10 + c] = gt[c] * inv_g;
         } else {
-            for (int c = 0; c < 7; ++c) g[6 + c] = 0.f;
+            for (int c = 6; c < pitch; ++c) g[c] = 0.f;
         }
     }
     lb = block_sum(lb, red);
@@ -271,14 +328,16 @@ __global__ __launch_bounds__(256) void actor_loss_kernel(const float* __restrict
 }
 
 extern "C" int gad_actor_loss(const float* pol13, const float* pi, const float* expert_action,
-                              const float* expert_flag, const float* ret, const float* goal, int B, float bc_scale,
-                              int policy_aux, const float* action_scale, const double* g_pi_critic, const float* inv_n,
-                              float* g_pol13, float* scalars, void* stream) {
+                              const float* expert_flag, const float* ret, const float* goal, int B, int pitch,
+                              float bc_scale, int policy_aux, const float* action_scale, const double* g_pi_critic,
+                              const float* inv_n, float* g_pol13, float* scalars, void* stream) {
     GAD_REQUIRE(pol13 && pi && expert_action && expert_flag && ret && goal && action_scale && g_pol13 && scalars,
                 GAD_ERR_NULL, "actor_loss: null pointer");
     GAD_REQUIRE(B >= 1, GAD_ERR_SHAPE, "actor_loss: B");
+    GAD_REQUIRE(pitch >= 6 && (!policy_aux || pitch >= 13), GAD_ERR_SHAPE,
+                "actor_loss: head pitch %d (6 mean columns, + 7 aux columns with policy_aux)", pitch);
     hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pol13, pi, expert_action,
-                       expert_flag, ret, goal, B, bc_scale, policy_aux, action_scale, g_pi_critic, inv_n, g_pol13,
+                       expert_flag, ret, goal, B, pitch, bc_scale, policy_aux, action_scale, g_pi_critic, inv_n, g_pol13,
                        scalars);
     GAD_CHECK_LAUNCH("actor_loss");
     return GAD_OK;
@@ -322,21 +381,23 @@ extern "C" int gad_actor_critic_loss(const float* out9, const float* expert_flag
 }
 
 __global__ __launch_bounds__(256) void target_noise_kernel(const float* __restrict__ pi, const float* __restrict__ u,
-                                                           int n, float level, float* __restrict__ out) {
+                                                           int n, float level, int normal, float* __restrict__ out) {
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
     const int c = q % 6;
-    float d = (u[q] * 3.f - 6.f) * level;                   // reference quirk: always negative
+    // uniform draw u in [0,1): (u*3-6)*level -- reference quirk: always negative;  normal draw u ~ N(0,1): u*level/2
+    float d = normal ? u[q] * level / 2.f : (u[q] * 3.f - 6.f) * level;
     if (c >= 3) d *= 5.f;
     else d = fminf(fmaxf(d, -0.01f), 0.01f);
     out[q] = pi[q] + d;
 }
 
-extern "C" int gad_target_noise(const float* pi, const float* u, int B, float level, float* out, void* stream) {
+extern "C" int gad_target_noise(const float* pi, const float* u, int B, float level, int normal, float* out,
+                                void* stream) {
     GAD_REQUIRE(pi && u && out, GAD_ERR_NULL, "target_noise: null pointer");
     if (B <= 0) return GAD_OK;
     hipLaunchKernelGGL(target_noise_kernel, dim3(gad_cdiv(B * 6, 256)), dim3(256), 0, (hipStream_t)stream, pi, u, B * 6,
-                       level, out);
+                       level, normal, out);
     GAD_CHECK_LAUNCH("target_noise");
     return GAD_OK;
 }

@@ -341,11 +341,13 @@ def coalesce_grads(flats):
 _DW_WS = {}
 
 
-def dw_workspace(device, elems=48 * 1024 * 1024, lane=0):
+def dw_workspace(device, elems=None, lane=0):
     """scratch for the weight-gradient split-K partial tiles: one per device and per stream lane (launches of a
     lane are stream-ordered; lane 0 = the main stream, 1.. = the dW side streams)"""
     key = (str(device), lane)
     if key not in _DW_WS:
+        if elems is None:                    # head lanes (>= 100): 16 splits of the widest head matrix (768 x 520) at most
+            elems = 48 * 1024 * 1024 if lane < 100 else 8 * 1024 * 1024
         _DW_WS[key] = torch.empty(elems, dtype=torch.float32, device=device)
     return _DW_WS[key]
 

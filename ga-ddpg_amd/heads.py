@@ -39,9 +39,12 @@ class PolicyNet(object):
         self.mean = MatSpec(m.mean.weight, m.mean.bias)
         self.extra = MatSpec(m.extra_pred.weight, m.extra_pred.bias)
         self.log_std = MatSpec(m.log_std_linear.weight, m.log_std_linear.bias)
-        # log_std_linear feeds nothing on the update path: never receives a gradient, never stepped
+        # log_std_linear feeds nothing on the update path: never receives a gradient, never stepped.  Without
+        # policy_aux (extra_pred_dim 1, reference core/agent.py:31-36) the extra head feeds no loss either: its .grad
+        # stays None in the reference and torch's Adam skips it (no weight decay) -- same here.
+        never = ("log_std_linear",) + (("extra_pred",) if self.extra.n_out != 7 else ())
         self.flat = FlatNet(list(module.named_parameters()), [self.l1, self.l2, self.mean, self.extra, self.log_std],
-                            device, never_trained=("log_std_linear",))
+                            device, never_trained=never)
         self.hidden = self.l1.n_out
         self.n_heads = self.mean.n_out + self.extra.n_out   # 6 + 7 = 13 (extra_pred_dim 7) or 6 + 1
         self.extra_dim = self.extra.n_out
@@ -63,11 +66,12 @@ class HeadSlot(object):
 
 
 def _feat_input(enc, eslot, time):
-    """heads' layer-1 input: [relu(bn(Zfc2)) (512), time, 1]"""
+    """heads' layer-1 input: [relu(bn(Zfc2)) (512), time, 1]; a plain feature tensor (runtime._FeatureSource:
+    `input_relu` 0, identity scale / shift) is taken as it is"""
     fc2 = enc.fc_mats[1]
     return dict(n_rows=eslot.B, mode=0, zin=_ptr(eslot.Zfc[1]), zin_pitch=fc2.n_out, c_in=fc2.n_out,
-                scale=_bn_vec(eslot, enc, fc2, "scale"), shift=_bn_vec(eslot, enc, fc2, "shift"), relu=1,
-                extra=_ptr(time), ones_col=fc2.n_out + 1)
+                scale=_bn_vec(eslot, enc, fc2, "scale"), shift=_bn_vec(eslot, enc, fc2, "shift"),
+                relu=getattr(enc, "input_relu", 1), extra=_ptr(time), ones_col=fc2.n_out + 1)
 
 
 def _hidden_input(B, z, pitch, hidden, offs):
@@ -93,9 +97,11 @@ def plan_critic_forward(cr, hs, enc, eslot, time):
     return plan
 
 
-def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True):
+def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True, dw_lane=1):
     """consumes hs.g_out (B,9); leaves dLoss/dfeature in hs.g_feat (B,512) and the BN-backward sums
-    of the encoder's last BatchNorm in eslot.bstats (which the caller must have zeroed)."""
+    of the encoder's last BatchNorm in eslot.bstats (which the caller must have zeroed).
+    dw_lane: the split-K workspace of the head's weight-gradient GEMMs (the lane of the encoder backward that
+    follows on the same stream: critic 1, actor 2 -- the two backward passes may run concurrently)."""
     plan = Plan()
     B, H, ng = hs.B, cr.hidden, cr.ng
     fl = cr.flat
@@ -112,7 +118,7 @@ def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True):
         for i, o in enumerate(dz_off):
             a.dz_off[i] = o
         a.gacc = _ptr(fl.gacc)
-        ws = dw_workspace(fl.device)
+        ws = dw_workspace(fl.device, lane=100 + dw_lane)     # never shared with a forked encoder dW (lanes 1, 2)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
         plan.call_struct("gad_gemm_dw", a)
 
@@ -168,7 +174,9 @@ class _Cat(object):
             assert b.w_off == a.w_off + a.n_out * a.Kp and a.Kp == b.Kp
 
 
-def plan_policy_forward(po, hs, enc, eslot, time):
+def plan_policy_forward(po, hs, enc, eslot, time, with_log_std=False):
+    """hs.out (B, 6 + extra) = [mean | extra]; with_log_std: (B, 6 + extra + 6) = [mean | extra | log_std] (the
+    three output matrices are consecutive in the packed layout: one GEMM either way)"""
     plan = Plan()
     B, H = hs.B, po.hidden
     fl = po.flat
@@ -176,14 +184,15 @@ def plan_policy_forward(po, hs, enc, eslot, time):
                                                **_feat_input(enc, eslot, time)))
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=fl.p_w(po.l2), Kp=po.l2.Kp, n_out=[H], zout=_ptr(hs.Z2), zout_pitch=H,
                                                **_hidden_input(B, hs.Z1, H, H, [0])))
-    cat = _Cat([po.mean, po.extra])
+    cat = _Cat([po.mean, po.extra] + ([po.log_std] if with_log_std else []))
+    assert hs.out.shape[1] >= cat.n_out
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=_ptr(fl.packed, cat.w_off), Kp=cat.Kp, n_out=[cat.n_out],
                                                zout=_ptr(hs.out), zout_pitch=hs.out.shape[1],
                                                **_hidden_input(B, hs.Z2, H, H, [0])))
     return plan
 
 
-def plan_policy_backward(po, hs, enc, eslot, time):
+def plan_policy_backward(po, hs, enc, eslot, time, dw_lane=2):
     """consumes hs.g_out (B,13); leaves dLoss/dfeature in hs.g_feat and fc[1]'s BN sums in eslot.bstats."""
     plan = Plan()
     B, H = hs.B, po.hidden
@@ -197,7 +206,7 @@ def plan_policy_backward(po, hs, enc, eslot, time):
         a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **inp)
         a.dz = dz
         a.gacc = _ptr(fl.gacc)
-        ws = dw_workspace(fl.device)
+        ws = dw_workspace(fl.device, lane=100 + dw_lane)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
         plan.call_struct("gad_gemm_dw", a)
 

@@ -64,7 +64,7 @@ class FusedRuntime(object):
             self.critic_sel = torch.from_numpy(sel).to(dev)
         self.hs_p = heads.HeadSlot(B, self.pol.hidden, self.pol.n_heads, dev)
         self.pi = torch.zeros(B, 6, **f32)
-        self.aux_pred = torch.zeros(B, 7, **f32)
+        self.aux_pred = torch.zeros(B, 7, **f32) if self.pol.n_heads == 13 else self.hs_p.out[:, 6:]
         self.action_scale = torch.as_tensor(np.asarray(agent.policy.action_scale, dtype=np.float32)).to(dev)
         # static batch buffers + pinned staging
         shapes = {"point_state_batch": (B, 4, NP), "next_point_state_batch": (B, 4, NP), "action_batch": (B, 6),
@@ -114,7 +114,7 @@ class FusedRuntime(object):
         c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
         t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
         t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
-        t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.action_scale, self.pi_t, None)
+        t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.pi_t, None)
         t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES)
         P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
@@ -204,11 +204,15 @@ class FusedRuntime(object):
         main = torch.cuda.current_stream()
         idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
+        normal_noise = getattr(ag, "noise_type", "uniform") != "uniform"     # core/utils.py:568-569
 
         def small_inits():
             # not needed by the geometry / first passes: enqueued after them so that the GPU starts the step earlier
             if noise_u is None:
-                self.noise_u.uniform_(0.0, 1.0)                     # torch.rand_like in the reference
+                if normal_noise:
+                    self.noise_u.normal_()                              # torch.randn_like (core/utils.py:573)
+                else:
+                    self.noise_u.uniform_(0.0, 1.0)                     # torch.rand_like (core/utils.py:575)
             else:
                 self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
             self.scal.zero_()
@@ -219,7 +223,8 @@ class FusedRuntime(object):
         # pass only computes batch statistics and its running-statistics momentum update is applied after the join.
         def actor_tail(g_pi):
             hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
-                     d["return_batch"], d["goal_batch"], B, 1.0 - ratio, int(bool(ag.policy_aux)), self.action_scale, g_pi,
+                     d["return_batch"], d["goal_batch"], B, self.pol.n_heads, 1.0 - ratio, int(bool(ag.policy_aux)),
+                     self.action_scale, g_pi,
                      self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
             P["p_bwd"].run()
             self._reduce([self.pol.flat, self.enc.flat])
@@ -271,14 +276,14 @@ class FusedRuntime(object):
             self._ev[2].record(main)
         # the rest of the target chain is enqueued BEFORE the actor pass: the host needs ~0.4 ms for the actor pass's
         # launches, and the main stream (the critical path) would sit idle behind them
-        hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), self.a_next)
+        hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), int(normal_noise), self.a_next)
         P["t2"].run()
         if OVERLAP_PASSES:
             s2.wait_event(self._ev[2])
             s2.wait_event(self._ev[4])
             with torch.cuda.stream(s2):
                 P["p_fwd"].run()
-                hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
+                self._policy_outputs()
                 if not policy_step:
                     actor_tail(None)
         if OVERLAP_PASSES:
@@ -300,7 +305,7 @@ class FusedRuntime(object):
             main.wait_event(self._ev[3])
         else:
             P["p_fwd"].run()
-            hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
+            self._policy_outputs()
         if policy_step:
             P["v_fwd"].run()
             hip.call("gad_actor_critic_loss", self.hs_cpi.out, d["expert_flag_batch"], d["return_batch"], B, ratio,
@@ -324,9 +329,9 @@ class FusedRuntime(object):
         self.scal.zero_()
         self.geo.run(d["point_state_batch"])
         P["p_fwd"].run()
-        hip.call("gad_policy_outputs", self.hs_p.out, B, self.action_scale, self.pi, self.aux_pred)
+        self._policy_outputs()
         hip.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
-                 d["return_batch"], d["goal_batch"], B, 1.0, int(bool(ag.policy_aux)), self.action_scale, None,
+                 d["return_batch"], d["goal_batch"], B, self.pol.n_heads, 1.0, int(bool(ag.policy_aux)), self.action_scale, None,
                  self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
         P["p_bwd"].run()
         self._reduce([self.pol.flat, self.enc.flat])
@@ -337,6 +342,12 @@ class FusedRuntime(object):
         self._stats()
         self.enc.bump_batches_tracked(1)
         return self._download()
+
+    def _policy_outputs(self):
+        """pi = tanh(mean) * scale and the aux pose (unit quaternion + translation) when the head has one"""
+        nh = self.pol.n_heads
+        hip.call("gad_policy_outputs", self.hs_p.out, self.B, nh, self.action_scale, self.pi,
+                 self.aux_pred if nh == 13 else None)
 
     # data-parallel hooks: device pointers to globally reduced 1/count pairs (None = local counts)
     def inv_n_critic(self):
@@ -457,7 +468,8 @@ def feature_forward(fe, pc, value=False):
 
 class _FeatureSource(object):
     """Stands in for an (encoder, slot) pair when a head is evaluated on a plain feature tensor: identity
-    'BatchNorm' (scale 1, shift 0) over a raw buffer that already holds the post-ReLU features."""
+    'BatchNorm' (scale 1, shift 0), no ReLU, over a raw buffer holding the features as given."""
+    input_relu = 0
 
     def __init__(self, B, dev):
         f32 = dict(dtype=torch.float32, device=dev)
@@ -474,12 +486,13 @@ class _FeatureSource(object):
         self.bn_off = [0]
 
     def load(self, state):
-        """state (B,513) = [feature (512, >= 0), remaining time]"""
+        """state (B,513) = [feature (512), remaining time]"""
         self.Zfc[1].copy_(state[:, :512])
         self.time.copy_(state[:, 512])
 
 
-def _head_runtime(module, kind, state):
+def _head_runtime(module, kind, state, full=False):
+    """full (policy only): the head plan also evaluates log_std_linear (GaussianPolicy.forward / sample)"""
     hip.require_cuda(state)
     B, dev = state.shape[0], state.device
     if state.shape[1] != 513:
@@ -493,10 +506,10 @@ def _head_runtime(module, kind, state):
             hs = heads.HeadSlot(B, net.width, 9, dev)
             plan = heads.plan_critic_forward(net, hs, src, src, src.time)
         else:
-            hs = heads.HeadSlot(B, net.hidden, net.n_heads, dev)
-            plan = heads.plan_policy_forward(net, hs, src, src, src.time)
+            hs = heads.HeadSlot(B, net.hidden, net.n_heads + (6 if full else 0), dev)
+            plan = heads.plan_policy_forward(net, hs, src, src, src.time, with_log_std=full)
         return dict(src=src, hs=hs, plan=plan)
-    rt = _module_runtime(module, ("B", B), build_b)
+    rt = _module_runtime(module, ("B", B, bool(full)), build_b)
     rt["src"].load(state)
     rt["plan"].run()
     return net, rt
@@ -526,8 +539,34 @@ def policy_forward(module, state):
     scale = torch.as_tensor(np.asarray(module.action_scale, dtype=np.float32)).to(dev)
     if net.extra_dim == 7:
         aux = torch.empty(B, 7, device=dev)
-        hip.call("gad_policy_outputs", out, B, scale, pi, aux)
+        hip.call("gad_policy_outputs", out, B, net.n_heads, scale, pi, aux)
     else:
-        hip.call("gad_policy_outputs", out, B, scale, pi, None)
+        hip.call("gad_policy_outputs", out, B, net.n_heads, scale, pi, None)
         aux = out[:, 6:6 + net.extra_dim].clone()
     return pi, aux
+
+
+def policy_sample(module, state, eps=None, draw=True):
+    """GaussianPolicy.forward + sample (reference core/networks.py:339-371) through the head GEMMs and gad_policy_sample.
+    eps (B,6): the N(0,1) draw of the reparameterised sample (default: torch.randn on the device, as Normal.rsample
+    draws it); draw=False evaluates at eps = 0.  -> dict(mean (raw), log_std (clamped), extra, mean_sq, log_prob (B,1),
+    action)."""
+    net, rt = _head_runtime(module, "policy", state, full=True)
+    out = rt["hs"].out
+    B, dev = out.shape[0], out.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    if eps is None and draw:
+        eps = torch.randn(B, 6, **f32)
+    elif eps is not None:
+        eps = torch.as_tensor(eps, dtype=torch.float32).to(dev).contiguous()
+    squash = module.action_space is not None
+    scale = torch.as_tensor(np.asarray(module.action_scale, dtype=np.float32)).to(dev).reshape(-1)
+    bias = torch.as_tensor(np.asarray(module.action_bias, dtype=np.float32)).to(dev).reshape(-1)
+    if scale.numel() == 1:
+        scale, bias = scale.expand(6).contiguous(), bias.expand(6).contiguous()
+    res = dict(mean_sq=torch.empty(B, 6, **f32), log_std=torch.empty(B, 6, **f32), log_prob=torch.empty(B, 1, **f32),
+               action=torch.empty(B, 6, **f32), extra=torch.empty(B, net.extra_dim, **f32))
+    hip.call("gad_policy_sample", out, B, out.shape[1], net.extra_dim, eps, scale, bias, int(squash), res["mean_sq"],
+             res["log_std"], res["log_prob"], res["action"], res["extra"])
+    res["mean"] = out[:, :6].clone()
+    return res

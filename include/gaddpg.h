@@ -36,7 +36,9 @@ typedef enum {
 } gad_status;
 
 int gad_abi_version(void);                 /* bumped on any signature change or new entry point (2: gad_set_option,
-                                            * gad_bn_running_update, gad_replay_gather)  */
+                                            * gad_bn_running_update, gad_replay_gather; 3: head pitch in gad_policy_outputs /
+                                            * gad_actor_loss, noise type in gad_target_noise, gad_policy_sample, the
+                                            * fused BatchNorm finalisation fields, gad_segment_pool via wave shuffles) */
 const char* gad_last_error(void);          /* thread-local description of the last <0   */
 /* Kernel-selection switches for A/B diagnostics (defaults in brackets).  "fwd_stream" [1]: route the wide and
  * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route
@@ -281,20 +283,31 @@ int gad_critic_loss(const float* out9, const float* tgt_out9, const float* rewar
  * scaled by bc_scale, goal aux over return>0 rows, and (optional) the gradient of
  * -ratio*mean(min(q1_pi,q2_pi)) wrt pi arriving as g_pi_critic (B,6) (already scaled).
  *   g_pol13 receives dLoss/d(pol13); scalars[0]=bc_loss (scaled), [1]=policy_grasp_aux_loss.     */
-int gad_policy_outputs(const float* pol13, int B, const float* action_scale, float* pi,
-                       float* aux_norm, void* stream);
+/* `pitch` = floats per row of the head output / gradient buffers: 6 + extra_pred_dim (13 with policy_aux, 7
+ * without: reference core/agent.py:31-36); aux_norm / policy_aux need pitch >= 13.                */
+int gad_policy_outputs(const float* pol13, int B, int pitch, const float* action_scale, float* pi,
+                       float* aux_norm /*nullable*/, void* stream);
 int gad_actor_loss(const float* pol13, const float* pi, const float* expert_action,
-                   const float* expert_flag, const float* ret, const float* goal, int B,
+                   const float* expert_flag, const float* ret, const float* goal, int B, int pitch,
                    float bc_scale, int policy_aux, const float* action_scale,
                    const double* g_pi_critic /*nullable*/, const float* inv_n, float* g_pol13,
                    float* scalars, void* stream);
+/* GaussianPolicy.forward + sample (core/networks.py:339-371) on the raw head outputs head (B,pitch) =
+ * [mean 6 | extra extra_dim | log_std 6]: log_std (B,6) clamped to [-10,2]; x = mean + exp(log_std)*eps with the
+ * caller's N(0,1) draw eps (B,6) (NULL -> 0); squash != 0: action = tanh(x)*scale+bias, mean_sq = tanh(mean)*scale+bias;
+ * log_prob (B) = sum_c N(x; mean, std).log_prob - log(scale*(1-tanh(x)^2)+1e-6); extra (B,extra_dim) with the
+ * quaternion part normalised when extra_dim == 7.  Every output is nullable.                      */
+int gad_policy_sample(const float* head, int B, int pitch, int extra_dim, const float* eps /*nullable*/,
+                      const float* action_scale /*nullable: 1*/, const float* action_bias /*nullable: 0*/, int squash,
+                      float* mean_sq, float* log_std, float* log_prob, float* action, float* extra, void* stream);
 /* -ratio * mean over rows NOT (expert & return>0) of min(q1,q2): value + dLoss/d(out9[:, :2])    */
 int gad_actor_critic_loss(const float* out9, const float* expert_flag, const float* ret, int B,
                           float ratio, const float* inv_n, float* g_out9, float* scalars,
                           void* stream);
 /* TD3 target-policy smoothing (core/utils.py:568-576 + core/ddpg.py:80-82, quirk preserved):
- * a = pi + clamp3(((u*3-6)*level) * [1,1,1,5,5,5])                                               */
-int gad_target_noise(const float* pi, const float* u, int B, float level, float* out,
+ * normal == 0 (noise_type "uniform"): u ~ U[0,1): a = pi + clamp3(((u*3-6)*level) * [1,1,1,5,5,5])
+ * normal != 0 (any other noise_type):  u ~ N(0,1): a = pi + clamp3((u*level/2) * [1,1,1,5,5,5])    */
+int gad_target_noise(const float* pi, const float* u, int B, float level, int normal, float* out,
                      void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -321,10 +321,23 @@ def gen_heads():
     q1, q2, aux = q(x, None)
     out.update(q1=_np(q1), q2=_np(q2), aux=_np(aux))
     p = fill_module_(rn.GaussianPolicy(513, 6, 256, PandaTaskSpace6D(), extra_pred_dim=7), "policy", SEED)
-    torch.manual_seed(0)
+    # Normal.rsample draws eps through torch.distributions.normal._standard_normal: inject a recorded draw so that the
+    # reparameterised action and its log-prob (networks.py:355-368) become fixtures too
+    import torch.distributions.normal as tdn
+    eps = torch.tensor(rng.normal(size=(B, 6)), dtype=torch.float32)
+    orig = tdn._standard_normal
+    tdn._standard_normal = lambda shape, dtype, device: eps.clone().to(dtype)
     mean, logp, act, extra = p.sample(x)
+    tdn._standard_normal = orig
     m0, logstd, _ = p.forward(x)
-    out.update(pi_mean=_np(mean), pi_extra=_np(extra), pi_raw_mean=_np(m0), pi_log_std=_np(logstd))
+    out.update(pi_mean=_np(mean), pi_extra=_np(extra), pi_raw_mean=_np(m0), pi_log_std=_np(logstd), pi_eps=_np(eps),
+               pi_log_prob=_np(logp), pi_action=_np(act))
+    # the head without policy_aux (extra_pred_dim = 1, core/agent.py:31-36): raw extra column, no quaternion
+    p1 = fill_module_(rn.GaussianPolicy(513, 6, 256, PandaTaskSpace6D(), extra_pred_dim=1), "policy", SEED)
+    tdn._standard_normal = lambda shape, dtype, device: eps.clone().to(dtype)
+    mean1, logp1, act1, extra1 = p1.sample(x)
+    tdn._standard_normal = orig
+    out.update(p1_mean=_np(mean1), p1_extra=_np(extra1), p1_log_prob=_np(logp1), p1_action=_np(act1))
     np.savez_compressed(os.path.join(OUT, "heads.npz"), **out)
 
 
@@ -429,17 +442,17 @@ def gen_replay_io():
 
 
 def main():
+    """python -m oracle.make_golden [name ...]: regenerate all fixtures, or only the named generators
+    (config losses heads replay replay_io encoder bc ddpg ...)"""
     os.makedirs(OUT, exist_ok=True)
     install_shims()
     torch.set_num_threads(8)
-    gen_config()
-    gen_losses()
-    gen_heads()
-    gen_replay()
-    gen_replay_io()
-    gen_encoder()
-    print("bc ->", gen_bc())
-    print("ddpg ->", gen_ddpg())
+    gens = [("config", gen_config), ("losses", gen_losses), ("heads", gen_heads), ("replay", gen_replay),
+            ("replay_io", gen_replay_io), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg)]
+    only = sys.argv[1:]
+    for name, fn in gens:
+        if not only or name in only:
+            print(name, "->", fn())
     for f in sorted(os.listdir(OUT)):
         print("%-28s %8.1f KB" % (f, os.path.getsize(os.path.join(OUT, f)) / 1024))
 

@@ -128,6 +128,23 @@ class PolicyNet(nn.Module):
         pi = torch.tanh(self.mean(h)) * self.action_scale          # action_bias = 0 (symmetric bounds)
         return pi, aux
 
+    def sample(self, s, eps):
+        """core/networks.py:339-371 (forward + sample) with the N(0,1) draw of Normal.rsample injected as `eps`:
+        -> (squashed mean, log_prob (B,1), action, extra_pred, raw mean, clamped log_std)"""
+        h = F.relu(self.linear2(F.relu(self.linear1(s))))
+        mean = self.mean(h)
+        extra = self.extra_pred(h)
+        if self.extra_pred_dim == 7:
+            extra = _unit_quat_head(extra)
+        log_std = torch.clamp(self.log_std_linear(h), min=-10, max=2)          # LOG_SIG_MIN / LOG_SIG_MAX (:20-21)
+        std = log_std.exp()
+        x_t = mean + std * eps
+        y_t = torch.tanh(x_t)
+        action = y_t * self.action_scale
+        log_prob = -((x_t - mean) ** 2) / (2 * std ** 2) - log_std - np.log(np.sqrt(2 * np.pi))
+        log_prob = log_prob - torch.log(self.action_scale * (1 - y_t.pow(2)) + 1e-6)
+        return (torch.tanh(mean) * self.action_scale, log_prob.sum(1, keepdim=True), action, extra, mean, log_std)
+
 
 # ----------------------------------------------------------------------------- losses / pose math
 _CP = np.array([[0, 0, 0], [0, 0, 0], [0.053, -0., 0.075], [-0.053, 0., 0.075],

@@ -220,10 +220,10 @@ def test_heads_forward_backward_vs_oracle():
     (bc + pa + (pi_o * gpc).sum()).backward()
     ascale = torch.tensor(np.asarray(pol.action_scale), dtype=torch.float32, device="cuda")
     pi = torch.empty(B, 6, device="cuda"); auxn = torch.empty(B, 7, device="cuda"); sp = torch.zeros(4, device="cuda")
-    hip.call("gad_policy_outputs", hs_p.out, B, ascale, pi, auxn)
+    hip.call("gad_policy_outputs", hs_p.out, B, 13, ascale, pi, auxn)
     assert_close(pi.cpu().numpy(), pi_o.detach().numpy(), 1e-4, 1e-6, "pi")
     assert_close(auxn.cpu().numpy(), aux_o.detach().numpy(), 1e-4, 1e-5, "policy aux")
-    hip.call("gad_actor_loss", hs_p.out, pi, dv(expert_act), dv(expert_flag), dv(ret), dv(goal), B, 0.9, 1, ascale,
+    hip.call("gad_actor_loss", hs_p.out, pi, dv(expert_act), dv(expert_flag), dv(ret), dv(goal), B, 13, 0.9, 1, ascale,
              dv(gpc.double()), None, hs_p.g_out, sp)
     s = sp.cpu().numpy()
     assert_close(s[0], bc.item(), 1e-4, 1e-6, "bc loss")
@@ -259,11 +259,18 @@ def test_target_noise_and_optimizer_kernels():
     pi = torch.tensor(rng.normal(size=(B, 6)) * 0.03, dtype=torch.float32)
     u = torch.tensor(rng.random((B, 6)), dtype=torch.float32)
     out = torch.empty(B, 6, device="cuda")
-    hip.call("gad_target_noise", pi.cuda(), u.cuda(), B, 0.03, out)
+    hip.call("gad_target_noise", pi.cuda(), u.cuda(), B, 0.03, 0, out)
     from oracle import ref_step
     d = ref_step.target_noise(u.clone(), 0.03)
     d[:, :3] = torch.clamp(d[:, :3], -0.01, 0.01)
     assert_close(out.cpu().numpy(), (pi + d).numpy(), 1e-6, 1e-8, "target noise")
+    # noise_type != "uniform": randn * level / 2 (reference core/utils.py:572-573), rotation part x5, translation clamped
+    z = torch.tensor(rng.normal(size=(B, 6)), dtype=torch.float32)
+    hip.call("gad_target_noise", pi.cuda(), z.cuda(), B, 0.03, 1, out)
+    d = z * 0.03 / 2.0
+    d[:, 3:] *= 5
+    d[:, :3] = torch.clamp(d[:, :3], -0.01, 0.01)
+    assert_close(out.cpu().numpy(), (pi + d).numpy(), 1e-6, 1e-8, "target noise (normal)")
 
     # Adam (+ weight decay, + clip) against torch.optim.Adam over a few steps
     n = 5000

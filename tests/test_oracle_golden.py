@@ -56,6 +56,17 @@ def test_heads(golden_dir):
     pi, extra = p(x)
     assert_close(pi.detach().numpy(), g["pi_mean"], RT, 1e-7, "pi")
     assert_close(extra.detach().numpy(), g["pi_extra"], RT, 1e-6, "pi extra")
+    # GaussianPolicy.forward / sample with the injected rsample draw (reference core/networks.py:339-371)
+    for tag, dim in (("pi", 7), ("p1", 1)):
+        p = fill_module_(ref_step.PolicyNet(513, 6, 256, dim), "policy", SEED)
+        msq, logp, act, extra, mean, log_std = [t.detach().numpy() for t in p.sample(x, torch.tensor(g["pi_eps"]))]
+        assert_close(msq, g[tag + "_mean"], RT, 1e-7, tag + " squashed mean")
+        assert_close(logp, g[tag + "_log_prob"], 1e-5, 1e-5, tag + " log_prob")
+        assert_close(act, g[tag + "_action"], RT, 1e-7, tag + " action")
+        assert_close(extra, g[tag + "_extra"], RT, 1e-6, tag + " extra")
+        if tag == "pi":
+            assert_close(mean, g["pi_raw_mean"], RT, 1e-6, "raw mean")
+            assert_close(log_std, g["pi_log_std"], RT, 1e-6, "log_std")
 
 
 def test_encoder_forward_backward(golden_dir):
