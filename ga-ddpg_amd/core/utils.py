@@ -43,6 +43,8 @@ def make_nets_opts_schedulers(model_spec, config, cuda_device="cuda"):
             if config.sa_channel_concat:
                 net_args["action_concat"] = True
         net = DataParallel(getattr(networks, spec["class"])(**net_args))
+        if cuda_device is not None and torch.cuda.is_available():       # reference :202-204 (before the optimisers exist)
+            net = net.to(cuda_device)
         d = {"net": net}
         if "opt" in spec:
             d["opt"] = getattr(optim, spec["opt"])(net.parameters(), **spec["opt_kwargs"])
@@ -69,12 +71,12 @@ def get_policy_class(policy_net_name, args):
     from . import networks
     cls = getattr(networks, policy_net_name)
     policy = cls(args.num_inputs, args.action_dim, args.hidden_size, args.action_space,
-                 extra_pred_dim=args.extra_pred_dim)
+                 extra_pred_dim=args.extra_pred_dim).to("cuda")          # reference :961-968: on the device from the start
     policy_optim = Adam(policy.parameters(), lr=args.lr, eps=1e-5, weight_decay=1e-5)
     policy_scheduler = torch.optim.lr_scheduler.MultiStepLR(policy_optim, milestones=list(args.policy_milestones),
                                                             gamma=args.lr_gamma)
     policy_target = cls(args.num_inputs, args.action_dim, args.hidden_size, args.action_space,
-                        extra_pred_dim=args.extra_pred_dim)
+                        extra_pred_dim=args.extra_pred_dim).to("cuda")
     return policy, policy_optim, policy_scheduler, policy_target
 
 
@@ -82,12 +84,12 @@ def get_critic(args):
     from . import networks
     model = networks.QNetwork
     critic = model(args.critic_num_input, args.critic_value_dim, args.hidden_size,
-                   extra_pred_dim=args.critic_extra_pred_dim)
+                   extra_pred_dim=args.critic_extra_pred_dim).to("cuda")
     critic_optim = Adam(critic.parameters(), lr=args.value_lr, eps=1e-5, weight_decay=1e-5)
     critic_scheduler = torch.optim.lr_scheduler.MultiStepLR(critic_optim, milestones=list(args.value_milestones),
                                                             gamma=args.value_lr_gamma)
     critic_target = model(args.critic_num_input, args.critic_value_dim, args.hidden_size,
-                          extra_pred_dim=args.critic_extra_pred_dim)
+                          extra_pred_dim=args.critic_extra_pred_dim).to("cuda")
     return critic, critic_optim, critic_scheduler, critic_target
 
 
@@ -107,6 +109,7 @@ def _polyak(target, source, tau, select):
     for (tn, tp), (_, sp) in zip(target.named_parameters(), source.named_parameters()):
         k = select(tn)
         if k:
+            hip.require_cuda(tp.data, sp.data)
             hip.call("gad_polyak", tp.data, sp.data, None, None, None, tp.numel(), float(tau) if k == 1 else 1.0, 0)
     from ..runtime import sync_module
     sync_module(target)

@@ -30,13 +30,19 @@ class MatSpec(object):
 
     def __init__(self, weight, bias=None, bn=None, gather_feat_c=None):
         """gather_feat_c: for an SA stage's first conv (input [xyz(3), feat, action]) the number of
-        feature channels; its packed columns are permuted to [feat, xyz, action] (16-B aligned gather)."""
+        feature channels; its packed columns are permuted to [feat, xyz, action] (16-B aligned gather).
+        It may exceed the real feature count (stand-alone modules pad the point features to a multiple of 4
+        with zero columns): the padding columns of the packed weight stay zero."""
         self.weight, self.bias, self.bn = weight, bias, bn
         self.gather_feat_c = gather_feat_c
         self.n_out = weight.shape[0]
         self.k_in = int(np.prod(weight.shape[1:]))
         self.ones_col = self.k_in if bias is not None else -1
-        self.Kp = round8(self.k_in + (1 if bias is not None else 0))
+        width = self.k_in
+        if gather_feat_c is not None and gather_feat_c + 3 > width:
+            width = gather_feat_c + 3                       # padded feature block: real inputs are [xyz, feat (< gather_feat_c)]
+        self.k_packed = width
+        self.Kp = round8(width + (1 if bias is not None else 0))
         self.w_off = self.g_off = self.b_off = -1          # packed offsets (filled by FlatNet)
         self.bn_index = -1                                 # index into the per-pass BN vectors
 
@@ -66,6 +72,7 @@ class FlatNet(object):
             if m.gather_feat_c is not None:
                 fc = m.gather_feat_c
                 cols = np.where(cols < 3, cols + fc, np.where(cols < 3 + fc, cols - 3, cols))
+                assert m.bias is None or m.k_packed == m.k_in
             cols = cols[None, :]
             mo = off_of[id(m.weight)]
             m2p[mo:mo + m.n_out * m.k_in] = (pk + rows * m.Kp + cols).reshape(-1)

@@ -20,6 +20,14 @@ BATCH_KEYS = ("point_state_batch", "next_point_state_batch", "action_batch", "ex
 OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on side streams
 
 
+def _dev_f32(x, dev):
+    """float32 device copy of a small host / device vector (module attributes such as action_scale live wherever
+    GaussianPolicy.to() last put them)"""
+    if torch.is_tensor(x):
+        return x.detach().to(device=dev, dtype=torch.float32).contiguous()
+    return torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
+
+
 class FusedRuntime(object):
     def __init__(self, agent, B, NP, device=None):
         dev = self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
@@ -65,7 +73,7 @@ class FusedRuntime(object):
         self.hs_p = heads.HeadSlot(B, self.pol.hidden, self.pol.n_heads, dev)
         self.pi = torch.zeros(B, 6, **f32)
         self.aux_pred = torch.zeros(B, 7, **f32) if self.pol.n_heads == 13 else self.hs_p.out[:, 6:]
-        self.action_scale = torch.as_tensor(np.asarray(agent.policy.action_scale, dtype=np.float32)).to(dev)
+        self.action_scale = _dev_f32(agent.policy.action_scale, dev)
         # static batch buffers + pinned staging
         shapes = {"point_state_batch": (B, 4, NP), "next_point_state_batch": (B, 4, NP), "action_batch": (B, 6),
                   "expert_action_batch": (B, 6), "goal_batch": (B, 7)}
@@ -536,7 +544,7 @@ def policy_forward(module, state):
     out = rt["hs"].out
     B, dev = out.shape[0], out.device
     pi = torch.empty(B, 6, device=dev)
-    scale = torch.as_tensor(np.asarray(module.action_scale, dtype=np.float32)).to(dev)
+    scale = _dev_f32(module.action_scale, dev)
     if net.extra_dim == 7:
         aux = torch.empty(B, 7, device=dev)
         hip.call("gad_policy_outputs", out, B, net.n_heads, scale, pi, aux)
@@ -560,8 +568,8 @@ def policy_sample(module, state, eps=None, draw=True):
     elif eps is not None:
         eps = torch.as_tensor(eps, dtype=torch.float32).to(dev).contiguous()
     squash = module.action_space is not None
-    scale = torch.as_tensor(np.asarray(module.action_scale, dtype=np.float32)).to(dev).reshape(-1)
-    bias = torch.as_tensor(np.asarray(module.action_bias, dtype=np.float32)).to(dev).reshape(-1)
+    scale = _dev_f32(module.action_scale, dev).reshape(-1)
+    bias = _dev_f32(module.action_bias, dev).reshape(-1)
     if scale.numel() == 1:
         scale, bias = scale.expand(6).contiguous(), bias.expand(6).contiguous()
     res = dict(mean_sq=torch.empty(B, 6, **f32), log_std=torch.empty(B, 6, **f32), log_prob=torch.empty(B, 1, **f32),

@@ -2,16 +2,20 @@
 (pointnet2_ops.pointnet2_modules.PointnetSAModule.forward): FPS -> ball query -> de-duplicated rows
 -> gather + 3 x (1x1 conv, BatchNorm, ReLU) as FP32-MFMA GEMMs -> segment max-pool.
 
-Forward only (train- or eval-mode BatchNorm, running statistics updated in train mode).  Training goes
-through the fused update step (core.agent / runtime), which owns the backward plans; calling this with
-tensors that require grad raises instead of silently detaching.
+Differentiable: the forward is wrapped in a torch.autograd.Function whose backward drives the same
+dX / dW kernels as the fused update step (BatchNorm-backward with weighted statistics, max-pool routing
+through the saved arg-max, scatter-add into the point features), so a network written against upstream's
+`pointnet2_ops` -- the reference's own core/networks.py:66-81,217-220 -- trains through this package
+with ordinary torch optimizers.  Gradients: wrt `features` and every parameter of the module; `xyz`
+is geometry (FPS / ball-query indices are not differentiable upstream either; the recentred xyz channels'
+gradient wrt the coordinates is not produced -- GA-DDPG never asks for it: xyz is detached).
 Upstream semantics mirrored: _PointnetSAModuleBase.forward: returns
 (new_xyz (B,npoint,3) | None, new_features (B, mlp[-1], npoint | 1)).
 """
 import torch
 
 from . import engine, hip
-from .engine import BN_EPS, BN_MOMENTUM, FlatNet, MatSpec, Plan, _fwd_args, _ptr
+from .engine import BN_EPS, BN_MOMENTUM, FlatNet, MatSpec, Plan, _dz, _fwd_args, _ptr
 
 
 class _StageNet(object):
@@ -20,11 +24,11 @@ class _StageNet(object):
     def __init__(self, mod, device):
         seq = mod.mlps[0]
         c_feat = seq[0].weight.shape[1] - 3
-        if c_feat % 4 != 0 or c_feat < 4:
-            raise NotImplementedError("stand-alone PointnetSAModule.forward needs a feature count that is a "
-                                      "positive multiple of 4 (got %d)" % c_feat)
-        self.c_feat = c_feat
-        self.mats = [MatSpec(seq[0].weight, None, seq[1], gather_feat_c=c_feat), MatSpec(seq[3].weight, None, seq[4]),
+        if c_feat < 1:
+            raise NotImplementedError("PointnetSAModule without input features is not used by GA-DDPG")
+        self.c_feat = c_feat                                  # channels of the `features` argument
+        self.c_pad = (c_feat + 3) // 4 * 4                    # point-major feature rows are padded to 16 bytes
+        self.mats = [MatSpec(seq[0].weight, None, seq[1], gather_feat_c=self.c_pad), MatSpec(seq[3].weight, None, seq[4]),
                      MatSpec(seq[6].weight, None, seq[7])]
         for i, m in enumerate(self.mats):
             m.bn_index = i
@@ -45,10 +49,13 @@ class _StageNet(object):
             m.bn.num_batches_tracked = self.batches_tracked[i]
             o += m.n_out
         self.bn_total = tot
+        self.free = {}                                        # (B, N) -> activation sets returned by finished backwards
 
 
 class _StageRun(object):
-    def __init__(self, net, mod, B, N, device):
+    """static buffers + launch plans of one forward (and its backward) at a fixed (B, N)"""
+
+    def __init__(self, net, mod, B, N, device, with_backward=False):
         f32 = dict(dtype=torch.float32, device=device)
         i32 = dict(dtype=torch.int32, device=device)
         self.B, self.N = B, N
@@ -59,7 +66,7 @@ class _StageRun(object):
         G = B * M
         cap = G * S
         self.xyz = torch.empty(B, N, 3, **f32)
-        self.feat = torch.empty(B * N, net.c_feat, **f32)
+        self.feat = torch.zeros(B * N, net.c_pad, **f32)      # padding columns stay zero
         self.new_xyz = torch.empty(B, M, 3, **f32)
         self.fps = torch.empty(B, M, **i32)
         self.idx = torch.empty(B, M, S, **i32) if not self.group_all else None
@@ -82,6 +89,29 @@ class _StageRun(object):
         self.istd = torch.empty(tot, **f32)
         self.count = float(G * S)
         self.plans = {t: self._plan(net, mod, t) for t in (True, False)}
+        self.bwd = None
+        if with_backward:
+            self.bstats = torch.zeros(hip.STAT_REPLICAS * 2 * tot, dtype=torch.float64, device=device)
+            self.coef = torch.empty(3 * tot, **f32)
+            self.G = [torch.empty(cap * net.mats[l].n_out, **f32) for l in (1, 0)]
+            self.dF = torch.zeros(G, c_out, **f32)
+            self.dfeat = torch.zeros(B * N, net.c_pad, **f32)
+            self.grad = torch.zeros(net.flat.n, **f32)        # this call's parameter gradients (master layout)
+            self.bwd = self._plan_backward(net)
+
+    def _input(self, net, mod, l):
+        """gad_gemm_fwd_args fields describing the input of layer l"""
+        r = self.rows
+        kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], row_w=_ptr(r["w"]))
+        if l == 0:
+            kw.update(mode=1, c_in=net.c_pad + 3, src_xyz=_ptr(self.xyz),
+                      ctr_xyz=None if self.group_all else _ptr(self.new_xyz), feat=_ptr(self.feat), feat_c=net.c_pad,
+                      action=None, act_c=0, grp_per_sample=self.M, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]))
+        else:
+            pm, po = net.mats[l - 1], net.bn_off[l - 1]
+            kw.update(mode=0, zin=_ptr(self.Z[l - 1]), zin_pitch=pm.n_out, c_in=pm.n_out, scale=_ptr(self.scale, po),
+                      shift=_ptr(self.shift, po), relu=1)
+        return kw
 
     def _plan(self, net, mod, train):
         plan = Plan()
@@ -94,19 +124,10 @@ class _StageRun(object):
         plan.zero(self.stats)
         for l, m in enumerate(net.mats):
             o = net.bn_off[l]
-            rows_kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], row_w=_ptr(r["w"]))
-            if l == 0:
-                inp = dict(mode=1, c_in=m.k_in, src_xyz=_ptr(self.xyz), ctr_xyz=None if self.group_all else _ptr(self.new_xyz),
-                           feat=_ptr(self.feat), feat_c=net.c_feat, action=None, act_c=0, grp_per_sample=M,
-                           row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]))
-            else:
-                pm = net.mats[l - 1]
-                po = net.bn_off[l - 1]
-                inp = dict(mode=0, zin=_ptr(self.Z[l - 1]), zin_pitch=pm.n_out, c_in=pm.n_out, scale=_ptr(self.scale, po),
-                           shift=_ptr(self.shift, po), relu=1)
             a = _fwd_args(W=net.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(self.Z[l]), zout_pitch=m.n_out,
                           stat_sum=_ptr(self.stats, o, 8) if train else None,
-                          stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot, **rows_kw, **inp)
+                          stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot,
+                          **self._input(net, mod, l))
             plan.call_struct("gad_gemm_fwd", a)
             if train:
                 plan.call("gad_bn_finalize", _ptr(self.stats, o, 8), _ptr(self.stats, tot + o, 8), 2 * tot,
@@ -122,32 +143,166 @@ class _StageRun(object):
                   r["G"], self.F, self.argmax)
         return plan
 
+    def _plan_backward(self, net):
+        """consumes self.dF (G, c_out) = dLoss/d(pooled output); leaves dLoss/dfeatures in self.dfeat (point-major,
+        padded) and this call's parameter gradients in self.grad.  Train-mode BatchNorm only (batch statistics)."""
+        plan = Plan()
+        r, tot = self.rows, self.tot
+        fl = net.flat
+        plan.zero_multi([fl.gacc, self.bstats, self.dfeat])
+        m1, m2, m3 = net.mats
+        o1, o2, o3 = net.bn_off
 
-def sa_module_forward(mod, xyz, features):
-    hip.require_cuda(xyz, features)
-    if features is None:
-        raise NotImplementedError("PointnetSAModule without input features is not used by GA-DDPG")
-    if torch.is_grad_enabled() and features.requires_grad:
-        raise RuntimeError("stand-alone PointnetSAModule.forward is inference-only; train through "
-                           "Agent.update_parameters (fused forward+backward)")
-    B, N, _ = xyz.shape
-    dev = xyz.device
+        def vec(which, o):
+            return _ptr(getattr(self, which), o)
+
+        def coef_ptrs(o):
+            return _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o)
+
+        def bn_coef(m, o):
+            P, Q, S = coef_ptrs(o)
+            plan.call("gad_bn_bwd_coef", _ptr(self.bstats, o, 8), _ptr(self.bstats, tot + o, 8), 2 * tot, vec("scale", o),
+                      vec("mean", o), vec("istd", o), m.n_out, hip.Dbl(self.count), P, Q, S, _ptr(fl.gacc, m.g_off, 8),
+                      _ptr(fl.gacc, m.b_off, 8))
+
+        def bn_dz(m, o, z, G=None, pooled=False):
+            P, Q, S = coef_ptrs(o)
+            d = dict(z=_ptr(z), z_pitch=m.n_out, scale=vec("scale", o), shift=vec("shift", o), relu=1, coefP=P, coefQ=Q,
+                     coefS=S, row_w=_ptr(r["w"]), c=m.n_out)
+            if pooled:
+                d.update(gmode=1, argmax=_ptr(self.argmax), dout=_ptr(self.dF), row_grp=_ptr(r["grp"]))
+            else:
+                d.update(gmode=0, G=_ptr(G), g_pitch=m.n_out)
+            return _dz(**d)
+
+        def dw(l, dz, m):
+            a = hip.GemmDwArgs()
+            a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **self._input(net, None, l))
+            a.dz = dz
+            a.gacc = _ptr(fl.gacc)
+            ws = engine.dw_workspace(fl.device, lane=0)
+            a.partial, a.partial_elems = _ptr(ws), ws.numel()
+            plan.call_struct("gad_gemm_dw", a)
+
+        def dx(dz, m, k_valid, **epi):
+            a = hip.GemmDxArgs()
+            a.n_rows_dev, a.n_rows = _ptr(r["n"]), r["cap"]
+            a.dz = dz
+            a.n_groups = 1
+            a.n_out[0] = m.n_out
+            a.W = fl.p_w(m)
+            a.Kp = m.Kp
+            a.k_valid = k_valid
+            a.grp_per_sample = 1
+            for k, v in epi.items():
+                setattr(a, k, v)
+            plan.call_struct("gad_gemm_dx", a)
+
+        def prev_stats(pm, po, zprev):
+            return dict(zprev=_ptr(zprev), zprev_pitch=pm.n_out, prev_scale=vec("scale", po), prev_shift=vec("shift", po),
+                        prev_mean=vec("mean", po), prev_istd=vec("istd", po), prev_dbeta=_ptr(self.bstats, po, 8),
+                        prev_dgamma=_ptr(self.bstats, tot + po, 8), stat_stride=2 * tot)
+
+        plan.call("gad_pool_bwd_stats", self.dF, self.argmax, r["G"], m3.n_out, self.Z[2], m3.n_out, vec("scale", o3),
+                  vec("shift", o3), vec("mean", o3), vec("istd", o3), _ptr(self.bstats, o3, 8),
+                  _ptr(self.bstats, tot + o3, 8), 2 * tot)
+        bn_coef(m3, o3)
+        d = bn_dz(m3, o3, self.Z[2], pooled=True)
+        dw(2, d, m3)
+        dx(d, m3, m2.n_out, epilogue=0, gout=_ptr(self.G[0]), gout_pitch=m2.n_out, **prev_stats(m2, o2, self.Z[1]))
+        bn_coef(m2, o2)
+        d = bn_dz(m2, o2, self.Z[1], G=self.G[0])
+        dw(1, d, m2)
+        dx(d, m2, m1.n_out, epilogue=0, gout=_ptr(self.G[1]), gout_pitch=m1.n_out, **prev_stats(m1, o1, self.Z[0]))
+        bn_coef(m1, o1)
+        d = bn_dz(m1, o1, self.Z[0], G=self.G[1])
+        dw(0, d, m1)
+        dx(d, m1, net.c_pad, epilogue=1, dfeat=_ptr(self.dfeat), feat_c=net.c_pad, row_pt=_ptr(r["pt"]),
+           row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
+        plan.call("gad_grad_from_arena", fl.gacc, fl.m2p, fl.n, self.grad, 0)
+        return plan
+
+
+def _stage_net(mod, dev):
     rt = mod.__dict__.get("_gad_rt")
     if rt is None:
         rt = {"net": _StageNet(mod, dev)}
         object.__setattr__(mod, "_gad_rt", rt)
-    net = rt["net"]
-    if features.shape[1] != net.c_feat:
-        raise RuntimeError("features have %d channels, module expects %d" % (features.shape[1], net.c_feat))
-    key = (B, N)
-    if key not in rt:
-        rt[key] = _StageRun(net, mod, B, N, dev)
-    run = rt[key]
+    return rt
+
+
+def _run_forward(mod, net, run, xyz, features):
+    B, N = run.B, run.N
+    net.flat.sync_packed()            # the parameters may have been stepped by an ordinary torch optimizer
     run.xyz.copy_(xyz)
-    run.feat.view(B, N, net.c_feat).copy_(features.transpose(1, 2))      # (B,C,N) -> point-major
+    run.feat.view(B, N, net.c_pad)[:, :, :net.c_feat].copy_(features.transpose(1, 2))     # (B,C,N) -> point-major
     run.plans[bool(mod.training)].run()
     if mod.training:
         net.batches_tracked += 1
     c_out = net.mats[2].n_out
     out = run.F.view(B, run.M, c_out).transpose(1, 2).contiguous()
     return (None if run.group_all else run.new_xyz.clone()), out
+
+
+class _SAFunction(torch.autograd.Function):
+    """forward / backward of one set-abstraction module over its own activation set (held by the graph node until the
+    backward has run, then recycled): several forwards of the same module may be in flight, as in the reference's
+    update step (value encoder on the current and on the next state)."""
+
+    @staticmethod
+    def forward(ctx, mod, xyz, features, *params):
+        rt = _stage_net(mod, xyz.device)
+        net = rt["net"]
+        B, N, _ = xyz.shape
+        pool = net.free.setdefault((B, N), [])
+        run = pool.pop() if pool else _StageRun(net, mod, B, N, xyz.device, with_backward=True)
+        new_xyz, out = _run_forward(mod, net, run, xyz, features)
+        ctx.run, ctx.net, ctx.key = run, net, (B, N)
+        ctx.feat_grad = features.requires_grad
+        ctx.mark_non_differentiable(*([new_xyz] if new_xyz is not None else []))
+        return (new_xyz if new_xyz is not None else xyz.new_zeros(0)), out
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_out):
+        run, net = ctx.run, ctx.net
+        B, N = ctx.key
+        c_out = net.mats[2].n_out
+        run.dF.view(B, run.M, c_out).copy_(g_out.transpose(1, 2))
+        run.bwd.run()
+        g_feat = None
+        if ctx.feat_grad:
+            g_feat = run.dfeat.view(B, N, net.c_pad)[:, :, :net.c_feat].transpose(1, 2).contiguous()
+        grads = []
+        for p, o in zip(net.flat.params, net.flat.offsets[:-1]):
+            o = int(o)
+            grads.append(run.grad[o:o + p.numel()].view(p.shape).clone() if p.requires_grad else None)
+        net.free[ctx.key].append(run)                          # recycled: everything handed out above is a copy
+        ctx.run = None
+        return (None, None, g_feat) + tuple(grads)
+
+
+def sa_module_forward(mod, xyz, features):
+    hip.require_cuda(xyz, features)
+    if features is None:
+        raise NotImplementedError("PointnetSAModule without input features is not used by GA-DDPG")
+    # xyz may arrive with requires_grad=True for bookkeeping reasons only (the reference slices it out of the tensor that
+    # carries the broadcast action channels, core/networks.py:239): it is treated as geometry, its gradient is None
+    xyz = xyz.detach()
+    B, N, _ = xyz.shape
+    dev = xyz.device
+    rt = _stage_net(mod, dev)
+    net = rt["net"]
+    if features.shape[1] != net.c_feat:
+        raise RuntimeError("features have %d channels, module expects %d" % (features.shape[1], net.c_feat))
+    params = net.flat.params
+    needs_grad = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in params))
+    if needs_grad:
+        if not mod.training:
+            raise RuntimeError("PointnetSAModule: backward through eval-mode BatchNorm (running statistics) is not "
+                               "implemented; call .train() or wrap the call in torch.no_grad()")
+        new_xyz, out = _SAFunction.apply(mod, xyz, features, *params)
+        return (None if new_xyz.numel() == 0 else new_xyz), out
+    key = (B, N)
+    if key not in rt:
+        rt[key] = _StageRun(net, mod, B, N, dev)
+    return _run_forward(mod, net, rt[key], xyz, features)

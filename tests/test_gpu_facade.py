@@ -1,0 +1,156 @@
+"""The `pointnet2_ops` facade as a trainable drop-in: a network written the way the reference's core/networks.py
+writes it (PointnetSAModule stack from the pointnet2_ops package + torch FC head, plain autograd, torch optimizers)
+runs forward AND backward through libgaddpg (ga_ddpg_amd.sa_function._SAFunction)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, check_summaries
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+
+
+class _Shell(torch.nn.Module):
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+
+def _encode(encoder, xyz, feats):
+    """reference core/networks.py:217-220 (PointNetFeature.encode)"""
+    for module in encoder[0]:
+        xyz, feats = module(xyz, feats)
+    return encoder[1](feats.squeeze(-1))
+
+
+def _forward(net, pc, feature_2):
+    """reference core/networks.py:222-250 (PointNetFeature.forward), verbatim control flow"""
+    x = pc
+    if x.shape[-1] != 1024:
+        x = x[..., 6:]
+    x = x[:, :net.critic_input_dim].contiguous() if feature_2 else x[:, :net.policy_input_dim].contiguous()
+    xyz = x.transpose(1, -1)[..., :3].contiguous()
+    return _encode(net.value_encoder if feature_2 else net.encoder, xyz, x)
+
+
+def test_reference_style_network_trains_through_the_facade(golden_dir):
+    """tests/golden/encoder_B16.npz: outputs and gradients of the REFERENCE's PointNetFeature (both encoders, probe loss,
+    gradient wrt the action that is broadcast over the point channels).  Here the same module tree is evaluated by
+    torch autograd with every PointnetSAModule going through the HIP facade (C = 4 and C = 10 input channels)."""
+    from ga_ddpg_amd.core import networks
+    from oracle.detfill import fill_module_
+    g = np.load(os.path.join(golden_dir, "encoder_B16.npz"))
+    net = networks.PointNetFeature(input_dim=5, extra_latent=1, action_concat=True)
+    fill_module_(_Shell(net), "state_feature_extractor", SEED)
+    net.cuda().train()
+    pc = torch.from_numpy(g["point_state"]).cuda()
+    act = torch.from_numpy(g["action"]).cuda().requires_grad_(True)
+    probe = torch.from_numpy(g["probe"]).cuda()
+    taps = {}
+    for tag, enc in (("policy", net.encoder), ("value", net.value_encoder)):
+        for i, sa in enumerate(enc[0]):
+            sa.register_forward_hook(lambda m, a, o, k="%s_sa%d" % (tag, i + 1): taps.__setitem__(k, o[1].detach().cpu().numpy()))
+    z_pol = _forward(net, pc, False)
+    pc10 = torch.cat((pc, act.unsqueeze(2).expand(-1, -1, pc.shape[2])), 1)
+    z_val = _forward(net, pc10, True)
+    ((z_pol * probe).sum() + (z_val * probe.flip(1)).sum()).backward()
+    for k, v in taps.items():
+        assert_close(v, g[k], 1e-4, 1e-5, k)
+    assert_close(z_pol.detach().cpu().numpy(), g["z_policy"], 1e-4, 1e-5 * np.abs(g["z_policy"]).max(), "z_policy")
+    assert_close(z_val.detach().cpu().numpy(), g["z_value"], 1e-4, 1e-5 * np.abs(g["z_value"]).max(), "z_value")
+    da = act.grad.cpu().numpy()
+    assert_close(da, g["action_grad"], 0.0, 5e-3 * np.abs(g["action_grad"]).max(), "action grad")
+    assert np.median(np.abs(da - g["action_grad"])) <= 5e-4 * np.abs(g["action_grad"]).max()
+    skip = (".1.0.bias", ".1.3.bias")          # bias in front of train-mode BN: analytically zero gradient (float noise)
+    check_summaries(g, "grad/", ((n, p.grad) for n, p in net.named_parameters()), 1e-3, 2e-6, skip=skip, normwise=True)
+    check_summaries(g, "state/", ((n, t) for n, t in net.state_dict().items() if "running" in n), 1e-4, 1e-6)
+
+
+@pytest.mark.parametrize("group_all,C", [(False, 8), (False, 10), (True, 5)])
+def test_sa_module_gradients_match_oracle(group_all, C):
+    """one module, probe loss: gradients wrt the features and every parameter against torch autograd over the CPU oracle
+    (padded-duplicate neighbourhoods, BatchNorm2d, max_pool2d); C = 10 / 5 exercise the zero-padded feature block"""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    from oracle.pointnet2_ops import pointnet2_modules as opm
+    from oracle.detfill import fill_module_
+    rng = np.random.default_rng(3)
+    B, N = 4, 512
+    kw = dict(mlp=[C, 32, 64, 64]) if group_all else dict(npoint=32, radius=0.08, nsample=32, mlp=[C, 32, 64, 64])
+    ref = fill_module_(opm.PointnetSAModule(**kw), "sa", SEED).train()
+    mine = fill_module_(pm.PointnetSAModule(**kw), "sa", SEED).cuda().train()
+    xyz = torch.tensor(rng.random((B, N, 3)) * 0.3 + 0.2, dtype=torch.float32)
+    feats = torch.tensor(rng.normal(size=(B, C, N)), dtype=torch.float32)
+    probe = torch.tensor(rng.normal(size=(B, 64, 1 if group_all else 32)), dtype=torch.float32)
+    f_ref = feats.clone().requires_grad_(True)
+    f_gpu = feats.cuda().requires_grad_(True)
+    _, w_out = ref(xyz, f_ref)
+    (w_out * probe).sum().backward()
+    _, g_out = mine(xyz.cuda(), f_gpu)
+    (g_out * probe.cuda()).sum().backward()
+    assert_close(g_out.detach().cpu().numpy(), w_out.detach().numpy(), 1e-4, 2e-5, "SA output")
+
+    def close(a, b, what):
+        scale = float(b.abs().max())
+        assert_close(a.cpu().numpy(), b.numpy(), 0.0, 3e-4 * scale + 1e-7, what)
+    close(f_gpu.grad, f_ref.grad, "d features")
+    for (n, a), (_, b) in zip(mine.named_parameters(), ref.named_parameters()):
+        close(a.grad, b.grad, "d " + n)
+    # a second call while the first graph is alive uses its own activation set; backward order is free
+    _, o1 = mine(xyz.cuda(), f_gpu)
+    _, o2 = mine((xyz * 1.01).cuda(), f_gpu)
+    for p in mine.parameters():
+        p.grad = None
+    (o2 * probe.cuda()).sum().backward()
+    (o1 * probe.cuda()).sum().backward()
+    _, w1 = ref(xyz, f_ref)
+    _, w2 = ref(xyz * 1.01, f_ref)
+    for p in ref.parameters():
+        p.grad = None
+    ((w1 * probe).sum() + (w2 * probe).sum()).backward()
+    for (n, a), (_, b) in zip(mine.named_parameters(), ref.named_parameters()):
+        close(a.grad, b.grad, "accumulated d " + n)
+
+
+def test_facade_follows_a_torch_optimizer():
+    """parameters stepped by an ordinary torch optimizer are picked up by the next forward (the packed compute copy is
+    refreshed), and two SGD steps track the CPU oracle"""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    from oracle.pointnet2_ops import pointnet2_modules as opm
+    from oracle.detfill import fill_module_
+    rng = np.random.default_rng(4)
+    B, N, C = 4, 256, 4
+    kw = dict(npoint=16, radius=0.1, nsample=16, mlp=[C, 16, 16, 32])
+    ref = fill_module_(opm.PointnetSAModule(**kw), "sa", SEED).train()
+    mine = fill_module_(pm.PointnetSAModule(**kw), "sa", SEED).cuda().train()
+    xyz = torch.tensor(rng.random((B, N, 3)) * 0.3 + 0.2, dtype=torch.float32)
+    feats = torch.tensor(rng.normal(size=(B, C, N)), dtype=torch.float32)
+    probe = torch.tensor(rng.normal(size=(B, 32, 16)), dtype=torch.float32)
+    o_ref, o_gpu = torch.optim.SGD(ref.parameters(), lr=1e-2), torch.optim.SGD(mine.parameters(), lr=1e-2)
+    losses = []
+    for it in range(3):
+        o_ref.zero_grad(); o_gpu.zero_grad()
+        lr_ = (ref(xyz, feats)[1] * probe).sum()
+        lg = (mine(xyz.cuda(), feats.cuda())[1] * probe.cuda()).sum()
+        lr_.backward(); lg.backward()
+        o_ref.step(); o_gpu.step()
+        losses.append((float(lr_), float(lg)))
+    for a, b in losses:
+        assert abs(a - b) <= 2e-4 * abs(a) + 1e-4, losses
+    assert abs(losses[0][0] - losses[2][0]) > 1e-3 * abs(losses[0][0])         # the steps did change the loss
+
+
+def test_eval_mode_backward_is_refused():
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    mine = pm.PointnetSAModule(npoint=8, radius=0.1, nsample=8, mlp=[4, 8, 8, 8]).cuda().eval()
+    xyz = torch.rand(2, 64, 3, device="cuda")
+    feats = torch.rand(2, 4, 64, device="cuda", requires_grad=True)
+    with pytest.raises(RuntimeError, match="eval-mode"):
+        mine(xyz, feats)
+    with torch.no_grad():
+        mine(xyz, feats)                       # inference in eval mode is fine
+    mine.train()
+    new_xyz, out = mine(xyz.clone().requires_grad_(True), feats)      # xyz is geometry: accepted, never differentiated
+    assert not new_xyz.requires_grad and out.requires_grad
