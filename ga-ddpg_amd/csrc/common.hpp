@@ -72,4 +72,53 @@ __device__ __forceinline__ float wave_max(float v) {
 // f64 / f32 device-scope atomic adds (hardware global_atomic_add_f64 / _f32 on gfx950)
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// Train-mode BatchNorm finalisation of ONE channel from the replicated f64 statistics (gad_bn_finalize's arithmetic;
+// also evaluated in consumer prologues, include/gaddpg.h gad_bn_fin).  `writer` (exactly one thread of the grid per
+// channel) publishes the vectors the backward pass reads and applies the running-statistics momentum update.
+__device__ __forceinline__ void gad_bn_fin_channel(const gad_bn_fin& b, int c, bool writer, float& sc, float& sh) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < GAD_STAT_REPLICAS; ++r) {
+        s1 += b.stat_sum[(size_t)r * b.stat_stride + c];
+        s2 += b.stat_sq[(size_t)r * b.stat_stride + c];
+    }
+    const double mean = s1 / b.count;
+    double var = s2 / b.count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float istd = (float)(1.0 / sqrt(var + (double)b.eps));
+    sc = b.gamma[c] * istd;
+    sh = b.beta[c] - (float)mean * sc;
+    if (writer) {
+        b.scale[c] = sc;
+        b.shift[c] = sh;
+        if (b.mean) b.mean[c] = (float)mean;
+        if (b.istd) b.istd[c] = istd;
+        if (b.running_mean) b.running_mean[c] = (1.f - b.momentum) * b.running_mean[c] + b.momentum * (float)mean;
+        if (b.running_var) {
+            const double unbiased = b.count > 1.0 ? var * b.count / (b.count - 1.0) : var;
+            b.running_var[c] = (1.f - b.momentum) * b.running_var[c] + b.momentum * (float)unbiased;
+        }
+    }
+}
+
+// BatchNorm-backward coefficients of ONE channel (gad_bn_bwd_coef's arithmetic): dZ = P*dY - w*(Q + S*z).
+// `writer` (one thread of the grid per channel, only when b.accumulate) adds dgamma / dbeta to the gradient arena.
+__device__ __forceinline__ void gad_bn_bwd_channel(const gad_bn_bwd& b, const float* scale, int c, bool writer, float& P,
+                                                   float& Q, float& S) {
+    double db = 0.0, dg = 0.0;
+#pragma unroll
+    for (int r = 0; r < GAD_STAT_REPLICAS; ++r) {
+        db += b.dbeta[(size_t)r * b.stat_stride + c];
+        dg += b.dgamma[(size_t)r * b.stat_stride + c];
+    }
+    const double sc = scale[c], is = b.istd[c], mu = b.mean[c];
+    P = (float)sc;
+    Q = (float)(sc * (db - mu * is * dg) / b.count);
+    S = (float)(sc * is * dg / b.count);
+    if (writer && b.accumulate) {
+        if (b.gacc_gamma) b.gacc_gamma[c] += dg;
+        if (b.gacc_beta) b.gacc_beta[c] += db;
+    }
+}
 #endif

@@ -46,16 +46,36 @@ struct XSrc {   // how a layer's INPUT row r, column c is produced (gad_gemm_fwd
     const float* src_xyz; const float* ctr_xyz; const float* feat; int feat_c;
     const float* action; int act_c; int gps;
     const int32_t* row_pt; const int32_t* row_grp;
+    int affine;          // ACT input: a per-channel affine is applied (given scale / shift, or the deferred BatchNorm `bn`)
+    gad_bn_fin bn;       // deferred BatchNorm finalisation of the input layer (bn.stat_sum == NULL: scale / shift as given)
 };
 
-static XSrc make_xsrc(const gad_gemm_fwd_args& a) {
+static XSrc make_xsrc(const gad_gemm_fwd_args& a, bool with_bn = true) {
     XSrc x;
     x.mode = a.mode; x.zin = a.zin; x.zin_pitch = a.zin_pitch; x.c_in = a.c_in;
     x.scale = a.scale; x.shift = a.shift; x.relu = a.relu; x.extra = a.extra; x.ones_col = a.ones_col;
     x.src_xyz = a.src_xyz; x.ctr_xyz = a.ctr_xyz; x.feat = a.feat; x.feat_c = a.feat_c;
     x.action = a.action; x.act_c = a.act_c; x.gps = a.grp_per_sample > 0 ? a.grp_per_sample : 1;
     x.row_pt = a.row_pt; x.row_grp = a.row_grp;
+    x.bn = a.in_bn;
+    if (!with_bn || a.mode != 0) x.bn.stat_sum = nullptr;
+    if (x.bn.stat_sum) { x.scale = x.bn.scale; x.shift = x.bn.shift; }
+    x.affine = (x.scale && x.shift) ? 1 : 0;
     return x;
+}
+
+// per-channel affine of an ACT input -> LDS: from the given vectors, or finalised here from the BatchNorm statistics
+template <int NT>
+__device__ __forceinline__ void stage_affine(float* sv, float* tv, const XSrc& x, int off, int n, bool writer) {
+    if (x.bn.stat_sum) {
+        for (int i = threadIdx.x; i < n; i += NT) {
+            float sc, sh;
+            gad_bn_fin_channel(x.bn, off + i, writer, sc, sh);
+            sv[i] = sc; tv[i] = sh;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += NT) { sv[i] = x.scale[off + i]; tv[i] = x.shift[off + i]; }
+    }
 }
 
 struct XRaw { float4 a; float4 s; };     // a: the 16 raw bytes; s: special columns (tail tiles only)
@@ -127,7 +147,7 @@ __device__ __forceinline__ float4 x_finish(const XSrc& x, const XRaw& raw, bool 
     float4 v = raw.a;
     if (XM == 0) {
         const int cc = inside ? c : x.c_in - 4;
-        if (x.scale) {
+        if (x.affine) {
             const float4 s = *reinterpret_cast<const float4*>(sv + cc), t = *reinterpret_cast<const float4*>(tv + cc);
             v.x = fmaf(v.x, s.x, t.x); v.y = fmaf(v.y, s.y, t.y); v.z = fmaf(v.z, s.z, t.z); v.w = fmaf(v.w, s.w, t.w);
         }
@@ -145,6 +165,9 @@ struct DzSrc {   // gad_dz_src on the device
     const float* P; const float* Q; const float* S; const float* row_w;
     int gmode; const float* G; int g_pitch; const int32_t* argmax; const float* dout;
     const int32_t* row_grp; int c;
+    int coef;            // BatchNorm backward applies (P/Q/S given, or formed from `bn` in the prologue)
+    int premasked;       // the ReLU mask is already in G / dout
+    gad_bn_bwd bn;
 };
 
 static DzSrc make_dzsrc(const gad_dz_src& d) {
@@ -153,7 +176,17 @@ static DzSrc make_dzsrc(const gad_dz_src& d) {
     s.P = d.coefP; s.Q = d.coefQ; s.S = d.coefS; s.row_w = d.row_w;
     s.gmode = d.gmode; s.G = d.G; s.g_pitch = d.g_pitch; s.argmax = d.argmax; s.dout = d.dout;
     s.row_grp = d.row_grp; s.c = d.c;
+    s.bn = d.bn;
+    s.premasked = d.premasked;
+    s.coef = (d.coefP != nullptr || d.bn.dbeta != nullptr) ? 1 : 0;
     return s;
+}
+
+// P, Q, S of channel ch: from the given vectors or formed from the deferred BatchNorm-backward sums
+__device__ __forceinline__ void dz_coef(const DzSrc& d, int ch, bool writer, float& P, float& Q, float& S) {
+    if (d.bn.dbeta) gad_bn_bwd_channel(d.bn, d.scale, ch, writer, P, Q, S);
+    else if (d.P) { P = d.P[ch]; Q = d.Q[ch]; S = d.S[ch]; }
+    else { P = 1.f; Q = 0.f; S = 0.f; }
 }
 
 struct DzRaw { float4 z; float4 g; int4 a; };
@@ -176,7 +209,7 @@ __device__ __forceinline__ float4 dz_scalar4(const DzSrc& d, int r, bool valid, 
             const int grp = d.row_grp[rr];
             g = d.argmax[(size_t)grp * d.c + ch] == r ? d.dout[(size_t)grp * d.c + ch] : 0.f;
         }
-        if (d.relu) {
+        if (d.relu && !d.premasked) {
             const float y = d.scale ? fmaf(z, d.scale[ch], d.shift[ch]) : z;
             g = y > 0.f ? g : 0.f;
         }
@@ -220,7 +253,7 @@ __device__ __forceinline__ float4 dz_finish(const DzSrc& d, const DzRaw& raw, in
         g.x = raw.a.x == r ? g.x : 0.f; g.y = raw.a.y == r ? g.y : 0.f;
         g.z = raw.a.z == r ? g.z : 0.f; g.w = raw.a.w == r ? g.w : 0.f;
     }
-    if (d.relu) {
+    if (d.relu && !d.premasked) {
         float4 y = z;
         if (d.scale) {
             const float4 s = *reinterpret_cast<const float4*>(vec + nn), t = *reinterpret_cast<const float4*>(vec + VM + nn);
@@ -229,7 +262,7 @@ __device__ __forceinline__ float4 dz_finish(const DzSrc& d, const DzRaw& raw, in
         g.x = y.x > 0.f ? g.x : 0.f; g.y = y.y > 0.f ? g.y : 0.f;
         g.z = y.z > 0.f ? g.z : 0.f; g.w = y.w > 0.f ? g.w : 0.f;
     }
-    if (d.P) {
+    if (d.coef) {
         const float4 P = *reinterpret_cast<const float4*>(vec + 2 * VM + nn);
         const float4 Q = *reinterpret_cast<const float4*>(vec + 3 * VM + nn);
         const float4 S = *reinterpret_cast<const float4*>(vec + 4 * VM + nn);
@@ -239,13 +272,18 @@ __device__ __forceinline__ float4 dz_finish(const DzSrc& d, const DzRaw& raw, in
     return f4sel(valid && inside, g, f4zero());
 }
 
+// writer: exactly one workgroup of the grid (it adds dgamma / dbeta to the gradient arena when d.bn.accumulate)
 template <int VM = VMAX>
-__device__ __forceinline__ void stage_dz_vecs(float* vec, const DzSrc& d, int off, int n) {
-    stage_vec(vec, d.scale, off, n, 1.f);
-    stage_vec(vec + VM, d.shift, off, n, 0.f);
-    stage_vec(vec + 2 * VM, d.P, off, n, 1.f);
-    stage_vec(vec + 3 * VM, d.Q, off, n, 0.f);
-    stage_vec(vec + 4 * VM, d.S, off, n, 0.f);
+__device__ __forceinline__ void stage_dz_vecs(float* vec, const DzSrc& d, int off, int n, bool writer) {
+    if (!d.premasked) {
+        stage_vec(vec, d.scale, off, n, 1.f);
+        stage_vec(vec + VM, d.shift, off, n, 0.f);
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float P, Q, S;
+        dz_coef(d, off + i, writer, P, Q, S);
+        vec[2 * VM + i] = P; vec[3 * VM + i] = Q; vec[4 * VM + i] = S;
+    }
 }
 
 static bool dz_vectorizable(const gad_dz_src& d, const int32_t* off, const int32_t* n_out, int ng) {
@@ -424,7 +462,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
     // the three global-load latencies of the prologue (tile, vectors, weights) overlap instead of chaining
     bool preloaded = false;
     if (XM == 0) { load_tile(0); preloaded = true; }
-    if (XM == 0 && x.scale) { stage_vec(sv, x.scale, zoff, x.c_in, 1.f); stage_vec(tv, x.shift, zoff, x.c_in, 0.f); }
+    if (XM == 0 && x.affine) stage_affine<256>(sv, tv, x, zoff, x.c_in, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     for (; row0 < n_rows; row0 += gridDim.x * BM) {
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -526,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
         }
     }
-    if (XM == 0 && tid < KP) { sv[tid] = x.scale[tid]; tv[tid] = x.shift[tid]; }
+    if (XM == 0) stage_affine<512>(sv, tv, x, 0, KP, blockIdx.x == 0);
     __syncthreads();
 
     const int n_slabs = (n_rows + 31) >> 5;
@@ -675,6 +713,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
                                                                      double* __restrict__ stat_sum,
                                                                      double* __restrict__ stat_sq, int stat_stride) {
     __shared__ float part[SK_NW * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float sv[8 * SK_NW * SK_CH * SK_MAXCH], tv[8 * SK_NW * SK_CH * SK_MAXCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -684,8 +723,6 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     if (n0 >= n_out) return;                                  // workgroup-uniform
     const float* Wg = W + gr.woff[g] + (size_t)min(n0 + l31, n_out - 1) * Kp + 4 * half;   // clamped: extra columns unused
     const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are neither stored nor counted
-    const float* sv = x.scale ? x.scale + zoff : nullptr;
-    const float* tv = x.shift ? x.shift + zoff : nullptr;
     const int nj = Kp >> 3;
     const int per = (nj + SK_NW - 1) / SK_NW;
     const int j0 = wave * per, j1 = min(nj, j0 + per);        // this wavefront's k groups (wave-uniform)
@@ -705,6 +742,10 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
         }
     };
     load_chunk(0, 0);
+    // the operand loads above are in flight while the input layer's per-channel affine is staged (or, with a deferred
+    // BatchNorm, finalised from its statistics) in LDS
+    if (x.affine) stage_affine<64 * SK_NW>(sv, tv, x, zoff, x.c_in, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    __syncthreads();
 #pragma unroll
     for (int c = 0; c < SK_MAXCH; ++c) {
         if (j0 + c * SK_CH < j1) {                            // wave-uniform
@@ -781,7 +822,7 @@ static bool fwd_streamable(const gad_gemm_fwd_args& a) {
     if (a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
     if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || a.zout_pitch != a.n_out[0]) return false;
     if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
-    if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && a.scale && a.shift && a.relu;
+    if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && ((a.scale && a.shift) || a.in_bn.stat_sum) && a.relu;
     return a.Kp == 16 && a.feat_c + 3 + a.act_c <= 16;
 }
 
@@ -816,6 +857,13 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_fwd: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0 && a->Kp >= 8, GAD_ERR_SHAPE, "gemm_fwd: Kp=%d must be a multiple of 8", a->Kp);
     if (int e = check_input(*a, "gemm_fwd")) return e;
+    if (a->in_bn.stat_sum) {
+        const gad_bn_fin& b = a->in_bn;
+        GAD_REQUIRE(a->mode == 0 && a->n_groups == 1 && a->zin_off[0] == 0, GAD_ERR_SHAPE,
+                    "gemm_fwd: a deferred BatchNorm needs an ACT input and a single group");
+        GAD_REQUIRE(b.stat_sq && b.gamma && b.beta && b.scale && b.shift && b.count >= 1.0, GAD_ERR_NULL,
+                    "gemm_fwd: incomplete gad_bn_fin");
+    }
     if (a->n_rows <= 0) return GAD_OK;
     XSrc x = make_xsrc(*a);
     Groups gr = make_groups(a->n_groups, a->zin_off, a->w_off, a->out_off, a->n_out);
@@ -864,7 +912,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 struct DxEpi {
     int mode; float* gout; int gout_pitch; int k_valid;
     const float* zprev; int zprev_pitch; const float* ps; const float* pt; const float* pm; const float* pi;
-    double* dbeta; double* dgamma; int stat_stride;
+    double* dbeta; double* dgamma; int stat_stride; int store_masked;
     float* dfeat; int feat_c; const int32_t* row_pt; const int32_t* row_grp; double* daction; int act_c; int gps;
 };
 
@@ -897,7 +945,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     if ((int)(blockIdx.x * BM) >= n_rows) return;
     const int nk = gad_cdiv_dev(n_out, KT);
-    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out);
+    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     const bool need_grp = e.mode == 1 || d.gmode != 0;
 
     float cb[TN], cg[TN];
@@ -982,11 +1030,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     if (r >= n_rows || !kok) continue;
                     const float gv = acc[tm][tn][v];
                     if (e.mode == 0) {
-                        e.gout[(size_t)r * e.gout_pitch + goff + k] = gv;
+                        float outv = gv;
                         if (stats) {
                             const float zp = e.zprev[(size_t)r * e.zprev_pitch + goff + k];
                             if (fmaf(zp, sc, sh) > 0.f) { sb += gv; sg = fmaf(gv, (zp - mu) * is, sg); }
+                            else if (e.store_masked) outv = 0.f;
                         }
+                        e.gout[(size_t)r * e.gout_pitch + goff + k] = outv;
                     } else {
                         // gather-layer columns: [feat (feat_c) | xyz (3) | action (act_c)]
                         if (k < e.feat_c) {
@@ -1034,7 +1084,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
                                                                  int n_rows_static, const float* __restrict__ W, DxEpi e) {
     constexpr int NO = 8 * NJ, PW = NO + 4, NCH = NJ / 4;
     __shared__ __attribute__((aligned(16))) float Wt[64 * PW];
-    __shared__ __attribute__((aligned(16))) float vec[5 * NO];
+    __shared__ __attribute__((aligned(16))) float vec[3 * NO];          // P | Q | S (the ReLU mask is already in dY: premasked)
     __shared__ float red[2 * 8 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1054,8 +1104,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
         }
     }
     for (int i = tid; i < NO; i += 512) {
-        vec[i] = d.scale[i]; vec[NO + i] = d.shift[i];
-        vec[2 * NO + i] = d.P[i]; vec[3 * NO + i] = d.Q[i]; vec[4 * NO + i] = d.S[i];
+        float P, Q, S;
+        dz_coef(d, i, blockIdx.x == 0, P, Q, S);
+        vec[i] = P; vec[NO + i] = Q; vec[2 * NO + i] = S;
     }
     __syncthreads();
     // previous layer's BatchNorm vectors of this lane's two output columns
@@ -1128,12 +1179,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
                     g.x = a.x == rr ? g.x : 0.f; g.y = a.y == rr ? g.y : 0.f;
                     g.z = a.z == rr ? g.z : 0.f; g.w = a.w == rr ? g.w : 0.f;
                 }
-                const float4 sc = *reinterpret_cast<const float4*>(vec + n), sh = *reinterpret_cast<const float4*>(vec + NO + n);
-                g.x = fmaf(z.x, sc.x, sh.x) > 0.f ? g.x : 0.f; g.y = fmaf(z.y, sc.y, sh.y) > 0.f ? g.y : 0.f;
-                g.z = fmaf(z.z, sc.z, sh.z) > 0.f ? g.z : 0.f; g.w = fmaf(z.w, sc.w, sh.w) > 0.f ? g.w : 0.f;
-                const float4 P = *reinterpret_cast<const float4*>(vec + 2 * NO + n);
-                const float4 Q = *reinterpret_cast<const float4*>(vec + 3 * NO + n);
-                const float4 S = *reinterpret_cast<const float4*>(vec + 4 * NO + n);
+                const float4 P = *reinterpret_cast<const float4*>(vec + n);
+                const float4 Q = *reinterpret_cast<const float4*>(vec + NO + n);
+                const float4 S = *reinterpret_cast<const float4*>(vec + 2 * NO + n);
                 float4 a4;
                 a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
                 a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
@@ -1160,21 +1208,14 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float gv = acc[t][v];
-                if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(gv), grsrc, glane + t * 128, rb, 0);
                 const float zv = zp[t][v];
                 const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
                 const float ga = act ? gv : 0.f;
+                // the previous layer's consumers take dY with its ReLU mask applied (premasked)
+                if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), grsrc, glane + t * 128, rb, 0);
+                else if (live) e.gout[(size_t)(slab * 32 + row) * 64 + t * 32 + l31] = ga;
                 sb[t] += ga;
                 sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
-            }
-        }
-        if (!full) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int rr = slab * 32 + acc_row(v, half);
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-                    if (rr < n_rows) e.gout[(size_t)rr * 64 + t * 32 + l31] = acc[t][v];
             }
         }
         r_cur = r_nxt;
@@ -1201,9 +1242,10 @@ static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
     if (!g_opt_dx_stream || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
     if (a.n_rows < 32768 || a.epilogue != 0 || a.k_valid != 64 || a.Kp != 64 || a.gout_pitch != 64) return false;
     if (a.n_out[0] != 64 && a.n_out[0] != 128) return false;
-    if (!a.prev_dbeta || a.zprev_pitch != 64) return false;
+    if (!a.prev_dbeta || a.zprev_pitch != 64 || !a.store_masked) return false;
     const gad_dz_src& d = a.dz;
-    if (!d.z || d.z_pitch != a.n_out[0] || !d.scale || !d.shift || !d.relu || !d.coefP || !d.coefQ || !d.coefS) return false;
+    const bool coef = (d.coefP && d.coefQ && d.coefS) || d.bn.dbeta;
+    if (!d.z || d.z_pitch != a.n_out[0] || !d.scale || !d.relu || !d.premasked || !coef) return false;
     if (d.gmode == 0 ? d.g_pitch != a.n_out[0] : d.c != a.n_out[0]) return false;
     return (long long)a.n_rows * 128 * 4 < (1ll << 31);
 }
@@ -1225,9 +1267,9 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     for (int i = tid; i < n_out; i += 64 * SK_NW) {
         vec[i] = d.scale ? d.scale[doff + i] : 1.f;
         vec[VMAX + i] = d.shift ? d.shift[doff + i] : 0.f;
-        vec[2 * VMAX + i] = d.P ? d.P[doff + i] : 1.f;
-        vec[3 * VMAX + i] = d.Q ? d.Q[doff + i] : 0.f;
-        vec[4 * VMAX + i] = d.S ? d.S[doff + i] : 0.f;
+        float P, Q, S;
+        dz_coef(d, doff + i, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, P, Q, S);
+        vec[2 * VMAX + i] = P; vec[3 * VMAX + i] = Q; vec[4 * VMAX + i] = S;
     }
     __syncthreads();
     const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are not stored
@@ -1294,11 +1336,13 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
         const int rr = row0 + acc_row(v, half);
         if (rr >= n_rows || !kok) continue;
         const float gv = acc[v];
-        e.gout[(size_t)rr * e.gout_pitch + goff + kk] = gv;
+        float outv = gv;
         if (stats) {
             const float zp = e.zprev[(size_t)rr * e.zprev_pitch + goff + kk];
             if (fmaf(zp, sc, sh) > 0.f) { sb += gv; sg = fmaf(gv, (zp - mu) * is, sg); }
+            else if (e.store_masked) outv = 0.f;
         }
+        e.gout[(size_t)rr * e.gout_pitch + goff + kk] = outv;
     }
     if (e.dbeta) {
         sb += __shfl_xor(sb, 32, 64);
@@ -1326,6 +1370,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     e.zprev = a->zprev; e.zprev_pitch = a->zprev_pitch; e.ps = a->prev_scale; e.pt = a->prev_shift;
     e.pm = a->prev_mean; e.pi = a->prev_istd; e.dbeta = a->prev_dbeta; e.dgamma = a->prev_dgamma;
     e.stat_stride = a->stat_stride;
+    e.store_masked = (a->store_masked && a->prev_dbeta) ? 1 : 0;
     e.dfeat = a->dfeat; e.feat_c = a->feat_c; e.row_pt = a->row_pt; e.row_grp = a->row_grp;
     e.daction = a->daction; e.act_c = a->act_c; e.gps = a->grp_per_sample > 0 ? a->grp_per_sample : 1;
     GAD_REQUIRE(e.mode == 0 || (e.row_pt && e.row_grp), GAD_ERR_NULL, "gemm_dx: scatter epilogue needs row maps");
@@ -1333,6 +1378,12 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows, kv = a->k_valid;
     const bool vec = dz_vectorizable(a->dz, a->dz_off, a->n_out, a->n_groups);
+    if (a->dz.bn.dbeta) {
+        GAD_REQUIRE(vec && a->n_groups == 1 && a->dz_off[0] == 0, GAD_ERR_SHAPE,
+                    "gemm_dx: deferred BatchNorm-backward coefficients need 16-byte aligned channels and a single group");
+        GAD_REQUIRE(a->dz.bn.dgamma && a->dz.bn.mean && a->dz.bn.istd && a->dz.scale && a->dz.bn.count >= 1.0, GAD_ERR_NULL,
+                    "gemm_dx: incomplete gad_bn_bwd");
+    }
     if (dx_streamable(*a, vec)) {
         const int slabs = gad_cdiv(rows, 32);
         int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;
@@ -1410,8 +1461,8 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     const int r_begin = blockIdx.y * chunk;
     const int r_end = min(r_begin + chunk, n_rows);
     if (r_begin >= r_end) return;     // the reducer skips the same splits (same chunk arithmetic)
-    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out);
-    if (XM == 0 && x.scale) { stage_vec(sv, x.scale, zoff, x.c_in, 1.f); stage_vec(tv, x.shift, zoff, x.c_in, 0.f); }
+    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    if (XM == 0 && x.affine) stage_affine<256>(sv, tv, x, zoff, x.c_in, false);
     __syncthreads();
 
     f32x16 acc[TM][TN];
@@ -1553,8 +1604,9 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSr
     const int n = n0 + l31;
     const bool n_ok = n < n_out;
     const int ch = doff + (n_ok ? n : 0);
-    const float dsc = d.scale ? d.scale[ch] : 1.f, dsh = d.scale ? d.shift[ch] : 0.f;
-    const float dP = d.P ? d.P[ch] : 1.f, dQ = d.P ? d.Q[ch] : 0.f, dS = d.P ? d.S[ch] : 0.f;
+    const float dsc = (d.scale && !d.premasked) ? d.scale[ch] : 1.f, dsh = (d.scale && !d.premasked) ? d.shift[ch] : 0.f;
+    float dP, dQ, dS;
+    dz_coef(d, ch, blockIdx.y == 0 && blockIdx.z == 0 && wave == 0 && half == 0 && n_ok, dP, dQ, dS);
     // B side: this lane's input column k: 0 = activation column, 1 = extra column, 2 = bias (ones) column, 3 = padding
     const int k = k0 + l31;
     const int kind = k < x.c_in ? 0 : ((k == x.c_in && x.extra) ? 1 : (k == x.ones_col ? 2 : 3));
@@ -1591,8 +1643,8 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSr
                 const bool live = r < n_rows;
                 const float z = rz[u][i];
                 float gq = rg[u][i];
-                if (d.relu) gq = fmaf(z, dsc, dsh) > 0.f ? gq : 0.f;
-                if (d.P) gq = dP * gq - rw[u][i] * fmaf(dS, z, dQ);
+                if (d.relu && !d.premasked) gq = fmaf(z, dsc, dsh) > 0.f ? gq : 0.f;
+                if (d.coef) gq = dP * gq - rw[u][i] * fmaf(dS, z, dQ);
                 a4[i] = (live && n_ok) ? gq : 0.f;
                 float xv = rx[u][i];
                 if (kind == 0) { xv = fmaf(xv, xs, xt); if (x.relu) xv = fmaxf(xv, 0.f); }
@@ -1644,11 +1696,11 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
     if (r_begin >= n_rows) return;                                 // inactive split: dw_reduce does not read it
 
     // per-lane constants: A side (dZ) output channels n = 64 cset + 32 j + l31, B side (X) input channels k = 32 b + l31
-    float dsc[2], dsh[2], dP[2], dQ[2], dS[2], xs[2], xt[2];
+    float dP[2], dQ[2], dS[2], xs[2], xt[2];          // (the ReLU mask is already in dY: premasked)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ch = 64 * cset + 32 * j + l31;
-        dsc[j] = d.scale[ch]; dsh[j] = d.shift[ch]; dP[j] = d.P[ch]; dQ[j] = d.Q[ch]; dS[j] = d.S[ch];
+        dz_coef(d, ch, blockIdx.x == 0 && wr == 0 && half == 0, dP[j], dQ[j], dS[j]);
         xs[j] = x.scale[32 * j + l31]; xt[j] = x.shift[32 * j + l31];
     }
     // Addressing of the main loop: raw buffer loads whose per-lane byte offset is a CONSTANT (channel block + the
@@ -1715,7 +1767,6 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
                 const float z = u.z[i][j];
                 float gq = u.g[i][j];
                 if (GM == 1) gq = u.a[i][j] == r ? gq : 0.f;
-                gq = fmaf(z, dsc[j], dsh[j]) > 0.f ? gq : 0.f;
                 gq = dP[j] * gq - u.w[i] * fmaf(dS[j], z, dQ[j]);
                 a2[j] = live ? gq : 0.f;
                 const float xv = fmaxf(fmaf(u.xv[i][j], xs[j], xt[j]), 0.f);
@@ -1788,12 +1839,9 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
     if (r_begin >= n_rows) return;
 
     const unsigned lane_n = 2u * l31;
-    float dsc[2], dsh[2], dP[2], dQ[2], dS[2];
+    float dP[2], dQ[2], dS[2];                        // (premasked dY)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ch = lane_n + j;
-        dsc[j] = d.scale[ch]; dsh[j] = d.shift[ch]; dP[j] = d.P[ch]; dQ[j] = d.Q[ch]; dS[j] = d.S[ch];
-    }
+    for (int j = 0; j < 2; ++j) dz_coef(d, lane_n + j, blockIdx.x == 0 && wave == 0 && half == 0, dP[j], dQ[j], dS[j]);
     // B side: what input column k = l31 is made of
     const int k = l31, fc = x.feat_c;
     const int kind = k < fc ? 0 : (k < fc + 3 ? 1 : ((x.action && k < fc + 3 + x.act_c) ? 2 : 3));
@@ -1865,8 +1913,7 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const float z = u.z[i][j];
-                float gq = fmaf(z, dsc[j], dsh[j]) > 0.f ? u.g[i][j] : 0.f;
-                gq = dP[j] * gq - u.w[i] * fmaf(dS[j], z, dQ[j]);
+                const float gq = dP[j] * u.g[i][j] - u.w[i] * fmaf(dS[j], z, dQ[j]);
                 acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(live ? gq : 0.f, xv, acc[j], 0, 0, 0);
             }
         }
@@ -1916,7 +1963,7 @@ static bool dw_gather_streamable(const gad_gemm_dw_args& a, int k_used) {
     const gad_dz_src& d = a.dz;
     if (!g_opt_dw_stream || in.mode != 1 || in.n_groups != 1 || in.Kp > 32 || in.n_out[0] != 64 || k_used > in.Kp) return false;
     if (in.zin_off[0] != 0 || a.dz_off[0] != 0 || in.n_rows < 32768 || d.gmode != 0 || !d.G) return false;
-    if (!d.z || !d.scale || !d.shift || !d.relu || !d.coefP || !d.coefQ || !d.coefS) return false;
+    if (!d.z || !d.scale || !d.relu || !d.premasked || !((d.coefP && d.coefQ && d.coefS) || d.bn.dbeta)) return false;
     if (in.feat_c + 3 + (in.action ? in.act_c : 0) > in.Kp) return false;
     if (!a.partial || 256ll * 64 * in.Kp > a.partial_elems) return false;
     return a.row_splits <= 0;
@@ -1929,7 +1976,7 @@ static bool dw_streamable(const gad_gemm_dw_args& a, int k_used) {
     if (!g_opt_dw_stream || in.mode != 0 || in.n_groups != 1 || in.Kp != 64 || in.c_in != 64 || k_used != 64) return false;
     if (in.zin_off[0] != 0 || a.dz_off[0] != 0 || (in.n_out[0] != 64 && in.n_out[0] != 128)) return false;   // w_off: arena offset, dw_reduce applies it
     if (in.n_rows < 32768 || !in.scale || !in.shift || !in.relu || in.extra || in.ones_col >= 0) return false;
-    if (!d.z || !d.scale || !d.shift || !d.relu || !d.coefP || !d.coefQ || !d.coefS) return false;
+    if (!d.z || !d.scale || !d.relu || !d.premasked || !((d.coefP && d.coefQ && d.coefS) || d.bn.dbeta)) return false;
     if (d.gmode != 0 && d.c != in.n_out[0]) return false;
     if (!a.partial || (long long)DW_STREAM_SPLITS * in.n_out[0] * 64 > a.partial_elems) return false;
     return a.row_splits <= 0;
@@ -1944,7 +1991,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     GAD_REQUIRE(a->dz.gmode == 0 ? a->dz.G != nullptr : (a->dz.argmax && a->dz.dout && a->dz.row_grp), GAD_ERR_NULL,
                 "gemm_dw: gradient source");
     if (in.n_rows <= 0) return GAD_OK;
-    XSrc x = make_xsrc(in);
+    XSrc x = make_xsrc(in, false);          // the input layer's affine was published by the forward pass
     DzSrc d = make_dzsrc(a->dz);
     // group g: dz channel offset dz_off[g], input channel offset zin_off[g], weights at w_off[g]
     Groups gr = make_groups(in.n_groups, a->dz_off, in.w_off, in.zin_off, in.n_out);
@@ -1955,6 +2002,12 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int rows = in.n_rows;
     const bool vec = dz_vectorizable(a->dz, a->dz_off, in.n_out, in.n_groups);
+    if (a->dz.bn.dbeta) {
+        GAD_REQUIRE(vec && in.n_groups == 1 && a->dz_off[0] == 0, GAD_ERR_SHAPE,
+                    "gemm_dw: deferred BatchNorm-backward coefficients need 16-byte aligned channels and a single group");
+        GAD_REQUIRE(a->dz.bn.dgamma && a->dz.bn.mean && a->dz.bn.istd && a->dz.scale && a->dz.bn.count >= 1.0, GAD_ERR_NULL,
+                    "gemm_dw: incomplete gad_bn_bwd");
+    }
     if (g_opt_dw_skinny && in.mode == 0 && a->dz.gmode == 0 && !in.n_rows_dev && rows <= 1024) {
         hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
                            gr, rows, in.Kp, k_used, a->gacc);

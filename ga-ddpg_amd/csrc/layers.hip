@@ -3,33 +3,13 @@
 // Reference arithmetic replaced: torch BatchNorm2d/1d (train) and F.max_pool2d(kernel=[1,nsample])
 // inside upstream _PointnetSAModuleBase.forward / reference core/networks.py:84-91.
 #include "common.hpp"
+#include <string.h>
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ ssum,
-                                                          const double* __restrict__ ssq, int stride,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, int C, double count,
-                                                          float eps, float momentum, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar, float* __restrict__ scale,
-                                                          float* __restrict__ shift, float* __restrict__ mean_o,
-                                                          float* __restrict__ istd_o) {
+__global__ __launch_bounds__(256) void bn_finalize_kernel(gad_bn_fin b, int C) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < GAD_STAT_REPLICAS; ++r) { s1 += ssum[(size_t)r * stride + c]; s2 += ssq[(size_t)r * stride + c]; }
-    const double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float istd = (float)(1.0 / sqrt(var + (double)eps));
-    const float sc = gamma[c] * istd;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)mean * sc;
-    if (mean_o) mean_o[c] = (float)mean;
-    if (istd_o) istd_o[c] = istd;
-    if (rmean) rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
-    if (rvar) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unbiased;
-    }
+    float sc, sh;
+    gad_bn_fin_channel(b, c, true, sc, sh);
 }
 
 extern "C" int gad_bn_finalize(const double* stat_sum, const double* stat_sq, int stat_stride, const float* gamma,
@@ -38,9 +18,11 @@ extern "C" int gad_bn_finalize(const double* stat_sum, const double* stat_sq, in
                                float* istd, void* stream) {
     GAD_REQUIRE(stat_sum && stat_sq && gamma && beta && scale && shift, GAD_ERR_NULL, "bn_finalize: null pointer");
     GAD_REQUIRE(C >= 1 && count >= 1.0, GAD_ERR_SHAPE, "bn_finalize: bad shape");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stat_sum,
-                       stat_sq, stat_stride, gamma, beta, C, count, eps, momentum, running_mean, running_var, scale, shift, mean,
-                       istd);
+    gad_bn_fin b;
+    b.stat_sum = stat_sum; b.stat_sq = stat_sq; b.stat_stride = stat_stride; b.count = count; b.gamma = gamma; b.beta = beta;
+    b.eps = eps; b.momentum = momentum; b.running_mean = running_mean; b.running_var = running_var; b.scale = scale;
+    b.shift = shift; b.mean = mean; b.istd = istd;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, b, C);
     GAD_CHECK_LAUNCH("bn_finalize");
     return GAD_OK;
 }
@@ -94,45 +76,130 @@ extern "C" int gad_bn_running_update(const float* mean, const float* istd, const
     return GAD_OK;
 }
 
-// out[g][c] = max over the group's rows of relu(scale*z+shift); arg-max = first maximal row
-__global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ z, int z_pitch, int C,
+// Segment max-pool with arg-max: out[g][c] = max over the group's rows of relu(scale*z+shift), arg-max = FIRST maximal
+// row (torch max_pool2d's tie rule over upstream's slot order).  A group's rows are contiguous (CSR), a row is C
+// consecutive floats: one wavefront per group, lane = (row phase, 16-byte channel quad), so every load is a coalesced
+// 16-byte access of consecutive rows; the row phases of a quad are folded with wavefront shuffles
+// (value first, then the smaller row index) -- north_star's "wavefront shuffle reductions for the max-pool".
+// QPR = quads per row handled per lane-row = min(C/4, 64); lanes cover RPW = 64/QPR rows per step and NQ = C/(4*QPR)
+// quads each.  The layer's BatchNorm may be finalised in the prologue (gad_bn_fin).
+template <int QPR, int NQ>
+__global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ z, int z_pitch,
                                                            const float* __restrict__ scale,
-                                                           const float* __restrict__ shift,
-                                                           const int32_t* __restrict__ off, long long total,
+                                                           const float* __restrict__ shift, gad_bn_fin bn,
+                                                           const int32_t* __restrict__ off, int G,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax) {
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= total) return;
-    const int g = (int)(q / C), c = (int)(q - (long long)g * C);
-    const int r0 = off[g], r1 = off[g + 1];
-    const float sc = scale ? scale[c] : 1.f, sh = shift ? shift[c] : 0.f;
-    float best = -1.f;
-    int arg = r0;
-    int r = r0;
-    for (; r + 4 <= r1; r += 4) {            // four independent loads in flight per thread (the loop is load-latency bound)
-        const float* p = z + (size_t)r * z_pitch + c;
-        const float z0 = p[0], z1 = p[z_pitch], z2 = p[2 * (size_t)z_pitch], z3 = p[3 * (size_t)z_pitch];
-        const float y0 = fmaxf(fmaf(z0, sc, sh), 0.f), y1 = fmaxf(fmaf(z1, sc, sh), 0.f);
-        const float y2 = fmaxf(fmaf(z2, sc, sh), 0.f), y3 = fmaxf(fmaf(z3, sc, sh), 0.f);
-        if (y0 > best) { best = y0; arg = r; }
-        if (y1 > best) { best = y1; arg = r + 1; }
-        if (y2 > best) { best = y2; arg = r + 2; }
-        if (y3 > best) { best = y3; arg = r + 3; }
+    constexpr int C = 4 * QPR * NQ, RPW = 64 / QPR;
+    __shared__ __attribute__((aligned(16))) float sv[C], tv[C];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool writer = blockIdx.x == 0;
+    for (int i = tid; i < C; i += 256) {
+        float sc = 1.f, sh = 0.f;
+        if (bn.stat_sum) gad_bn_fin_channel(bn, i, writer, sc, sh);
+        else if (scale) { sc = scale[i]; sh = shift[i]; }
+        sv[i] = sc; tv[i] = sh;
     }
-    for (; r < r1; ++r) {
-        const float y = fmaxf(fmaf(z[(size_t)r * z_pitch + c], sc, sh), 0.f);
-        if (y > best) { best = y; arg = r; }
+    __syncthreads();
+    const int sub = lane / QPR, q = lane % QPR;
+    float4 s4[NQ], t4[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        s4[k] = *reinterpret_cast<const float4*>(sv + 4 * (q + k * QPR));
+        t4[k] = *reinterpret_cast<const float4*>(tv + 4 * (q + k * QPR));
     }
-    out[q] = best < 0.f ? 0.f : best;
-    if (argmax) argmax[q] = arg;
+    for (int g = blockIdx.x * 4 + wave; g < G; g += gridDim.x * 4) {
+        const int r0 = off[g], r1 = off[g + 1];
+        float best[NQ][4];
+        int arg[NQ][4];
+#pragma unroll
+        for (int k = 0; k < NQ; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { best[k][e] = -1.f; arg[k][e] = r0; }
+        auto upd = [&](int k, int r, const float4& zz) {
+            const float y0 = fmaxf(fmaf(zz.x, s4[k].x, t4[k].x), 0.f), y1 = fmaxf(fmaf(zz.y, s4[k].y, t4[k].y), 0.f);
+            const float y2 = fmaxf(fmaf(zz.z, s4[k].z, t4[k].z), 0.f), y3 = fmaxf(fmaf(zz.w, s4[k].w, t4[k].w), 0.f);
+            if (y0 > best[k][0]) { best[k][0] = y0; arg[k][0] = r; }
+            if (y1 > best[k][1]) { best[k][1] = y1; arg[k][1] = r; }
+            if (y2 > best[k][2]) { best[k][2] = y2; arg[k][2] = r; }
+            if (y3 > best[k][3]) { best[k][3] = y3; arg[k][3] = r; }
+        };
+        int r = r0 + sub;
+        for (; r + 3 * RPW < r1; r += 4 * RPW) {             // four rows per lane in flight
+            float4 za[4][NQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < NQ; ++k)
+                    za[u][k] = *reinterpret_cast<const float4*>(z + (size_t)(r + u * RPW) * z_pitch + 4 * (q + k * QPR));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < NQ; ++k) upd(k, r + u * RPW, za[u][k]);
+        }
+        for (; r < r1; r += RPW) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+                upd(k, r, *reinterpret_cast<const float4*>(z + (size_t)r * z_pitch + 4 * (q + k * QPR)));
+        }
+        // fold the RPW row phases of every quad: larger value wins, on equal values the smaller row index
+#pragma unroll
+        for (int o = 32; o >= QPR; o >>= 1) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ob = __shfl_xor(best[k][e], o, 64);
+                    const int oa = __shfl_xor(arg[k][e], o, 64);
+                    const bool take = ob > best[k][e] || (ob == best[k][e] && oa < arg[k][e]);
+                    best[k][e] = take ? ob : best[k][e];
+                    arg[k][e] = take ? oa : arg[k][e];
+                }
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int k = 0; k < NQ; ++k) {
+                const size_t o4 = (size_t)g * C + 4 * (q + k * QPR);
+                *reinterpret_cast<float4*>(out + o4) = make_float4(fmaxf(best[k][0], 0.f), fmaxf(best[k][1], 0.f),
+                                                                  fmaxf(best[k][2], 0.f), fmaxf(best[k][3], 0.f));
+                if (argmax) *reinterpret_cast<int4*>(argmax + o4) = make_int4(arg[k][0], arg[k][1], arg[k][2], arg[k][3]);
+            }
+        }
+    }
 }
 
 extern "C" int gad_segment_pool(const float* z, int z_pitch, int C, const float* scale, const float* shift,
-                                const int32_t* grp_off, int G, float* out, int32_t* argmax, void* stream) {
+                                const gad_bn_fin* host_bn, const int32_t* grp_off, int G, float* out, int32_t* argmax,
+                                void* stream) {
     GAD_REQUIRE(z && grp_off && out, GAD_ERR_NULL, "segment_pool: null pointer");
-    const long long total = (long long)G * C;
-    if (total == 0) return GAD_OK;
-    hipLaunchKernelGGL(segment_pool_kernel, dim3(gad_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, z, z_pitch,
-                       C, scale, shift, grp_off, total, out, argmax);
+    GAD_REQUIRE((scale == nullptr) == (shift == nullptr), GAD_ERR_NULL, "segment_pool: scale and shift come together");
+    GAD_REQUIRE(z_pitch % 4 == 0, GAD_ERR_SHAPE, "segment_pool: row pitch %d must be a multiple of 4", z_pitch);
+    if (G <= 0 || C <= 0) return GAD_OK;
+    gad_bn_fin bn;
+    memset(&bn, 0, sizeof(bn));
+    if (host_bn && host_bn->stat_sum) {
+        bn = *host_bn;
+        GAD_REQUIRE(bn.stat_sq && bn.gamma && bn.beta && bn.scale && bn.shift && bn.count >= 1.0, GAD_ERR_NULL,
+                    "segment_pool: incomplete gad_bn_fin");
+    }
+    int gx = gad_cdiv(G, 4);
+    if (gx > 2048) gx = 2048;
+#define LAUNCH_POOL(QPR, NQ)                                                                                      \
+    hipLaunchKernelGGL((segment_pool_kernel<QPR, NQ>), dim3(gx), dim3(256), 0, (hipStream_t)stream, z, z_pitch, scale, \
+                       shift, bn, grp_off, G, out, argmax)
+    switch (C) {
+        case 8: LAUNCH_POOL(2, 1); break;
+        case 16: LAUNCH_POOL(4, 1); break;
+        case 32: LAUNCH_POOL(8, 1); break;
+        case 64: LAUNCH_POOL(16, 1); break;
+        case 128: LAUNCH_POOL(32, 1); break;
+        case 256: LAUNCH_POOL(64, 1); break;
+        case 512: LAUNCH_POOL(64, 2); break;
+        case 1024: LAUNCH_POOL(64, 4); break;
+        default:
+            GAD_REQUIRE(false, GAD_ERR_SHAPE, "segment_pool: C=%d (supported: 8, 16, 32, 64, 128, 256, 512, 1024)", C);
+    }
+#undef LAUNCH_POOL
     GAD_CHECK_LAUNCH("segment_pool");
     return GAD_OK;
 }
@@ -162,7 +229,7 @@ extern "C" int gad_affine_act(const float* z, int z_pitch, int rows, int C, cons
 }
 
 // dbeta[c] += sum_g dout[g][c]*[y*>0],  dgamma[c] += sum_g dout[g][c]*[y*>0]*xhat*  (* = arg-max row)
-__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __restrict__ dout,
+__global__ __launch_bounds__(256) void pool_bwd_stats_kernel(float* __restrict__ dout,
                                                              const int32_t* __restrict__ argmax, int G, int C,
                                                              const float* __restrict__ z, int z_pitch,
                                                              const float* __restrict__ scale,
@@ -170,7 +237,7 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __rest
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ istd,
                                                              double* __restrict__ dbeta,
-                                                             double* __restrict__ dgamma, int stride) {
+                                                             double* __restrict__ dgamma, int stride, int mask) {
     const int cpb = C < 256 ? C : 256;          // channels per block (C is a multiple of 32)
     const int gl = 256 / cpb;                   // groups processed side by side
     const int c = blockIdx.x * cpb + threadIdx.x % cpb;
@@ -183,15 +250,17 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(const float* __rest
         const int r = argmax[(size_t)g * C + c];
         const float zp = z[(size_t)r * z_pitch + c];
         if (fmaf(zp, sc, sh) > 0.f) { sb += v; sg = fmaf(v, (zp - mu) * is, sg); }
+        else if (mask) dout[(size_t)g * C + c] = 0.f;
     }
     const int rep = blockIdx.y % GAD_STAT_REPLICAS;
     atomic_add_f64(dbeta + (size_t)rep * stride + c, (double)sb);
     atomic_add_f64(dgamma + (size_t)rep * stride + c, (double)sg);
 }
 
-extern "C" int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int G, int C, const float* z,
+extern "C" int gad_pool_bwd_stats(float* dout, const int32_t* argmax, int G, int C, const float* z,
                                   int z_pitch, const float* scale, const float* shift, const float* mean,
-                                  const float* istd, double* dbeta, double* dgamma, int stat_stride, void* stream) {
+                                  const float* istd, double* dbeta, double* dgamma, int stat_stride, int mask_in_place,
+                                  void* stream) {
     GAD_REQUIRE(dout && argmax && z && scale && shift && mean && istd && dbeta && dgamma, GAD_ERR_NULL,
                 "pool_bwd_stats: null pointer");
     GAD_REQUIRE(C % 32 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), GAD_ERR_SHAPE, "pool_bwd_stats: C=%d", C);
@@ -201,37 +270,30 @@ extern "C" int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int 
     if (gy > 512) gy = 512;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(C / cpb, gy), dim3(256), 0, (hipStream_t)stream, dout, argmax, G, C,
-                       z, z_pitch, scale, shift, mean, istd, dbeta, dgamma, stat_stride);
+                       z, z_pitch, scale, shift, mean, istd, dbeta, dgamma, stat_stride, mask_in_place);
     GAD_CHECK_LAUNCH("pool_bwd_stats");
     return GAD_OK;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const double* __restrict__ dbeta,
-                                                          const double* __restrict__ dgamma, int stride,
-                                                          const float* __restrict__ scale,
-                                                          const float* __restrict__ mean,
-                                                          const float* __restrict__ istd, int C, double count,
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(gad_bn_bwd b, const float* __restrict__ scale, int C,
                                                           float* __restrict__ P, float* __restrict__ Q,
-                                                          float* __restrict__ S, double* __restrict__ gg,
-                                                          double* __restrict__ gb) {
+                                                          float* __restrict__ S) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double db = 0.0, dg = 0.0;
-    for (int r = 0; r < GAD_STAT_REPLICAS; ++r) { db += dbeta[(size_t)r * stride + c]; dg += dgamma[(size_t)r * stride + c]; }
-    const double sc = scale[c], is = istd[c], mu = mean[c];
-    P[c] = (float)sc;
-    Q[c] = (float)(sc * (db - mu * is * dg) / count);
-    S[c] = (float)(sc * is * dg / count);
-    if (gg) gg[c] += dg;
-    if (gb) gb[c] += db;
+    float p, q, sv;
+    gad_bn_bwd_channel(b, scale, c, true, p, q, sv);
+    P[c] = p; Q[c] = q; S[c] = sv;
 }
 
 extern "C" int gad_bn_bwd_coef(const double* dbeta, const double* dgamma, int stat_stride, const float* scale, const float* mean,
                                const float* istd, int C, double count, float* coefP, float* coefQ, float* coefS,
                                double* gacc_gamma, double* gacc_beta, void* stream) {
     GAD_REQUIRE(dbeta && dgamma && scale && mean && istd && coefP && coefQ && coefS, GAD_ERR_NULL, "bn_bwd_coef: null pointer");
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, dbeta, dgamma, stat_stride, scale,
-                       mean, istd, C, count, coefP, coefQ, coefS, gacc_gamma, gacc_beta);
+    gad_bn_bwd b;
+    b.dbeta = dbeta; b.dgamma = dgamma; b.stat_stride = stat_stride; b.count = count; b.mean = mean; b.istd = istd;
+    b.gacc_gamma = gacc_gamma; b.gacc_beta = gacc_beta; b.accumulate = 1;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(gad_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, b, scale, C, coefP, coefQ,
+                       coefS);
     GAD_CHECK_LAUNCH("bn_bwd_coef");
     return GAD_OK;
 }

@@ -305,7 +305,10 @@ def _fwd_args(**kw):
     a.ones_col = -1
     a.grp_per_sample = 1
     for k, v in kw.items():
-        if k in ("zin_off", "w_off", "out_off", "n_out"):
+        if k == "in_bn":
+            if v is not None:
+                a.in_bn = v
+        elif k in ("zin_off", "w_off", "out_off", "n_out"):
             arr = getattr(a, k)
             for i, x in enumerate(v):
                 arr[i] = int(x)
@@ -317,8 +320,43 @@ def _fwd_args(**kw):
 def _dz(**kw):
     d = hip.DzSrc()
     for k, v in kw.items():
-        setattr(d, k, v)
+        if k == "bn":
+            if v is not None:
+                d.bn = v
+        else:
+            setattr(d, k, v)
     return d
+
+
+def bn_fin(enc, slot, m, count, update_running=True):
+    """gad_bn_fin of layer m in `slot`: its consumer finalises the BatchNorm in its own prologue (no launch between the
+    producing GEMM and the consumer); workgroup 0 of the consumer publishes scale / shift / mean / istd into the slot
+    and applies the running-statistics update"""
+    o, tot = enc.bn_off[m.bn_index], slot.tot
+    b = hip.BnFin()
+    b.stat_sum, b.stat_sq, b.stat_stride = _ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), 2 * tot
+    b.count = float(count)
+    b.gamma, b.beta = enc.flat.p_gamma(m), enc.flat.p_beta(m)
+    b.eps, b.momentum = BN_EPS, BN_MOMENTUM
+    if update_running:
+        b.running_mean, b.running_var = _ptr(enc.running_mean, o), _ptr(enc.running_var, o)
+    b.scale, b.shift = _ptr(slot.scale, o), _ptr(slot.shift, o)
+    b.mean, b.istd = _ptr(slot.mean, o), _ptr(slot.istd, o)
+    return b
+
+
+def bn_bwd(enc, slot, m, count, want_dw, accumulate):
+    """gad_bn_bwd of layer m: its dX / dW kernels form P, Q, S from the slot's (dbeta, dgamma) sums in their prologue;
+    `accumulate` marks the ONE consumer that also adds dgamma / dbeta to the gradient arena"""
+    o, tot = enc.bn_off[m.bn_index], slot.tot
+    b = hip.BnBwd()
+    b.dbeta, b.dgamma, b.stat_stride = _ptr(slot.bstats, o, 8), _ptr(slot.bstats, tot + o, 8), 2 * tot
+    b.count = float(count)
+    b.mean, b.istd = _ptr(slot.mean, o), _ptr(slot.istd, o)
+    if want_dw and accumulate:
+        b.gacc_gamma, b.gacc_beta = _ptr(enc.flat.gacc, m.g_off, 8), _ptr(enc.flat.gacc, m.b_off, 8)
+        b.accumulate = 1
+    return b
 
 
 TIMING = {"enabled": False, "tag": None, "events": []}     # bench.py: HIP-event bracket of one tagged launch
@@ -547,35 +585,46 @@ def plan_running_update(enc, slot):
     return plan
 
 
-def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True):
-    """SA1 -> SA2 -> SA3 -> FC.  The last BN+ReLU is left to the consumer (scale/shift of fc[1]).
+def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True, finalize_last=False):
+    """SA1 -> SA2 -> SA3 -> FC.  Train mode: no BatchNorm launch at all -- every layer's statistics are finalised in the
+    prologue of its consumer (the next GEMM, the segment pool; gad_bn_fin).  The LAST BatchNorm (fc[1]) is left to the
+    consumer as well: a head's first GEMM takes `bn_fin(enc, slot, enc.fc_mats[1], B, update_running)`;
+    finalize_last=True emits an explicit gad_bn_finalize instead (callers that read slot.scale / shift themselves).
     update_running=False: batch statistics only; the running-statistics momentum update is applied later by
     plan_running_update (for a pass that overlaps another pass of the same network on a second stream)."""
+    import ctypes as C
     geo = slot.geo
     plan = Plan()
     plan.zero(slot.stats)
     tot = slot.tot
+
+    def gemm(m, zout, count_prev, prev, s, l, tag):
+        o = enc.bn_off[m.bn_index]
+        kw = _layer_input(enc, slot, geo, s, l, action)
+        if train and prev is not None:
+            kw["in_bn"] = bn_fin(enc, slot, prev, count_prev, update_running)
+        a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(zout), zout_pitch=m.n_out,
+                      stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot, **kw)
+        plan.call_struct("gad_gemm_fwd", a)
+        plan.tag_last(tag)
+        if not train:
+            _finalize(plan, enc, slot, m, 0.0, False)
+
     for s in range(3):
         r = geo.rows[s]
         for l, m in enumerate(enc.sa_mats[s]):
-            o = enc.bn_off[m.bn_index]
-            a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(slot.Z[s][l]),
-                          zout_pitch=m.n_out, stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8),
-                          stat_stride=2 * tot, **_layer_input(enc, slot, geo, s, l, action))
-            plan.call_struct("gad_gemm_fwd", a)
-            plan.tag_last("fwd.sa%d.l%d" % (s + 1, l + 1))
-            _finalize(plan, enc, slot, m, geo.counts[s], train, update_running)
+            gemm(m, slot.Z[s][l], geo.counts[s], enc.sa_mats[s][l - 1] if l > 0 else None, s, l,
+                 "fwd.sa%d.l%d" % (s + 1, l + 1))
         m = enc.sa_mats[s][2]
+        b = bn_fin(enc, slot, m, geo.counts[s], update_running) if train else None
         plan.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, _bn_vec(slot, enc, m, "scale"),
-                  _bn_vec(slot, enc, m, "shift"), r["off"], r["G"], slot.F[s], slot.argmax[s])
+                  _bn_vec(slot, enc, m, "shift"), C.byref(b) if b is not None else None, r["off"], r["G"], slot.F[s],
+                  slot.argmax[s])
+        plan.tag_last("pool.sa%d" % (s + 1))
     for l, m in enumerate(enc.fc_mats):
-        o = enc.bn_off[m.bn_index]
-        a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(slot.Zfc[l]), zout_pitch=m.n_out,
-                      stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot,
-                      **_layer_input(enc, slot, geo, 3, l, action))
-        plan.call_struct("gad_gemm_fwd", a)
-        plan.tag_last("fwd.fc%d" % (l + 1))
-        _finalize(plan, enc, slot, m, float(slot.B), train, update_running)
+        gemm(m, slot.Zfc[l], float(slot.B), enc.fc_mats[0] if l > 0 else None, 3, l, "fwd.fc%d" % (l + 1))
+    if finalize_last and train:
+        _finalize(plan, enc, slot, enc.fc_mats[1], float(slot.B), True, update_running)
     return plan
 
 
@@ -584,20 +633,12 @@ def _coef_ptrs(slot, enc, m):
     return _ptr(slot.coef, o), _ptr(slot.coef, tot + o), _ptr(slot.coef, 2 * tot + o)
 
 
-def _bn_coef(plan, enc, slot, m, count, want_dw):
-    o, tot = enc.bn_off[m.bn_index], slot.tot
-    P, Q, S = _coef_ptrs(slot, enc, m)
-    gacc = enc.flat.gacc
-    plan.call("gad_bn_bwd_coef", _ptr(slot.bstats, o, 8), _ptr(slot.bstats, tot + o, 8), 2 * tot,
-              _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "mean"), _bn_vec(slot, enc, m, "istd"),
-              m.n_out, hip.Dbl(count), P, Q, S, _ptr(gacc, m.g_off, 8) if want_dw else None,
-              _ptr(gacc, m.b_off, 8) if want_dw else None)
-
-
 def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1, zero_scatter=True):
     # zero_scatter=False: the caller has cleared slot.dF[0], slot.dF[1] (and slot.daction) at the head of its plan
-    """Backward of plan_encoder_forward.  g_fc2 (B, 512) is dLoss/d(relu(bn(Zfc[1]))) as produced by
-    the consumer head's dX kernel, whose epilogue must also have filled this slot's bstats for fc[1].
+    """Backward of plan_encoder_forward.  g_fc2 (B, 512) is dLoss/d(relu(bn(Zfc[1]))) WITH the ReLU mask applied, as
+    produced by the consumer head's dX kernel (store_masked), whose epilogue must also have filled this slot's bstats
+    for fc[1].  No BatchNorm launch: every layer's backward coefficients P, Q, S are formed in the prologue of its
+    dX / dW kernels (gad_bn_bwd); every dX stores the next gradient already masked by the previous layer's ReLU.
     Weight gradients accumulate (f64) into enc.flat.gacc when want_dw; their GEMMs are forked onto side stream
     `dw_lane` (two backward passes that may run concurrently -- critic and actor -- get different lanes: each lane has
     its own split-K workspace and is stream-ordered)."""
@@ -611,12 +652,12 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         return dict(zprev=_ptr(zprev), zprev_pitch=pm.n_out, prev_scale=_bn_vec(slot, enc, pm, "scale"),
                     prev_shift=_bn_vec(slot, enc, pm, "shift"), prev_mean=_bn_vec(slot, enc, pm, "mean"),
                     prev_istd=_bn_vec(slot, enc, pm, "istd"), prev_dbeta=_ptr(slot.bstats, o, 8),
-                    prev_dgamma=_ptr(slot.bstats, tot + o, 8), stat_stride=2 * tot)
+                    prev_dgamma=_ptr(slot.bstats, tot + o, 8), stat_stride=2 * tot, store_masked=1)
 
-    def bn_dz(m, z, G=None, pooled=None, row_w=None):
-        P, Q, S = _coef_ptrs(slot, enc, m)
+    def bn_dz(m, z, count, accumulate, G=None, pooled=None, row_w=None):
         d = dict(z=_ptr(z), z_pitch=m.n_out, scale=_bn_vec(slot, enc, m, "scale"),
-                 shift=_bn_vec(slot, enc, m, "shift"), relu=1, coefP=P, coefQ=Q, coefS=S, row_w=row_w, c=m.n_out)
+                 shift=_bn_vec(slot, enc, m, "shift"), relu=1, premasked=1, row_w=row_w, c=m.n_out,
+                 bn=bn_bwd(enc, slot, m, count, want_dw, accumulate))
         if pooled is None:
             d.update(gmode=0, G=_ptr(G), g_pitch=m.n_out)
         else:
@@ -657,16 +698,19 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         plan.call_struct("gad_gemm_dw", a, side=lane)
         plan.tag_last("dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1))
 
+    def layer(s, l, m, z, count, has_dx, **src):
+        """(dz for the dW, dz for the dX) of one layer: the dX carries the arena accumulation of dgamma / dbeta when
+        there is one, else the dW does"""
+        d_dw = bn_dz(m, z, count, not has_dx, **src)
+        dw(s, l, d_dw, m, action)
+        return bn_dz(m, z, count, True, **src) if has_dx else None
+
     # ---- FC head ----
     fc1, fc2 = enc.fc_mats
-    _bn_coef(plan, enc, slot, fc2, float(B), want_dw)
-    d = bn_dz(fc2, slot.Zfc[1], G=g_fc2)
-    dw(3, 1, d, fc2, action)
+    d = layer(3, 1, fc2, slot.Zfc[1], float(B), True, G=g_fc2)
     dx(dict(n_rows=B), d, fc2, fc1.n_out, epilogue=0, gout=_ptr(slot.Gfc), gout_pitch=fc1.n_out,
        **prev_stats(fc1, slot.Zfc[0]))
-    _bn_coef(plan, enc, slot, fc1, float(B), want_dw)
-    d = bn_dz(fc1, slot.Zfc[0], G=slot.Gfc)
-    dw(3, 0, d, fc1, action)
+    d = layer(3, 0, fc1, slot.Zfc[0], float(B), True, G=slot.Gfc)
     dx(dict(n_rows=B), d, fc1, slot.F[2].shape[1], epilogue=0, gout=_ptr(slot.dF[2]), gout_pitch=slot.F[2].shape[1])
     # ---- SA3 -> SA1 ----
     for s in (2, 1, 0):
@@ -675,27 +719,24 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         m1, m2, m3 = enc.sa_mats[s]
         gbuf = slot.G[s]
         o3 = enc.bn_off[m3.bn_index]
+        cnt = geo.counts[s]
+        # dbeta / dgamma of the pooled layer; the pooled gradient is ReLU-masked in place for its consumers
         plan.call("gad_pool_bwd_stats", slot.dF[s], slot.argmax[s], r["G"], m3.n_out, slot.Z[s][2], m3.n_out,
                   _bn_vec(slot, enc, m3, "scale"), _bn_vec(slot, enc, m3, "shift"), _bn_vec(slot, enc, m3, "mean"),
-                  _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8), 2 * tot)
-        _bn_coef(plan, enc, slot, m3, geo.counts[s], want_dw)
-        d = bn_dz(m3, slot.Z[s][2], pooled=(slot.argmax[s], slot.dF[s], r["grp"]), row_w=_ptr(r["w"]))
-        dw(s, 2, d, m3, action)
+                  _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8), 2 * tot, 1)
+        d = layer(s, 2, m3, slot.Z[s][2], cnt, True, pooled=(slot.argmax[s], slot.dF[s], r["grp"]), row_w=_ptr(r["w"]))
         dx(rows_kw, d, m3, m2.n_out, epilogue=0, gout=_ptr(gbuf[0]), gout_pitch=m2.n_out, **prev_stats(m2, slot.Z[s][1]))
-        _bn_coef(plan, enc, slot, m2, geo.counts[s], want_dw)
-        d = bn_dz(m2, slot.Z[s][1], G=gbuf[0], row_w=_ptr(r["w"]))
-        dw(s, 1, d, m2, action)
+        d = layer(s, 1, m2, slot.Z[s][1], cnt, True, G=gbuf[0], row_w=_ptr(r["w"]))
         dx(rows_kw, d, m2, m1.n_out, epilogue=0, gout=_ptr(gbuf[1]), gout_pitch=m1.n_out, **prev_stats(m1, slot.Z[s][0]))
-        _bn_coef(plan, enc, slot, m1, geo.counts[s], want_dw)
-        d = bn_dz(m1, slot.Z[s][0], G=gbuf[1], row_w=_ptr(r["w"]))
-        dw(s, 0, d, m1, action)
+        has_dx = s > 0 or (want_daction and action is not None)
+        d = layer(s, 0, m1, slot.Z[s][0], cnt, has_dx, G=gbuf[1], row_w=_ptr(r["w"]))
         if s > 0:
             fc = slot.F[s - 1].shape[1]
             if zero_scatter:
                 plan.zero(slot.dF[s - 1])
             dx(rows_kw, d, m1, fc, epilogue=1, dfeat=_ptr(slot.dF[s - 1]), feat_c=fc, row_pt=_ptr(r["pt"]),
                row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
-        elif want_daction and action is not None:
+        elif has_dx:
             if zero_scatter:
                 plan.zero(slot.daction)
             dx(rows_kw, d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),

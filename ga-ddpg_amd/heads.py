@@ -65,13 +65,14 @@ class HeadSlot(object):
         self.g_feat = torch.empty(B, 512, **f32)
 
 
-def _feat_input(enc, eslot, time):
+def _feat_input(enc, eslot, time, bn=None):
     """heads' layer-1 input: [relu(bn(Zfc2)) (512), time, 1]; a plain feature tensor (runtime._FeatureSource:
-    `input_relu` 0, identity scale / shift) is taken as it is"""
+    `input_relu` 0, identity scale / shift) is taken as it is.  bn: engine.bn_fin(...) of the encoder's last BatchNorm
+    when this GEMM is its (first) consumer -- the statistics are then finalised in this kernel's prologue."""
     fc2 = enc.fc_mats[1]
     return dict(n_rows=eslot.B, mode=0, zin=_ptr(eslot.Zfc[1]), zin_pitch=fc2.n_out, c_in=fc2.n_out,
                 scale=_bn_vec(eslot, enc, fc2, "scale"), shift=_bn_vec(eslot, enc, fc2, "shift"),
-                relu=getattr(enc, "input_relu", 1), extra=_ptr(time), ones_col=fc2.n_out + 1)
+                relu=getattr(enc, "input_relu", 1), extra=_ptr(time), ones_col=fc2.n_out + 1, in_bn=bn)
 
 
 def _hidden_input(B, z, pitch, hidden, offs):
@@ -79,13 +80,13 @@ def _hidden_input(B, z, pitch, hidden, offs):
                 zin_off=offs)
 
 
-def plan_critic_forward(cr, hs, enc, eslot, time):
+def plan_critic_forward(cr, hs, enc, eslot, time, bn=None):
     plan = Plan()
     B, H, ng = hs.B, cr.hidden, cr.ng
     fl = cr.flat
     offs = [i * H for i in range(ng)]
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=fl.p_w(cr.l1[0]), Kp=cr.l1[0].Kp, n_out=[cr.width], zout=_ptr(hs.Z1),
-                                               zout_pitch=cr.width, **_feat_input(enc, eslot, time)))
+                                               zout_pitch=cr.width, **_feat_input(enc, eslot, time, bn)))
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=_ptr(fl.packed), Kp=cr.l2[0].Kp, n_groups=ng,
                                                w_off=[m.w_off for m in cr.l2], n_out=[H] * ng, out_off=offs,
                                                zout=_ptr(hs.Z2), zout_pitch=cr.width,
@@ -160,7 +161,8 @@ def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True, dw_lane=1):
     dx(d1, [0], [cat], fc2.n_out, hs.g_feat, [0], zprev=_ptr(eslot.Zfc[1]), zprev_pitch=fc2.n_out,
        prev_scale=_bn_vec(eslot, enc, fc2, "scale"), prev_shift=_bn_vec(eslot, enc, fc2, "shift"),
        prev_mean=_bn_vec(eslot, enc, fc2, "mean"), prev_istd=_bn_vec(eslot, enc, fc2, "istd"),
-       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8), stat_stride=2 * tot)
+       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8), stat_stride=2 * tot,
+       store_masked=1)          # g_feat carries the encoder's last ReLU mask (engine.plan_encoder_backward: premasked)
     return plan
 
 
@@ -174,14 +176,14 @@ class _Cat(object):
             assert b.w_off == a.w_off + a.n_out * a.Kp and a.Kp == b.Kp
 
 
-def plan_policy_forward(po, hs, enc, eslot, time, with_log_std=False):
+def plan_policy_forward(po, hs, enc, eslot, time, with_log_std=False, bn=None):
     """hs.out (B, 6 + extra) = [mean | extra]; with_log_std: (B, 6 + extra + 6) = [mean | extra | log_std] (the
     three output matrices are consecutive in the packed layout: one GEMM either way)"""
     plan = Plan()
     B, H = hs.B, po.hidden
     fl = po.flat
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=fl.p_w(po.l1), Kp=po.l1.Kp, n_out=[H], zout=_ptr(hs.Z1), zout_pitch=H,
-                                               **_feat_input(enc, eslot, time)))
+                                               **_feat_input(enc, eslot, time, bn)))
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=fl.p_w(po.l2), Kp=po.l2.Kp, n_out=[H], zout=_ptr(hs.Z2), zout_pitch=H,
                                                **_hidden_input(B, hs.Z1, H, H, [0])))
     cat = _Cat([po.mean, po.extra] + ([po.log_std] if with_log_std else []))
@@ -241,5 +243,6 @@ def plan_policy_backward(po, hs, enc, eslot, time, dw_lane=2):
     dx(d1, po.l1, fc2.n_out, hs.g_feat, zprev=_ptr(eslot.Zfc[1]), zprev_pitch=fc2.n_out,
        prev_scale=_bn_vec(eslot, enc, fc2, "scale"), prev_shift=_bn_vec(eslot, enc, fc2, "shift"),
        prev_mean=_bn_vec(eslot, enc, fc2, "mean"), prev_istd=_bn_vec(eslot, enc, fc2, "istd"),
-       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8), stat_stride=2 * tot)
+       prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8), stat_stride=2 * tot,
+       store_masked=1)          # g_feat carries the encoder's last ReLU mask (engine.plan_encoder_backward: premasked)
     return plan

@@ -14,6 +14,17 @@ STAT_REPLICAS = 8
 _i32, _f32, _f64, _vp = C.c_int32, C.c_float, C.c_double, C.c_void_p
 
 
+class BnFin(C.Structure):
+    _fields_ = [("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32), ("count", _f64), ("gamma", _vp), ("beta", _vp),
+                ("eps", _f32), ("momentum", _f32), ("running_mean", _vp), ("running_var", _vp), ("scale", _vp),
+                ("shift", _vp), ("mean", _vp), ("istd", _vp)]
+
+
+class BnBwd(C.Structure):
+    _fields_ = [("dbeta", _vp), ("dgamma", _vp), ("stat_stride", _i32), ("count", _f64), ("mean", _vp), ("istd", _vp),
+                ("gacc_gamma", _vp), ("gacc_beta", _vp), ("accumulate", _i32)]
+
+
 class GemmFwdArgs(C.Structure):
     _fields_ = [("n_rows_dev", _vp), ("n_rows", _i32), ("row_w", _vp), ("mode", _i32),
                 ("zin", _vp), ("zin_pitch", _i32), ("c_in", _i32), ("scale", _vp), ("shift", _vp),
@@ -24,14 +35,14 @@ class GemmFwdArgs(C.Structure):
                 ("n_groups", _i32), ("zin_off", _i32 * MAX_GROUPS), ("w_off", _i32 * MAX_GROUPS),
                 ("out_off", _i32 * MAX_GROUPS), ("n_out", _i32 * MAX_GROUPS),
                 ("W", _vp), ("Kp", _i32), ("zout", _vp), ("zout_pitch", _i32),
-                ("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32)]
+                ("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32), ("in_bn", BnFin)]
 
 
 class DzSrc(C.Structure):
     _fields_ = [("z", _vp), ("z_pitch", _i32), ("scale", _vp), ("shift", _vp), ("relu", _i32),
                 ("coefP", _vp), ("coefQ", _vp), ("coefS", _vp), ("row_w", _vp), ("gmode", _i32),
                 ("G", _vp), ("g_pitch", _i32), ("argmax", _vp), ("dout", _vp), ("row_grp", _vp),
-                ("c", _i32)]
+                ("c", _i32), ("bn", BnBwd), ("premasked", _i32)]
 
 
 class GemmDxArgs(C.Structure):
@@ -41,7 +52,7 @@ class GemmDxArgs(C.Structure):
                 ("k_valid", _i32), ("epilogue", _i32), ("gout", _vp), ("gout_pitch", _i32),
                 ("zprev", _vp), ("zprev_pitch", _i32), ("prev_scale", _vp), ("prev_shift", _vp),
                 ("prev_mean", _vp), ("prev_istd", _vp), ("prev_dbeta", _vp), ("prev_dgamma", _vp),
-                ("stat_stride", _i32), ("dfeat", _vp), ("feat_c", _i32), ("row_pt", _vp), ("row_grp", _vp),
+                ("stat_stride", _i32), ("store_masked", _i32), ("dfeat", _vp), ("feat_c", _i32), ("row_pt", _vp), ("row_grp", _vp),
                 ("daction", _vp), ("act_c", _i32), ("grp_per_sample", _i32)]
 
 

@@ -105,8 +105,12 @@ class FusedRuntime(object):
         enc, pol = self.enc, self.pol
         P = self.plans = {}
         P["geo"] = None
+        def last_bn(e, slot, update_running=True):
+            """the encoder's last BatchNorm is finalised by the head's first GEMM (its consumer)"""
+            return engine.bn_fin(e, slot, e.fc_mats[1], float(self.B), update_running)
         P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None)
-        P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
+        P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"],
+                                                    bn=last_bn(enc, self.slot_p)))
         bw = Plan()
         bw.zero_multi([pol.flat.gacc, enc.flat.gacc, self.slot_p.bstats, self.slot_p.dF[0], self.slot_p.dF[1]])
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
@@ -119,13 +123,14 @@ class FusedRuntime(object):
             return
         venc, cr = self.venc, self.cr
         c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"])
-        c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"], bn=last_bn(venc, self.slot_v)))
         t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
-        t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
+        t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"], bn=last_bn(enc, self.slot_t)))
         t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.pi_t, None)
         t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES)
         P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
-        t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
+        t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"],
+                                            bn=last_bn(venc, self.slot_t, not OVERLAP_PASSES)))
         P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
         cb = Plan()
         cb.zero_multi([cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1]])
@@ -137,7 +142,7 @@ class FusedRuntime(object):
         P["c_bwd"] = cb
         # actor-critic term: Q(s, pi(s)) through the freshly updated critic, gradient back to pi
         v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi)
-        v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
+        v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"], bn=last_bn(venc, self.slot_v)))
         P["v_fwd"] = v
         vb = Plan()
         vb.zero_multi([cr.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.slot_v.daction])
@@ -455,7 +460,7 @@ def feature_forward(fe, pc, value=False):
                               engine.SAConfig(32, 0.04, 128), dev)
         slot = engine.EncoderSlot(geo, encs[False], dev, with_backward=False)
         act = torch.zeros(B, 6, device=dev)
-        plans = {(v, t): engine.plan_encoder_forward(encs[v], slot, action=act if v else None, train=t)
+        plans = {(v, t): engine.plan_encoder_forward(encs[v], slot, action=act if v else None, train=t, finalize_last=True)
                  for v in (False, True) for t in (False, True)}
         return dict(geo=geo, slot=slot, action=act, out=torch.empty(B, 512, device=dev), plans=plans)
     rt = _module_runtime(fe, ("shape", B, NP), build_b)

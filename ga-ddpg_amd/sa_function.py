@@ -92,7 +92,6 @@ class _StageRun(object):
         self.bwd = None
         if with_backward:
             self.bstats = torch.zeros(hip.STAT_REPLICAS * 2 * tot, dtype=torch.float64, device=device)
-            self.coef = torch.empty(3 * tot, **f32)
             self.G = [torch.empty(cap * net.mats[l].n_out, **f32) for l in (1, 0)]
             self.dF = torch.zeros(G, c_out, **f32)
             self.dfeat = torch.zeros(B * N, net.c_pad, **f32)
@@ -122,25 +121,24 @@ class _StageRun(object):
             plan.call("gad_rows_from_ball_query", self.idx, self.cnt, B * M, M, N, S, r["off"], r["pt"], r["grp"],
                       r["w"], r["n"])
         plan.zero(self.stats)
+        import ctypes as C
         for l, m in enumerate(net.mats):
             o = net.bn_off[l]
+            kw = self._input(net, mod, l)
+            if train and l > 0:           # the previous layer's BatchNorm is finalised in this GEMM's prologue
+                kw["in_bn"] = engine.bn_fin(net, self, net.mats[l - 1], self.count)
             a = _fwd_args(W=net.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(self.Z[l]), zout_pitch=m.n_out,
                           stat_sum=_ptr(self.stats, o, 8) if train else None,
-                          stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot,
-                          **self._input(net, mod, l))
+                          stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot, **kw)
             plan.call_struct("gad_gemm_fwd", a)
-            if train:
-                plan.call("gad_bn_finalize", _ptr(self.stats, o, 8), _ptr(self.stats, tot + o, 8), 2 * tot,
-                          net.flat.p_gamma(m), net.flat.p_beta(m), m.n_out, hip.Dbl(self.count), BN_EPS, BN_MOMENTUM,
-                          _ptr(net.running_mean, o), _ptr(net.running_var, o), _ptr(self.scale, o), _ptr(self.shift, o),
-                          _ptr(self.mean, o), _ptr(self.istd, o))
-            else:
+            if not train:
                 plan.call("gad_bn_eval_affine", net.flat.p_gamma(m), net.flat.p_beta(m), _ptr(net.running_mean, o),
                           _ptr(net.running_var, o), m.n_out, BN_EPS, _ptr(self.scale, o), _ptr(self.shift, o))
         m = net.mats[2]
         o = net.bn_off[2]
-        plan.call("gad_segment_pool", self.Z[2], m.n_out, m.n_out, _ptr(self.scale, o), _ptr(self.shift, o), r["off"],
-                  r["G"], self.F, self.argmax)
+        b = engine.bn_fin(net, self, m, self.count) if train else None
+        plan.call("gad_segment_pool", self.Z[2], m.n_out, m.n_out, _ptr(self.scale, o), _ptr(self.shift, o),
+                  C.byref(b) if b is not None else None, r["off"], r["G"], self.F, self.argmax)
         return plan
 
     def _plan_backward(self, net):
@@ -156,19 +154,9 @@ class _StageRun(object):
         def vec(which, o):
             return _ptr(getattr(self, which), o)
 
-        def coef_ptrs(o):
-            return _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o)
-
-        def bn_coef(m, o):
-            P, Q, S = coef_ptrs(o)
-            plan.call("gad_bn_bwd_coef", _ptr(self.bstats, o, 8), _ptr(self.bstats, tot + o, 8), 2 * tot, vec("scale", o),
-                      vec("mean", o), vec("istd", o), m.n_out, hip.Dbl(self.count), P, Q, S, _ptr(fl.gacc, m.g_off, 8),
-                      _ptr(fl.gacc, m.b_off, 8))
-
-        def bn_dz(m, o, z, G=None, pooled=False):
-            P, Q, S = coef_ptrs(o)
-            d = dict(z=_ptr(z), z_pitch=m.n_out, scale=vec("scale", o), shift=vec("shift", o), relu=1, coefP=P, coefQ=Q,
-                     coefS=S, row_w=_ptr(r["w"]), c=m.n_out)
+        def bn_dz(m, o, z, accumulate, G=None, pooled=False):
+            d = dict(z=_ptr(z), z_pitch=m.n_out, scale=vec("scale", o), shift=vec("shift", o), relu=1, premasked=1,
+                     row_w=_ptr(r["w"]), c=m.n_out, bn=engine.bn_bwd(net, self, m, self.count, True, accumulate))
             if pooled:
                 d.update(gmode=1, argmax=_ptr(self.argmax), dout=_ptr(self.dF), row_grp=_ptr(r["grp"]))
             else:
@@ -201,24 +189,21 @@ class _StageRun(object):
         def prev_stats(pm, po, zprev):
             return dict(zprev=_ptr(zprev), zprev_pitch=pm.n_out, prev_scale=vec("scale", po), prev_shift=vec("shift", po),
                         prev_mean=vec("mean", po), prev_istd=vec("istd", po), prev_dbeta=_ptr(self.bstats, po, 8),
-                        prev_dgamma=_ptr(self.bstats, tot + po, 8), stat_stride=2 * tot)
+                        prev_dgamma=_ptr(self.bstats, tot + po, 8), stat_stride=2 * tot, store_masked=1)
 
+        # no BatchNorm launches: P, Q, S are formed in the dX / dW prologues (gad_bn_bwd), gradients travel ReLU-masked
         plan.call("gad_pool_bwd_stats", self.dF, self.argmax, r["G"], m3.n_out, self.Z[2], m3.n_out, vec("scale", o3),
                   vec("shift", o3), vec("mean", o3), vec("istd", o3), _ptr(self.bstats, o3, 8),
-                  _ptr(self.bstats, tot + o3, 8), 2 * tot)
-        bn_coef(m3, o3)
-        d = bn_dz(m3, o3, self.Z[2], pooled=True)
-        dw(2, d, m3)
-        dx(d, m3, m2.n_out, epilogue=0, gout=_ptr(self.G[0]), gout_pitch=m2.n_out, **prev_stats(m2, o2, self.Z[1]))
-        bn_coef(m2, o2)
-        d = bn_dz(m2, o2, self.Z[1], G=self.G[0])
-        dw(1, d, m2)
-        dx(d, m2, m1.n_out, epilogue=0, gout=_ptr(self.G[1]), gout_pitch=m1.n_out, **prev_stats(m1, o1, self.Z[0]))
-        bn_coef(m1, o1)
-        d = bn_dz(m1, o1, self.Z[0], G=self.G[1])
-        dw(0, d, m1)
-        dx(d, m1, net.c_pad, epilogue=1, dfeat=_ptr(self.dfeat), feat_c=net.c_pad, row_pt=_ptr(r["pt"]),
-           row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
+                  _ptr(self.bstats, tot + o3, 8), 2 * tot, 1)
+        dw(2, bn_dz(m3, o3, self.Z[2], False, pooled=True), m3)
+        dx(bn_dz(m3, o3, self.Z[2], True, pooled=True), m3, m2.n_out, epilogue=0, gout=_ptr(self.G[0]), gout_pitch=m2.n_out,
+           **prev_stats(m2, o2, self.Z[1]))
+        dw(1, bn_dz(m2, o2, self.Z[1], False, G=self.G[0]), m2)
+        dx(bn_dz(m2, o2, self.Z[1], True, G=self.G[0]), m2, m1.n_out, epilogue=0, gout=_ptr(self.G[1]), gout_pitch=m1.n_out,
+           **prev_stats(m1, o1, self.Z[0]))
+        dw(0, bn_dz(m1, o1, self.Z[0], False, G=self.G[1]), m1)
+        dx(bn_dz(m1, o1, self.Z[0], True, G=self.G[1]), m1, net.c_pad, epilogue=1, dfeat=_ptr(self.dfeat), feat_c=net.c_pad,
+           row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
         plan.call("gad_grad_from_arena", fl.gacc, fl.m2p, fl.n, self.grad, 0)
         return plan
 

@@ -114,6 +114,43 @@ int gad_rows_group_all(int G, int pts_per_group, int32_t* grp_off, int32_t* row_
  * same-address atomic contention); gad_bn_finalize / gad_bn_bwd_coef sum the replicas.               */
 #define GAD_STAT_REPLICAS 8
 
+/* Deferred train-mode BatchNorm finalisation: a layer's consumer (the next GEMM, the segment pool, a head's first
+ * GEMM) turns the f64 statistics of the producing GEMM into the per-channel affine in its own prologue -- every
+ * workgroup for the channels it needs, identical arithmetic to gad_bn_finalize -- instead of a single-workgroup launch
+ * on the dependency chain between the two kernels.  Workgroup 0 also publishes scale / shift / mean / istd (read by the
+ * backward pass, a later launch) and applies the running-statistics momentum update.  stat_sum == NULL: not used.   */
+typedef struct {
+    const double* stat_sum;    /* (GAD_STAT_REPLICAS, stat_stride) accumulators, this layer's first channel      */
+    const double* stat_sq;
+    int32_t stat_stride;
+    double count;              /* rows behind the statistics (padded duplicates included)                       */
+    const float* gamma;
+    const float* beta;
+    float eps;
+    float momentum;
+    float* running_mean;       /* nullable (pass overlapped with another pass of the same network)              */
+    float* running_var;
+    float* scale;              /* outputs, written by workgroup 0: scale = gamma*istd, shift = beta - mean*scale */
+    float* shift;
+    float* mean;               /* nullable */
+    float* istd;               /* nullable */
+} gad_bn_fin;
+
+/* Deferred BatchNorm-backward coefficients: the dX / dW kernels of a layer form P, Q, S (gad_bn_bwd_coef) from the
+ * f64 sums (dbeta, dgamma) in their prologue.  `accumulate`: workgroup 0 of THIS launch also adds dgamma / dbeta to
+ * the gradient arena (set on exactly one consumer per layer).  dbeta == NULL: not used (coefP/Q/S as given).     */
+typedef struct {
+    const double* dbeta;       /* (GAD_STAT_REPLICAS, stat_stride)                                              */
+    const double* dgamma;
+    int32_t stat_stride;
+    double count;
+    const float* mean;         /* saved by the forward pass                                                     */
+    const float* istd;
+    double* gacc_gamma;        /* nullable                                                                      */
+    double* gacc_beta;
+    int32_t accumulate;
+} gad_bn_bwd;
+
 typedef struct {
     /* rows */
     const int32_t* n_rows_dev; /* device scalar with the live row count, or NULL -> n_rows       */
@@ -156,6 +193,8 @@ typedef struct {
     double* stat_sum;          /* per output channel sum_r w*z and sum_r w*z^2 (f64 atomics),    */
     double* stat_sq;           /*   NULL -> no statistics                                        */
     int32_t stat_stride;       /* elements between the GAD_STAT_REPLICAS replicas of the sums     */
+    gad_bn_fin in_bn;          /* ACT input: finalise the input layer's BatchNorm here (scale/shift above are then
+                                * ignored; in_bn.scale / .shift receive the affine).  One group only.          */
 } gad_gemm_fwd_args;
 
 int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);
@@ -182,6 +221,7 @@ int gad_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 /* segment max-pool over each group's rows of act(scale*z+shift): out (G,C) point-major,
  * argmax (G,C) = global row index of the first maximum.                                          */
 int gad_segment_pool(const float* z, int z_pitch, int C, const float* scale, const float* shift,
+                     const gad_bn_fin* host_bn /*nullable: finalise the layer's BatchNorm in the prologue*/,
                      const int32_t* grp_off, int G, float* out, int32_t* argmax, void* stream);
 
 /* apply act(scale*z+shift) elementwise -> out (rows,C) (used at API boundaries only)            */
@@ -206,13 +246,18 @@ typedef struct {
     const float* dout;         /* pooled: (groups, C)                                            */
     const int32_t* row_grp;    /* pooled: (rows)                                                 */
     int32_t c;                 /* channels of this layer (n_out)                                 */
+    gad_bn_bwd bn;             /* deferred coefficients (coefP/Q/S ignored when bn.dbeta != NULL) */
+    int32_t premasked;         /* the ReLU mask is already applied to G / dout (dX epilogue with store_masked,
+                                * gad_pool_bwd_stats with mask_in_place): `relu`, scale and shift are not needed   */
 } gad_dz_src;
 
 /* pooled-gradient statistics for the BN that feeds a segment pool: dbeta/dgamma f64 sums        */
-int gad_pool_bwd_stats(const float* dout, const int32_t* argmax, int G, int C, const float* z,
+/* mask_in_place != 0: dout[g][c] is also overwritten with its ReLU-masked value (0 where the arg-max row's
+ * activation is not positive), so that the layer's dX / dW can take it as `premasked`.             */
+int gad_pool_bwd_stats(float* dout, const int32_t* argmax, int G, int C, const float* z,
                        int z_pitch, const float* scale, const float* shift, const float* mean,
                        const float* istd, double* dbeta, double* dgamma, int stat_stride,
-                       void* stream);
+                       int mask_in_place, void* stream);
 
 /* BN backward coefficients from (dbeta,dgamma): P,Q,S above; also accumulates dgamma/dbeta into
  * the f64 gradient arena slots gacc_gamma/gacc_beta (nullable).                                 */
@@ -242,6 +287,8 @@ typedef struct {
     const float* zprev; int32_t zprev_pitch;
     const float* prev_scale; const float* prev_shift; const float* prev_mean; const float* prev_istd;
     double* prev_dbeta; double* prev_dgamma; int32_t stat_stride;
+    int32_t store_masked;            /* with prev statistics: gout receives the ReLU-masked gradient (dY where the previous
+                                      * layer's activation is positive, else 0) -> its consumer's dz is `premasked`    */
     /* epilogue 1: gather-layer scatter (packed column order): columns [0,feat_c) atomically added to
      * dfeat[row_pt], columns [feat_c+3, feat_c+3+act_c) to daction[row_grp/grp_per_sample] (f64:
      * the per-sample action gradient is a sum of many cancelling terms)                            */

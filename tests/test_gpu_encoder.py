@@ -35,7 +35,7 @@ def _geometry(B):
 
 def _run_encoder(enc, slot, action, probe, want_daction):
     from ga_ddpg_amd import engine, hip
-    engine.plan_encoder_forward(enc, slot, action=action).run()
+    engine.plan_encoder_forward(enc, slot, action=action, finalize_last=True).run()   # no head here: finalise fc[1] explicitly
     fc2 = enc.fc_mats[1]
     o = enc.bn_off[fc2.bn_index]
     sc, sh = slot.scale[o:o + 512], slot.shift[o:o + 512]
@@ -48,7 +48,9 @@ def _run_encoder(enc, slot, action, probe, want_daction):
     slot.bstats[o:o + 512] = (probe * mask).double().sum(0)
     slot.bstats[slot.tot + o:slot.tot + o + 512] = (probe * mask * xhat).double().sum(0)
     enc.flat.gacc.zero_()
-    engine.plan_encoder_backward(enc, slot, probe, action=action, want_dw=True, want_daction=want_daction).run()
+    # ... and hands over the gradient with the last ReLU's mask applied (store_masked)
+    masked = (probe * mask).contiguous()
+    engine.plan_encoder_backward(enc, slot, masked, action=action, want_dw=True, want_daction=want_daction).run()
     hip.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
     torch.cuda.synchronize()
     return z
@@ -199,8 +201,9 @@ def test_heads_forward_backward_vs_oracle():
         assert n == n2
         assert_close(p.grad.cpu().numpy(), p2.grad.numpy(), 2e-4, 2e-6, "critic grad " + n)
     # dLoss/dfeature: only where the feature is > 0 (the heads' ReLU mask on relu(bn(z)) input)
+    # (handed to the encoder backward with that mask applied: store_masked)
     gf = hs_c.g_feat.cpu().numpy()
-    assert_close(gf, f.grad.numpy() , 2e-4, 2e-6, "critic dfeature")
+    assert_close(gf, f.grad.numpy() * (feat > 0).numpy(), 2e-4, 2e-6, "critic dfeature")
     # fc[1] BN-backward sums accumulated by the dX epilogue: dbeta = sum(g*mask), dgamma = sum(g*mask*xhat)
     mask = (feat > 0).numpy()
     bs = slot.bstats.view(-1, 2, slot.tot).sum(0).cpu().numpy()      # sum the accumulator replicas
@@ -239,7 +242,7 @@ def test_heads_forward_backward_vs_oracle():
             assert float(p.grad.abs().max()) == 0.0, n
             continue
         assert_close(p.grad.cpu().numpy(), p2.grad.numpy(), 2e-4, 2e-6, "policy grad " + n)
-    assert_close(hs_p.g_feat.cpu().numpy(), f2.grad.numpy(), 2e-4, 2e-6, "policy dfeature")
+    assert_close(hs_p.g_feat.cpu().numpy(), f2.grad.numpy() * (feat > 0).numpy(), 2e-4, 2e-6, "policy dfeature")
 
     # ---- actor-critic term: -ratio * mean(min(q1,q2)) over non (expert & return>0) rows
     q1d, q2d = q1.detach().squeeze(), q2.detach().squeeze()
