@@ -16,6 +16,14 @@ from . import hip
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
+# Deferred BatchNorm (include/gaddpg.h gad_bn_fin / gad_bn_bwd): finalise a layer's statistics / backward coefficients in
+# the prologue of the consuming kernels instead of a single-workgroup launch between producer and consumer.  Built,
+# parity-green and MEASURED SLOWER on MI355X (276 -> 223 steps/s, profiles/README.md round 2): every consumer workgroup
+# re-reads the 8 x 2 x C f64 accumulators -- lines that the producer's device-scope atomics left outside the XCD L2s --
+# so ~900 workgroups hammer the same few hundred lines through the fabric; the 77 launches it removes cost less.
+# Default off; GAD_DEFER_BN=1 switches the plans over (both paths satisfy the same tests).
+import os as _os
+DEFER_BN = _os.environ.get("GAD_DEFER_BN", "0") == "1"
 
 
 def round8(k):
@@ -590,6 +598,8 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     prologue of its consumer (the next GEMM, the segment pool; gad_bn_fin).  The LAST BatchNorm (fc[1]) is left to the
     consumer as well: a head's first GEMM takes `bn_fin(enc, slot, enc.fc_mats[1], B, update_running)`;
     finalize_last=True emits an explicit gad_bn_finalize instead (callers that read slot.scale / shift themselves).
+    That is the DEFER_BN schedule; by default (DEFER_BN off, see the note at the top) every GEMM is followed by its
+    gad_bn_finalize launch and the consumers read the published scale / shift.
     update_running=False: batch statistics only; the running-statistics momentum update is applied later by
     plan_running_update (for a pass that overlaps another pass of the same network on a second stream)."""
     import ctypes as C
@@ -601,7 +611,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     def gemm(m, zout, count_prev, prev, s, l, tag):
         o = enc.bn_off[m.bn_index]
         kw = _layer_input(enc, slot, geo, s, l, action)
-        if train and prev is not None:
+        if train and prev is not None and DEFER_BN:
             kw["in_bn"] = bn_fin(enc, slot, prev, count_prev, update_running)
         a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(zout), zout_pitch=m.n_out,
                       stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot, **kw)
@@ -609,21 +619,26 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
         plan.tag_last(tag)
         if not train:
             _finalize(plan, enc, slot, m, 0.0, False)
+        elif not DEFER_BN:
+            _finalize(plan, enc, slot, m, count_self[0], True, update_running)
 
+    count_self = [0.0]
     for s in range(3):
+        count_self[0] = geo.counts[s]
         r = geo.rows[s]
         for l, m in enumerate(enc.sa_mats[s]):
             gemm(m, slot.Z[s][l], geo.counts[s], enc.sa_mats[s][l - 1] if l > 0 else None, s, l,
                  "fwd.sa%d.l%d" % (s + 1, l + 1))
         m = enc.sa_mats[s][2]
-        b = bn_fin(enc, slot, m, geo.counts[s], update_running) if train else None
+        b = bn_fin(enc, slot, m, geo.counts[s], update_running) if (train and DEFER_BN) else None
         plan.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, _bn_vec(slot, enc, m, "scale"),
                   _bn_vec(slot, enc, m, "shift"), C.byref(b) if b is not None else None, r["off"], r["G"], slot.F[s],
                   slot.argmax[s])
         plan.tag_last("pool.sa%d" % (s + 1))
+    count_self[0] = float(slot.B)
     for l, m in enumerate(enc.fc_mats):
         gemm(m, slot.Zfc[l], float(slot.B), enc.fc_mats[0] if l > 0 else None, 3, l, "fwd.fc%d" % (l + 1))
-    if finalize_last and train:
+    if finalize_last and train and DEFER_BN:
         _finalize(plan, enc, slot, enc.fc_mats[1], float(slot.B), True, update_running)
     return plan
 
@@ -631,6 +646,16 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
 def _coef_ptrs(slot, enc, m):
     o, tot = enc.bn_off[m.bn_index], slot.tot
     return _ptr(slot.coef, o), _ptr(slot.coef, tot + o), _ptr(slot.coef, 2 * tot + o)
+
+
+def _bn_coef(plan, enc, slot, m, count, want_dw):
+    o, tot = enc.bn_off[m.bn_index], slot.tot
+    P, Q, S = _coef_ptrs(slot, enc, m)
+    gacc = enc.flat.gacc
+    plan.call("gad_bn_bwd_coef", _ptr(slot.bstats, o, 8), _ptr(slot.bstats, tot + o, 8), 2 * tot,
+              _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "mean"), _bn_vec(slot, enc, m, "istd"),
+              m.n_out, hip.Dbl(count), P, Q, S, _ptr(gacc, m.g_off, 8) if want_dw else None,
+              _ptr(gacc, m.b_off, 8) if want_dw else None)
 
 
 def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1, zero_scatter=True):
@@ -656,8 +681,11 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
 
     def bn_dz(m, z, count, accumulate, G=None, pooled=None, row_w=None):
         d = dict(z=_ptr(z), z_pitch=m.n_out, scale=_bn_vec(slot, enc, m, "scale"),
-                 shift=_bn_vec(slot, enc, m, "shift"), relu=1, premasked=1, row_w=row_w, c=m.n_out,
-                 bn=bn_bwd(enc, slot, m, count, want_dw, accumulate))
+                 shift=_bn_vec(slot, enc, m, "shift"), relu=1, premasked=1, row_w=row_w, c=m.n_out)
+        if DEFER_BN:
+            d["bn"] = bn_bwd(enc, slot, m, count, want_dw, accumulate)
+        else:
+            d["coefP"], d["coefQ"], d["coefS"] = _coef_ptrs(slot, enc, m)
         if pooled is None:
             d.update(gmode=0, G=_ptr(G), g_pitch=m.n_out)
         else:
@@ -701,6 +729,8 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     def layer(s, l, m, z, count, has_dx, **src):
         """(dz for the dW, dz for the dX) of one layer: the dX carries the arena accumulation of dgamma / dbeta when
         there is one, else the dW does"""
+        if not DEFER_BN:
+            _bn_coef(plan, enc, slot, m, count, want_dw)
         d_dw = bn_dz(m, z, count, not has_dx, **src)
         dw(s, l, d_dw, m, action)
         return bn_dz(m, z, count, True, **src) if has_dx else None

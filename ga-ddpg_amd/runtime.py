@@ -106,9 +106,10 @@ class FusedRuntime(object):
         P = self.plans = {}
         P["geo"] = None
         def last_bn(e, slot, update_running=True):
-            """the encoder's last BatchNorm is finalised by the head's first GEMM (its consumer)"""
-            return engine.bn_fin(e, slot, e.fc_mats[1], float(self.B), update_running)
-        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None)
+            """engine.DEFER_BN: the encoder's last BatchNorm is finalised by the head's first GEMM (its consumer)"""
+            return engine.bn_fin(e, slot, e.fc_mats[1], float(self.B), update_running) if engine.DEFER_BN else None
+        fl = not engine.DEFER_BN                                   # explicit gad_bn_finalize for fc[1] otherwise
+        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None, finalize_last=fl)
         P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"],
                                                     bn=last_bn(enc, self.slot_p)))
         bw = Plan()
@@ -122,12 +123,13 @@ class FusedRuntime(object):
         if not self.has_critic:
             return
         venc, cr = self.venc, self.cr
-        c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"])
+        c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"], finalize_last=fl)
         c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"], bn=last_bn(venc, self.slot_v)))
-        t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
+        t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None, finalize_last=fl)
         t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"], bn=last_bn(enc, self.slot_t)))
         t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.pi_t, None)
-        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES)
+        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES,
+                                         finalize_last=fl)
         P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"],
                                             bn=last_bn(venc, self.slot_t, not OVERLAP_PASSES)))
@@ -141,7 +143,7 @@ class FusedRuntime(object):
         cb.call("gad_grad_from_arena", venc.flat.gacc, venc.flat.m2p, venc.flat.n, venc.flat.grad, 0)
         P["c_bwd"] = cb
         # actor-critic term: Q(s, pi(s)) through the freshly updated critic, gradient back to pi
-        v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi)
+        v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi, finalize_last=fl)
         v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"], bn=last_bn(venc, self.slot_v)))
         P["v_fwd"] = v
         vb = Plan()

@@ -92,6 +92,7 @@ class _StageRun(object):
         self.bwd = None
         if with_backward:
             self.bstats = torch.zeros(hip.STAT_REPLICAS * 2 * tot, dtype=torch.float64, device=device)
+            self.coef = torch.empty(3 * tot, **f32)
             self.G = [torch.empty(cap * net.mats[l].n_out, **f32) for l in (1, 0)]
             self.dF = torch.zeros(G, c_out, **f32)
             self.dfeat = torch.zeros(B * N, net.c_pad, **f32)
@@ -125,18 +126,23 @@ class _StageRun(object):
         for l, m in enumerate(net.mats):
             o = net.bn_off[l]
             kw = self._input(net, mod, l)
-            if train and l > 0:           # the previous layer's BatchNorm is finalised in this GEMM's prologue
+            if train and l > 0 and engine.DEFER_BN:      # the previous layer's BatchNorm finalised in this GEMM's prologue
                 kw["in_bn"] = engine.bn_fin(net, self, net.mats[l - 1], self.count)
             a = _fwd_args(W=net.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(self.Z[l]), zout_pitch=m.n_out,
                           stat_sum=_ptr(self.stats, o, 8) if train else None,
                           stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot, **kw)
             plan.call_struct("gad_gemm_fwd", a)
+            if train and not engine.DEFER_BN:
+                plan.call("gad_bn_finalize", _ptr(self.stats, o, 8), _ptr(self.stats, tot + o, 8), 2 * tot,
+                          net.flat.p_gamma(m), net.flat.p_beta(m), m.n_out, hip.Dbl(self.count), BN_EPS, BN_MOMENTUM,
+                          _ptr(net.running_mean, o), _ptr(net.running_var, o), _ptr(self.scale, o), _ptr(self.shift, o),
+                          _ptr(self.mean, o), _ptr(self.istd, o))
             if not train:
                 plan.call("gad_bn_eval_affine", net.flat.p_gamma(m), net.flat.p_beta(m), _ptr(net.running_mean, o),
                           _ptr(net.running_var, o), m.n_out, BN_EPS, _ptr(self.scale, o), _ptr(self.shift, o))
         m = net.mats[2]
         o = net.bn_off[2]
-        b = engine.bn_fin(net, self, m, self.count) if train else None
+        b = engine.bn_fin(net, self, m, self.count) if (train and engine.DEFER_BN) else None
         plan.call("gad_segment_pool", self.Z[2], m.n_out, m.n_out, _ptr(self.scale, o), _ptr(self.shift, o),
                   C.byref(b) if b is not None else None, r["off"], r["G"], self.F, self.argmax)
         return plan
@@ -156,7 +162,16 @@ class _StageRun(object):
 
         def bn_dz(m, o, z, accumulate, G=None, pooled=False):
             d = dict(z=_ptr(z), z_pitch=m.n_out, scale=vec("scale", o), shift=vec("shift", o), relu=1, premasked=1,
-                     row_w=_ptr(r["w"]), c=m.n_out, bn=engine.bn_bwd(net, self, m, self.count, True, accumulate))
+                     row_w=_ptr(r["w"]), c=m.n_out)
+            if engine.DEFER_BN:
+                d["bn"] = engine.bn_bwd(net, self, m, self.count, True, accumulate)
+            else:
+                if not accumulate:            # first use of the layer's coefficients (the dW precedes the dX below)
+                    plan.call("gad_bn_bwd_coef", _ptr(self.bstats, o, 8), _ptr(self.bstats, tot + o, 8), 2 * tot,
+                              vec("scale", o), vec("mean", o), vec("istd", o), m.n_out, hip.Dbl(self.count),
+                              _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o),
+                              _ptr(fl.gacc, m.g_off, 8), _ptr(fl.gacc, m.b_off, 8))
+                d["coefP"], d["coefQ"], d["coefS"] = _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o)
             if pooled:
                 d.update(gmode=1, argmax=_ptr(self.argmax), dout=_ptr(self.dF), row_grp=_ptr(r["grp"]))
             else:
