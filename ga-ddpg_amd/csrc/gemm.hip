@@ -795,18 +795,206 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     }
 }
 
+static int g_opt_dx_slab = 1;
 static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// slab forward for the MID-SIZE layers (SA2 / SA3: 8e3 - 3e4 de-duplicated rows, K 128 - 264, 128 - 512 outputs).
+// The 64x64 tile kernel runs these at 0.2 - 0.35 of the FP32-MFMA peak: every workgroup lives for 4 - 8 K-tiles, so
+// its prologue (index / vector staging, first loads), its 2 barriers per K-tile and its epilogue never overlap anything,
+// and each operand element staged through LDS feeds ONE MFMA per wavefront (9 - 12 vector instructions per MFMA).
+// Here the streaming structure of the SA1 kernel is kept for any K: a workgroup owns a slice of 32*TN output columns
+// whose weights stay in LDS ([n][Kp+4], conflict-free ds_read_b128) for its whole life, every wavefront walks 32-row
+// slabs and feeds the MFMA A operand straight from 16-byte global loads (k = 8j+4h+i order), K is consumed in chunks
+// of 64 with the next chunk (or the next slab's first chunk) in flight during the current chunk's 32*TN MFMAs -- no
+// barrier after the prologue, ~2 vector instructions per MFMA.  Grid = (row groups) x (column slices) ~ one workgroup
+// per CU; the X rows a slab needs are re-read once per column slice (L2).
+// ------------------------------------------------------------------------------------------------
+template <int TN, int XM>
+__global__ __launch_bounds__(512, 2) void gemm_fwd_slab_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                                int n_rows_static, const float* __restrict__ row_w,
+                                                                const float* __restrict__ W, int Kp, int n_out,
+                                                                float* __restrict__ zout, int zout_pitch,
+                                                                double* __restrict__ stat_sum,
+                                                                double* __restrict__ stat_sq, int stat_stride) {
+    constexpr int NO = 32 * TN, CH = 8;
+    extern __shared__ __attribute__((aligned(16))) float slab_smem[];
+    const int PW = Kp + 4;
+    float* Ws = slab_smem;                               // [NO][PW]
+    float* sv = Ws + NO * PW;                            // [Kp]
+    float* tv = sv + Kp;                                 // [Kp]
+    float* red = tv + Kp;                                // [2 * 8 * NO]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    const int n0 = blockIdx.y * NO;
+    {   // this slice's weight rows -> LDS
+        const int upr = Kp >> 2;
+        for (int u = tid; u < NO * upr; u += 512) {
+            const int n = u / upr, c = (u - n * upr) << 2;
+            *reinterpret_cast<float4*>(Ws + n * PW + c) = ldg4(W + (size_t)min(n0 + n, n_out - 1) * Kp + c);
+        }
+    }
+    if (XM == 0) stage_affine<512>(sv, tv, x, 0, Kp, blockIdx.x == 0 && blockIdx.y == 0);
+    __syncthreads();
+
+    const int n_slabs = (n_rows + 31) >> 5;
+    const int stride = gridDim.x * 8;
+    int slab = wave * gridDim.x + blockIdx.x;            // wave-uniform; dealt wave-major like the SA1 kernel
+    const int nj = Kp >> 3, nch = (nj + CH - 1) / CH;
+    const __amdgpu_buffer_rsrc_t zrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(zout, 0, n_rows * zout_pitch * 4, 0x00020000);
+    const int zlane = (4 * half * zout_pitch + n0 + l31) * 4;
+    const int pitch4 = zout_pitch * 4;
+
+    f32x2 csum[TN], csq[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { csum[t] = f32x2{0.f, 0.f}; csq[t] = f32x2{0.f, 0.f}; }
+
+    // one 8-wide k group of this lane's row: the 16 bytes [8j+4h, 8j+4h+4) of the layer input
+    auto load_group = [&](int r, int pt, int grp, int j) -> float4 {
+        const int c = 8 * j + 4 * half;
+        if (XM == 0) return ldg4(x.zin + (size_t)r * x.zin_pitch + c);
+        if (8 * j < x.feat_c) return ldg4(x.feat + (size_t)pt * x.feat_c + c);            // (feat_c % 8 == 0: wave-uniform)
+        float4 o = f4zero();
+        if (c == x.feat_c) {                                                               // [x - cx, y - cy, z - cz, 0]
+            const float* p = x.src_xyz + (size_t)pt * 3;
+            o.x = p[0]; o.y = p[1]; o.z = p[2];
+            if (x.ctr_xyz) {
+                const float* cp = x.ctr_xyz + (size_t)grp * 3;
+                o.x = __fsub_rn(o.x, cp[0]); o.y = __fsub_rn(o.y, cp[1]); o.z = __fsub_rn(o.z, cp[2]);
+            }
+        }
+        return o;
+    };
+    auto load_chunk = [&](float4 (&dst)[CH], int r, int pt, int grp, int c) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int j = min(c * CH + u, nj - 1);       // clamped; groups past nj are skipped at the MFMA
+            dst[u] = load_group(r, pt, grp, j);
+        }
+    };
+    auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+    int r_cur = row_of(slab);
+    int pt_cur = XM == 1 ? x.row_pt[r_cur] : 0, grp_cur = (XM == 1 && x.ctr_xyz) ? x.row_grp[r_cur] : 0;
+    float4 ra[CH], rn[CH];
+    load_chunk(ra, r_cur, pt_cur, grp_cur, 0);
+    for (; slab < n_slabs; slab += stride) {
+        const int r_nxt = row_of(slab + stride);
+        const int pt_nxt = XM == 1 ? x.row_pt[r_nxt] : 0, grp_nxt = (XM == 1 && x.ctr_xyz) ? x.row_grp[r_nxt] : 0;
+        float4 w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r0 = slab * 32 + 8 * q + 4 * half;
+            w4[q] = row_w ? ldg4(row_w + (r0 + 3 < n_rows_static ? r0 : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
+        }
+        if (slab * 32 + 32 > n_rows) {                   // ragged last slab (wave-uniform): zero the missing rows' weights
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float* wq = &w4[q].x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) wq[e] = (slab * 32 + 8 * q + 4 * half + e < n_rows) ? wq[e] : 0.f;
+            }
+        }
+        f32x16 acc[TN];
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        for (int c = 0; c < nch; ++c) {
+            if (c + 1 < nch) load_chunk(rn, r_cur, pt_cur, grp_cur, c + 1);
+            else load_chunk(rn, r_nxt, pt_nxt, grp_nxt, 0);
+            __asm__ volatile("" ::: "memory");           // keep the LDS reads of W inside the loop (registers)
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = c * CH + u;
+                if (j < nj) {                            // wave-uniform
+                    float4 a4 = ra[u];
+                    if (XM == 0) {
+                        const float4 s4 = *reinterpret_cast<const float4*>(sv + 8 * j + 4 * half);
+                        const float4 t4 = *reinterpret_cast<const float4*>(tv + 8 * j + 4 * half);
+                        a4 = make_float4(__builtin_fmaxf(fmaf(a4.x, s4.x, t4.x), 0.f), __builtin_fmaxf(fmaf(a4.y, s4.y, t4.y), 0.f),
+                                         __builtin_fmaxf(fmaf(a4.z, s4.z, t4.z), 0.f), __builtin_fmaxf(fmaf(a4.w, s4.w, t4.w), 0.f));
+                    }
+                    float4 b4[TN];
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) b4[t] = *reinterpret_cast<const float4*>(Ws + (t * 32 + l31) * PW + 8 * j + 4 * half);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) ra[u] = rn[u];
+        }
+        // epilogue: raw layer output (buffer stores: rows past n_rows fall outside num_records) + weighted statistics
+        const int zrow = slab * 32 * pitch4;
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+            const int rb = ((v & 3) + 8 * (v >> 2)) * pitch4;
+            const f32x2 wr = f32x2{(&w4[v >> 2].x)[v & 3], (&w4[v >> 2].x)[(v & 3) + 1]};
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const f32x2 zv = f32x2{acc[t][v], acc[t][v + 1]};
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + pitch4, 0);
+                const f32x2 wz = wr * zv;
+                csum[t] += wz;
+                csq[t] += wz * zv;
+            }
+        }
+        r_cur = r_nxt; pt_cur = pt_nxt; grp_cur = grp_nxt;
+    }
+    if (stat_sum) {
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            const float c0 = csum[t].x + csum[t].y, c1 = csq[t].x + csq[t].y;
+            const float s0 = c0 + __shfl_xor(c0, 32, 64);
+            const float s1 = c1 + __shfl_xor(c1, 32, 64);
+            if (lane < 32) { red[wave * NO + t * 32 + lane] = s0; red[(8 + wave) * NO + t * 32 + lane] = s1; }
+        }
+        __syncthreads();
+        if (tid < NO) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s0 += red[w * NO + tid]; s1 += red[(8 + w) * NO + tid]; }
+            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+            atomic_add_f64(stat_sum + (size_t)rep * stat_stride + n0 + tid, (double)s0);
+            atomic_add_f64(stat_sq + (size_t)rep * stat_stride + n0 + tid, (double)s1);
+        }
+    }
+}
+
+static int g_opt_fwd_slab = 1;
+// the slab kernel covers: one group, K = the channel count itself (no bias / extra column), outputs a multiple of 64
+static bool fwd_slabable(const gad_gemm_fwd_args& a) {
+    if (!g_opt_fwd_slab || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
+    if (a.n_rows < 2048 || a.n_out[0] % 64 != 0 || a.n_out[0] < 64 || a.Kp > 520) return false;
+    if ((long long)a.n_rows * a.zout_pitch * 4 >= (1ll << 31)) return false;            // buffer-descriptor byte offsets
+    if (a.mode == 0)
+        return a.Kp == a.c_in && a.c_in % 8 == 0 && a.ones_col < 0 && !a.extra && ((a.scale && a.shift) || a.in_bn.stat_sum) && a.relu;
+    return a.feat_c % 8 == 0 && a.act_c == 0 && a.Kp == ((a.feat_c + 3 + 7) & ~7);
 }
 
 static int g_opt_fwd_stream = 1;
 extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
+    if (!strcmp(name, "fwd_slab")) { g_opt_fwd_slab = value; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
+    if (!strcmp(name, "dx_slab")) { g_opt_dx_slab = value; return GAD_OK; }
     if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dw_stream")) { g_opt_dw_stream = value; return GAD_OK; }
     int found = 0;
@@ -895,6 +1083,31 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1); else LAUNCH_STREAM(2, 4, 1); }
 #undef LAUNCH_STREAM
         GAD_CHECK_LAUNCH("gemm_fwd(stream)");
+        return GAD_OK;
+    }
+    if (fwd_slabable(*a)) {
+        const int slabs = gad_cdiv(rows, 32), n = a->n_out[0];
+        // 32*TN columns per workgroup: 64 unless that leaves fewer wavefront tasks (slabs x slices) than the chip has slots
+        const int tn = (long long)slabs * (n / 64) >= 1536 ? 2 : 1;
+        const int slices = n / (32 * tn);
+        int gx = 256 / slices; if (gx < 1) gx = 1;
+        if (gx > gad_cdiv(slabs, 8)) gx = gad_cdiv(slabs, 8);
+        const size_t lds = ((size_t)32 * tn * (a->Kp + 4) + 2 * (size_t)a->Kp + 2 * 8 * 32 * tn) * sizeof(float);
+#define LAUNCH_SLAB(TN, XM)                                                                                         \
+        do {                                                                                                        \
+            static bool attr_set = false;                                                                           \
+            if (!attr_set) {                                                                                        \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fwd_slab_kernel<TN, XM>),            \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+                attr_set = true;                                                                                    \
+            }                                                                                                       \
+            hipLaunchKernelGGL((gemm_fwd_slab_kernel<TN, XM>), dim3(gx, slices), dim3(512), lds, st, x, a->n_rows_dev, rows, \
+                               a->row_w, a->W, a->Kp, n, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride); \
+        } while (0)
+        if (a->mode == 0) { if (tn == 2) LAUNCH_SLAB(2, 0); else LAUNCH_SLAB(1, 0); }
+        else { if (tn == 2) LAUNCH_SLAB(2, 1); else LAUNCH_SLAB(1, 1); }
+#undef LAUNCH_SLAB
+        GAD_CHECK_LAUNCH("gemm_fwd(slab)");
         return GAD_OK;
     }
     // 64 x 64 tiles throughout: with K <= 1024 these launches are prologue/epilogue-bound, more and smaller
@@ -1238,6 +1451,198 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// slab dX for the MID-SIZE layers (the backward twin of gemm_fwd_slab_kernel): a workgroup owns 64 input-channel
+// columns of gout; the matching 64-column slice of W (n_out x 64, as stored: no transposition) stays in LDS, the B
+// operand W[8j+4h+i][k] is four conflict-free ds_read_b32 per k group.  Every wavefront walks 32-row slabs; the A operand
+// dZ[r][8j+4h..+3] = P*dY - w*(Q + S*z) is formed in registers from 16-byte loads of z and dY (or of the pooled
+// arg-max / gradient pair) -- the ReLU mask is already in dY (premasked) -- four k groups per register chunk, the next
+// chunk (or the next slab's first) in flight during the current chunk's 32 MFMAs.  Epilogue: dY of the previous layer,
+// masked by that layer's ReLU (store_masked), + its BatchNorm-backward sums.
+// ------------------------------------------------------------------------------------------------
+template <int GM>
+__global__ __launch_bounds__(512, 2) void gemm_dx_slab_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev,
+                                                               int n_rows_static, const float* __restrict__ W, int Kp,
+                                                               int n_out, DxEpi e) {
+    extern __shared__ __attribute__((aligned(16))) float slab_smem[];
+    float* Ws = slab_smem;                               // [n_out][64]
+    float* vec = Ws + n_out * 64;                        // P | Q | S   (3 * n_out)
+    float* red = vec + 3 * n_out;                        // [2 * 8 * 64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    const int k0 = blockIdx.y * 64;
+    for (int u = tid; u < n_out * 16; u += 512) {        // W[n][k0 .. k0+63] -> Ws[n][0..63], 16-byte units
+        const int n = u >> 4, c = (u & 15) << 2;
+        *reinterpret_cast<float4*>(Ws + n * 64 + c) = ldg4(W + (size_t)n * Kp + k0 + c);
+    }
+    for (int i = tid; i < n_out; i += 512) {
+        float P, Q, S;
+        dz_coef(d, i, blockIdx.x == 0 && blockIdx.y == 0, P, Q, S);
+        vec[i] = P; vec[n_out + i] = Q; vec[2 * n_out + i] = S;
+    }
+    __syncthreads();
+    const bool stats = e.dbeta != nullptr;
+    float ps[2] = {0.f, 0.f}, pt[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f}, pi[2] = {0.f, 0.f};
+    if (stats) {
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk) {
+            const int k = k0 + tk * 32 + l31;
+            ps[tk] = e.ps[k]; pt[tk] = e.pt[k]; pm[tk] = e.pm[k]; pi[tk] = e.pi[k];
+        }
+    }
+    const int n_slabs = (n_rows + 31) >> 5;
+    const int stride = gridDim.x * 8;
+    int slab = wave * gridDim.x + blockIdx.x;
+    const int gp4 = e.gout_pitch * 4, zp4 = e.zprev_pitch * 4;
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * gp4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(stats ? e.zprev : e.gout), 0, stats ? n_rows_static * zp4 : 4, 0x00020000);
+    const int glane = (4 * half * e.gout_pitch + k0 + l31) * 4;
+    const int zlane = (4 * half * e.zprev_pitch + k0 + l31) * 4;
+    const int nch = n_out >> 5;                          // chunks of four 8-wide k groups
+    const int zpitch = d.z_pitch, gpitch = GM == 0 ? d.g_pitch : d.c;
+
+    float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
+    float4 rz[2][4], rg[2][4];
+    int4 ra[2][4];
+    auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+    auto load_chunk = [&](int r, int grp, int c, int buf) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = 8 * (4 * c + u) + 4 * half;
+            rz[buf][u] = ldg4(d.z + (size_t)r * zpitch + n);
+            if (GM == 0) {
+                rg[buf][u] = ldg4(d.G + (size_t)r * gpitch + n);
+            } else {
+                ra[buf][u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * gpitch + n);
+                rg[buf][u] = ldg4(d.dout + (size_t)grp * gpitch + n);
+            }
+        }
+    };
+    int r_cur = row_of(slab);
+    int grp_cur = GM == 1 ? d.row_grp[r_cur] : 0;
+    load_chunk(r_cur, grp_cur, 0, 0);
+    for (; slab < n_slabs; slab += stride) {
+        const int r_nxt = row_of(slab + stride);
+        const int grp_nxt = GM == 1 ? d.row_grp[r_nxt] : 0;
+        const float wrow = d.row_w ? d.row_w[r_cur] : 1.f;
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        float zp[2][16];
+        const int zrow = slab * 32 * zp4;
+        const int rr = slab * 32 + l31;                  // true row (clamped rows never match an arg-max)
+        for (int c2 = 0; c2 < nch; c2 += 2) {            // two chunks per trip: the register double buffer is static
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int c = c2 + b;
+                if (c >= nch) break;                     // wave-uniform (n_out = 32 * odd)
+                if (c + 1 < nch) load_chunk(r_cur, grp_cur, c + 1, b ^ 1);
+                else {
+                    load_chunk(r_nxt, grp_nxt, 0, 0);    // (nch even: the last chunk is b == 1, buffer 0 is free)
+                    if (stats) {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v)
+#pragma unroll
+                            for (int t = 0; t < 2; ++t)
+                                zp[t][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                    zrsrc, zlane + t * 128, zrow + ((v & 3) + 8 * (v >> 2)) * zp4, 0));
+                    }
+                }
+                __asm__ volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = 8 * (4 * c + u) + 4 * half;
+                    const float4 z = rz[b][u];
+                    float4 g = rg[b][u];
+                    if (GM == 1) {
+                        const int4 a = ra[b][u];
+                        g.x = a.x == rr ? g.x : 0.f; g.y = a.y == rr ? g.y : 0.f;
+                        g.z = a.z == rr ? g.z : 0.f; g.w = a.w == rr ? g.w : 0.f;
+                    }
+                    const float4 P = *reinterpret_cast<const float4*>(vec + n);
+                    const float4 Q = *reinterpret_cast<const float4*>(vec + n_out + n);
+                    const float4 S = *reinterpret_cast<const float4*>(vec + 2 * n_out + n);
+                    float4 a4;
+                    a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
+                    a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
+                    const float* wp = Ws + n * 64 + l31;
+                    float b0[4], b1[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { b0[i] = wp[i * 64]; b1[i] = wp[i * 64 + 32]; }
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0[0], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1[0], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0[1], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1[1], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0[2], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1[2], acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0[3], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1[3], acc[1], 0, 0, 0);
+                }
+            }
+        }
+        const bool full = slab * 32 + 32 <= n_rows;
+        const int grow = slab * 32 * gp4;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int row = acc_row(v, half);
+            const bool live = slab * 32 + row < n_rows;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float gv = acc[t][v];
+                float outv = gv;
+                if (stats) {
+                    const float zv = zp[t][v];
+                    const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
+                    const float ga = act ? gv : 0.f;
+                    sb[t] += ga;
+                    sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
+                    if (e.store_masked) outv = ga;
+                }
+                if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv), grsrc, glane + t * 128,
+                                                                grow + ((v & 3) + 8 * (v >> 2)) * gp4, 0);
+                else if (live) e.gout[(size_t)(slab * 32 + row) * e.gout_pitch + k0 + t * 32 + l31] = outv;
+            }
+        }
+        r_cur = r_nxt;
+        grp_cur = grp_nxt;
+    }
+    if (stats) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float s0 = sb[t] + __shfl_xor(sb[t], 32, 64);
+            const float s1 = sg[t] + __shfl_xor(sg[t], 32, 64);
+            if (lane < 32) { red[wave * 64 + t * 32 + lane] = s0; red[(8 + wave) * 64 + t * 32 + lane] = s1; }
+        }
+        __syncthreads();
+        if (tid < 64) {
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) { s0 += red[w * 64 + tid]; s1 += red[(8 + w) * 64 + tid]; }
+            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+            atomic_add_f64(e.dbeta + (size_t)rep * e.stat_stride + k0 + tid, (double)s0);
+            atomic_add_f64(e.dgamma + (size_t)rep * e.stat_stride + k0 + tid, (double)s1);
+        }
+    }
+}
+
+static bool dx_slabable(const gad_gemm_dx_args& a, bool vec) {
+    if (!g_opt_dx_slab || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
+    if (a.n_rows < 2048 || a.epilogue != 0 || a.k_valid % 64 != 0 || a.k_valid < 64 || a.k_valid > a.Kp) return false;
+    if (a.n_out[0] % 64 != 0 || a.n_out[0] < 64 || a.n_out[0] > 512) return false;    // chunk pairs; W slice <= 128 KB of LDS
+    if (a.prev_dbeta && !(a.zprev && a.prev_scale && a.prev_shift && a.prev_mean && a.prev_istd && a.prev_dgamma)) return false;
+    const gad_dz_src& d = a.dz;
+    const bool coef = (d.coefP && d.coefQ && d.coefS) || d.bn.dbeta;
+    if (!d.z || d.z_pitch % 4 != 0 || !d.scale || !d.relu || !d.premasked || !coef) return false;
+    if (d.gmode == 0 ? (d.g_pitch % 4 != 0 || !d.G) : (d.c % 4 != 0)) return false;
+    return (long long)a.n_rows * (a.gout_pitch > a.zprev_pitch ? a.gout_pitch : a.zprev_pitch) * 4 < (1ll << 31);
+}
+
 static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
     if (!g_opt_dx_stream || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
     if (a.n_rows < 32768 || a.epilogue != 0 || a.k_valid != 64 || a.Kp != 64 || a.gout_pitch != 64) return false;
@@ -1392,6 +1797,27 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
         else { if (a->dz.gmode == 0) LAUNCH_DXS(8, 0); else LAUNCH_DXS(8, 1); }
 #undef LAUNCH_DXS
         GAD_CHECK_LAUNCH("gemm_dx(stream)");
+        return GAD_OK;
+    }
+    if (dx_slabable(*a, vec)) {
+        const int slabs = gad_cdiv(rows, 32), slices = kv / 64, n = a->n_out[0];
+        int gx = 256 / slices; if (gx < 1) gx = 1;
+        if (gx > gad_cdiv(slabs, 8)) gx = gad_cdiv(slabs, 8);
+        const size_t lds = ((size_t)n * 64 + 3 * (size_t)n + 2 * 8 * 64) * sizeof(float);
+#define LAUNCH_DXSLAB(GM)                                                                                           \
+        do {                                                                                                        \
+            static bool attr_set = false;                                                                           \
+            if (!attr_set) {                                                                                        \
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dx_slab_kernel<GM>),                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
+                attr_set = true;                                                                                    \
+            }                                                                                                       \
+            hipLaunchKernelGGL((gemm_dx_slab_kernel<GM>), dim3(gx, slices), dim3(512), lds, st, d, a->n_rows_dev, rows, \
+                               a->W, a->Kp, n, e);                                                                  \
+        } while (0)
+        if (a->dz.gmode == 0) LAUNCH_DXSLAB(0); else LAUNCH_DXSLAB(1);
+#undef LAUNCH_DXSLAB
+        GAD_CHECK_LAUNCH("gemm_dx(slab)");
         return GAD_OK;
     }
     int nmax_dx = 0;

@@ -154,15 +154,18 @@ class FlatNet(object):
     def p_beta(self, m):
         return hip.Ptr(self.packed.data_ptr() + 4 * m.b_off)
 
-    def set_adam_hyper(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    def set_adam_hyper(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, grad_scale=1.0, upload=True):
+        """this step's Adam scalars -> the pinned host block (and, unless upload=False, on to the device block: a step
+        replayed from a HIP graph carries that copy as a node that reads the pinned block at replay time)"""
         self.step_count += 1
         t = self.step_count
-        h = self.hyper_host
+        h = self.hyper_host.numpy()
         h[0], h[1], h[2], h[3], h[4] = lr, betas[0], betas[1], eps, weight_decay
         h[5] = 1.0 - betas[0] ** t
         h[6] = float(np.sqrt(1.0 - betas[1] ** t))
         h[7] = grad_scale
-        self.hyper.copy_(h, non_blocking=True)
+        if upload:
+            self.hyper.copy_(self.hyper_host, non_blocking=True)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -18,6 +18,13 @@ BATCH_KEYS = ("point_state_batch", "next_point_state_batch", "action_batch", "ex
 
 
 OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on side streams
+# Replay the DDPG step from a HIP graph (torch.cuda.CUDAGraph over the multi-stream schedule): the ~330 launches of a step
+# cost the host 1.9 - 2.7 ms to enqueue, and on steps without the actor-critic term the critic backward -- the critical
+# chain -- used to start 0.4 - 0.6 ms late because the host was still enqueueing the actor pass (tests/diag_phases.py).
+# A graph is captured per (policy step?, hard target update?, noise level, mix ratio, batch source) on the second step that
+# needs it; per-step scalars (Adam bias corrections, learning rates) travel through pinned blocks that graph nodes read.
+import os as _os
+GRAPHS = _os.environ.get("GAD_GRAPH", "1") == "1"
 
 
 def _dev_f32(x, dev):
@@ -98,6 +105,10 @@ class FusedRuntime(object):
         self._ev = [torch.cuda.Event() for _ in range(5)]
         self._ev_counts = torch.cuda.Event()
         self._ev_in = torch.cuda.Event()
+        self.noise_host = torch.zeros(B, 6, dtype=torch.float32).pin_memory()
+        self._graphs = {}                # step signature -> torch.cuda.CUDAGraph (None: seen once, capture on the next use)
+        self._prestaged = None           # "host" | "dev": the step's inputs were staged before the enqueue (graph mode)
+        self.graph_replays = 0
 
     # ------------------------------------------------------------------ plans over static buffers
     def _build_plans(self):
@@ -192,9 +203,14 @@ class FusedRuntime(object):
                 np.subtract(self.hbuf["time_batch"].numpy(), 1.0, out=h.numpy())
                 self.dbuf["time_m1"].copy_(h, non_blocking=True)
 
-    def _adam(self, flat, optim, clip=None):
+    def _adam_host(self, flat, optim):
         g = optim.param_groups[0]
-        flat.set_adam_hyper(g["lr"], g["betas"], g["eps"], g["weight_decay"])
+        flat.set_adam_hyper(g["lr"], g["betas"], g["eps"], g["weight_decay"], upload=False)
+
+    def _adam(self, flat, optim, clip=None):
+        if self._prestaged is None:
+            self._adam_host(flat, optim)
+        flat.hyper.copy_(flat.hyper_host, non_blocking=True)
         hip.call("gad_adam_step", flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq, flat.active, flat.m2p,
                  flat.packed, flat.n, flat.hyper, clip, float(self.agent.clip_grad) if clip is not None else 0.0)
 
@@ -206,16 +222,95 @@ class FusedRuntime(object):
 
     # ------------------------------------------------------------------ the update steps
     def ddpg_step(self, batch, noise_u=None):
+        """one DDPG / TD3 update: eager multi-stream enqueue, or -- GRAPHS, single process, no per-launch timing -- the
+        same enqueue captured once per step signature into a HIP graph and replayed"""
+        ag = self.agent
+        policy_step = ag.update_step % ag.policy_update_gap == 0
+        use_graph = (GRAPHS and OVERLAP_PASSES and self.dp is None and not engine.SERIAL and not engine.TIMING["enabled"]
+                     and batch is not None)
+        if not use_graph:
+            self._prestaged = None
+            self._ddpg_enqueue(batch, noise_u, policy_step)
+            torch.cuda.current_stream().synchronize()
+            return self.scal_host.numpy()
+        # ---- everything the host contributes to this step, before a single launch: inputs, noise draw, Adam scalars
+        kind = self._stage_inputs(batch)
+        if noise_u is not None:
+            np.copyto(self.noise_host.numpy(), np.asarray(noise_u, dtype=np.float32).reshape(self.B, 6))
+        self._adam_host(self.venc.flat, ag.state_feat_val_encoder_optim)
+        self._adam_host(self.cr.flat, ag.critic_optim)
+        self._adam_host(self.pol.flat, ag.policy_optim)
+        if ag.train_feature:
+            self._adam_host(self.enc.flat, ag.state_feat_encoder_optim)
+        idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
+        key = (policy_step, int(ag.update_step % ag.target_update_interval == 0), idx, float(ag.mix_policy_ratio),
+               getattr(ag, "noise_type", "uniform"), noise_u is not None, kind, bool(ag.train_feature))
+        self._prestaged = kind
+        try:
+            g = self._graphs.get(key, False)
+            if g is False:                       # first step with this signature: eager (lazy allocations, attribute calls)
+                self._graphs[key] = None
+                self._ddpg_enqueue(batch, noise_u, policy_step)
+            else:
+                if g is None:
+                    g = torch.cuda.CUDAGraph()
+                    cur = torch.cuda.current_stream()
+                    cap = engine.side_stream(which=9)
+                    cap.wait_stream(cur)
+                    with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
+                        self._ddpg_enqueue(batch, noise_u, policy_step)
+                    cur.wait_stream(cap)
+                    self._graphs[key] = g
+                g.replay()
+                self.graph_replays += 1
+        finally:
+            self._prestaged = None
+        torch.cuda.current_stream().synchronize()
+        return self.scal_host.numpy()
+
+    def _stage_inputs(self, batch):
+        """graph mode: put the minibatch where the captured step reads it.  Host dict -> the pinned staging buffers (the
+        graph's copy nodes move them to the device); device-resident dict / replay-gather handle -> straight into the
+        static device buffers, eagerly on the current stream, ahead of the replay."""
+        if "replay_gather" in batch or torch.is_tensor(batch["point_state_batch"]):
+            self.upload(batch)
+            return "dev"
+        B = self.B
+        for k in BATCH_KEYS:
+            if k not in batch:
+                continue
+            a = np.asarray(batch[k])
+            if a.shape[0] != B:
+                raise RuntimeError("batch size changed: runtime was built for B=%d, got %d" % (B, a.shape[0]))
+            h = self.hbuf[k]
+            np.copyto(h.numpy(), a.reshape(h.shape), casting="same_kind")
+        np.subtract(self.hbuf["time_batch"].numpy(), 1.0, out=self.hbuf["time_m1"].numpy())
+        return "host"
+
+    def _copy_in(self, batch, keys):
+        """the enqueue's view of the upload: staged already (graph mode: pinned -> device copies only, or nothing for
+        device-resident batches), or the eager staged upload"""
+        if self._prestaged is None:
+            return self.upload(batch, keys)
+        if self._prestaged == "host":
+            for k in (BATCH_KEYS if keys is None else keys):
+                if k in batch:
+                    self.dbuf[k].copy_(self.hbuf[k], non_blocking=True)
+                    if k == "time_batch":
+                        self.dbuf["time_m1"].copy_(self.hbuf["time_m1"], non_blocking=True)
+
+    def _ddpg_enqueue(self, batch, noise_u, policy_step):
+        """enqueue one update step on the current stream + the side streams (no host synchronisation inside: this is
+        what a graph capture records); ends with the 32-float result block on its way to the pinned host buffer"""
         ag, d, P = self.agent, self.dbuf, self.plans
         B = self.B
         ratio = float(ag.mix_policy_ratio)
-        policy_step = ag.update_step % ag.policy_update_gap == 0
         # staged upload (dict batches): the target chain on the main stream is the critical path of the step, so its
         # inputs go first and its geometry is enqueued before anything else
         staged = OVERLAP_PASSES and batch is not None and "replay_gather" not in batch
         first = ("next_point_state_batch", "time_batch")
         second = ("point_state_batch", "action_batch")
-        self.upload(batch, first if staged else None)
+        self._copy_in(batch, first if staged else None)
         main = torch.cuda.current_stream()
         idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
@@ -228,6 +323,8 @@ class FusedRuntime(object):
                     self.noise_u.normal_()                              # torch.randn_like (core/utils.py:573)
                 else:
                     self.noise_u.uniform_(0.0, 1.0)                     # torch.rand_like (core/utils.py:575)
+            elif self._prestaged is not None:
+                self.noise_u.copy_(self.noise_host, non_blocking=True)  # staged in the pinned block by ddpg_step
             else:
                 self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
             self.scal.zero_()
@@ -251,14 +348,14 @@ class FusedRuntime(object):
             s1, s2 = engine.side_stream(which=1), engine.side_stream(which=2)
             self.geo_next.run(d["next_point_state_batch"])
             if staged:
-                self.upload(batch, second)
+                self._copy_in(batch, second)
             self._ev[0].record(main)
             s1.wait_event(self._ev[0])
             with torch.cuda.stream(s1):
                 self.geo.run(d["point_state_batch"])
                 self._ev[4].record(s1)                      # geometry of the current state ready (the actor pass needs it)
             if staged:
-                self.upload(batch, tuple(k for k in BATCH_KEYS if k not in first + second))
+                self._copy_in(batch, tuple(k for k in BATCH_KEYS if k not in first + second))
             # small independent launches (noise draw, result-slot clear, and for data-parallel runs the global mask counts: a
             # 4-double all-reduce) would sit on the critical chain in front of t1: on their own stream they overlap the
             # geometry and t1; the main stream -- and through _ev[2] the actor stream -- waits for them after t1
@@ -333,7 +430,7 @@ class FusedRuntime(object):
         self._stats()
         self.enc.bump_batches_tracked(2)
         self.venc.bump_batches_tracked(3 if policy_step else 2)
-        return self._download()
+        self._download(sync=False)
 
     def bc_step(self, batch):
         ag, d, P = self.agent, self.dbuf, self.plans
@@ -392,11 +489,12 @@ class FusedRuntime(object):
     def _host_flags(self):
         return {k: self.dbuf[k].cpu().numpy() for k in ("return_batch", "expert_flag_batch", "perturb_flag_batch")}
 
-    def _download(self):
+    def _download(self, sync=True):
         if self.dp is not None:
             self.dp.reduce_scalars(self.scal)
         self.scal_host.copy_(self.scal, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        if sync:
+            torch.cuda.current_stream().synchronize()
         return self.scal_host.numpy()
 
 
