@@ -483,13 +483,20 @@ class Plan(object):
         for i, t in other.tags.items():
             self.tags[n + i] = t
 
-    def run(self):
+    def run(self, inline=False):
+        """inline=True: calls marked `side` run on the caller's stream, forks / joins are skipped (a plan replayed on a
+        stream that is itself a fork of a stream under HIP-graph capture: hipStreamEndCapture of ROCm 7.2 crashes on
+        nested forks -- tests/diag_graph.py -- so the captured non-policy actor pass keeps its dW GEMMs in line)"""
         import ctypes as C
         main = torch.cuda.current_stream()
         st = hip.stream()
         sides = {}            # lane -> (torch stream, raw handle); dW lanes use side_stream(which = 10 + lane)
         timed = TIMING["enabled"]
         for i, (name, f, args, s, lane) in enumerate(self.calls):
+            if inline:
+                if name in ("fork", "join"):
+                    continue
+                lane = 0
             if name == "fork":
                 if lane not in sides:
                     so = side_stream(which=10 + lane)

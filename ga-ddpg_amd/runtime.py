@@ -338,7 +338,8 @@ class FusedRuntime(object):
                      d["return_batch"], d["goal_batch"], B, self.pol.n_heads, 1.0 - ratio, int(bool(ag.policy_aux)),
                      self.action_scale, g_pi,
                      self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
-            P["p_bwd"].run()
+            # under graph capture the non-policy actor tail runs on a forked stream: no nested dW forks there
+            P["p_bwd"].run(inline=(g_pi is None and OVERLAP_PASSES and torch.cuda.is_current_stream_capturing()))
             self._reduce([self.pol.flat, self.enc.flat])
             self._adam(self.pol.flat, ag.policy_optim)
             if ag.train_feature:
