@@ -25,6 +25,7 @@ OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on 
 # needs it; per-step scalars (Adam bias corrections, learning rates) travel through pinned blocks that graph nodes read.
 import os as _os
 GRAPHS = _os.environ.get("GAD_GRAPH", "1") == "1"
+GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
 
 def _dev_f32(x, dev):
@@ -248,11 +249,11 @@ class FusedRuntime(object):
         self._prestaged = kind
         try:
             g = self._graphs.get(key, False)
-            if g is False:                       # first step with this signature: eager (lazy allocations, attribute calls)
+            if g is False and GRAPH_EAGER_FIRST:  # first step with this signature: eager (lazy allocations, attribute calls)
                 self._graphs[key] = None
                 self._ddpg_enqueue(batch, noise_u, policy_step)
             else:
-                if g is None:
+                if g is None or g is False:
                     g = torch.cuda.CUDAGraph()
                     cur = torch.cuda.current_stream()
                     cap = engine.side_stream(which=9)
