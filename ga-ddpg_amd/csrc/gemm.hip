@@ -795,7 +795,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     }
 }
 
-static int g_opt_dx_slab = 1;
+static int g_opt_dx_slab = 0;    // (see g_opt_fwd_slab)
 static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_slab_kernel(XSrc x, const int
     }
 }
 
-static int g_opt_fwd_slab = 1;
+static int g_opt_fwd_slab = 0;   // measured neutral-to-slower inside the overlapped step (profiles/README.md round 2): off by default
 // the slab kernel covers: one group, K = the channel count itself (no bias / extra column), outputs a multiple of 64
 static bool fwd_slabable(const gad_gemm_fwd_args& a) {
     if (!g_opt_fwd_slab || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
@@ -1633,6 +1633,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_slab_kernel(DzSrc d, const int
 
 static bool dx_slabable(const gad_gemm_dx_args& a, bool vec) {
     if (!g_opt_dx_slab || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
+    if (a.dz.gmode != 0 && g_opt_dx_slab < 2) return false;      // pooled source: 57 spilled registers at 256 VGPRs, slower than the tile kernel (option value 2 forces it)
     if (a.n_rows < 2048 || a.epilogue != 0 || a.k_valid % 64 != 0 || a.k_valid < 64 || a.k_valid > a.Kp) return false;
     if (a.n_out[0] % 64 != 0 || a.n_out[0] < 64 || a.n_out[0] > 512) return false;    // chunk pairs; W slice <= 128 KB of LDS
     if (a.prev_dbeta && !(a.zprev && a.prev_scale && a.prev_shift && a.prev_mean && a.prev_istd && a.prev_dgamma)) return false;

@@ -25,6 +25,9 @@ OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on 
 # needs it; per-step scalars (Adam bias corrections, learning rates) travel through pinned blocks that graph nodes read.
 import os as _os
 GRAPHS = _os.environ.get("GAD_GRAPH", "1") == "1"
+# start the actor phase's policy forward right after the geometry, beside t1 and the value pass (three forward passes of
+# latency-bound kernels share the GPU); its BatchNorm running-statistics update is deferred until t1's is in (reference order)
+EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "1") == "1"
 GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
 
@@ -121,9 +124,11 @@ class FusedRuntime(object):
             """engine.DEFER_BN: the encoder's last BatchNorm is finalised by the head's first GEMM (its consumer)"""
             return engine.bn_fin(e, slot, e.fc_mats[1], float(self.B), update_running) if engine.DEFER_BN else None
         fl = not engine.DEFER_BN                                   # explicit gad_bn_finalize for fc[1] otherwise
-        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None, finalize_last=fl)
+        early = EARLY_ACTOR and OVERLAP_PASSES and self.has_critic
+        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None, finalize_last=fl, update_running=not early)
         P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"],
-                                                    bn=last_bn(enc, self.slot_p)))
+                                                    bn=last_bn(enc, self.slot_p, not early)))
+        P["p_run"] = engine.plan_running_update(enc, self.slot_p) if early else None
         bw = Plan()
         bw.zero_multi([pol.flat.gacc, enc.flat.gacc, self.slot_p.bstats, self.slot_p.dF[0], self.slot_p.dF[1]])
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
@@ -393,11 +398,15 @@ class FusedRuntime(object):
         hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), int(normal_noise), self.a_next)
         P["t2"].run()
         if OVERLAP_PASSES:
-            s2.wait_event(self._ev[2])
+            if P["p_run"] is None:
+                s2.wait_event(self._ev[2])
             s2.wait_event(self._ev[4])
             with torch.cuda.stream(s2):
                 P["p_fwd"].run()
                 self._policy_outputs()
+                if P["p_run"] is not None:                  # the encoder's running statistics: t1's update first
+                    s2.wait_event(self._ev[2])
+                    P["p_run"].run()
                 if not policy_step:
                     actor_tail(None)
         if OVERLAP_PASSES:

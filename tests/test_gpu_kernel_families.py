@@ -43,14 +43,14 @@ def _run(B, value, options):
         out["rows"] = n
     finally:
         for k in options:
-            hip.set_option(k, 1)
+            hip.set_option(k, 0)                       # library defaults of the two slab switches
     return out
 
 
 @pytest.mark.parametrize("value", [False, True])
 def test_slab_and_tile_kernels_agree(value):
     B = 96                                             # SA2 ~ 1e4 rows, SA3 3072 rows: both above the slab threshold
-    a = _run(B, value, {})
+    a = _run(B, value, {"fwd_slab": 1, "dx_slab": 2})          # slab kernels for every layer they cover (pooled dX too)
     b = _run(B, value, {"fwd_slab": 0, "dx_slab": 0})
     assert a["rows"] == b["rows"] and a["rows"][2] >= 2048
     bad = []
