@@ -15,12 +15,18 @@ minibatch-steps per second summed over the ranks (= optimiser iterations/s x N; 
 iteration rate), time = max over ranks between two barrier + synchronize fences.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel: algorithmic FLOPs of the layer as the reference computes it (dense
-                padded neighbourhoods) / measured launch duration (HIP events on the launch
-                stream), against the FP32 MFMA peak; `executed_frac` is the same with the FLOPs the
-                de-duplicated kernel really executes.
-  cpu_baseline  the CPU oracle (pure-PyTorch port of the reference step) timed on this box's cores,
-                rank 0 / N=1 only, on a bounded sample (64 rows of one B=256 step, scaled).
+  roofline      the DOMINANT kernel of the step = the kernel symbol with the largest summed launch time per step
+                (HIP events around every tagged launch, on the launch stream, inside the overlapped step; an extra
+                pass of `--probe-steps` eager steps right after the timed region).  MFMA-bound kernels (64x64 tile
+                family): `achieved` = EXECUTED FLOPs (de-duplicated rows x K x N x 2, summed over the layers the
+                symbol serves) / their summed duration, against the 157.3 TFLOP/s FP32-MFMA peak.  HBM-bound kernels
+                (streaming SA1 family): algorithmic bytes / duration against 8 TB/s.  `frac` <= 1 by construction;
+                `dense_equiv` is the same time priced with the padded-neighbourhood FLOPs the reference computes
+                (SURVEY 8d); `traffic` = HBM bytes per launch from this round's rocprofv3 PMC passes
+                (profiles/r02_traffic.json) or null; `kernel_avg_us` is what profiles/r02_*kernel_stats* must agree with.
+  kernels       the per-symbol table behind that choice (per-step time, launches, achieved fraction of its bound).
+  cpu_baseline  the CPU oracle (pure-PyTorch port of the reference step) timed on this box's cores, rank 0 / N=1
+                only: ONE full B=256 update step (about 20 - 30 s of CPU work) after a small warm-up step.
   sa_kernel_hbm BASELINE's second metric: HBM GB/s of the streaming set-abstraction kernels of this workload
                 (HIP events; algorithmic bytes and PMC traffic) and of the materialising configs[3] kernel.
   value_host_inclusive / value_device_replay: the same loop fed by host sampling + PCIe upload / by the
@@ -100,17 +106,17 @@ def parse():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--buffer", type=int, default=20000, help="synthetic replay transitions per rank")
     ap.add_argument("--ring", type=int, default=8, help="pre-sampled minibatches kept resident in HBM")
-    ap.add_argument("--roofline-tag", default="fwd.sa1.l3", help="launch tag of the kernel priced against the roofline")
+    ap.add_argument("--probe-steps", type=int, default=10, help="eager steps with HIP events around every tagged launch "
+                                                                "(roofline / kernel table), after the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-rate", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, batch, noise, rows=64):
-    """Bounded sample of the same workload on the host cores: ONE DDPG step of the CPU oracle (a port of the
-    reference step; the reference itself cannot travel) on the first `rows` rows of a bench minibatch, scaled
-    to B=256-step units (the step is linear in rows).  Threads capped at 64: torch's CPU kernels get slower
-    beyond that on this many-core host (256 threads: 185 s for a B=256 step)."""
+def cpu_baseline(cfg, batch, noise):
+    """The same workload on the host cores: ONE full DDPG update step (B = the bench batch, N = 1024) of the CPU oracle
+    (a port of the reference step; the reference itself cannot travel) after an 8-row warm-up step.  Threads capped at
+    64: torch's CPU kernels get slower beyond that on this many-core host (256 threads: 185 s for a B=256 step)."""
     from ga_ddpg_amd.experiments.config import load_cfg
     from oracle import ref_step
     cores = min(os.cpu_count() or 1, 64)
@@ -123,11 +129,82 @@ def cpu_baseline(cfg, batch, noise, rows=64):
         return {k: (v[:n] if hasattr(v, "shape") and v.ndim > 0 and v.shape[0] == B else v) for k, v in batch.items()}
     oracle.update_parameters(head(8), noise_u=noise[:8])                 # page-in / warm-up on 8 rows
     t0 = time.time()
-    oracle.update_parameters(head(rows), noise_u=noise[:rows])
+    oracle.update_parameters(batch, noise_u=noise)
     dt = time.time() - t0
-    return {"value": (rows / float(B)) / dt, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": "1 DDPG update step of the CPU oracle on %d of the %d rows (N=1024), %.1f s, scaled by %d/%d"
-                      % (rows, B, dt, rows, B)}
+    return {"value": 1.0 / dt, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "1 full DDPG update step of the CPU oracle (B=%d, N=1024), %.1f s on %d threads" % (B, dt, cores)}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# kernel table: tag -> (kernel symbol, bound, executed FLOPs, algorithmic bytes) per launch.  Mirrors the routing of
+# gad_gemm_fwd / _dx / _dw (csrc/gemm.hip): SA1 (>= 32768 rows, 64-wide) -> streaming kernels (HBM-bound), SA2 / SA3 ->
+# 64x64 tile kernels (FP32 MFMA-bound), FC / heads (<= 1024 rows) -> skinny split-K kernels (latency-bound).
+# ----------------------------------------------------------------------------------------------------------------------
+SA_DIMS = {"sa1": [(None, 64), (64, 64), (64, 128)], "sa2": [(131, 128), (128, 128), (128, 256)],
+           "sa3": [(259, 256), (256, 256), (256, 512)], "fc": [(512, 1024), (1024, 512)]}
+DENSE_ROWS = {"sa1": 32 * 64, "sa2": 32 * 128, "sa3": 32, "fc": 1}
+
+
+def tag_info(tag, rows, B):
+    """(symbol, bound, executed_flops, algorithmic_bytes, dense_flops) of one launch of `tag`; rows = de-duplicated rows
+    per stage"""
+    parts = tag.split(".")
+    kind, stage = parts[0], parts[1]
+    if kind == "pool":
+        c = {"sa1": 128, "sa2": 256, "sa3": 512}[stage]
+        r = rows[stage]
+        return "segment_pool_kernel", "hbm", 0.0, r * c * 4.0 + 2.0 * (B * (32 if stage != "sa3" else 1)) * c * 4, 0.0
+    layer = int(parts[2][1:]) if len(parts) > 2 else 0
+    if stage.startswith("fc"):                      # fwd.fc1 / fwd.fc2 carry the layer in the stage name
+        layer, stage = (int(stage[2:]) if len(stage) > 2 else layer), "fc"
+    if layer == 0:
+        return None
+    k, n = SA_DIMS[stage][layer - 1]
+    if k is None:
+        k = 13.0                                    # SA1 layer 1: 3 + 4 (policy encoder) or 3 + 10 (value encoder) inputs
+    r = float(rows[stage])
+    flops = 2.0 * r * k * n
+    dense = 2.0 * B * DENSE_ROWS[stage] * k * n
+    stream = stage == "sa1"
+    skinny = stage == "fc"
+    if kind == "fwd":
+        sym = "gemm_fwd_stream_kernel" if stream else ("gemm_fwd_skinny_kernel" if skinny else "gemm_fwd_kernel")
+        nbytes = r * (min(k, 16 if stream and layer == 1 else k) + n) * 4.0
+    elif kind == "dx":
+        sym = "gemm_dx_stream_kernel" if (stream and layer > 1) else ("gemm_dx_skinny_kernel" if skinny else "gemm_dx_kernel")
+        nbytes = r * (2 * n + 2 * k) * 4.0           # z and dY of this layer in, dY of the previous layer out, its z for the sums
+    else:
+        sym = ("gemm_dw_gather_stream_kernel" if layer == 1 else "gemm_dw_stream_kernel") if stream else \
+            ("gemm_dw_skinny_kernel" if skinny else "gemm_dw_kernel")
+        nbytes = r * (2 * n + k) * 4.0               # z, dY of this layer and the layer input
+    bound = "hbm" if stream else ("latency" if skinny else "mfma")
+    return sym, bound, flops, nbytes, dense
+
+
+def kernel_table(by_tag, rows, B, steps):
+    """aggregate the tagged launches by kernel symbol: per-step time, launches, executed TFLOP/s, algorithmic GB/s"""
+    fam = {}
+    for tag, ms in by_tag.items():
+        info = tag_info(tag, rows, B)
+        if info is None:
+            continue
+        sym, bound, fl, by, dense = info
+        f = fam.setdefault(sym, {"bound": bound, "ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "dense": 0.0, "tags": []})
+        f["ms"] += float(np.sum(ms))
+        f["launches"] += len(ms)
+        f["flops"] += fl * len(ms)
+        f["bytes"] += by * len(ms)
+        f["dense"] += dense * len(ms)
+        f["tags"].append(tag)
+    out = {}
+    for sym, f in fam.items():
+        sec = f["ms"] * 1e-3
+        tf, gb = f["flops"] / sec / 1e12, f["bytes"] / sec / 1e9
+        frac = gb / 8000.0 if f["bound"] == "hbm" else tf / (FP32_MFMA_PEAK / 1e12)
+        out[sym] = {"bound": f["bound"], "ms_per_step": f["ms"] / steps, "launches_per_step": f["launches"] / float(steps),
+                    "kernel_avg_us": 1e3 * f["ms"] / f["launches"], "executed_tflops": tf, "algorithmic_gbps": gb,
+                    "frac": frac, "dense_equiv_tflops": f["dense"] / sec / 1e12, "tags": sorted(f["tags"])}
+    return out
 
 
 def main():
@@ -186,7 +263,32 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    engine.TIMING.update(enabled=True, tag=args.roofline_tag, events=[])
+
+    # ---- which kernel dominates?  HIP events around every tagged launch (on its launch stream) during a few extra warm-up
+    # steps, inside the overlapped step -- and once more with the step serialised on one stream (the kernel by itself)
+    def probe(serial, n):
+        engine.SERIAL = serial
+        engine.TIMING.update(enabled=True, tag="*", events=[])
+        for i in range(n):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        engine.TIMING["enabled"] = False
+        engine.SERIAL = False
+        acc = {}
+        for e0, e1, tag in engine.TIMING["events"]:
+            acc.setdefault(tag, []).append(e0.elapsed_time(e1))
+        return acc
+    probe_n = args.probe_steps + args.probe_steps % 2            # policy and non-policy steps in equal number
+    by_tag = probe(False, probe_n)
+    alone = probe(True, probe_n) if world == 1 else {}
+    rows = {"sa1": int(rt.geo.rows[0]["n"].item()), "sa2": int(rt.geo.rows[1]["n"].item()),
+            "sa3": int(rt.geo.rows[2]["n"].item()), "fc": B}
+    table = kernel_table(by_tag, rows, B, probe_n)
+    table_alone = kernel_table(alone, rows, B, probe_n) if alone else {}
+    priced = {k: v for k, v in table.items() if v["bound"] in ("mfma", "hbm")}
+    dom = max(priced, key=lambda k: priced[k]["ms_per_step"])
+    # ---- the timed region: K steps, HIP events around the launches of the dominant kernel only
+    engine.TIMING.update(enabled=True, tag=frozenset(table[dom]["tags"]), events=[])
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -200,33 +302,24 @@ def main():
         dt = float(t.item())
     if rank != 0:
         return
-    ev = engine.TIMING["events"]
-    kernel_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) if ev else None
-    n_launch = len(ev) / max(args.steps, 1)
-    # roofline of the tagged launch: which encoder does it belong to? both encoders run it; use the
-    # critic encoder's input width (C=10) for SA1 layer 1, irrelevant for the others.
-    macs = dense_layer_macs(args.roofline_tag, 10) * B
-    mult = {"fwd": 1}.get(args.roofline_tag.split(".")[0], 1)
-    flops = 2.0 * macs * mult
-    stage = int(args.roofline_tag.split(".")[1][2:]) - 1
-    n_rows = int(rt.geo.rows[stage]["n"].item())
-    dense_rows = rt.geo.counts[stage]
-    roof = None
-    if kernel_ms:
-        ach = flops / (kernel_ms * 1e-3)
-        # HBM bytes per launch of this kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950
-        # correction of MI355X_MICROARCH.md + WRITE_SIZE), see profiles/README.md; null when not collected for the tag
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.roofline_tag, {}).get("bytes_per_launch")
-        kname = "gemm_fwd_stream_kernel" if args.roofline_tag.startswith("fwd.sa1") else "gemm_fwd_kernel"
-        roof = {"bound": "mfma", "kernel": "%s (%s: shared-MLP layer, FP32 MFMA)" % (kname, args.roofline_tag),
-                "achieved": ach / 1e12, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK,
-                "traffic": traffic, "launch_ms": kernel_ms, "launches_per_step": n_launch,
-                "algorithmic_flops_per_launch": flops,
-                "executed_frac": ach / FP32_MFMA_PEAK * n_rows / dense_rows,
-                "dedup_rows": n_rows, "dense_rows": int(dense_rows)}
+    timed_tags = {}
+    for e0, e1, tag in engine.TIMING["events"]:
+        timed_tags.setdefault(tag, []).append(e0.elapsed_time(e1))
+    table_timed = kernel_table(timed_tags, rows, B, args.steps)
+    d0 = table_timed.get(dom, table[dom])                           # measured over the timed region itself
+    tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
+    tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    roof = {"bound": d0["bound"], "kernel": dom, "layers": d0["tags"],
+            "achieved": d0["executed_tflops"] if d0["bound"] == "mfma" else d0["algorithmic_gbps"],
+            "peak": FP32_MFMA_PEAK / 1e12 if d0["bound"] == "mfma" else 8000.0,
+            "unit": "TFLOP/s" if d0["bound"] == "mfma" else "GB/s", "frac": d0["frac"],
+            "traffic": tj.get(dom, {}).get("bytes_per_launch"),
+            "kernel_avg_us": d0["kernel_avg_us"], "launches_per_step": d0["launches_per_step"],
+            "ms_per_step": d0["ms_per_step"], "dense_equiv_tflops": d0["dense_equiv_tflops"],
+            "frac_alone": table_alone.get(dom, {}).get("frac"), "kernel_avg_us_alone": table_alone.get(dom, {}).get("kernel_avg_us"),
+            "how": "HIP events around every launch of the symbol, on its launch stream, during the %d timed steps (the symbol "
+                   "was chosen from a %d-step probe of every tagged launch); executed FLOPs = de-duplicated rows (sa1 %d, "
+                   "sa2 %d, sa3 %d) x K x N x 2 per layer" % (args.steps, probe_n, rows["sa1"], rows["sa2"], rows["sa3"])}
     steps_per_s = args.steps * 1.0 / dt
     # whole-job aggregate: every rank processes one B=256 minibatch per optimiser step (weak scaling), so the job does
     # world x (B=256 minibatch-steps) per iteration; at N=1 this is the plain step rate
@@ -262,54 +355,23 @@ def main():
             agent.update_parameters(dmem.sample_lazy(B, rng2), agent.update_step, i)
         torch.cuda.synchronize()
         res["value_device_replay"] = n / (time.perf_counter() - t0)
+    res["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "tags"}
+                      for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}
     if world == 1 and not args.no_sa_kernel:
-        # BASELINE.json's second metric, "SA-kernel HBM GB/s": the streaming set-abstraction forward kernels of THIS
-        # workload (HBM-bound: 0.5-0.75 KB moved per row against 8-16 kFLOP), HIP-event duration from a short extra
-        # pass that brackets every tagged launch, bytes = the committed PMC traffic (profiles/r01_traffic.json) and,
-        # next to it, the algorithmic bytes (rows x (c_in + c_out) x 4); plus the materialising configs[3] kernel.
-        engine.TIMING.update(enabled=True, tag="*", events=[])
-        for i in range(10):
-            step(args.warmup + args.steps + i)
-        torch.cuda.synchronize()
-        engine.TIMING["enabled"] = False
-        by_tag = {}
-        for e0, e1, tag in engine.TIMING["events"]:
-            by_tag.setdefault(tag, []).append(e0.elapsed_time(e1))
-        # the same launches with the whole step on ONE stream: the kernel by itself, without the other passes of the
-        # step competing for CUs and HBM (in the overlapped step two or three encoder passes run side by side)
-        engine.SERIAL = True
-        engine.TIMING.update(enabled=True, tag="*", events=[])
-        for i in range(6):
-            step(args.warmup + args.steps + 10 + i)
-        torch.cuda.synchronize()
-        engine.TIMING["enabled"] = False
-        engine.SERIAL = False
-        alone = {}
-        for e0, e1, tag in engine.TIMING["events"]:
-            alone.setdefault(tag, []).append(e0.elapsed_time(e1))
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_traffic.json")
-        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        n1 = int(rt.geo.rows[0]["n"].item())
+        # BASELINE.json's second metric, "SA-kernel HBM GB/s": the streaming set-abstraction kernels of THIS workload (HBM-bound:
+        # 0.5-1 KB moved per row) from the table above -- inside the overlapped step and alone -- plus the materialising
+        # configs[3] kernel behind pointnet2_utils.query_and_group
         sa = {}
-        for tag, cin, cout in (("fwd.sa1.l2", 64, 64), ("fwd.sa1.l3", 64, 128)):
-            if tag in by_tag:
-                ms = float(np.mean(by_tag[tag]))
-                ms1 = float(np.mean(alone[tag])) if tag in alone else None
-                alg = n1 * (cin + cout) * 4.0
-                pmc = tj.get(tag, {}).get("bytes_per_launch")
-                sa[tag] = {"kernel": "gemm_fwd_stream_kernel", "bound": "hbm", "launch_ms": ms, "rows": n1,
-                           "algorithmic_bytes": alg, "traffic": pmc, "achieved": alg / (ms * 1e-3) / 1e9, "peak": 8000.0,
-                           "unit": "GB/s", "frac": alg / (ms * 1e-3) / 8e12,
-                           "launch_ms_alone": ms1, "frac_alone": None if ms1 is None else alg / (ms1 * 1e-3) / 8e12,
-                           "note": "launch_ms / frac: inside the overlapped step (other encoder passes run beside it); "
-                                   "*_alone: the same launch with the step serialised on one stream"}
-        if args.roofline_tag in alone and res.get("roofline"):
-            ms1 = float(np.mean(alone[args.roofline_tag]))
-            res["roofline"]["launch_ms_alone"] = ms1
-            res["roofline"]["frac_alone"] = res["roofline"]["algorithmic_flops_per_launch"] / (ms1 * 1e-3) / 1e12 / res["roofline"]["peak"]
+        for sym in ("gemm_fwd_stream_kernel", "gemm_dx_stream_kernel", "gemm_dw_stream_kernel"):
+            if sym in table:
+                t, a1 = table[sym], table_alone.get(sym, {})
+                sa[sym] = {"bound": "hbm", "kernel_avg_us": t["kernel_avg_us"], "achieved": t["algorithmic_gbps"], "peak": 8000.0,
+                           "unit": "GB/s", "frac": t["frac"], "frac_alone": a1.get("frac"),
+                           "traffic": tj.get(sym, {}).get("bytes_per_launch"),
+                           "note": "frac: inside the overlapped step (other encoder passes run beside it); frac_alone: the "
+                                   "same launches with the step serialised on one stream"}
         sa["query_and_group"] = sa_kernel_hbm()
-        sa["query_and_group"]["traffic"] = (json.load(open(tpath)).get("query_and_group", {}).get("bytes_per_launch")
-                                            if os.path.exists(tpath) else None)
+        sa["query_and_group"]["traffic"] = tj.get("query_and_group", {}).get("bytes_per_launch")
         res["sa_kernel_hbm"] = sa
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, host_batches[0], np.random.default_rng(3).random((B, 6)).astype(np.float32))

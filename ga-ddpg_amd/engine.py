@@ -511,7 +511,8 @@ class Plan(object):
                 continue
             lane = int(lane)
             ev = None
-            if timed and i in self.tags and TIMING["tag"] in (self.tags[i], "*"):
+            if timed and i in self.tags and (TIMING["tag"] == "*" or self.tags[i] == TIMING["tag"] or
+                                             (isinstance(TIMING["tag"], (set, frozenset, tuple, list)) and self.tags[i] in TIMING["tag"])):
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(sides[lane][0] if lane else main)
             q = sides[lane][1] if lane else st
@@ -716,7 +717,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         for k, v in epi.items():
             setattr(a, k, v)
         plan.call_struct("gad_gemm_dx", a)
-        plan.tag_last("dx.%s" % rows_kw.get("name", "fc"))
+        plan.tag_last("dx.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
 
     dw_lanes = []
 
@@ -748,10 +749,10 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     # ---- FC head ----
     fc1, fc2 = enc.fc_mats
     d = layer(3, 1, fc2, slot.Zfc[1], float(B), True, G=g_fc2)
-    dx(dict(n_rows=B), d, fc2, fc1.n_out, epilogue=0, gout=_ptr(slot.Gfc), gout_pitch=fc1.n_out,
+    dx(dict(n_rows=B, layer=2), d, fc2, fc1.n_out, epilogue=0, gout=_ptr(slot.Gfc), gout_pitch=fc1.n_out,
        **prev_stats(fc1, slot.Zfc[0]))
     d = layer(3, 0, fc1, slot.Zfc[0], float(B), True, G=slot.Gfc)
-    dx(dict(n_rows=B), d, fc1, slot.F[2].shape[1], epilogue=0, gout=_ptr(slot.dF[2]), gout_pitch=slot.F[2].shape[1])
+    dx(dict(n_rows=B, layer=1), d, fc1, slot.F[2].shape[1], epilogue=0, gout=_ptr(slot.dF[2]), gout_pitch=slot.F[2].shape[1])
     # ---- SA3 -> SA1 ----
     for s in (2, 1, 0):
         r = geo.rows[s]
@@ -765,21 +766,23 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
                   _bn_vec(slot, enc, m3, "scale"), _bn_vec(slot, enc, m3, "shift"), _bn_vec(slot, enc, m3, "mean"),
                   _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8), 2 * tot, 1)
         d = layer(s, 2, m3, slot.Z[s][2], cnt, True, pooled=(slot.argmax[s], slot.dF[s], r["grp"]), row_w=_ptr(r["w"]))
-        dx(rows_kw, d, m3, m2.n_out, epilogue=0, gout=_ptr(gbuf[0]), gout_pitch=m2.n_out, **prev_stats(m2, slot.Z[s][1]))
+        dx(dict(rows_kw, layer=3), d, m3, m2.n_out, epilogue=0, gout=_ptr(gbuf[0]), gout_pitch=m2.n_out,
+           **prev_stats(m2, slot.Z[s][1]))
         d = layer(s, 1, m2, slot.Z[s][1], cnt, True, G=gbuf[0], row_w=_ptr(r["w"]))
-        dx(rows_kw, d, m2, m1.n_out, epilogue=0, gout=_ptr(gbuf[1]), gout_pitch=m1.n_out, **prev_stats(m1, slot.Z[s][0]))
+        dx(dict(rows_kw, layer=2), d, m2, m1.n_out, epilogue=0, gout=_ptr(gbuf[1]), gout_pitch=m1.n_out,
+           **prev_stats(m1, slot.Z[s][0]))
         has_dx = s > 0 or (want_daction and action is not None)
         d = layer(s, 0, m1, slot.Z[s][0], cnt, has_dx, G=gbuf[1], row_w=_ptr(r["w"]))
         if s > 0:
             fc = slot.F[s - 1].shape[1]
             if zero_scatter:
                 plan.zero(slot.dF[s - 1])
-            dx(rows_kw, d, m1, fc, epilogue=1, dfeat=_ptr(slot.dF[s - 1]), feat_c=fc, row_pt=_ptr(r["pt"]),
+            dx(dict(rows_kw, layer=1), d, m1, fc, epilogue=1, dfeat=_ptr(slot.dF[s - 1]), feat_c=fc, row_pt=_ptr(r["pt"]),
                row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)
         elif has_dx:
             if zero_scatter:
                 plan.zero(slot.daction)
-            dx(rows_kw, d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),
+            dx(dict(rows_kw, layer=1), d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),
                daction=_ptr(slot.daction), act_c=6, grp_per_sample=geo.M1)
     for lane in sorted(set(dw_lanes) - {0}):
         plan.join(lane)

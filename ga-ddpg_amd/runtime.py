@@ -23,8 +23,11 @@ OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on 
 # chain -- used to start 0.4 - 0.6 ms late because the host was still enqueueing the actor pass (tests/diag_phases.py).
 # A graph is captured per (policy step?, hard target update?, noise level, mix ratio, batch source) on the second step that
 # needs it; per-step scalars (Adam bias corrections, learning rates) travel through pinned blocks that graph nodes read.
+# MEASURED (MI355X, ROCm 7.2, profiles/README.md round 2): replay == eager within noise (269 - 274 vs 276 steps/s) -- with
+# the enqueue order of round 1 the step is GPU-bound, and hipStreamEndCapture crashes on forks taken from a forked stream,
+# so the captured non-policy actor pass runs its dW GEMMs in line.  Supported and tested (GAD_GRAPH=1), off by default.
 import os as _os
-GRAPHS = _os.environ.get("GAD_GRAPH", "1") == "1"
+GRAPHS = _os.environ.get("GAD_GRAPH", "0") == "1"
 # start the actor phase's policy forward right after the geometry, beside t1 and the value pass (three forward passes of
 # latency-bound kernels share the GPU); its BatchNorm running-statistics update is deferred until t1's is in (reference order)
 EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "1") == "1"

@@ -1,0 +1,53 @@
+"""HBM traffic per launch of every kernel from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass:
+MI355X_MICROARCH.md, TCC slots) -> profiles/rNN_traffic.json, keyed by the kernel's base symbol (template arguments
+folded).  bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE under-counts 16-byte coalesced loads by 2x on
+gfx950 (the guide's correction); both counters are in KB.
+    python tests/prof_traffic.py <fetch_dir> <write_dir> <out.json>"""
+import glob
+import json
+import re
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = glob.glob(path + "/**/*.db", recursive=True)[0]
+    c = sqlite3.connect(db)
+    tabs = [r[0] for r in c.execute("select name from sqlite_master where type='table' or type='view'")]
+    pmc = [t for t in tabs if "pmc_event" in t][0]
+    info = [t for t in tabs if "info_pmc" in t][0]
+    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
+    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
+    # a dispatch reports the counter once per shader-engine instance: sum the instances of a dispatch, then average
+    q = ("select s.kernel_name, d.event_id, sum(p.value), d.end - d.start from %s p join %s i on p.pmc_id=i.id join %s d on "
+         "p.event_id=d.event_id join %s s on d.kernel_id=s.id where i.name=? group by d.event_id" % (pmc, info, kd, ks))
+    acc = {}
+    for name, _, val, dur in c.execute(q, (counter,)):
+        base = re.sub(r"\(.*", "", name)
+        base = re.sub(r"^_Z\d+", "", base)
+        base = re.sub(r"I[LbN].*", "", base)             # template arguments
+        base = re.sub(r"(P|[0-9]+gad_|[0-9]+DzSrc|[0-9]+XSrc|4XSrc|5DzSrc|\.kd).*", "", base)
+        a = acc.setdefault(base, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += val
+        a[2] += dur
+    return {k: (v[0], v[1] / v[0], v[2] / v[0] / 1e3) for k, v in acc.items()}
+
+
+def main(fetch_dir, write_dir, out):
+    f, w = per_kernel(fetch_dir, "FETCH_SIZE"), per_kernel(write_dir, "WRITE_SIZE")
+    res = {"_about": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes of "
+                     "`python bench.py --steps 6 --warmup 4 --probe-steps 2 --no-cpu-baseline --no-host-rate --no-sa-kernel`, "
+                     "B=256; kernels are serialised under --pmc); FETCH_SIZE doubled (gfx950: 16-byte coalesced loads are tallied "
+                     "at half their size, MI355X_MICROARCH.md); KB = 1024 B; averaged over every launch of the symbol"}
+    for k in sorted(set(f) & set(w), key=lambda k: -(2 * f[k][1] + w[k][1]) * f[k][0]):
+        res[k] = {"launches": f[k][0], "fetch_kb": round(f[k][1], 1), "write_kb": round(w[k][1], 1),
+                  "bytes_per_launch": round((2 * f[k][1] + w[k][1]) * 1024.0, 0), "avg_us_under_pmc": round(f[k][2], 2)}
+    json.dump(res, open(out, "w"), indent=1)
+    for k, v in list(res.items())[1:25]:
+        print("%-40s n=%5d fetch %10.1f KB write %10.1f KB -> %8.2f MB / launch" % (k, v["launches"], v["fetch_kb"], v["write_kb"],
+                                                                                    v["bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
