@@ -16,8 +16,9 @@ iteration rate), time = max over ranks between two barrier + synchronize fences.
 
 Extra objects on the JSON line:
   roofline      the DOMINANT kernel of the step = the kernel symbol with the largest summed launch time per step
-                (HIP events around every tagged launch, on the launch stream, inside the overlapped step; an extra
-                pass of `--probe-steps` eager steps right after the timed region).  MFMA-bound kernels (64x64 tile
+                (every tagged launch stamps its own first-wavefront-start / last-wavefront-end on the device wall clock:
+                gad_timing_slot -- the dispatch duration a profiler reports; a `--probe-steps` pass during warm-up picks the symbol,
+                its launches are then timed during the K timed steps).  MFMA-bound kernels (64x64 tile
                 family): `achieved` = EXECUTED FLOPs (de-duplicated rows x K x N x 2, summed over the layers the
                 symbol serves) / their summed duration, against the 157.3 TFLOP/s FP32-MFMA peak.  HBM-bound kernels
                 (streaming SA1 family): algorithmic bytes / duration against 8 TB/s.  `frac` <= 1 by construction;
@@ -264,19 +265,15 @@ def main():
     for i in range(args.warmup):
         step(i)
 
-    # ---- which kernel dominates?  HIP events around every tagged launch (on its launch stream) during a few extra warm-up
+    # ---- which kernel dominates?  in-kernel wall-clock stamps of every tagged launch during a few extra warm-up
     # steps, inside the overlapped step -- and once more with the step serialised on one stream (the kernel by itself)
     def probe(serial, n):
         engine.SERIAL = serial
-        engine.TIMING.update(enabled=True, tag="*", events=[])
+        engine.timing_start("*")
         for i in range(n):
             step(args.warmup + i)
-        torch.cuda.synchronize()
-        engine.TIMING["enabled"] = False
+        acc = engine.timing_stop()
         engine.SERIAL = False
-        acc = {}
-        for e0, e1, tag in engine.TIMING["events"]:
-            acc.setdefault(tag, []).append(e0.elapsed_time(e1))
         return acc
     probe_n = args.probe_steps + args.probe_steps % 2            # policy and non-policy steps in equal number
     by_tag = probe(False, probe_n)
@@ -288,23 +285,20 @@ def main():
     priced = {k: v for k, v in table.items() if v["bound"] in ("mfma", "hbm")}
     dom = max(priced, key=lambda k: priced[k]["ms_per_step"])
     # ---- the timed region: K steps, HIP events around the launches of the dominant kernel only
-    engine.TIMING.update(enabled=True, tag=frozenset(table[dom]["tags"]), events=[])
+    engine.timing_start(frozenset(table[dom]["tags"]), capacity=max(1024, int(args.steps * table[dom]["launches_per_step"] * 1.2) + 64))
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    engine.TIMING["enabled"] = False
+    timed_tags = engine.timing_stop()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
         return
-    timed_tags = {}
-    for e0, e1, tag in engine.TIMING["events"]:
-        timed_tags.setdefault(tag, []).append(e0.elapsed_time(e1))
     table_timed = kernel_table(timed_tags, rows, B, args.steps)
     d0 = table_timed.get(dom, table[dom])                           # measured over the timed region itself
     tpath = os.path.join(ROOT, "profiles", "r02_traffic.json")
@@ -317,7 +311,7 @@ def main():
             "kernel_avg_us": d0["kernel_avg_us"], "launches_per_step": d0["launches_per_step"],
             "ms_per_step": d0["ms_per_step"], "dense_equiv_tflops": d0["dense_equiv_tflops"],
             "frac_alone": table_alone.get(dom, {}).get("frac"), "kernel_avg_us_alone": table_alone.get(dom, {}).get("kernel_avg_us"),
-            "how": "HIP events around every launch of the symbol, on its launch stream, during the %d timed steps (the symbol "
+            "how": "in-kernel wall-clock stamps (gad_timing_slot) of every launch of the symbol during the %d timed steps (the symbol "
                    "was chosen from a %d-step probe of every tagged launch); executed FLOPs = de-duplicated rows (sa1 %d, "
                    "sa2 %d, sa3 %d) x K x N x 2 per layer" % (args.steps, probe_n, rows["sa1"], rows["sa2"], rows["sa3"])}
     steps_per_s = args.steps * 1.0 / dt

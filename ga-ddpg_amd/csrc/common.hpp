@@ -33,6 +33,8 @@ __device__ __forceinline__ int gad_cdiv_dev(int a, int b) { return (a + b - 1) /
 #endif
 
 void gad_geometry_set_option(const char* name, int value, int* found);
+// the timing slot armed by gad_timing_slot() for the NEXT launch of the calling thread (NULL if none); consumed once
+unsigned long long* gad_take_timing_slot();
 
 #ifdef __HIPCC__
 // squared distance with the evaluation order pinned to the oracle's (oracle/pn2_ref.c sqdist):
@@ -72,6 +74,19 @@ __device__ __forceinline__ float wave_max(float v) {
 // f64 / f32 device-scope atomic adds (hardware global_atomic_add_f64 / _f32 on gfx950)
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
+
+// First-wavefront-start / last-wavefront-end stamps of a launch (include/gaddpg.h: gad_timing_slot) on the constant-rate
+// wall clock: slot[0] = min over workgroups of the start stamp, slot[1] = max over wavefronts of the end stamp -- the
+// quantity a profiler reports as the dispatch duration, measurable inside an untraced, multi-stream run.
+struct KTimer {
+    unsigned long long* p;
+    __device__ __forceinline__ explicit KTimer(unsigned long long* q) : p(q) {
+        if (p && threadIdx.x == 0) atomicMin(p, (unsigned long long)wall_clock64());
+    }
+    __device__ __forceinline__ ~KTimer() {
+        if (p && (threadIdx.x & 63) == 0) atomicMax(p + 1, (unsigned long long)wall_clock64());
+    }
+};
 
 // Train-mode BatchNorm finalisation of ONE channel from the replicated f64 statistics (gad_bn_finalize's arithmetic;
 // also evaluated in consumer prologues, include/gaddpg.h gad_bn_fin).  `writer` (exactly one thread of the grid per

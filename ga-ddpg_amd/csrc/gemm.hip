@@ -390,7 +390,8 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
                                                         const float* __restrict__ W, int Kp,
                                                         float* __restrict__ zout, int zout_pitch,
                                                         double* __restrict__ stat_sum,
-                                                        double* __restrict__ stat_sq, int stat_stride) {
+                                                        double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchT<BM>::v, PB = PitchT<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
@@ -540,7 +541,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
                                                                   int n_rows_static, const float* __restrict__ row_w,
                                                                   const float* __restrict__ W, float* __restrict__ zout,
                                                                   double* __restrict__ stat_sum,
-                                                                  double* __restrict__ stat_sq, int stat_stride) {
+                                                                  double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int KP = 8 * KJ, NO = 32 * TN, PW = KP + 4;
     __shared__ __attribute__((aligned(16))) float Ws[NO * PW];
     __shared__ __attribute__((aligned(16))) float sv[KP], tv[KP];
@@ -711,7 +713,8 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
                                                                      const float* __restrict__ W, int Kp,
                                                                      float* __restrict__ zout, int zout_pitch,
                                                                      double* __restrict__ stat_sum,
-                                                                     double* __restrict__ stat_sq, int stat_stride) {
+                                                                     double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     __shared__ float part[SK_NW * 16 * 64];
     __shared__ __attribute__((aligned(16))) float sv[8 * SK_NW * SK_CH * SK_MAXCH], tv[8 * SK_NW * SK_CH * SK_MAXCH];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -820,7 +823,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_slab_kernel(XSrc x, const int
                                                                 const float* __restrict__ W, int Kp, int n_out,
                                                                 float* __restrict__ zout, int zout_pitch,
                                                                 double* __restrict__ stat_sum,
-                                                                double* __restrict__ stat_sq, int stat_stride) {
+                                                                double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int NO = 32 * TN, CH = 8;
     extern __shared__ __attribute__((aligned(16))) float slab_smem[];
     const int PW = Kp + 4;
@@ -1041,6 +1045,7 @@ static int check_input(const gad_gemm_fwd_args& a, const char* who) {
 }
 
 extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
+    unsigned long long* ts = gad_take_timing_slot();
     GAD_REQUIRE(a && a->W && a->zout, GAD_ERR_NULL, "gemm_fwd: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_fwd: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0 && a->Kp >= 8, GAD_ERR_SHAPE, "gemm_fwd: Kp=%d must be a multiple of 8", a->Kp);
@@ -1060,7 +1065,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     const int rows = a->n_rows;
     if (fwd_skinny(*a)) {
         hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(nmax, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
-                           gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride);
+                           gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
         GAD_CHECK_LAUNCH("gemm_fwd(skinny)");
         return GAD_OK;
     }
@@ -1070,7 +1075,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         int gx = gad_cdiv(rows, BM); if (gx > 2048) gx = 2048;                                             \
         hipLaunchKernelGGL((gemm_fwd_kernel<WM, WN, TM, TN, XM>), dim3(gx, gad_cdiv(nmax, BN), gr.n), dim3(256), \
                            0, st, x, gr, a->n_rows_dev, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, \
-                           a->stat_sum, a->stat_sq, a->stat_stride);                                       \
+                           a->stat_sum, a->stat_sq, a->stat_stride, ts);                                       \
     } while (0)
 #define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0); else LAUNCH_FWD2(WM, WN, TM, TN, 1); } while (0)
     if (fwd_streamable(*a)) {
@@ -1078,7 +1083,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;              // one 8-wavefront workgroup per CU
 #define LAUNCH_STREAM(KJ, TN, XM)                                                                          \
         hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
-                           a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride)
+                           a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride, ts)
         if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0); else LAUNCH_STREAM(8, 4, 0); }
         else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1); else LAUNCH_STREAM(2, 4, 1); }
 #undef LAUNCH_STREAM
@@ -1102,7 +1107,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
                 attr_set = true;                                                                                    \
             }                                                                                                       \
             hipLaunchKernelGGL((gemm_fwd_slab_kernel<TN, XM>), dim3(gx, slices), dim3(512), lds, st, x, a->n_rows_dev, rows, \
-                               a->row_w, a->W, a->Kp, n, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride); \
+                               a->row_w, a->W, a->Kp, n, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts); \
         } while (0)
         if (a->mode == 0) { if (tn == 2) LAUNCH_SLAB(2, 0); else LAUNCH_SLAB(1, 0); }
         else { if (tn == 2) LAUNCH_SLAB(2, 1); else LAUNCH_SLAB(1, 1); }
@@ -1132,7 +1137,8 @@ struct DxEpi {
 template <int WM, int WN, int TM, int TN, bool VEC, int VM>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_dx_kernel(DzSrc d, Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                        int n_rows_static, const float* __restrict__ W, int Kp,
-                                                       DxEpi e) {
+                                                       DxEpi e, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchT<BM>::v, PB = PitchD<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
@@ -1294,7 +1300,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ------------------------------------------------------------------------------------------------
 template <int NJ, int GM>
 __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev,
-                                                                 int n_rows_static, const float* __restrict__ W, DxEpi e) {
+                                                                 int n_rows_static, const float* __restrict__ W, DxEpi e, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int NO = 8 * NJ, PW = NO + 4, NCH = NJ / 4;
     __shared__ __attribute__((aligned(16))) float Wt[64 * PW];
     __shared__ __attribute__((aligned(16))) float vec[3 * NO];          // P | Q | S (the ReLU mask is already in dY: premasked)
@@ -1464,7 +1471,8 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
 template <int GM>
 __global__ __launch_bounds__(512, 2) void gemm_dx_slab_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev,
                                                                int n_rows_static, const float* __restrict__ W, int Kp,
-                                                               int n_out, DxEpi e) {
+                                                               int n_out, DxEpi e, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     extern __shared__ __attribute__((aligned(16))) float slab_smem[];
     float* Ws = slab_smem;                               // [n_out][64]
     float* vec = Ws + n_out * 64;                        // P | Q | S   (3 * n_out)
@@ -1661,7 +1669,8 @@ static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
 // z and G, BatchNorm-backward applied in registers), B operand = W[8j+4h+i][k0+lane%32]: four 4-byte loads per group
 // of 8 channels, each a fully coalesced 128-byte row segment -- no transposed weight copy needed.
 __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Groups gr, int n_rows,
-                                                                    const float* __restrict__ W, int Kp, DxEpi e) {
+                                                                    const float* __restrict__ W, int Kp, DxEpi e, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     __shared__ float part[SK_NW * 16 * 64];
     __shared__ __attribute__((aligned(16))) float vec[5 * VMAX];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1762,6 +1771,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
 }
 
 extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
+    unsigned long long* ts = gad_take_timing_slot();
     GAD_REQUIRE(a && a->W, GAD_ERR_NULL, "gemm_dx: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_dx: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0, GAD_ERR_SHAPE, "gemm_dx: Kp must be a multiple of 8");
@@ -1793,7 +1803,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     if (dx_streamable(*a, vec)) {
         const int slabs = gad_cdiv(rows, 32);
         int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;
-#define LAUNCH_DXS(NJ, GM) hipLaunchKernelGGL((gemm_dx_stream_kernel<NJ, GM>), dim3(gx), dim3(512), 0, st, d, a->n_rows_dev, rows, a->W, e)
+#define LAUNCH_DXS(NJ, GM) hipLaunchKernelGGL((gemm_dx_stream_kernel<NJ, GM>), dim3(gx), dim3(512), 0, st, d, a->n_rows_dev, rows, a->W, e, ts)
         if (a->n_out[0] == 128) { if (a->dz.gmode == 0) LAUNCH_DXS(16, 0); else LAUNCH_DXS(16, 1); }
         else { if (a->dz.gmode == 0) LAUNCH_DXS(8, 0); else LAUNCH_DXS(8, 1); }
 #undef LAUNCH_DXS
@@ -1814,7 +1824,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
                 attr_set = true;                                                                                    \
             }                                                                                                       \
             hipLaunchKernelGGL((gemm_dx_slab_kernel<GM>), dim3(gx, slices), dim3(512), lds, st, d, a->n_rows_dev, rows, \
-                               a->W, a->Kp, n, e);                                                                  \
+                               a->W, a->Kp, n, e, ts);                                                                  \
         } while (0)
         if (a->dz.gmode == 0) LAUNCH_DXSLAB(0); else LAUNCH_DXSLAB(1);
 #undef LAUNCH_DXSLAB
@@ -1826,7 +1836,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     if (g_opt_dx_skinny && vec && e.mode == 0 && a->dz.gmode == 0 && !a->n_rows_dev && rows <= 1024 &&
         nmax_dx <= 8 * SK_NW * SK_CH * SK_MAXCH && nmax_dx <= VMAX) {
         hipLaunchKernelGGL(gemm_dx_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(kv, 32), gr.n), dim3(64 * SK_NW), 0, st, d, gr,
-                           rows, a->W, a->Kp, e);
+                           rows, a->W, a->Kp, e, ts);
         GAD_CHECK_LAUNCH("gemm_dx(skinny)");
         return GAD_OK;
     }
@@ -1836,10 +1846,10 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
         int gx = gad_cdiv(rows, BM); if (gx > 2048) gx = 2048;                                           \
         if (nmax_dx <= 512)                                                                              \
             hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V, 512>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
-                               st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                          \
+                               st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e, ts);                          \
         else                                                                                             \
             hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V, VMAX>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
-                               st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e);                          \
+                               st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e, ts);                          \
     } while (0)
 #define LAUNCH_DX(WM, WN, TM, TN) do { if (vec) LAUNCH_DX2(WM, WN, TM, TN, true); else LAUNCH_DX2(WM, WN, TM, TN, false); } while (0)
     // 64 x 64 tiles (or 128 x 32 for narrow outputs): measured best on the whole step, also for the 2e5-row SA1
@@ -1862,7 +1872,8 @@ template <int WM, int WN, int TM, int TN, int XM, bool VEC, int VM>
 __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr,
                                                        const int32_t* __restrict__ n_rows_dev, int n_rows_static,
                                                        int Kp, int k_used, int n_ktiles, double* __restrict__ gacc,
-                                                       float* __restrict__ partial, long long group_stride) {
+                                                       float* __restrict__ partial, long long group_stride, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchD<BM>::v, PB = PitchD<BN>::v;
     constexpr int UA = BM * 8 / 256, UB = BN * 8 / 256;
@@ -2018,7 +2029,8 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
 // all loads of a wavefront's rows in flight before its first MFMA; partial tiles summed through LDS, then f64 atomics
 // straight into the gradient arena (no split-K workspace, no reduce launch).
 __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSrc x, Groups gr, int n_rows, int Kp,
-                                                                    int k_used, double* __restrict__ gacc) {
+                                                                    int k_used, double* __restrict__ gacc, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     __shared__ float part[SK_NW * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2109,7 +2121,8 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSr
 // blocks are summed through LDS into the split's partial tile.
 template <int NG, int GM>
 __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
-                                                             int n_rows_static, int splits, float* __restrict__ partial) {
+                                                             int n_rows_static, int splits, float* __restrict__ partial, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int NO = 64 * NG, KP = 64, RW = 8 / NG;              // RW: wavefronts that share the rows of one column set
     __shared__ float red[8 * 16 * 64];                             // one accumulator tile of every wavefront
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2252,7 +2265,8 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
 // mapping (accumulator row i of tile j = output channel 2 i + j, one 8-byte load per row for z and for dY).
 __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
                                                                     int n_rows_static, int splits, int Kp, int k_used,
-                                                                    float inv_gps, float* __restrict__ partial) {
+                                                                    float inv_gps, float* __restrict__ partial, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int RW = 8;
     typedef unsigned gad_u32x2 __attribute__((ext_vector_type(2)));
     __shared__ float red[8 * 16 * 64];
@@ -2410,6 +2424,7 @@ static bool dw_streamable(const gad_gemm_dw_args& a, int k_used) {
 }
 
 extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
+    unsigned long long* ts = gad_take_timing_slot();
     GAD_REQUIRE(a && a->gacc, GAD_ERR_NULL, "gemm_dw: null pointer");
     const gad_gemm_fwd_args& in = a->in;
     GAD_REQUIRE(in.n_groups >= 1 && in.n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_dw: n_groups");
@@ -2437,7 +2452,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     }
     if (g_opt_dw_skinny && in.mode == 0 && a->dz.gmode == 0 && !in.n_rows_dev && rows <= 1024) {
         hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
-                           gr, rows, in.Kp, k_used, a->gacc);
+                           gr, rows, in.Kp, k_used, a->gacc, ts);
         GAD_CHECK_LAUNCH("gemm_dw(skinny)");
         return GAD_OK;
     }
@@ -2445,7 +2460,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         const int splits = 256;
         const int gps = in.grp_per_sample > 0 ? in.grp_per_sample : 1;
         hipLaunchKernelGGL(gemm_dw_gather_stream_kernel, dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, in.Kp, k_used,
-                           1.0f / (float)gps, a->partial);
+                           1.0f / (float)gps, a->partial, ts);
         GAD_CHECK_LAUNCH("gemm_dw(gather stream)");
         hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256), 0,
                            st, a->partial, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
@@ -2456,11 +2471,11 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         const int splits = DW_STREAM_SPLITS;
         float* part = a->partial;
         if (in.n_out[0] == 64) {
-            if (a->dz.gmode == 0) hipLaunchKernelGGL((gemm_dw_stream_kernel<1, 0>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
-            else                  hipLaunchKernelGGL((gemm_dw_stream_kernel<1, 1>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
+            if (a->dz.gmode == 0) hipLaunchKernelGGL((gemm_dw_stream_kernel<1, 0>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part, ts);
+            else                  hipLaunchKernelGGL((gemm_dw_stream_kernel<1, 1>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part, ts);
         } else {
-            if (a->dz.gmode == 0) hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 0>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
-            else                  hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 1>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part);
+            if (a->dz.gmode == 0) hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 0>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part, ts);
+            else                  hipLaunchKernelGGL((gemm_dw_stream_kernel<2, 1>), dim3(splits), dim3(512), 0, st, d, x, in.n_rows_dev, rows, splits, part, ts);
         }
         GAD_CHECK_LAUNCH("gemm_dw(stream)");
         hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256), 0,
@@ -2471,7 +2486,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     long long group_stride = 0;
 #define LAUNCH_DW4(WM, WN, TM, TN, XM, V, VM)                                                              \
     hipLaunchKernelGGL((gemm_dw_kernel<WM, WN, TM, TN, XM, V, VM>), dim3(tn_ * tk_, splits, gr.n), dim3(256), 0, st, d, \
-                       x, gr, in.n_rows_dev, rows, in.Kp, k_used, tk_, a->gacc, part, group_stride)
+                       x, gr, in.n_rows_dev, rows, in.Kp, k_used, tk_, a->gacc, part, group_stride, ts)
 #define LAUNCH_DW3(WM, WN, TM, TN, XM, V)                                                                  \
     do { if (narrow) LAUNCH_DW4(WM, WN, TM, TN, XM, V, 512); else LAUNCH_DW4(WM, WN, TM, TN, XM, V, VMAX); } while (0)
 #define LAUNCH_DW(WM, WN, TM, TN)                                                                          \

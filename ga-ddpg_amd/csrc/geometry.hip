@@ -12,6 +12,25 @@
 #include <string.h>
 
 static thread_local char g_err[512] = "";
+static thread_local unsigned long long* g_timing_slot = nullptr;
+
+unsigned long long* gad_take_timing_slot() {
+    unsigned long long* p = g_timing_slot;
+    g_timing_slot = nullptr;
+    return p;
+}
+
+extern "C" int gad_timing_slot(void* slot) {
+    g_timing_slot = static_cast<unsigned long long*>(slot);
+    return GAD_OK;
+}
+
+extern "C" int gad_wall_clock_khz(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+    return khz;
+}
 void gad_set_error(const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, gad_bn_fin bn,
                                                            const int32_t* __restrict__ off, int G,
-                                                           float* __restrict__ out, int32_t* __restrict__ argmax) {
+                                                           float* __restrict__ out, int32_t* __restrict__ argmax,
+                                                           unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
     constexpr int C = 4 * QPR * NQ, RPW = 64 / QPR;
     __shared__ __attribute__((aligned(16))) float sv[C], tv[C];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
 extern "C" int gad_segment_pool(const float* z, int z_pitch, int C, const float* scale, const float* shift,
                                 const gad_bn_fin* host_bn, const int32_t* grp_off, int G, float* out, int32_t* argmax,
                                 void* stream) {
+    unsigned long long* ts = gad_take_timing_slot();
     GAD_REQUIRE(z && grp_off && out, GAD_ERR_NULL, "segment_pool: null pointer");
     GAD_REQUIRE((scale == nullptr) == (shift == nullptr), GAD_ERR_NULL, "segment_pool: scale and shift come together");
     GAD_REQUIRE(z_pitch % 4 == 0, GAD_ERR_SHAPE, "segment_pool: row pitch %d must be a multiple of 4", z_pitch);
@@ -186,7 +189,7 @@ extern "C" int gad_segment_pool(const float* z, int z_pitch, int C, const float*
     if (gx > 2048) gx = 2048;
 #define LAUNCH_POOL(QPR, NQ)                                                                                      \
     hipLaunchKernelGGL((segment_pool_kernel<QPR, NQ>), dim3(gx), dim3(256), 0, (hipStream_t)stream, z, z_pitch, scale, \
-                       shift, bn, grp_off, G, out, argmax)
+                       shift, bn, grp_off, G, out, argmax, ts)
     switch (C) {
         case 8: LAUNCH_POOL(2, 1); break;
         case 16: LAUNCH_POOL(4, 1); break;

@@ -370,7 +370,35 @@ def bn_bwd(enc, slot, m, count, want_dw, accumulate):
     return b
 
 
-TIMING = {"enabled": False, "tag": None, "events": []}     # bench.py: HIP-event bracket of one tagged launch
+# bench.py / diagnostics: durations of tagged launches, stamped by the kernels themselves (gad_timing_slot: first
+# wavefront start -> last wavefront end on the device wall clock -- what a profiler reports as the dispatch duration;
+# HIP events around a 25 us launch inside a five-stream step read 8 - 20 us high: event packets, queue waits)
+TIMING = {"enabled": False, "tag": None, "slots": None, "next": 0, "tags": []}
+_TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_segment_pool")
+
+
+def timing_start(tag="*", capacity=1 << 16):
+    """time every launch whose plan tag is `tag` ("*": all, or a set of tags) until timing_stop()"""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    slots = torch.zeros(capacity, 2, dtype=torch.int64, device=dev)
+    slots[:, 0] = -1                                      # all ones: the kernels take the unsigned minimum
+    TIMING.update(enabled=True, tag=tag, slots=slots, next=0, tags=[])
+
+
+def timing_stop():
+    """-> {tag: [milliseconds per launch, ...]} of the launches timed since timing_start()"""
+    TIMING["enabled"] = False
+    torch.cuda.synchronize()
+    khz = hip.lib().gad_wall_clock_khz()
+    n, slots = TIMING["next"], TIMING["slots"]
+    out = {}
+    if slots is not None and n:
+        v = slots[:n].cpu().numpy()
+        for tag, (t0, t1) in zip(TIMING["tags"], v):
+            if t1 > 0 and t0 >= 0:
+                out.setdefault(tag, []).append(float(t1 - t0) / float(khz))        # ticks / kHz = ms
+    TIMING.update(slots=None, next=0, tags=[])
+    return out
 
 
 def coalesce_grads(flats):
@@ -510,11 +538,13 @@ class Plan(object):
                     main.wait_event(args)
                 continue
             lane = int(lane)
-            ev = None
-            if timed and i in self.tags and (TIMING["tag"] == "*" or self.tags[i] == TIMING["tag"] or
-                                             (isinstance(TIMING["tag"], (set, frozenset, tuple, list)) and self.tags[i] in TIMING["tag"])):
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record(sides[lane][0] if lane else main)
+            if timed and name in _TIMED_CALLS and i in self.tags and TIMING["next"] < TIMING["slots"].shape[0] and (
+                    TIMING["tag"] == "*" or self.tags[i] == TIMING["tag"] or
+                    (isinstance(TIMING["tag"], (set, frozenset, tuple, list)) and self.tags[i] in TIMING["tag"])):
+                k = TIMING["next"]
+                TIMING["next"] = k + 1
+                TIMING["tags"].append(self.tags[i])
+                hip.lib().gad_timing_slot(C.c_void_p(TIMING["slots"].data_ptr() + 16 * k))   # consumed by the call below
             q = sides[lane][1] if lane else st
             if name == "zero":
                 args.zero_()
@@ -524,9 +554,6 @@ class Plan(object):
                 hip.check(f(C.byref(s), q), name)
             else:
                 hip.check(f(*(args + [q])), name)
-            if ev is not None:
-                ev[1].record(sides[lane][0] if lane else main)
-                TIMING["events"].append(ev + (self.tags[i],))
 
 
 # ----------------------------------------------------------------------------------------------

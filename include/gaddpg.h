@@ -46,6 +46,13 @@ const char* gad_last_error(void);          /* thread-local description of the la
  * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.          */
 int gad_set_option(const char* name, int value);
 
+/* In-kernel launch timing (diagnostics / bench.py roofline): arm `slot` (device, 2 x uint64: initialise slot[0] to all ones,
+ * slot[1] to 0) for the NEXT gad_gemm_fwd / gad_gemm_dx / gad_gemm_dw / gad_segment_pool call of this thread; the kernel
+ * leaves min(start) / max(end) wall-clock stamps of its wavefronts there (ticks of gad_wall_clock_khz()): the dispatch
+ * duration a profiler would report, without tracing and regardless of what other streams do.  NULL disarms.           */
+int gad_timing_slot(void* slot);
+int gad_wall_clock_khz(void);              /* rate of that clock (hipDeviceAttributeWallClockRate), 0 if unavailable    */
+
 /* ---------------------------------------------------------------------------------------------
  * A. pointnet2_ops._ext operator parity (materialising, reference API shapes)
  * ------------------------------------------------------------------------------------------- */

@@ -1,5 +1,5 @@
 """Diagnostic: per-layer GEMM launch durations of the B=256 update step with the step serialised on one stream
-(engine.SERIAL: every kernel has the GPU to itself), HIP events around every tagged launch.
+(engine.SERIAL: every kernel has the GPU to itself), every tagged launch stamped by the kernel itself (engine.timing_start).
     python tests/diag_alone.py [tag-prefix ...]      e.g.  python tests/diag_alone.py dw. dx."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,15 +24,11 @@ def main():
     for i in range(6):
         agent.update_parameters(d, agent.update_step, i)
     engine.SERIAL = True
-    engine.TIMING.update(enabled=True, tag="*", events=[])
+    engine.timing_start("*")
     for i in range(8):
         agent.update_parameters(d, agent.update_step, i)
-    torch.cuda.synchronize()
-    engine.TIMING["enabled"] = False
+    by = {t: [1e3 * x for x in v] for t, v in engine.timing_stop().items()}
     engine.SERIAL = False
-    by = {}
-    for e0, e1, tag in engine.TIMING["events"]:
-        by.setdefault(tag, []).append(e0.elapsed_time(e1) * 1e3)
     pre = sys.argv[1:] or [""]
     tot = 0.0
     for tag in sorted(by):

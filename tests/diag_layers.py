@@ -1,4 +1,4 @@
-"""Diagnostic: per-launch-tag durations of the DDPG step (HIP events around every tagged GEMM)."""
+"""Diagnostic: per-launch-tag durations of the DDPG step (every tagged launch stamped by the kernel itself: engine.timing_start)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sys
@@ -21,14 +21,12 @@ def main(B=256, steps=6):
     batch = sample_valid_batch(mem, B, rng)
     for i in range(4):
         agent.update_parameters(batch, agent.update_step, i)
-    engine.TIMING.update(enabled=True, tag="*", events=[])
+    engine.timing_start("*")
     for i in range(steps):
         agent.update_parameters(batch, agent.update_step, i)
-    torch.cuda.synchronize()
-    engine.TIMING["enabled"] = False
     acc = defaultdict(list)
-    for a, b, tag in engine.TIMING["events"]:
-        acc[tag].append(a.elapsed_time(b) * 1e3)
+    for tag, v in engine.timing_stop().items():
+        acc[tag] = [1e3 * x for x in v]
     rt = agent._rt
     print("rows: sa1 %d  sa2 %d  sa3 %d" % tuple(int(rt.geo.rows[s]["n"].item()) for s in range(3)))
     tot = 0.0
