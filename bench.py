@@ -269,7 +269,7 @@ def main():
     # steps, inside the overlapped step -- and once more with the step serialised on one stream (the kernel by itself)
     def probe(serial, n):
         engine.SERIAL = serial
-        engine.timing_start("*")
+        engine.timing_start("*", capacity=n * 200)
         for i in range(n):
             step(args.warmup + i)
         acc = engine.timing_stop()
@@ -285,7 +285,7 @@ def main():
     priced = {k: v for k, v in table.items() if v["bound"] in ("mfma", "hbm")}
     dom = max(priced, key=lambda k: priced[k]["ms_per_step"])
     # ---- the timed region: K steps, HIP events around the launches of the dominant kernel only
-    engine.timing_start(frozenset(table[dom]["tags"]), capacity=max(1024, int(args.steps * table[dom]["launches_per_step"] * 1.2) + 64))
+    engine.timing_start(frozenset(table[dom]["tags"]), capacity=min(8192, int(args.steps * table[dom]["launches_per_step"] * 1.1) + 64))
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -75,16 +75,21 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 
-// First-wavefront-start / last-wavefront-end stamps of a launch (include/gaddpg.h: gad_timing_slot) on the constant-rate
-// wall clock: slot[0] = min over workgroups of the start stamp, slot[1] = max over wavefronts of the end stamp -- the
+// Start / end stamps of every wavefront of a launch (include/gaddpg.h: gad_timing_slot) on the constant-rate wall clock,
+// written with plain 8-byte stores into the wavefront's own entry of the slot (same-address atomics from ~2000 workgroups
+// cost ~25 ns each: a 25 us kernel took 200 us with an atomic min/max pair).  The host takes min(start) / max(end): the
 // quantity a profiler reports as the dispatch duration, measurable inside an untraced, multi-stream run.
 struct KTimer {
     unsigned long long* p;
-    __device__ __forceinline__ explicit KTimer(unsigned long long* q) : p(q) {
-        if (p && threadIdx.x == 0) atomicMin(p, (unsigned long long)wall_clock64());
+    __device__ __forceinline__ explicit KTimer(unsigned long long* q) : p(nullptr) {
+        if (q && (threadIdx.x & 63) == 0) {
+            const unsigned blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned w = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);
+            if (w < GAD_TIMING_WAVES) { p = q + 2 * (size_t)w; p[0] = (unsigned long long)wall_clock64(); }
+        }
     }
     __device__ __forceinline__ ~KTimer() {
-        if (p && (threadIdx.x & 63) == 0) atomicMax(p + 1, (unsigned long long)wall_clock64());
+        if (p) p[1] = (unsigned long long)wall_clock64();
     }
 };
 

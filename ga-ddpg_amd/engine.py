@@ -377,11 +377,15 @@ TIMING = {"enabled": False, "tag": None, "slots": None, "next": 0, "tags": []}
 _TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_segment_pool")
 
 
-def timing_start(tag="*", capacity=1 << 16):
-    """time every launch whose plan tag is `tag` ("*": all, or a set of tags) until timing_stop()"""
+TIMING_WAVES = 16384          # include/gaddpg.h GAD_TIMING_WAVES
+
+
+def timing_start(tag="*", capacity=2048):
+    """time every launch whose plan tag is `tag` ("*": all, or a set of tags) until timing_stop(); capacity = launches
+    (256 KB of stamps each)"""
     dev = torch.device("cuda", torch.cuda.current_device())
-    slots = torch.zeros(capacity, 2, dtype=torch.int64, device=dev)
-    slots[:, 0] = -1                                      # all ones: the kernels take the unsigned minimum
+    slots = torch.zeros(capacity, TIMING_WAVES, 2, dtype=torch.int64, device=dev)
+    slots[:, :, 0] = torch.iinfo(torch.int64).max
     TIMING.update(enabled=True, tag=tag, slots=slots, next=0, tags=[])
 
 
@@ -393,33 +397,13 @@ def timing_stop():
     n, slots = TIMING["next"], TIMING["slots"]
     out = {}
     if slots is not None and n:
-        v = slots[:n].cpu().numpy()
-        for tag, (t0, t1) in zip(TIMING["tags"], v):
-            if t1 > 0 and t0 >= 0:
-                out.setdefault(tag, []).append(float(t1 - t0) / float(khz))        # ticks / kHz = ms
+        t0 = slots[:n, :, 0].min(dim=1).values.cpu().numpy()
+        t1 = slots[:n, :, 1].max(dim=1).values.cpu().numpy()
+        for tag, a, b in zip(TIMING["tags"], t0, t1):
+            if b > 0 and a < b:
+                out.setdefault(tag, []).append(float(b - a) / float(khz))          # ticks / kHz = ms
     TIMING.update(slots=None, next=0, tags=[])
     return out
-
-
-def coalesce_grads(flats):
-    """Put the gradients of the networks that one optimiser phase updates into ONE buffer (each network's slice padded to
-    64 floats), so that a data-parallel run needs a single all-reduce per phase.  Must run before any plan that bakes
-    the .grad pointers is built; idempotent for the same group of networks (cached FlatNets are shared by runtimes)."""
-    key = tuple(id(f) for f in flats)
-    have = getattr(flats[0], "_grad_bucket", None)
-    if have is not None:
-        assert have[0] == key, "a FlatNet can be part of one gradient bucket only"
-        return have[1]
-    assert all(getattr(f, "_grad_bucket", None) is None for f in flats)
-    pad = lambda n: (n + 63) // 64 * 64
-    buf = torch.zeros(sum(pad(f.n) for f in flats), dtype=torch.float32, device=flats[0].device)
-    off = 0
-    for f in flats:
-        f.rebind_grad(buf[off:off + f.n])
-        off += pad(f.n)
-    for f in flats:
-        f._grad_bucket = (key, buf)
-    return buf
 
 
 _DW_WS = {}
@@ -544,7 +528,7 @@ class Plan(object):
                 k = TIMING["next"]
                 TIMING["next"] = k + 1
                 TIMING["tags"].append(self.tags[i])
-                hip.lib().gad_timing_slot(C.c_void_p(TIMING["slots"].data_ptr() + 16 * k))   # consumed by the call below
+                hip.lib().gad_timing_slot(C.c_void_p(TIMING["slots"].data_ptr() + 16 * TIMING_WAVES * k))   # consumed by the call below
             q = sides[lane][1] if lane else st
             if name == "zero":
                 args.zero_()

@@ -46,10 +46,12 @@ const char* gad_last_error(void);          /* thread-local description of the la
  * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.          */
 int gad_set_option(const char* name, int value);
 
-/* In-kernel launch timing (diagnostics / bench.py roofline): arm `slot` (device, 2 x uint64: initialise slot[0] to all ones,
- * slot[1] to 0) for the NEXT gad_gemm_fwd / gad_gemm_dx / gad_gemm_dw / gad_segment_pool call of this thread; the kernel
- * leaves min(start) / max(end) wall-clock stamps of its wavefronts there (ticks of gad_wall_clock_khz()): the dispatch
- * duration a profiler would report, without tracing and regardless of what other streams do.  NULL disarms.           */
+/* In-kernel launch timing (diagnostics / bench.py roofline): arm `slot` -- device memory, GAD_TIMING_WAVES x {start, end}
+ * uint64 pairs, starts initialised to a large value, ends to 0 -- for the NEXT gad_gemm_fwd / gad_gemm_dx / gad_gemm_dw /
+ * gad_segment_pool call of this thread.  Every wavefront of that launch stores its own start / end wall-clock stamp (ticks of
+ * gad_wall_clock_khz()) into its entry; max(end) - min(start) is the dispatch duration a profiler would report, without
+ * tracing and regardless of what other streams do.  Wavefronts beyond GAD_TIMING_WAVES are not recorded.  NULL disarms. */
+#define GAD_TIMING_WAVES 16384
 int gad_timing_slot(void* slot);
 int gad_wall_clock_khz(void);              /* rate of that clock (hipDeviceAttributeWallClockRate), 0 if unavailable    */
 
