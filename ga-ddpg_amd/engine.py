@@ -406,6 +406,27 @@ def timing_stop():
     return out
 
 
+def coalesce_grads(flats):
+    """Put the gradients of the networks that one optimiser phase updates into ONE buffer (each network's slice padded to
+    64 floats), so that a data-parallel run needs a single all-reduce per phase.  Must run before any plan that bakes
+    the .grad pointers is built; idempotent for the same group of networks (cached FlatNets are shared by runtimes)."""
+    key = tuple(id(f) for f in flats)
+    have = getattr(flats[0], "_grad_bucket", None)
+    if have is not None:
+        assert have[0] == key, "a FlatNet can be part of one gradient bucket only"
+        return have[1]
+    assert all(getattr(f, "_grad_bucket", None) is None for f in flats)
+    pad = lambda n: (n + 63) // 64 * 64
+    buf = torch.zeros(sum(pad(f.n) for f in flats), dtype=torch.float32, device=flats[0].device)
+    off = 0
+    for f in flats:
+        f.rebind_grad(buf[off:off + f.n])
+        off += pad(f.n)
+    for f in flats:
+        f._grad_bucket = (key, buf)
+    return buf
+
+
 _DW_WS = {}
 
 
