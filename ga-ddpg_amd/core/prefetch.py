@@ -1,0 +1,133 @@
+"""Sample prefetch for the update loop (BASELINE configs[4]: "overlapped sample-prefetch and all-reduce").
+
+The reference's loop samples synchronously between two updates (core/train_test_offline.py:119): 17 MB of float64 fancy
+indexing per minibatch (core/replay_memory.py:109-127) while the GPU idles.  `PrefetchSampler` moves that to a background
+thread: it keeps `depth` minibatches ready in PINNED float32 staging sets, so `update_parameters` only issues the
+host-to-device copies (FusedRuntime.upload takes dicts of pinned tensors as they are), and the gather of batch k+1 overlaps
+the update on batch k.  Batches come out in exactly the order -- and with exactly the contents -- a synchronous
+`memory.sample(batch_size)` loop on the same random stream would give (one producer, FIFO queue):
+tests/test_prefetch.py.
+
+    sampler = PrefetchSampler(memory, batch_size=512, rng=np.random.default_rng(seed))
+    for i in range(n):
+        agent.update_parameters(sampler.next(), agent.update_step, i)
+    sampler.close()
+
+With a DeviceReplay (GPU-resident buffer) the handles of `sample_lazy` are prefetched instead (index vectors only).
+"""
+import queue
+import threading
+
+import numpy as np
+import torch
+
+KEYS = ("point_state_batch", "next_point_state_batch", "action_batch", "expert_action_batch", "reward_batch",
+        "return_batch", "mask_batch", "time_batch", "goal_batch", "expert_flag_batch", "perturb_flag_batch")
+
+
+class PrefetchSampler(object):
+    def __init__(self, memory, batch_size, depth=2, rng=None, pin=None, sample=None):
+        """memory: BaseMemory (host sampling into pinned staging sets) or DeviceReplay (lazy gather handles).
+        sample: optional callable(batch_size) -> batch dict replacing memory.sample (e.g. a validity-checking sampler)."""
+        self.memory, self.batch_size, self.depth = memory, int(batch_size), int(depth)
+        self.rng = rng
+        self.lazy = hasattr(memory, "sample_lazy")
+        self.pin = torch.cuda.is_available() if pin is None else bool(pin)
+        self._sample = sample
+        self._free = queue.Queue()
+        self._ready = queue.Queue(maxsize=self.depth)
+        self._sets = []
+        self._held = None
+        self._stop = threading.Event()
+        self._error = None
+        self._thread = threading.Thread(target=self._run, name="gad-prefetch", daemon=True)
+        self._thread.start()
+
+    # ------------------------------------------------------------------ producer
+    def _draw(self):
+        if self._sample is not None:
+            return self._sample(self.batch_size)
+        if self.lazy:
+            return self.memory.sample_lazy(self.batch_size, self.rng)
+        try:
+            return self.memory.sample(self.batch_size, rng=self.rng)
+        except TypeError:
+            return self.memory.sample(batch_size=self.batch_size)
+
+    def _staging(self, batch):
+        """one pinned float32 staging set shaped like `batch` (allocated on first use: depth + 1 sets circulate)"""
+        st = {}
+        for k in KEYS:
+            if k in batch:
+                t = torch.empty(tuple(np.asarray(batch[k]).shape), dtype=torch.float32)
+                st[k] = t.pin_memory() if self.pin else t
+        return st
+
+    def _run(self):
+        try:
+            while not self._stop.is_set():
+                batch = self._draw()
+                if self.lazy:
+                    item = batch
+                else:
+                    try:
+                        st = self._free.get_nowait()
+                    except queue.Empty:
+                        if len(self._sets) < self.depth + 1:
+                            st = self._staging(batch)
+                            self._sets.append(st)
+                        else:
+                            st = None
+                            while st is None and not self._stop.is_set():
+                                try:
+                                    st = self._free.get(timeout=0.05)
+                                except queue.Empty:
+                                    pass
+                            if st is None:
+                                return
+                    for k, t in st.items():
+                        np.copyto(t.numpy(), np.asarray(batch[k]).reshape(t.shape), casting="same_kind")
+                    item = dict(st)
+                    for k, v in batch.items():                      # bookkeeping fields (indices, counts) ride along
+                        if k not in item and k not in ("image_state_batch", "next_image_state_batch"):
+                            item[k] = v
+                    item["_staging"] = st
+                while not self._stop.is_set():
+                    try:
+                        self._ready.put(item, timeout=0.05)
+                        break
+                    except queue.Full:
+                        pass
+        except BaseException as e:                                  # surfaced by next()
+            self._error = e
+            self._ready.put(None)
+
+    # ------------------------------------------------------------------ consumer
+    def next(self):
+        """the next minibatch; the staging set handed out by the PREVIOUS call returns to the pool (its host-to-device
+        copies were enqueued and the update that consumed it has synchronised by then)"""
+        if self._held is not None:
+            self._free.put(self._held)
+            self._held = None
+        item = self._ready.get()
+        if item is None:
+            raise RuntimeError("prefetch thread failed") from self._error
+        self._held = item.pop("_staging", None) if isinstance(item, dict) else None
+        return item
+
+    __call__ = lambda self, batch_size=None: self.next()           # drop-in for memory.sample(batch_size=...)
+
+    def close(self):
+        self._stop.set()
+        try:
+            while True:
+                self._ready.get_nowait()
+        except queue.Empty:
+            pass
+        self._thread.join(timeout=2.0)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

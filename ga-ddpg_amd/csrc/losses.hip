@@ -380,6 +380,35 @@ extern "C" int gad_actor_critic_loss(const float* out9, const float* expert_flag
     return GAD_OK;
 }
 
+// local mask counts of a minibatch (the numbers the masked means divide by): [kept, goal rows, expert rows,
+// rows not (expert & reward)] as doubles -- a data-parallel run all-reduces them (ga_ddpg_amd/parallel.py)
+__global__ __launch_bounds__(256) void mask_counts_kernel(const float* __restrict__ ret, const float* __restrict__ expert,
+                                                          const float* __restrict__ perturb, int B,
+                                                          double* __restrict__ out4) {
+    __shared__ float red[4];
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < B; i += 256) {
+        const bool reward = ret[i] > 0.f, exp = expert[i] >= 1.f;
+        c[0] += perturb[i] < 1.f ? 1.f : 0.f;
+        c[1] += reward ? 1.f : 0.f;
+        c[2] += exp ? 1.f : 0.f;
+        c[3] += (reward && exp) ? 0.f : 1.f;
+    }
+    for (int k = 0; k < 4; ++k) {
+        const float s = block_sum(c[k], red);
+        if (threadIdx.x == 0) out4[k] = (double)s;
+    }
+}
+
+extern "C" int gad_mask_counts(const float* ret, const float* expert_flag, const float* perturb_flag, int B, double* out4,
+                               void* stream) {
+    GAD_REQUIRE(ret && expert_flag && perturb_flag && out4, GAD_ERR_NULL, "mask_counts: null pointer");
+    GAD_REQUIRE(B >= 1, GAD_ERR_SHAPE, "mask_counts: B");
+    hipLaunchKernelGGL(mask_counts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, ret, expert_flag, perturb_flag, B, out4);
+    GAD_CHECK_LAUNCH("mask_counts");
+    return GAD_OK;
+}
+
 __global__ __launch_bounds__(256) void target_noise_kernel(const float* __restrict__ pi, const float* __restrict__ u,
                                                            int n, float level, int normal, float* __restrict__ out) {
     const int q = blockIdx.x * 256 + threadIdx.x;

@@ -701,7 +701,8 @@ def _bn_coef(plan, enc, slot, m, count, want_dw):
               _ptr(gacc, m.b_off, 8) if want_dw else None)
 
 
-def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1, zero_scatter=True):
+def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1, zero_scatter=True,
+                          early_hook=None):
     # zero_scatter=False: the caller has cleared slot.dF[0], slot.dF[1] (and slot.daction) at the head of its plan
     """Backward of plan_encoder_forward.  g_fc2 (B, 512) is dLoss/d(relu(bn(Zfc[1]))) WITH the ReLU mask applied, as
     produced by the consumer head's dX kernel (store_masked), whose epilogue must also have filled this slot's bstats
@@ -709,7 +710,10 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     dX / dW kernels (gad_bn_bwd); every dX stores the next gradient already masked by the previous layer's ReLU.
     Weight gradients accumulate (f64) into enc.flat.gacc when want_dw; their GEMMs are forked onto side stream
     `dw_lane` (two backward passes that may run concurrently -- critic and actor -- get different lanes: each lane has
-    its own split-K workspace and is stream-ordered)."""
+    its own split-K workspace and is stream-ordered).
+    early_hook(plan): called once the weight gradients of everything but SA1 are complete (FC head, SA3, SA2 = 99 % of
+    the encoder's parameters; the dW lanes are joined first): a data-parallel run converts and all-reduces that bucket
+    there, under the SA1 backward -- the longest stage of the pass."""
     geo = slot.geo
     plan = Plan()
     B = slot.B
@@ -787,6 +791,10 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     dx(dict(n_rows=B, layer=1), d, fc1, slot.F[2].shape[1], epilogue=0, gout=_ptr(slot.dF[2]), gout_pitch=slot.F[2].shape[1])
     # ---- SA3 -> SA1 ----
     for s in (2, 1, 0):
+        if s == 0 and early_hook is not None and want_dw:
+            for lane in sorted(set(dw_lanes) - {0}):
+                plan.join(lane)
+            early_hook(plan)
         r = geo.rows[s]
         rows_kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], name="sa%d" % (s + 1))
         m1, m2, m3 = enc.sa_mats[s]

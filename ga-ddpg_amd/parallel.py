@@ -10,12 +10,21 @@ whole batch, so every masked mean is a GLOBAL-batch mean.  To reproduce that wit
     step), so the SUM of the ranks' gradients is the global-mean gradient -- no post-division;
   * clip_grad_norm_ is evaluated after the all-reduce, identically on every rank;
   * optimiser / target-network state is replicated and advances identically (no exchange).
-Bucket sizes: critic phase 594 441 + 1 398 720 floats, actor phase 202 259 + 1 398 336 floats
-(2.4 MB + 5.6 MB): each is a single flat tensor, already contiguous, so there is nothing to bucket.
+Buckets (BASELINE configs[4]: "overlapped sample-prefetch and all-reduce"): the backward pass finishes its weight gradients in
+the order head -> FC -> SA3 -> SA2 -> SA1, and SA1 -- 13 k of the encoder's 1.4 M parameters -- is the longest stage.  So each
+optimiser phase exchanges [head | encoder without SA1] (critic phase 0.59 M + 1.39 M floats = 7.9 MB, actor phase 0.20 M +
+1.39 M = 6.4 MB) asynchronously as soon as the SA2 backward is done, under the SA1 backward, and the 52 KB SA1 slice at
+the end (FusedRuntime.enable_bucketed_reduce; ring all-reduce of 8 MB over xGMI ~ 91 us per-link bound, the SA1 backward
+~ 0.3 ms).  The result is bit-identical to one exchange of the whole buffer (tests/test_parallel_gloo.py).
+Mask counts are formed on the device (gad_mask_counts) and exchanged stream-ordered: no host pass over the flags.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+BUCKETED = os.environ.get("GAD_DP_BUCKETS", "1") == "1"      # 0: one exchange per phase after the whole backward pass
 
 
 def mask_counts(batch):
@@ -64,16 +73,40 @@ class DataParallelContext(object):
         # inv_n[0:5] = numer / counts[pick]   (layout: inverse_counts)
         self._numer = torch.tensor([1.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0, 1.0], dtype=torch.float64, device=rt.dev)
         self._pick = torch.tensor([0, 1, 2, 1, 3], dtype=torch.int64, device=rt.dev)
+        self._inflight = {}
+        if BUCKETED and hasattr(rt, "enable_bucketed_reduce"):
+            rt.enable_bucketed_reduce()
+
+    def reduce_early(self, tag, tensors):
+        """start the exchange of a bucket whose gradients are complete (asynchronous: the collective runs on the backend's
+        own stream, ordered after the launches enqueued so far on the current stream)"""
+        self._inflight.setdefault(tag, [])
+        for t in tensors:
+            self._inflight[tag].append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduce_finish(self, tag, tensors):
+        """exchange the rest of the phase's gradients and make the current stream wait for every bucket of the phase"""
+        works = self._inflight.pop(tag, [])
+        for t in tensors:
+            works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
 
     def allreduce_grads(self, tensors):
         for t in tensors:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def set_counts(self, batch):
-        """global mask counts -> rt.inv_n: one 4-double all-reduce per step, stream-ordered (no host sync: the
+        """global mask counts -> rt.inv_n: one 4-double all-reduce per step, stream-ordered (no host sync: counts and
         reciprocals are formed on the device; an empty mask gives inf -> NaN losses, like the reference)"""
-        self._counts_host.numpy()[:] = mask_counts(batch)
-        self._counts.copy_(self._counts_host, non_blocking=True)
+        d = getattr(self.rt, "dbuf", None)
+        if d is not None and self._counts.is_cuda:
+            from . import hip
+            hip.call("gad_mask_counts", d["return_batch"], d["expert_flag_batch"], d["perturb_flag_batch"], self.rt.B,
+                     self._counts)
+        else:
+            self._counts_host.numpy()[:] = mask_counts(batch)
+            self._counts.copy_(self._counts_host, non_blocking=True)
         dist.all_reduce(self._counts, op=dist.ReduceOp.SUM, group=self.group)
         self.rt.inv_n[0:5] = (self._numer / self._counts.index_select(0, self._pick)).float()
 

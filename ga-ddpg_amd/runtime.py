@@ -100,6 +100,7 @@ class FusedRuntime(object):
         self._one = torch.ones(1, **f32)
         self._minus_one = -torch.ones(1, **f32)
         self.scal_host = torch.zeros(32, dtype=torch.float32).pin_memory()
+        self.bucketed = False
         self.seg = {}
         for nm, fl in (("pol", self.pol.flat),) + ((("cr", self.cr.flat),) if self.has_critic else ()):
             self.seg[nm] = torch.tensor([0, fl.n], dtype=torch.int32, device=dev)
@@ -118,6 +119,40 @@ class FusedRuntime(object):
         self.graph_replays = 0
 
     # ------------------------------------------------------------------ plans over static buffers
+    def enable_bucketed_reduce(self):
+        """data-parallel runs: rebuild the backward plans so that each optimiser phase's gradients leave in two buckets --
+        [head | encoder FC + SA3 + SA2] as soon as the SA2 backward is done (99 % of the bytes, all-reduced under the SA1
+        backward) and [encoder SA1] at the end -- instead of one exchange after the whole pass (parallel.py)"""
+        self.bucketed = True
+        self._build_plans()
+
+    def _grad_tail(self, plan, head, enc, tag, early):
+        """arena (f64, packed) -> flat .grad (f32, master order) at the end of a backward plan; bucketed: only what the
+        early hook has not converted yet (the encoder's SA1 parameters, which lead its flat buffer)"""
+        if not (self.bucketed and early):
+            plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
+            plan.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
+            return
+        lo, hi = enc.flat.segment("0.0.")                       # base_network[0][0] = SA1 (core/networks.py:65-92)
+        assert lo == 0
+        plan.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, hi, enc.flat.grad, 0)
+
+    def _early_hook(self, head, enc, tag):
+        if not self.bucketed:
+            return None
+        lo, hi = enc.flat.segment("0.0.")
+        n_rest = enc.flat.n - hi
+
+        def hook(plan):
+            plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
+            plan.call("gad_grad_from_arena", enc.flat.gacc, engine._ptr(enc.flat.m2p, hi), n_rest, engine._ptr(enc.flat.grad, hi), 0)
+            plan.fn(lambda: self._reduce_early(tag, [head.flat.grad, enc.flat.grad[hi:]]))
+        return hook
+
+    def _reduce_early(self, tag, tensors):
+        if self.dp is not None:
+            self.dp.reduce_early(tag, tensors)
+
     def _build_plans(self):
         d = self.dbuf
         enc, pol = self.enc, self.pol
@@ -136,9 +171,8 @@ class FusedRuntime(object):
         bw.zero_multi([pol.flat.gacc, enc.flat.gacc, self.slot_p.bstats, self.slot_p.dF[0], self.slot_p.dF[1]])
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
         bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True, dw_lane=2,
-                                               zero_scatter=False))
-        bw.call("gad_grad_from_arena", pol.flat.gacc, pol.flat.m2p, pol.flat.n, pol.flat.grad, 0)
-        bw.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
+                                               zero_scatter=False, early_hook=self._early_hook(pol, enc, "a")))
+        self._grad_tail(bw, pol, enc, "a", True)
         P["p_bwd"] = bw
         if not self.has_critic:
             return
@@ -158,9 +192,8 @@ class FusedRuntime(object):
         cb.zero_multi([cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1]])
         cb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
         cb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=d["action_batch"], want_dw=True,
-                                               zero_scatter=False))
-        cb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 0)
-        cb.call("gad_grad_from_arena", venc.flat.gacc, venc.flat.m2p, venc.flat.n, venc.flat.grad, 0)
+                                               zero_scatter=False, early_hook=self._early_hook(cr, venc, "c")))
+        self._grad_tail(cb, cr, venc, "c", True)
         P["c_bwd"] = cb
         # actor-critic term: Q(s, pi(s)) through the freshly updated critic, gradient back to pi
         v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi, finalize_last=fl)
@@ -223,11 +256,16 @@ class FusedRuntime(object):
         hip.call("gad_adam_step", flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq, flat.active, flat.m2p,
                  flat.packed, flat.n, flat.hyper, clip, float(self.agent.clip_grad) if clip is not None else 0.0)
 
-    def _reduce(self, flats):
-        if self.allreduce is not None:
-            b = getattr(flats[0], "_grad_bucket", None)
-            whole = b is not None and b[0] == tuple(id(f) for f in flats)
-            self.allreduce([b[1]] if whole else [f.grad for f in flats])
+    def _reduce(self, flats, tag=None):
+        if self.allreduce is None:
+            return
+        if self.bucketed and tag is not None:                 # the early bucket is in flight: SA1's slice + wait for both
+            lo, hi = flats[1].segment("0.0.")
+            self.dp.reduce_finish(tag, [flats[1].grad[:hi]])
+            return
+        b = getattr(flats[0], "_grad_bucket", None)
+        whole = b is not None and b[0] == tuple(id(f) for f in flats)
+        self.allreduce([b[1]] if whole else [f.grad for f in flats])
 
     # ------------------------------------------------------------------ the update steps
     def ddpg_step(self, batch, noise_u=None):
@@ -349,7 +387,7 @@ class FusedRuntime(object):
                      self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
             # under graph capture the non-policy actor tail runs on a forked stream: no nested dW forks there
             P["p_bwd"].run(inline=(g_pi is None and OVERLAP_PASSES and torch.cuda.is_current_stream_capturing()))
-            self._reduce([self.pol.flat, self.enc.flat])
+            self._reduce([self.pol.flat, self.enc.flat], "a")
             self._adam(self.pol.flat, ag.policy_optim)
             if ag.train_feature:
                 self._adam(self.enc.flat, ag.state_feat_encoder_optim)
@@ -376,14 +414,14 @@ class FusedRuntime(object):
             with torch.cuda.stream(sc):
                 small_inits()
                 if self.dp is not None:
-                    self.dp.set_counts(batch if batch is not None else self._host_flags())
+                    self.dp.set_counts(batch)
                 self._ev_counts.record(sc)
             main.wait_event(self._ev_counts)
             with torch.cuda.stream(s1):
                 P["c_fwd"].run()
         else:
             if self.dp is not None:
-                self.dp.set_counts(batch if batch is not None else self._host_flags())
+                self.dp.set_counts(batch)
             self.geo.run(d["point_state_batch"])
             self.geo_next.run(d["next_point_state_batch"])
             P["c_fwd"].run()
@@ -420,7 +458,7 @@ class FusedRuntime(object):
                  d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
                  self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
         P["c_bwd"].run()
-        self._reduce([self.cr.flat, self.venc.flat])
+        self._reduce([self.cr.flat, self.venc.flat], "c")
         self.clip_sumsq.zero_()
         hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
         self._adam(self.venc.flat, ag.state_feat_val_encoder_optim)
@@ -451,7 +489,7 @@ class FusedRuntime(object):
         B = self.B
         self.upload(batch)
         if self.dp is not None:
-            self.dp.set_counts(batch if batch is not None else self._host_flags())
+            self.dp.set_counts(batch)
         self.scal.zero_()
         self.geo.run(d["point_state_batch"])
         P["p_fwd"].run()

@@ -360,6 +360,10 @@ int gad_policy_sample(const float* head, int B, int pitch, int extra_dim, const 
 int gad_actor_critic_loss(const float* out9, const float* expert_flag, const float* ret, int B,
                           float ratio, const float* inv_n, float* g_out9, float* scalars,
                           void* stream);
+/* local mask counts of a minibatch as doubles: out4 = [#(perturb < 1), #(return > 0), #(expert >= 1), #not(expert & reward)]
+ * (core/agent.py:224-229): what the masked means divide by; a data-parallel run sums them over the ranks.            */
+int gad_mask_counts(const float* ret, const float* expert_flag, const float* perturb_flag, int B, double* out4,
+                    void* stream);
 /* TD3 target-policy smoothing (core/utils.py:568-576 + core/ddpg.py:80-82, quirk preserved):
  * normal == 0 (noise_type "uniform"): u ~ U[0,1): a = pi + clamp3(((u*3-6)*level) * [1,1,1,5,5,5])
  * normal != 0 (any other noise_type):  u ~ N(0,1): a = pi + clamp3((u*level/2) * [1,1,1,5,5,5])    */

@@ -252,6 +252,47 @@ def gen_ddpg(B=32):
     return ret
 
 
+def gen_ddpg_f64(B=32):
+    """The reference's OWN update step evaluated in float64 on the a0 / b0 inputs of gen_ddpg (same det-filled weights,
+    same batches, the recorded noise draw): the yardstick for gradient accuracy -- a float32 implementation is judged by
+    its distance to this, relative to the distance of the reference's float32 run (ddpg_steps_B32.npz) to it."""
+    g32 = np.load(os.path.join(OUT, "ddpg_steps_B%d.npz" % B))
+    out = {}
+    orig_rand_like, orig_ft, orig_float = torch.rand_like, torch.cuda.FloatTensor, torch.Tensor.float
+    torch.cuda.FloatTensor = torch.DoubleTensor
+    torch.Tensor.float = lambda self, *a, **k: self.double()        # the reference's hard-coded .float() casts (control points)
+    try:
+        for run, start in (("a", 1), ("b", 2)):
+            agent, cfg = _make_agent("DDPG", "td3_critic_aux_policy_aux.yaml")
+            _fill_agent(agent, SEED)
+            for net in _nets_of(agent).values():
+                net.double()
+            agent.policy.action_scale = agent.policy.action_scale.double()
+            agent.policy.action_bias = agent.policy.action_bias.double()
+            agent.policy_target.action_scale = agent.policy_target.action_scale.double()
+            agent.policy_target.action_bias = agent.policy_target.action_bias.double()
+            agent.update_step = start
+            feats, crit_snap = [], {}
+            _hooked(agent, feats, [], crit_snap)
+            p = "%s0/" % run
+            batch = make_batch("ddpg_td3_aux.yaml", B, 1200, SEED + (100 if run == "b" else 0))     # gen_ddpg's s = 0 batches
+            assert np.array_equal(batch["point_state_batch"], g32[p + "batch/point_state_batch"])
+            u = g32[p + "noise_u"]
+            torch.rand_like = lambda x, *a, **k: torch.tensor(u, dtype=x.dtype)
+            ret = agent.update_parameters(batch, agent.update_step, 0)
+            for k, v in ret.items():
+                out[p + "ret/" + k] = np.float64(v)
+            for k in ("qf1", "qf2", "next_q_value", "pi"):
+                out[p + "t/" + k] = _np(getattr(agent, k))
+            for k, v in crit_snap.items():
+                out[p + "critic_phase/" + k] = v
+            _record_grads(agent, out, p + "end/", ["policy", "critic", "state_feature_extractor"])
+    finally:
+        torch.rand_like, torch.cuda.FloatTensor, torch.Tensor.float = orig_rand_like, orig_ft, orig_float
+    np.savez_compressed(os.path.join(OUT, "ddpg_steps_B%d_f64.npz" % B), **out)
+    return {k: float(v) for k, v in out.items() if "/ret/" in k and "loss" in k}
+
+
 def gen_bc(B=32, steps=2):
     agent, cfg = _make_agent("BC", "bc_aux_dagger.yaml")
     _fill_agent(agent, SEED + 1)
@@ -448,7 +489,8 @@ def main():
     install_shims()
     torch.set_num_threads(8)
     gens = [("config", gen_config), ("losses", gen_losses), ("heads", gen_heads), ("replay", gen_replay),
-            ("replay_io", gen_replay_io), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg)]
+            ("replay_io", gen_replay_io), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg),
+            ("ddpg_f64", gen_ddpg_f64)]
     only = sys.argv[1:]
     for name, fn in gens:
         if not only or name in only:

@@ -60,3 +60,22 @@ def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise
 def golden_batch(golden, prefix):
     p = prefix + "batch/"
     return {k[len(p):]: golden[k] for k in golden.files if k.startswith(p)}
+
+
+def grad_accuracy_rows(g32, g64, prefix, named, skip=()):
+    """Per-tensor accuracy of gradients against the REFERENCE's float64 evaluation (tests/golden/ddpg_steps_B32_f64.npz),
+    with the reference's own float32 run (ddpg_steps_B32.npz) as the yardstick.  Both goldens hold strided samples
+    (oracle.detfill.summarize).  -> rows (name, scale, e_hip_median, e_hip_max, e_ref32_median, e_ref32_max), errors
+    relative to the tensor's max |entry| in float64."""
+    rows = []
+    for name, t in named:
+        kv, ks = prefix + name + "#vals", prefix + name + "#stats"
+        if t is None or kv not in g64.files or any(s in name for s in skip):
+            continue
+        _, vals = summarize(t)
+        ref = g64[kv].astype(np.float64)
+        scale = float(g64[ks][3]) + 1e-300
+        e_hip = np.abs(np.asarray(vals, np.float64) - ref) / scale
+        e_r32 = np.abs(g32[kv].astype(np.float64) - ref) / scale
+        rows.append((name, scale, float(np.median(e_hip)), float(e_hip.max()), float(np.median(e_r32)), float(e_r32.max())))
+    return rows

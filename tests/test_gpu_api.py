@@ -215,3 +215,35 @@ def test_reinit_optim_restarts_the_lr_schedule(tmp_path):
     a3, _ = make_agent(cfg)
     a3.load_model(str(tmp_path), set_init_step=False)            # without set_init_step the loaded lr stays
     assert a3.policy_optim.param_groups[0]["lr"] == 3e-4
+
+
+def test_prefetched_pinned_batches_feed_the_update():
+    """BASELINE configs[4] 'sample-prefetch': minibatches staged by the background sampler (pinned float32 tensors) go
+    through update_parameters exactly like the host dict the reference's loop would have sampled"""
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.prefetch import PrefetchSampler
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle.detfill import fill_module_
+    res = {}
+    for mode in ("host", "prefetch"):
+        agent, cfg = make_agent("ddpg_td3_aux.yaml")
+        for name in ("policy", "policy_target", "critic", "critic_target", "state_feature_extractor"):
+            fill_module_(getattr(agent, name), name, 5)
+        mem = BaseMemory(600, cfg, point_dtype=np.float32)
+        fill_synthetic_buffer(mem, 600, seed=4)
+        rng = np.random.default_rng(2)
+        u = np.random.default_rng(3).random((16, 6)).astype(np.float32)
+        if mode == "host":
+            b = sample_valid_batch(mem, 16, rng)
+            res[mode] = agent.update_parameters(b, agent.update_step, 0, noise_u=u)
+        else:
+            with PrefetchSampler(mem, 16, sample=lambda n: sample_valid_batch(mem, n, rng)) as s:
+                b = s.next()
+                assert b["point_state_batch"].is_pinned() and b["point_state_batch"].dtype == torch.float32
+                res[mode] = agent.update_parameters(b, agent.update_step, 0, noise_u=u)
+                for i in range(3):                                  # staging sets recycle while updates keep running
+                    out = agent.update_parameters(s.next(), agent.update_step, i + 1)
+                    assert np.isfinite(list(out.values())).all()
+    for k in res["host"]:
+        assert_close(res["prefetch"][k], res["host"][k], 1e-5, 1e-7, k)

@@ -130,6 +130,45 @@ def test_ddpg_steps_vs_reference_golden(golden_dir):
             _check_step(agent, nets, g, "%s%d/" % (run, s), "ddpg", s, tight=(s == 0))
 
 
+@pytest.mark.parametrize("run,start", [("a", 1), ("b", 2)])
+def test_gradients_vs_reference_float64(golden_dir, run, start):
+    """Gradient accuracy with a reference-held yardstick: tests/golden/ddpg_steps_B32_f64.npz is the REFERENCE's own
+    update step evaluated in float64 (oracle/make_golden.py gen_ddpg_f64) on the a0 / b0 inputs; ddpg_steps_B32.npz its
+    float32 run.  Per tensor, the HIP gradient's error against float64 (median over the sampled entries, relative to the
+    tensor's max entry) may not exceed 3x the reference-float32 error, with a 1e-4 floor; the worst entry 3x / 5e-3.
+    Skipped: biases in front of a train-mode BatchNorm (analytically zero: both sides hold rounding noise) and, on the
+    policy step, the value encoder (the reference accumulates a gradient there that it discards; we skip that work)."""
+    from tests.helpers import grad_accuracy_rows
+    g32 = np.load(os.path.join(golden_dir, "ddpg_steps_B32.npz"))
+    g64 = np.load(os.path.join(golden_dir, "ddpg_steps_B32_f64.npz"))
+    agent, nets = _filled_agent("ddpg_td3_aux.yaml", SEED)
+    agent.update_step = start
+    p = "%s0/" % run
+    ret = agent.update_parameters(golden_batch(g32, p), agent.update_step, 0, noise_u=g32[p + "noise_u"])
+    torch.cuda.synchronize()
+    policy_step = start % 2 == 0
+    for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss"):
+        assert_close(ret[k], float(g64[p + "ret/" + k]), 1e-4, 1e-6, k)           # losses against the float64 reference
+    assert_close(agent.qf1.cpu().numpy(), g64[p + "t/qf1"], 0.0, 1e-4 * np.abs(g64[p + "t/qf1"]).max(), "qf1 vs float64")
+    assert_close(agent.pi.cpu().numpy(), g64[p + "t/pi"], 0.0, 1e-4 * np.abs(g64[p + "t/pi"]).max(), "pi vs float64")
+    rows, bad = [], []
+    for name in ("policy", "state_feature_extractor", "critic"):
+        named = [(n, q.grad) for n, q in nets[name].named_parameters()
+                 if not (policy_step and ("value_encoder" in n or name == "critic"))]
+        rows += [(name + "/" + r[0],) + r[1:] for r in
+                 grad_accuracy_rows(g32, g64, p + "end/grad/" + name + "/", named, skip=SKIP)]
+    assert len(rows) > 100
+    lines = ["%-72s %10s %10s %10s %10s %10s" % ("tensor (run %s0, B=32)" % run, "max|ref64|", "hip med", "hip max", "ref32 med", "ref32 max")]
+    for name, scale, hm, hx, rm, rx in sorted(rows, key=lambda r: -r[2] / max(3 * r[4], 1e-4)):
+        lines.append("%-72s %10.3e %10.2e %10.2e %10.2e %10.2e" % (name, scale, hm, hx, rm, rx))
+        if hm > max(3 * rm, 1e-4) or hx > max(3 * rx, 5e-3):
+            bad.append(lines[-1])
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "grad_accuracy_%s0.txt" % run), "w").write("\n".join(lines) + "\n")
+    assert not bad, "\n".join([lines[0]] + bad)
+
+
 def test_bc_steps_vs_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "bc_steps_B32.npz"))
     agent, nets = _filled_agent("bc_dagger_aux.yaml", SEED + 1)

@@ -1,0 +1,182 @@
+"""Teacher-forced follow-up steps: after every HIP update step the COMPLETE training state -- parameters, BatchNorm
+running statistics, Adam moments and step counts, scheduler positions, update_step -- is copied into the CPU oracle, and
+the next step runs on both from that common state.  Float32 trajectories of any two implementations separate after an
+Adam step (sign-like first steps on noise-only coordinates), so free-running comparisons can only be sanity bounds; with
+teacher forcing every step is a first step again and the tight tolerances apply to ALL of them.  What this pins:
+Adam bias correction at t > 1 and weight decay (torch.optim.Adam run on the HIP gradient as the referee), clip_grad_norm_
+on the critic, the MultiStepLR schedules crossing milestones, polyak averaging with tau (policy, critic linear1-3), the
+hard copy of linear4-6 when update_step % target_update_interval == 0 and the never-updated aux trunk of the target
+critic (reference core/utils.py:750-774, core/agent.py:166-209, core/ddpg.py:132-143)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+SEED = 77
+
+
+def _cfg():
+    from ga_ddpg_amd.experiments.config import load_cfg
+    c = load_cfg("ddpg_td3_aux.yaml")
+    t = c.RL_TRAIN
+    t.tau = 0.05                               # visible polyak steps (default 1e-4 drowns in float32 rounding of the target)
+    t.target_update_interval = 3               # the hard copy of Q2's trunk happens at update_step 3
+    t.policy_milestones = [2, 4]               # every schedule crosses a milestone inside the four steps
+    t.value_milestones = [3]
+    t.overwrite_feat_milestone = [2]
+    return c
+
+
+def _sync_oracle(agent, oracle):
+    """HIP training state -> oracle (teacher forcing)"""
+    rt = agent._rt
+    for name, net in oracle.nets().items():
+        src = getattr(agent, name)
+        sd = {k: v.detach().cpu().clone() for k, v in src.state_dict().items()}
+        net.load_state_dict(sd)
+    pairs = [(rt.pol.flat, oracle.policy_optim, agent.policy_optim), (rt.cr.flat, oracle.critic_optim, agent.critic_optim),
+             (rt.enc.flat, oracle.encoder_optim, agent.state_feat_encoder_optim),
+             (rt.venc.flat, oracle.val_encoder_optim, agent.state_feat_val_encoder_optim)]
+    for flat, o_opt, a_opt in pairs:
+        act = flat.active.cpu().numpy()
+        o_params = o_opt.param_groups[0]["params"]
+        assert len(o_params) == len(flat.params)
+        o_opt.state.clear()
+        for p_o, p, off in zip(o_params, flat.params, flat.offsets[:-1]):
+            off = int(off)
+            assert tuple(p_o.shape) == tuple(p.shape)
+            if act[off] and flat.step_count > 0:
+                n = p.numel()
+                o_opt.state[p_o] = {"step": torch.tensor(float(flat.step_count)),
+                                    "exp_avg": flat.exp_avg[off:off + n].view(p.shape).cpu().clone(),
+                                    "exp_avg_sq": flat.exp_avg_sq[off:off + n].view(p.shape).cpu().clone()}
+        o_opt.param_groups[0]["lr"] = a_opt.param_groups[0]["lr"]
+    oracle.policy_scheduler.load_state_dict(agent.policy_scheduler.state_dict())
+    oracle.critic_scheduler.load_state_dict(agent.critic_scheduler.state_dict())
+    oracle.encoder_scheduler.load_state_dict(agent.state_feat_encoder_scheduler.state_dict())
+    oracle.update_step = agent.update_step
+
+
+def _snapshot(rt):
+    snap = {}
+    for n in ("pol", "cr", "enc", "venc", "pol_t", "cr_t"):
+        f = getattr(rt, n).flat
+        snap[n] = dict(p=f.master.clone(), m=f.exp_avg.clone(), v=f.exp_avg_sq.clone(), t=f.step_count)
+    return snap
+
+
+def _torch_adam_reference(p0, g, m0, v0, t0, lr, eps, wd, active):
+    """torch.optim.Adam.step() on a copy of the parameters, fed the HIP gradient and the pre-step state"""
+    p = torch.nn.Parameter(p0.detach().cpu().clone())
+    opt = torch.optim.Adam([p], lr=lr, eps=eps, weight_decay=wd)
+    if t0 > 0:
+        opt.state[p] = {"step": torch.tensor(float(t0)), "exp_avg": m0.cpu().clone(), "exp_avg_sq": v0.cpu().clone()}
+    p.grad = g.detach().cpu().clone()
+    opt.step()
+    out = p.detach()
+    a = torch.as_tensor(active.cpu().numpy().astype(bool))
+    return torch.where(a, out, p0.detach().cpu())           # parameters without a gradient are not stepped (grad None in torch)
+
+
+def test_teacher_forced_steps():
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    cfg = _cfg()
+    agent, _ = make_agent(cfg)
+    for name in ("policy", "policy_target", "critic", "critic_target", "state_feature_extractor"):
+        fill_module_(getattr(agent, name), name, SEED)
+    spec = {"opt_kwargs": {"lr": 1e-3}, "scheduler_kwargs": {"milestones": [2], "gamma": 0.3}}
+    oracle = ref_step.OracleAgent(_cfg().RL_TRAIN, spec=spec)
+    for name, net in oracle.nets().items():
+        fill_module_(net, name, SEED)
+    mem = BaseMemory(1200, cfg, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 1200, seed=8)
+    rng = np.random.default_rng(5)
+    B = 32
+    train = cfg.RL_TRAIN
+    lrs = []
+    for s in range(4):
+        batch = sample_valid_batch(mem, B, rng)
+        u = rng.random((B, 6)).astype(np.float32)
+        policy_step = agent.update_step % train.policy_update_gap == 0
+        hard = agent.update_step % train.target_update_interval == 0
+        if agent._rt is not None:
+            _sync_oracle(agent, oracle)
+            before = _snapshot(agent._rt)
+        else:
+            before = None                                    # first step: both sides hold the same deterministic fill
+        lr_before = {"pol": agent.policy_optim.param_groups[0]["lr"], "cr": agent.critic_optim.param_groups[0]["lr"],
+                     "enc": agent.state_feat_encoder_optim.param_groups[0]["lr"],
+                     "venc": agent.state_feat_val_encoder_optim.param_groups[0]["lr"]}
+        got = agent.update_parameters(batch, agent.update_step, s, noise_u=u)
+        want = oracle.update_parameters(batch, noise_u=u)
+        torch.cuda.synchronize()
+        rt = agent._rt
+        tag = "step %d (update_step %d%s%s): " % (s, agent.update_step - 1, ", policy" if policy_step else "", ", hard" if hard else "")
+        # ---- A. the step's outputs, tight on EVERY step
+        for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss", "reward_mask_num"):
+            assert_close(got[k], want[k], 1e-4, 1e-6, tag + k)
+        if policy_step:          # looks through the critic updated in this very step (Adam on noise-only coordinates: DESIGN 6)
+            assert_close(got["actor_critic_loss"], want["actor_critic_loss"], 3e-2, 1e-5, tag + "actor_critic_loss")
+        d = oracle.dbg
+        for mine, ref, what in ((agent.qf1, d["q1"], "qf1"), (agent.qf2, d["q2"], "qf2"), (agent.next_q_value, d["y"], "td target"),
+                                (agent.pi, d["pi"], "pi"), (agent.aux_pred, d["aux_pred"], "aux_pred")):
+            ref = ref.numpy()
+            assert_close(mine.cpu().numpy(), ref, 0.0, 1e-4 * np.abs(ref).max() + 1e-6, tag + what)
+        assert agent.update_step == oracle.update_step
+        # ---- B. Adam: torch.optim.Adam on the HIP gradient from the pre-step state must land on the HIP parameters
+        if before is not None:
+            opts = {"pol": (agent.policy_optim, 1e-5), "cr": (agent.critic_optim, 1e-5),
+                    "enc": (agent.state_feat_encoder_optim, 1e-8), "venc": (agent.state_feat_val_encoder_optim, 1e-8)}
+            for n, (opt, eps) in opts.items():
+                if n == "cr" and policy_step:
+                    continue           # critic.grad is overwritten by the actor term after its Adam step (reference: same)
+                f = getattr(rt, n).flat
+                grp = opt.param_groups[0]
+                assert grp["eps"] == eps and f.step_count == before[n]["t"] + 1
+                ref_p = _torch_adam_reference(before[n]["p"], f.grad, before[n]["m"], before[n]["v"], before[n]["t"],
+                                              lr_before[n], grp["eps"], grp["weight_decay"], f.active)
+                got_p = f.master.cpu()
+                step = (got_p - before[n]["p"].cpu()).abs().max().item()
+                assert step > 0.2 * lr_before[n], (tag, n, "parameters did not move", step)
+                err = (got_p - ref_p).abs().max().item()
+                assert err <= 2e-3 * lr_before[n] + 1e-9, (tag, n, "Adam step differs from torch.optim.Adam", err, step)
+        # ---- C. target networks: exact relations on the HIP tensors themselves
+        if before is not None:
+            tau = float(train.tau)
+            pt0, pt1, p1 = before["pol_t"]["p"], rt.pol_t.flat.master, rt.pol.flat.master
+            assert_close(pt1.cpu().numpy(), (pt0 * (1 - tau) + p1 * tau).cpu().numpy(), 1e-6, 1e-8, tag + "policy target (polyak)")
+            ct0, ct1, c1 = before["cr_t"]["p"], rt.cr_t.flat.master, rt.cr.flat.master
+            for name, p, off in zip(rt.cr.flat.names, rt.cr.flat.params, rt.cr.flat.offsets[:-1]):
+                sl = slice(int(off), int(off) + p.numel())
+                if name[:7] in ("linear1", "linear2", "linear3"):
+                    ref = ct0[sl] * (1 - tau) + c1[sl] * tau
+                elif name[:7] in ("linear4", "linear5", "linear6") and hard:
+                    ref = c1[sl]
+                else:
+                    ref = ct0[sl]                                  # Q2 trunk off-interval, aux trunk always: untouched
+                assert_close(ct1[sl].cpu().numpy(), ref.cpu().numpy(), 1e-6, 1e-8, tag + "critic target " + name)
+            assert (ct1 != ct0).any()
+        # ---- D. schedulers (both sides step theirs), E. BatchNorm running statistics after the step
+        agent.step_scheduler(agent.update_step)
+        oracle.step_scheduler()
+        lr = agent.get_lr()
+        want_lr = (oracle.policy_optim.param_groups[0]["lr"], oracle.encoder_optim.param_groups[0]["lr"],
+                   oracle.critic_optim.param_groups[0]["lr"])
+        assert_close([lr["policy_lr"], lr["feature_lr"], lr["value_lr"]], want_lr, 1e-7, 0, tag + "lr")
+        lrs.append(tuple(round(x, 8) for x in want_lr))
+        osd = oracle.state_feature_extractor.state_dict()
+        for k, v in agent.state_feature_extractor.state_dict().items():
+            if "running" in k:
+                # value encoder on policy steps: its third pass runs after its own Adam step (noise-coordinate moves)
+                loose = policy_step and "value_encoder" in k
+                assert_close(v.cpu().numpy(), osd[k].numpy(), 2e-2 if loose else 1e-4, 2e-3 if loose else 1e-6, tag + k)
+            elif "num_batches" in k:
+                assert int(v) == int(osd[k]), (tag, k)
+    # the schedules did cross their milestones: policy 3e-4 -> 1.5e-4 -> 7.5e-5, encoder 1e-3 -> 3e-4, critic 3e-4 -> 1.5e-4
+    assert lrs[0][0] == 3e-4 and lrs[-1][0] == 7.5e-5 and lrs[-1][1] == 3e-4 and lrs[-1][2] == 1.5e-4, lrs

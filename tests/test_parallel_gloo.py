@@ -93,3 +93,38 @@ def test_mask_counts_and_inverse_layout():
     inv = inverse_counts(c)
     np.testing.assert_allclose(inv[:5], [1 / 3, 1 / 12, 1 / 12, 1 / 12, 1 / 3])
     assert np.isinf(inverse_counts(np.array([0.0, 1, 1, 1]))[0])    # empty mask -> NaN loss, like the reference
+
+
+def _bucket_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ga_ddpg_amd.parallel import DataParallelContext
+
+    class RT(object):
+        dev = torch.device("cpu")
+    ctx = DataParallelContext()
+    ctx.attach(RT())
+    g = torch.Generator().manual_seed(100 + rank)
+    n_head, n_sa1, n_rest = 1000, 130, 7001                # bucket layout of a phase: [head | encoder SA1 | encoder rest]
+    local = torch.randn(n_head + n_sa1 + n_rest, generator=g) * torch.logspace(-6, 3, n_head + n_sa1 + n_rest)
+    whole = local.clone()
+    ctx.allreduce_grads([whole])                           # one exchange after the whole backward pass
+    parts = local.clone()
+    head, enc = parts[:n_head], parts[n_head:]
+    ctx.reduce_early("c", [head, enc[n_sa1:]])             # ... vs the early bucket under the SA1 backward
+    ctx.reduce_finish("c", [enc[:n_sa1]])                  # ... + the SA1 slice at the end
+    assert not ctx._inflight
+    if rank == 0:
+        torch.save({"whole": whole, "parts": parts, "local": local}, out)
+    dist.destroy_process_group()
+
+
+def test_bucketed_reduce_is_bit_identical_to_one_exchange(tmp_path):
+    """row X1 (BASELINE configs[4]): the overlapped two-bucket exchange of a phase's gradients must give the bits of the
+    single all-reduce it replaces (elementwise sums over the same ranks: no re-association)"""
+    port = 31500 + os.getpid() % 2000
+    out = str(tmp_path / "b0.pt")
+    mp.spawn(_bucket_worker, args=(2, port, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert torch.equal(got["whole"], got["parts"])
+    assert not torch.equal(got["whole"], got["local"])
