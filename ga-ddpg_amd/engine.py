@@ -500,8 +500,10 @@ class Plan(object):
             a += [None, C.c_longlong(0)] * (6 - len(grp))
             self.call("gad_zero_buffers", *a)
 
-    def fn(self, f):
-        self.calls.append(("py", f, None, None, False))
+    def fn(self, f, side=False):
+        """host callback at this point of the plan; side=lane: called with that lane's stream current (whatever it
+        enqueues -- a collective -- is ordered after the lane's launches, not after the main stream's)"""
+        self.calls.append(("py", f, None, None, side))
 
     def fork(self, k=1):
         self.calls.append(("fork", None, torch.cuda.Event(), None, k))
@@ -554,7 +556,11 @@ class Plan(object):
             if name == "zero":
                 args.zero_()
             elif name == "py":
-                f()
+                if lane:
+                    with torch.cuda.stream(sides[lane][0]):
+                        f()
+                else:
+                    f()
             elif s is not None:
                 hip.check(f(C.byref(s), q), name)
             else:
@@ -792,9 +798,10 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     # ---- SA3 -> SA1 ----
     for s in (2, 1, 0):
         if s == 0 and early_hook is not None and want_dw:
-            for lane in sorted(set(dw_lanes) - {0}):
-                plan.join(lane)
-            early_hook(plan)
+            # on the dW lane itself: its launches so far are the weight gradients of everything but SA1 (each fork made
+            # the lane wait for the main stream up to that point, the heads' dW GEMMs included); no join, the dX chain
+            # on the main stream goes straight on into SA1
+            early_hook(plan, dw_lanes[-1] if dw_lanes else 0)
         r = geo.rows[s]
         rows_kw = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], name="sa%d" % (s + 1))
         m1, m2, m3 = enc.sa_mats[s]

@@ -58,8 +58,9 @@ class FusedRuntime(object):
             self.cr = _head_net(agent.critic, "critic", dev)
             self.cr_t = _head_net(agent.critic_target, "critic", dev)
         # one gradient buffer per optimiser phase (a data-parallel run all-reduces it in one call); before any plan exists
-        self.bucket_a = engine.coalesce_grads([self.pol.flat, self.enc.flat])
-        self.bucket_c = engine.coalesce_grads([self.cr.flat, self.venc.flat]) if self.has_critic else None
+        # encoder first: its leading SA1 slice is the late bucket of a data-parallel run, [encoder rest | head] the early one
+        self.bucket_a = engine.coalesce_grads([self.enc.flat, self.pol.flat])
+        self.bucket_c = engine.coalesce_grads([self.venc.flat, self.cr.flat]) if self.has_critic else None
         sa1 = engine.SAConfig(fe.pointnet_nclusters, fe.pointnet_radius, 64)
         sa2 = engine.SAConfig(32, 0.04, 128)
         self.geo = engine.Geometry(B, self.N, sa1, sa2, dev)
@@ -142,11 +143,14 @@ class FusedRuntime(object):
             return None
         lo, hi = enc.flat.segment("0.0.")
         n_rest = enc.flat.n - hi
+        bucket = self.bucket_a if tag == "a" else self.bucket_c
+        assert bucket.data_ptr() == enc.flat.grad.data_ptr()       # [encoder (SA1 first) | pad | head]: the early bucket is one slice
 
-        def hook(plan):
-            plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
-            plan.call("gad_grad_from_arena", enc.flat.gacc, engine._ptr(enc.flat.m2p, hi), n_rest, engine._ptr(enc.flat.grad, hi), 0)
-            plan.fn(lambda: self._reduce_early(tag, [head.flat.grad, enc.flat.grad[hi:]]))
+        def hook(plan, lane):
+            plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0, side=lane)
+            plan.call("gad_grad_from_arena", enc.flat.gacc, engine._ptr(enc.flat.m2p, hi), n_rest, engine._ptr(enc.flat.grad, hi),
+                      0, side=lane)
+            plan.fn(lambda: self._reduce_early(tag, [bucket[hi:]]), side=lane)
         return hook
 
     def _reduce_early(self, tag, tensors):
@@ -259,12 +263,13 @@ class FusedRuntime(object):
     def _reduce(self, flats, tag=None):
         if self.allreduce is None:
             return
+        head, enc = flats
         if self.bucketed and tag is not None:                 # the early bucket is in flight: SA1's slice + wait for both
-            lo, hi = flats[1].segment("0.0.")
-            self.dp.reduce_finish(tag, [flats[1].grad[:hi]])
+            lo, hi = enc.segment("0.0.")
+            self.dp.reduce_finish(tag, [enc.grad[:hi]])
             return
-        b = getattr(flats[0], "_grad_bucket", None)
-        whole = b is not None and b[0] == tuple(id(f) for f in flats)
+        b = getattr(enc, "_grad_bucket", None)
+        whole = b is not None and b[0] == (id(enc), id(head))
         self.allreduce([b[1]] if whole else [f.grad for f in flats])
 
     # ------------------------------------------------------------------ the update steps

@@ -201,6 +201,61 @@ def _hooked(agent, feats, rands, crit_snap):
         agent.critic_optimize = critic_optimize
 
 
+# Minibatch seeds of the golden DDPG runs.  They are CHOSEN (find_ddpg_seeds below) so that no pre-activation of the two FC
+# BatchNorm1d layers -- 32 rows per channel -- lies within 2e-5 of the ReLU kink in the reference's float64 evaluation: one
+# such tie resolved differently by two float32 evaluations removes / adds a whole row's contribution (1/32) to every
+# gradient upstream (measured: one flip at fc[1] moved every value-encoder tensor by 2 - 4e-3 of its scale), so a fixture
+# sitting on a tie cannot pin anybody's arithmetic to better than that.  With 5e4 such pre-activations per pass a random
+# minibatch carries a tie with probability ~ 0.4; the layers with thousands of rows (SA stages) keep their ties -- there
+# a flip is one row in 1e3 - 3e4.
+DDPG_BATCH_SEED = {"a": SEED + 8000, "b": SEED + 100 + 3000}     # min |fc pre-activation| 1.8e-5 / 1.8e-5 (float64)
+
+
+def _fc_kink_distance(agent, fn):
+    """min |BatchNorm1d output| over every pass `fn()` runs through the agent's feature extractor"""
+    dist = [np.inf]
+    hooks = []
+    for m in agent.state_feature_extractor.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            hooks.append(m.register_forward_hook(lambda mod, i, o: dist.__setitem__(0, min(dist[0], float(o.detach().abs().min())))))
+    try:
+        out = fn()
+    finally:
+        for h in hooks:
+            h.remove()
+    return dist[0], out
+
+
+def find_ddpg_seeds(B=32, tries=12, margin=2e-5):
+    """python -m oracle.make_golden seeds: candidate minibatch seeds whose float64 reference step stays `margin` away from
+    every FC-level ReLU kink (prints the distances; the chosen ones go into DDPG_BATCH_SEED)"""
+    orig_rand_like, orig_ft, orig_float = torch.rand_like, torch.cuda.FloatTensor, torch.Tensor.float
+    torch.cuda.FloatTensor = torch.DoubleTensor
+    torch.Tensor.float = lambda self, *a, **k: self.double()
+    found = {}
+    try:
+        for run, start, base in (("a", 1, SEED), ("b", 2, SEED + 100)):
+            for t in range(tries):
+                seed = base + 1000 * t
+                agent, cfg = _make_agent("DDPG", "td3_critic_aux_policy_aux.yaml")
+                _fill_agent(agent, SEED)
+                for net in _nets_of(agent).values():
+                    net.double()
+                for pol in (agent.policy, agent.policy_target):
+                    pol.action_scale, pol.action_bias = pol.action_scale.double(), pol.action_bias.double()
+                agent.update_step = start
+                batch = make_batch("ddpg_td3_aux.yaml", B, 1200, seed)
+                torch.manual_seed(SEED)
+                d, _ = _fc_kink_distance(agent, lambda: agent.update_parameters(batch, agent.update_step, 0))
+                print("run %s seed %d: min |fc pre-activation| = %.3e %s" % (run, seed, d, "OK" if d > margin else ""), flush=True)
+                if d > margin:
+                    found[run] = seed
+                    break
+    finally:
+        torch.rand_like, torch.cuda.FloatTensor, torch.Tensor.float = orig_rand_like, orig_ft, orig_float
+    return found
+
+
 def gen_ddpg(B=32):
     """Runs: 'a' starts at update_step 1 (no actor-critic term), 'b' at update_step 2 (policy step) and
     continues for a second step.  a0 and b0 start from identical det-filled parameters, so they pin the
@@ -222,7 +277,7 @@ def gen_ddpg(B=32):
         _hooked(agent, feats, rands, crit_snap)
         torch.manual_seed(SEED)
         for s in range(nsteps):
-            batch = make_batch("ddpg_td3_aux.yaml", B, 1200, SEED + 10 * s + (100 if run == "b" else 0))
+            batch = make_batch("ddpg_td3_aux.yaml", B, 1200, DDPG_BATCH_SEED[run] + 10 * s)
             feats.clear(); rands.clear()
             p = "%s%d/" % (run, s)
             for k, v in batch.items():
@@ -275,7 +330,7 @@ def gen_ddpg_f64(B=32):
             feats, crit_snap = [], {}
             _hooked(agent, feats, [], crit_snap)
             p = "%s0/" % run
-            batch = make_batch("ddpg_td3_aux.yaml", B, 1200, SEED + (100 if run == "b" else 0))     # gen_ddpg's s = 0 batches
+            batch = make_batch("ddpg_td3_aux.yaml", B, 1200, DDPG_BATCH_SEED[run])                  # gen_ddpg's s = 0 batches
             assert np.array_equal(batch["point_state_batch"], g32[p + "batch/point_state_batch"])
             u = g32[p + "noise_u"]
             torch.rand_like = lambda x, *a, **k: torch.tensor(u, dtype=x.dtype)
@@ -491,6 +546,9 @@ def main():
     gens = [("config", gen_config), ("losses", gen_losses), ("heads", gen_heads), ("replay", gen_replay),
             ("replay_io", gen_replay_io), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg),
             ("ddpg_f64", gen_ddpg_f64)]
+    if sys.argv[1:] == ["seeds"]:
+        print(find_ddpg_seeds())
+        return
     only = sys.argv[1:]
     for name, fn in gens:
         if not only or name in only:

@@ -75,5 +75,5 @@ def test_slab_and_tile_kernels_agree(value):
     bad = _compare(fwd, tile, acts, 2e-5, 2e-6, "forward slab vs tile:")
     bad += _compare(dx, tile, acts, 1e-6, 1e-7, "same forward kernels:")       # (BatchNorm sums: f64 atomics, order varies)
     bad += _compare(dx, tile, grads, 2e-4, 1e-5, "dX slab vs tile:")
-    bad += _compare(fwd, tile, grads, 1.0, 5e-5, "forward slab vs tile (gradients, median):")
+    bad += _compare(fwd, tile, grads, 1.0, 2e-4, "forward slab vs tile (gradients, median):")
     assert not bad, "\n".join(bad)

