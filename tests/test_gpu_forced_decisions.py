@@ -1,0 +1,78 @@
+"""Gradients of a whole update step against the float64 oracle with the ReLU / max-pool decisions of the HIP pass imposed
+on the oracle (tests/kink_forcing.py): the tight, tie-proof version of the gradient parity check."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+SKIP = (".1.0.bias", ".1.3.bias")          # biases in front of a train-mode BatchNorm: analytically zero gradient
+
+
+@pytest.mark.parametrize("B,seed", [(32, 1), (64, 2)])
+def test_step_gradients_with_forced_decisions(B, seed):
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    from tests.kink_forcing import decisions_from_slot, forced_forward
+    from tests.test_gpu_step import _filled_agent
+    c = load_cfg("ddpg_td3_aux.yaml")
+    mem = BaseMemory(2000, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 2000, seed=5 + seed)
+    rng = np.random.default_rng(seed)
+    batch = sample_valid_batch(mem, B, rng)
+    u = rng.random((B, 6)).astype(np.float32)
+    agent, nets = _filled_agent("ddpg_td3_aux.yaml", 3)
+    agent.update_step = 1                                  # no actor-critic term: slot_v still holds the critic-phase value pass
+    got = agent.update_parameters(batch, agent.update_step, 0, noise_u=u)
+    torch.cuda.synchronize()
+    rt = agent._rt
+    # value encoder call 0 = the critic phase's value pass; encoder call 1 = the actor phase's policy pass (call 0: TD target)
+    dec = {("value", 0): decisions_from_slot(rt.venc, rt.slot_v), ("policy", 1): decisions_from_slot(rt.enc, rt.slot_p)}
+
+    def oracle(dtype):
+        o = ref_step.OracleAgent(c.RL_TRAIN)
+        for n, net in o.nets().items():
+            fill_module_(net, n, 3)
+        o.to_dtype(dtype)
+        o.update_step = 1
+        with forced_forward(o.state_feature_extractor.module, dec) as ff:
+            out = o.update_ddpg(batch, noise_u=u)
+        assert ff.calls == {"value": 2, "policy": 2}
+        return out, {nn + "/" + n: p.grad.double() for nn, net in o.nets().items()
+                     for n, p in net.named_parameters() if p.grad is not None}, o
+    out64, g64, o64 = oracle(torch.float64)
+    out32, g32, _ = oracle(torch.float32)
+    for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss"):
+        assert_close(got[k], out64[k], 2e-5, 1e-7, k)
+    d = o64.dbg
+    for mine, ref, what in ((agent.qf1, d["q1"], "qf1"), (agent.qf2, d["q2"], "qf2"), (agent.next_q_value, d["y"], "td target"),
+                            (agent.pi, d["pi"], "pi"), (agent.aux_pred, d["aux_pred"], "aux_pred")):
+        ref = ref.numpy()
+        assert_close(mine.cpu().numpy(), ref, 0.0, 2e-5 * np.abs(ref).max(), what)
+    lines = ["%-64s %10s %10s %10s %10s %10s" % ("tensor (B=%d, forced decisions)" % B, "max|f64|", "hip med", "hip max", "f32 med", "f32 max")]
+    bad = []
+    for key, ref in sorted(g64.items()):
+        nn, n = key.split("/", 1)
+        if any(x in n for x in SKIP):
+            continue
+        mine = dict(nets[nn].named_parameters())[n].grad.double().cpu()
+        scale = float(ref.abs().max()) + 1e-300
+        eh, e3 = (mine - ref).abs() / scale, (g32[key] - ref).abs() / scale
+        row = (float(eh.median()), float(eh.max()), float(e3.median()), float(e3.max()))
+        lines.append("%-64s %10.3e %10.2e %10.2e %10.2e %10.2e" % ((key, scale) + row))
+        # as accurate as torch's own float32 evaluation of the same smooth function (x3), floors at float32 resolution of a
+        # sum of ~1e5 cancelling terms
+        if row[0] > max(3 * row[2], 2e-6) or row[1] > max(3 * row[3], 1e-4):
+            bad.append(lines[-1])
+    lines.append("violations of  hip med <= max(3 f32 med, 2e-6)  and  hip max <= max(3 f32 max, 1e-4): %d of %d" % (len(bad), len(lines) - 1))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "grad_accuracy_forced_B%d.txt" % B), "w").write("\n".join(lines) + "\n")
+    assert len(lines) > 90
+    assert not bad, "\n".join([lines[0]] + bad)
