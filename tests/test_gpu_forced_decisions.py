@@ -47,14 +47,18 @@ def test_step_gradients_with_forced_decisions(B, seed):
         return out, {nn + "/" + n: p.grad.double() for nn, net in o.nets().items()
                      for n, p in net.named_parameters() if p.grad is not None}, o
     out64, g64, o64 = oracle(torch.float64)
-    out32, g32, _ = oracle(torch.float32)
+    out32, g32, o32 = oracle(torch.float32)
     for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss"):
         assert_close(got[k], out64[k], 2e-5, 1e-7, k)
-    d = o64.dbg
-    for mine, ref, what in ((agent.qf1, d["q1"], "qf1"), (agent.qf2, d["q2"], "qf2"), (agent.next_q_value, d["y"], "td target"),
-                            (agent.pi, d["pi"], "pi"), (agent.aux_pred, d["aux_pred"], "aux_pred")):
-        ref = ref.numpy()
-        assert_close(mine.cpu().numpy(), ref, 0.0, 2e-5 * np.abs(ref).max(), what)
+    d, d32 = o64.dbg, o32.dbg
+    for mine, key, what in ((agent.qf1, "q1", "qf1"), (agent.qf2, "q2", "qf2"), (agent.next_q_value, "y", "td target"),
+                            (agent.pi, "pi", "pi"), (agent.aux_pred, "aux_pred", "aux_pred")):
+        ref = d[key].numpy()
+        scale = np.abs(ref).max()
+        e32 = np.abs(d32[key].double().numpy() - ref).max() / scale      # torch float32's own distance from float64
+        eh = np.abs(mine.cpu().numpy() - ref).max() / scale
+        print("%-10s max err / max|ref|: hip %.2e   oracle-f32 %.2e" % (what, eh, e32))
+        assert eh <= max(3 * e32, 2e-5), (what, eh, e32)
     lines = ["%-64s %10s %10s %10s %10s %10s" % ("tensor (B=%d, forced decisions)" % B, "max|f64|", "hip med", "hip max", "f32 med", "f32 max")]
     bad = []
     for key, ref in sorted(g64.items()):
