@@ -1428,7 +1428,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const float gv = acc[t][v];
-                const float zv = zp[t][v];
+                const float zv = live ? zp[t][v] : 0.f;       // rows past n_rows hold whatever the allocation held (NaN x 0 = NaN)
                 const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
                 const float ga = act ? gv : 0.f;
                 // the previous layer's consumers take dY with its ReLU mask applied (premasked)
@@ -1605,7 +1605,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_slab_kernel(DzSrc d, const int
                 const float gv = acc[t][v];
                 float outv = gv;
                 if (stats) {
-                    const float zv = zp[t][v];
+                    const float zv = live ? zp[t][v] : 0.f;       // (see gemm_dx_stream_kernel: no NaN x 0 from unwritten rows)
                     const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
                     const float ga = act ? gv : 0.f;
                     sb[t] += ga;
