@@ -61,8 +61,10 @@ def test_step_gradients_with_forced_decisions(B, seed, policy_step):
                      for n, p in net.named_parameters() if p.grad is not None}, o
     out64, g64, o64 = oracle(torch.float64)
     out32, g32, o32 = oracle(torch.float32)
-    for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss") + (("actor_critic_loss",) if policy_step else ()):
+    for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss"):
         assert_close(got[k], out64[k], 2e-5, 1e-7, k)
+    if policy_step:      # a mean of cancelling Q values through the critic updated in this very step
+        assert_close(got["actor_critic_loss"], out64["actor_critic_loss"], 2e-4, 1e-6, "actor_critic_loss")
     d, d32 = o64.dbg, o32.dbg
     for mine, key, what in ((agent.qf1, "q1", "qf1"), (agent.qf2, "q2", "qf2"), (agent.next_q_value, "y", "td target"),
                             (agent.pi, "pi", "pi"), (agent.aux_pred, "aux_pred", "aux_pred")):

@@ -16,6 +16,10 @@ from tests.helpers import assert_close
 pytestmark = pytest.mark.gpu
 SEED = 77
 TOL_OUT = 1e-4
+# the TD target chains four train-mode BatchNorm passes (encoder -> target policy -> value encoder -> target critic): torch's own
+# float32 evaluation sits 3.6 - 4.0e-5 of max|y| from its float64 one, ours 4.8 - 5.5e-5 (tests/test_gpu_forced_decisions.py
+# prints both) -> two float32 evaluations may be 1e-4 apart
+TOL_Y = 3e-4
 
 
 def _cfg():
@@ -130,7 +134,7 @@ def test_teacher_forced_steps():
             ref = ref.numpy()
             err = np.abs(mine.cpu().numpy() - ref).max() / np.abs(ref).max()
             print(tag + "%-10s max err / max|ref| = %.2e" % (what, err))
-            assert_close(mine.cpu().numpy(), ref, 0.0, TOL_OUT * np.abs(ref).max() + 1e-6, tag + what)
+            assert_close(mine.cpu().numpy(), ref, 0.0, (TOL_Y if what == "td target" else TOL_OUT) * np.abs(ref).max() + 1e-6, tag + what)
         assert agent.update_step == oracle.update_step
         # ---- B. Adam: torch.optim.Adam on the HIP gradient from the pre-step state must land on the HIP parameters
         if before is not None:
