@@ -251,9 +251,16 @@ def main():
         d = {k: torch.as_tensor(np.ascontiguousarray(hb[k], dtype=np.float32)).cuda() for k in BATCH_KEYS}
         d["mask_counts"] = mask_counts(hb)
         ring.append(d)
+    torch.cuda.synchronize()
+    ready = torch.cuda.Event()
+    ready.record()
+    for d in ring:
+        d["ready_event"] = ready          # resident and complete: the runtime's prefetch stream need not wait for the caller's
 
-    def step(i):
-        out = agent.update_parameters(ring[i % len(ring)], agent.update_step, i)
+    def step(i, sync=False):
+        # sync=False: the call returns once the step is enqueued (its result dict fills in on first read); the host stages
+        # and enqueues the next step while this one runs.  Every step is complete at the closing fence.
+        out = agent.update_parameters(ring[i % len(ring)], agent.update_step, i, sync=sync)
         agent.step_scheduler(agent.update_step)
         return out
 
@@ -293,6 +300,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     timed_tags = engine.timing_stop()
+    # the same steps with the host waiting for each result before it enqueues the next (the reference's loop reads its
+    # losses with .item() every step): uploads, geometry and ~2 ms of launch calls then sit in front of every step
+    n_sync = max(10, args.steps // 5)
+    fence()
+    t1 = time.perf_counter()
+    for i in range(n_sync):
+        step(args.warmup + args.steps + i, sync=True)
+    fence()
+    rate_sync = n_sync / (time.perf_counter() - t1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -324,6 +340,8 @@ def main():
                                   "batch=%d per GPU, 1024-pt clouds, synthetic replay buffer" % B,
                       "batch_per_gpu": B, "global_batch": B * world, "points": 1024,
                       "parallelism": "dp%d" % world, "iterations_per_s": steps_per_s,
+                      "enqueue": "run-ahead (update_parameters(sync=False), all steps complete at the closing fence)",
+                      "iterations_per_s_sync_each_step": rate_sync,
                       "value_definition": "B=%d minibatch gradient steps per second summed over ranks (= iterations/s x n_gpus)" % B, "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
            "losses": {k: out[k] for k in ("critic_loss", "bc_loss", "actor_critic_loss")},
            "roofline": roof}

@@ -10,6 +10,35 @@ import torch
 from .utils import get_loss_info_dict, get_policy_class, hard_update
 
 
+class PendingLog(dict):
+    """Result dict of an update that was enqueued without waiting for it: same keys and floats as the reference's
+    (core/utils.py:1008-1020); the first read of any entry waits for the step to finish on the GPU."""
+
+    def __init__(self, resolve):
+        dict.__init__(self)
+        self._resolve = resolve
+
+    def _fill(self):
+        if self._resolve is not None:
+            r, self._resolve = self._resolve, None
+            dict.update(self, r())
+        return self
+
+    def done(self):
+        return self._resolve is None
+
+
+def _lazy(name):
+    def f(self, *a, **k):
+        return getattr(dict, name)(self._fill(), *a, **k)
+    f.__name__ = name
+    return f
+
+
+for _n in ("__getitem__", "__iter__", "__len__", "__contains__", "__repr__", "__eq__", "get", "items", "keys", "values", "copy"):
+    setattr(PendingLog, _n, _lazy(_n))
+
+
 class Agent(object):
     def __init__(self, num_inputs, action_space, args, name):
         for key, val in args.items():
@@ -118,6 +147,15 @@ class Agent(object):
         else:
             aux_pred = np.asarray(goal_state, dtype=np.float32).reshape(-1) if goal_state is not None else None
         return action, extra_pred, action_sample, aux_pred
+
+    def _pending_result(self, pend, has_critic):
+        """update_parameters(sync=False): the reference's result dict, filled in on first access (which waits for the step)"""
+        return PendingLog(lambda: self._result(pend.wait(), has_critic))
+
+    def flush(self):
+        """wait for every update enqueued with sync=False"""
+        if self._rt is not None:
+            self._rt.flush()
 
     def _result(self, s, has_critic):
         """map the runtime's scalar block to the reference's 11-key dict (core/utils.py:1008-1020)"""

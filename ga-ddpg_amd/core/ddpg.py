@@ -39,9 +39,11 @@ class DDPG(Agent):
         mix_value_ratio = min(get_valid_index(self.mix_value_ratio_list, idx), self.ddpg_coefficients[3])
         return mix_value_ratio, mix_policy_ratio
 
-    def update_parameters(self, batch_data, updates, k, test=False, noise_u=None):
+    def update_parameters(self, batch_data, updates, k, test=False, noise_u=None, sync=True):
         """One gradient step.  `noise_u` (B,6) optionally injects the uniform draw of the TD3
-        target-policy noise (the reference draws it with torch.rand_like, core/utils.py:575)."""
+        target-policy noise (the reference draws it with torch.rand_like, core/utils.py:575).
+        sync=False: return as soon as the step is enqueued -- the result dict fills in on first read (PendingLog), the
+        host goes on to sample / stage / enqueue the next step while this one runs (agent.flush() waits for all)."""
         self.mix_value_ratio, self.mix_policy_ratio = self.get_mix_ratio(self.update_step)
         if test:
             # reference core/agent.py:276-280 would run the SAME update with eval-mode BatchNorm; no driver of the
@@ -50,10 +52,10 @@ class DDPG(Agent):
         self.set_mode(test)
         ps = batch_data["point_state_batch"]
         rt = self.runtime(ps.shape[0], ps.shape[2])
-        s = rt.ddpg_step(batch_data, noise_u=noise_u)
+        s = rt.ddpg_step(batch_data, noise_u=noise_u, sync=sync)
         self.update_step += 1
         # tensors the reference leaves on the agent after a step
         self.pi, self.aux_pred = rt.pi, rt.aux_pred
         self.qf1, self.qf2 = rt.hs_c.out[:, 0], rt.hs_c.out[:, 1]
         self.next_q_value, self.critic_grasp_aux = rt.y, rt.critic_aux_norm
-        return self._result(s, True)
+        return self._result(s, True) if sync else self._pending_result(s, True)

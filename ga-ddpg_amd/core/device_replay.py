@@ -44,6 +44,8 @@ class DeviceReplay(object):
         self.rows = {src: torch.empty(tuple(getattr(memory, src).shape), **f32) for src, _ in _ROW_KEYS}
         self.timestep = torch.empty(cap, **f32)
         self._stage = {}
+        self._copy_stream = None
+        self._ev_refresh = None
         self.refresh()
 
     # ------------------------------------------------------------------ host -> device
@@ -62,17 +64,42 @@ class DeviceReplay(object):
         for src, _ in _ROW_KEYS:
             self.rows[src][sl].copy_(torch.from_numpy(np.ascontiguousarray(getattr(m, src)[sl], dtype=np.float32)))
         self.timestep[sl].copy_(torch.from_numpy(np.ascontiguousarray(m.timestep[sl], dtype=np.float32)))
+        if self._ev_refresh is None:
+            self._ev_refresh = torch.cuda.Event()
+        self._ev_refresh.record(torch.cuda.current_stream())      # later handles become ready after this upload
 
-    def _indices(self, name, idx):
-        """pinned staging -> device int64 index vector"""
-        n = idx.shape[0]
-        st = self._stage.get((name, n))
-        if st is None:
-            st = (torch.empty(n, dtype=torch.int64).pin_memory(), torch.empty(n, dtype=torch.int64, device=self.device))
-            self._stage[(name, n)] = st
-        st[0].numpy()[:] = idx
-        st[1].copy_(st[0], non_blocking=True)
-        return st[1]
+    RING = 8        # index staging sets: a handle stays valid while this many later ones are drawn
+
+    def _stage_set(self, n):
+        """(pinned (3,n) int64, device (3,n) int64, event) of the next handle.  The copies run on a stream of their own and
+        the handle carries the event: a runtime that enqueues steps ahead of the GPU (update_parameters(sync=False)) starts
+        the gather as soon as the indices are on the device, not after everything queued on the caller's stream."""
+        key = ("sets", n)
+        sets = self._stage.get(key)
+        if sets is None:
+            sets = self._stage[key] = {"next": 0, "items": [None] * self.RING}
+        j = sets["next"]
+        sets["next"] = (j + 1) % self.RING
+        it = sets["items"][j]
+        if it is None:
+            it = sets["items"][j] = (torch.empty(3, n, dtype=torch.int64).pin_memory(),
+                                     torch.empty(3, n, dtype=torch.int64, device=self.device), torch.cuda.Event())
+        else:
+            it[2].synchronize()                  # the copy that last read this pinned block (RING handles ago)
+        return it
+
+    def _indices3(self, idx, nxt, end):
+        host, dev, ev = self._stage_set(idx.shape[0])
+        h = host.numpy()
+        h[0], h[1], h[2] = idx, nxt, end
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        if self._ev_refresh is not None:
+            self._copy_stream.wait_event(self._ev_refresh)
+        with torch.cuda.stream(self._copy_stream):
+            dev.copy_(host, non_blocking=True)
+            ev.record(self._copy_stream)
+        return dev, ev
 
     # ------------------------------------------------------------------ sampling
     def sample_lazy(self, batch_size, rng=None, batch_idx=None):
@@ -86,8 +113,9 @@ class DeviceReplay(object):
         nxt = m.next_indices(batch_idx)
         end = np.asarray(m.episode_map[batch_idx], dtype=np.int64)
         B = batch_idx.shape[0]
-        return {"replay_gather": self, "idx": self._indices("i", batch_idx), "nxt": self._indices("n", nxt),
-                "end": self._indices("e", end), "batch_idx": np.uint8(batch_idx),
+        dev, ev = self._indices3(batch_idx, nxt, end)
+        return {"replay_gather": self, "idx": dev[0], "nxt": dev[1], "end": dev[2], "ready_event": ev,
+                "batch_idx": np.uint8(batch_idx),
                 "point_state_batch": _Shape((B,) + tuple(self.point_state.shape[1:])),
                 "mask_counts": self._mask_counts(batch_idx)}
 
@@ -127,7 +155,9 @@ class DeviceReplay(object):
         batch_idx = np.asarray(batch_idx, dtype=np.int64)
         nxt = m.next_indices(batch_idx)
         end = np.asarray(m.episode_map[batch_idx], dtype=np.int64)
-        d_idx, d_nxt, d_end = self._indices("i", batch_idx), self._indices("n", nxt), self._indices("e", end)
+        dev, ev = self._indices3(batch_idx, nxt, end)
+        torch.cuda.current_stream().wait_event(ev)
+        d_idx, d_nxt, d_end = dev[0], dev[1], dev[2]
         out = {"point_state_batch": self.point_state.index_select(0, d_idx),
                "next_point_state_batch": self.point_state.index_select(0, d_nxt)}
         for src, dst in _ROW_KEYS:

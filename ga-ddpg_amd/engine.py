@@ -55,6 +55,9 @@ class MatSpec(object):
         self.bn_index = -1                                 # index into the per-pass BN vectors
 
 
+HOST_RING = 4             # steps the host may run ahead of the GPU (pinned staging blocks per FlatNet / FusedRuntime)
+
+
 class FlatNet(object):
     """Flat float32 master buffer holding every parameter of a network (the nn.Parameters become
     views into it), a packed/padded compute copy for the GEMMs, flat .grad / Adam state, an f64
@@ -115,8 +118,12 @@ class FlatNet(object):
                 active[o:o + p.numel()] = 0
         self.active = torch.from_numpy(active).to(device)
         self.hyper = torch.zeros(8, **f32)                 # {lr,b1,b2,eps,wd,bc1,sqrt(bc2),grad_scale}
-        self.hyper_host = torch.zeros(8, dtype=torch.float32).pin_memory() if device.type == "cuda" \
-            else torch.zeros(8, dtype=torch.float32)
+        # pinned host blocks for the scalars, one per in-flight step (runtime.HOST_RING): the host may enqueue step
+        # N+1 while the copy node of step N has not run yet
+        self.hyper_ring = torch.zeros(HOST_RING, 8, dtype=torch.float32)
+        if device.type == "cuda":
+            self.hyper_ring = self.hyper_ring.pin_memory()
+        self.hyper_host = self.hyper_ring[0]
         self.step_count = 0
         # re-home the parameters into the flat buffers
         with torch.no_grad():
@@ -305,6 +312,16 @@ class EncoderSlot(object):
         self.tot = tot
 
 
+def slot_view(slot, geo):
+    """the same activation buffers bound to another Geometry of the same shape (the runtime alternates between two input /
+    geometry sets; the multi-GB activation scratch exists once)"""
+    import copy
+    assert [r["cap"] for r in geo.rows] == [r["cap"] for r in slot.geo.rows] and geo.B == slot.B
+    v = copy.copy(slot)
+    v.geo = geo
+    return v
+
+
 def _ptr(t, off_elems=0, size=4):
     """raw device address of element `off_elems` of tensor t (element size in bytes)"""
     return None if t is None else hip.Ptr(t.data_ptr() + size * off_elems)
@@ -452,6 +469,7 @@ def side_stream(device=None, which=0):
     if SERIAL:                                   # diagnostics: every fork / join degenerates to the caller's stream
         return torch.cuda.current_stream(dev)
     if (dev, which) not in _SIDE:
+        # (measured: giving the prefetch stream 20 a high priority costs 40 % of the step rate -- 262 -> 147 steps/s)
         _SIDE[(dev, which)] = torch.cuda.Stream(device=dev)
     return _SIDE[(dev, which)]
 

@@ -67,7 +67,8 @@ class DataParallelContext(object):
         rt.allreduce = self.allreduce_grads
         rt.inv_n = torch.zeros(8, dtype=torch.float32, device=rt.dev)
         self._counts = torch.zeros(4, dtype=torch.float64, device=rt.dev)
-        self._counts_host = torch.zeros(4, dtype=torch.float64)
+        from . import engine
+        self._counts_host = torch.zeros(engine.HOST_RING, 4, dtype=torch.float64)      # one row per in-flight step
         if torch.device(rt.dev).type == "cuda":
             self._counts_host = self._counts_host.pin_memory()
         # inv_n[0:5] = numer / counts[pick]   (layout: inverse_counts)
@@ -105,8 +106,9 @@ class DataParallelContext(object):
             hip.call("gad_mask_counts", d["return_batch"], d["expert_flag_batch"], d["perturb_flag_batch"], self.rt.B,
                      self._counts)
         else:
-            self._counts_host.numpy()[:] = mask_counts(batch)
-            self._counts.copy_(self._counts_host, non_blocking=True)
+            h = self._counts_host[getattr(self.rt, "_slot", 0)]
+            h.numpy()[:] = mask_counts(batch)
+            self._counts.copy_(h, non_blocking=True)
         dist.all_reduce(self._counts, op=dist.ReduceOp.SUM, group=self.group)
         self.rt.inv_n[0:5] = (self._numer / self._counts.index_select(0, self._pick)).float()
 

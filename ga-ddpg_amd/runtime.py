@@ -31,6 +31,7 @@ GRAPHS = _os.environ.get("GAD_GRAPH", "0") == "1"
 # start the actor phase's policy forward right after the geometry, beside t1 and the value pass (three forward passes of
 # latency-bound kernels share the GPU); its BatchNorm running-statistics update is deferred until t1's is in (reference order)
 EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "1") == "1"
+INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
 GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
 
@@ -40,6 +41,24 @@ def _dev_f32(x, dev):
     if torch.is_tensor(x):
         return x.detach().to(device=dev, dtype=torch.float32).contiguous()
     return torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
+
+
+class PendingStep(object):
+    """result block of a step that was enqueued without waiting for it (ddpg_step(sync=False)); wait() blocks until the
+    step has run and returns a private copy of the 32 floats"""
+
+    def __init__(self, event, view):
+        self.event, self._view, self._value = event, view, None
+
+    def done(self):
+        return self._value is not None or self.event.query()
+
+    def wait(self):
+        if self._value is None:
+            self.event.synchronize()
+            self._value = self._view.copy()
+            self._view = None
+        return self._value
 
 
 class FusedRuntime(object):
@@ -93,19 +112,43 @@ class FusedRuntime(object):
         shapes = {"point_state_batch": (B, 4, NP), "next_point_state_batch": (B, 4, NP), "action_batch": (B, 6),
                   "expert_action_batch": (B, 6), "goal_batch": (B, 7)}
         self.dbuf, self.hbuf = {}, {}
+        self._hshapes = {}
         for k in BATCH_KEYS + ("time_m1",):
             shp = shapes.get(k, (B,))
+            self._hshapes[k] = shp
             self.dbuf[k] = torch.zeros(*shp, **f32)
             self.hbuf[k] = torch.zeros(*shp, dtype=torch.float32).pin_memory()
+        # Two input / geometry sets (INPUT_SETS): the uploads and the geometry of step N+1 are enqueued on their own stream
+        # into the set that step N is not using, so with a host that runs ahead (sync=False) they execute under step N's
+        # backward pass instead of in front of step N+1's critical chain.  Activation scratch is shared (engine.slot_view).
+        self._sets = [dict(dbuf=self.dbuf, geo=self.geo, geo_next=getattr(self, "geo_next", None), slot_p=self.slot_p,
+                           slot_v=getattr(self, "slot_v", None), slot_t=getattr(self, "slot_t", None))]
+        if INPUT_SETS > 1 and self.has_critic:
+            geo2, geon2 = engine.Geometry(B, self.N, sa1, sa2, dev), engine.Geometry(B, self.N, sa1, sa2, dev)
+            self._sets.append(dict(dbuf={k: torch.zeros_like(v) for k, v in self.dbuf.items()}, geo=geo2, geo_next=geon2,
+                                   slot_p=engine.slot_view(self.slot_p, geo2), slot_v=engine.slot_view(self.slot_v, geo2),
+                                   slot_t=engine.slot_view(self.slot_t, geon2)))
+        for st in self._sets:
+            st.update(ev_in=torch.cuda.Event(), ev_gn=torch.cuda.Event(), ev_g=torch.cuda.Event(), ev_free=None, plans=None)
+        self._set = 0
         self.scal = torch.zeros(32, **f32)
         self._one = torch.ones(1, **f32)
         self._minus_one = -torch.ones(1, **f32)
-        self.scal_host = torch.zeros(32, dtype=torch.float32).pin_memory()
+        # host-side staging, one set per in-flight step (ddpg_step(sync=False) lets the host run ahead of the GPU)
+        R = engine.HOST_RING
+        self._scal_ring = torch.zeros(R, 32, dtype=torch.float32).pin_memory()
+        self._noise_ring = torch.zeros(R, B, 6, dtype=torch.float32).pin_memory()
+        self._hbuf_ring = [self.hbuf] + [None] * (R - 1)       # further sets are allocated when a host batch needs them
+        self._ev_done = [None] * R
+        self._pending = [None] * R
+        self._nsteps = 0
+        self._slot = 0
+        self.scal_host = self._scal_ring[0]
         self.bucketed = False
         self.seg = {}
         for nm, fl in (("pol", self.pol.flat),) + ((("cr", self.cr.flat),) if self.has_critic else ()):
             self.seg[nm] = torch.tensor([0, fl.n], dtype=torch.int32, device=dev)
-        self._build_plans()
+        self._build_all_plans()
         self.world_size = 1
         self.dp = None                   # parallel.DataParallelContext (set by its attach())
         self.allreduce = None            # callable(list of flat grad tensors)
@@ -114,7 +157,8 @@ class FusedRuntime(object):
         self._ev = [torch.cuda.Event() for _ in range(5)]
         self._ev_counts = torch.cuda.Event()
         self._ev_in = torch.cuda.Event()
-        self.noise_host = torch.zeros(B, 6, dtype=torch.float32).pin_memory()
+        self._ev_pre = torch.cuda.Event()
+        self.noise_host = self._noise_ring[0]
         self._graphs = {}                # step signature -> torch.cuda.CUDAGraph (None: seen once, capture on the next use)
         self._prestaged = None           # "host" | "dev": the step's inputs were staged before the enqueue (graph mode)
         self.graph_replays = 0
@@ -125,7 +169,7 @@ class FusedRuntime(object):
         [head | encoder FC + SA3 + SA2] as soon as the SA2 backward is done (99 % of the bytes, all-reduced under the SA1
         backward) and [encoder SA1] at the end -- instead of one exchange after the whole pass (parallel.py)"""
         self.bucketed = True
-        self._build_plans()
+        self._build_all_plans()
 
     def _grad_tail(self, plan, head, enc, tag, early):
         """arena (f64, packed) -> flat .grad (f32, master order) at the end of a backward plan; bucketed: only what the
@@ -156,6 +200,22 @@ class FusedRuntime(object):
     def _reduce_early(self, tag, tensors):
         if self.dp is not None:
             self.dp.reduce_early(tag, tensors)
+
+    def _bind_set(self, i):
+        """make input / geometry set i the current one (self.dbuf, self.geo, self.slot_*, self.plans)"""
+        st = self._sets[i]
+        self._set = i
+        self.dbuf, self.geo, self.slot_p = st["dbuf"], st["geo"], st["slot_p"]
+        if self.has_critic:
+            self.geo_next, self.slot_v, self.slot_t = st["geo_next"], st["slot_v"], st["slot_t"]
+        self.plans = st["plans"]
+        return st
+
+    def _build_all_plans(self):
+        for i in reversed(range(len(self._sets))):
+            self._bind_set(i)
+            self._build_plans()
+            self._sets[i]["plans"] = self.plans
 
     def _build_plans(self):
         d = self.dbuf
@@ -273,18 +333,66 @@ class FusedRuntime(object):
         self.allreduce([b[1]] if whole else [f.grad for f in flats])
 
     # ------------------------------------------------------------------ the update steps
-    def ddpg_step(self, batch, noise_u=None):
+    def _begin_step(self, slot=None, alternate=False):
+        """pick the host staging set of this step (pinned result / noise / Adam-scalar / input blocks).  A set is reused
+        every engine.HOST_RING steps: wait for the step that used it last -- that is what bounds the host's run-ahead."""
+        R = engine.HOST_RING
+        if slot is None:
+            slot = self._nsteps % R
+        self._nsteps += 1
+        pend = self._pending[slot]
+        if pend is not None:
+            pend.wait()                      # its numbers leave the pinned block before the block is reused
+            self._pending[slot] = None
+        elif self._ev_done[slot] is not None:
+            self._ev_done[slot].synchronize()
+        self._slot = slot
+        self._bind_set((self._set + 1) % len(self._sets) if (alternate and len(self._sets) > 1) else 0)
+        self.scal_host = self._scal_ring[slot]
+        self.noise_host = self._noise_ring[slot]
+        if self._hbuf_ring[slot] is None:
+            self._hbuf_ring[slot] = {k: torch.zeros(*shp, dtype=torch.float32).pin_memory() for k, shp in self._hshapes.items()}
+        self.hbuf = self._hbuf_ring[slot]
+        for net in (self.enc, self.venc, self.pol) + ((self.cr,) if self.has_critic else ()):
+            net.flat.hyper_host = net.flat.hyper_ring[slot]
+        return slot
+
+    def _end_step(self, slot, sync):
+        ev = self._ev_done[slot]
+        if ev is None:
+            ev = self._ev_done[slot] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._sets[self._set]["ev_free"] = ev        # every stream of the step has been joined into this one by now
+        if sync:
+            ev.synchronize()
+            return self.scal_host.numpy()
+        pend = self._pending[slot] = PendingStep(ev, self.scal_host.numpy())
+        return pend
+
+    def flush(self):
+        """wait for every step enqueued so far"""
+        for p in self._pending:
+            if p is not None:
+                p.wait()
+        torch.cuda.current_stream().synchronize()
+
+    def ddpg_step(self, batch, noise_u=None, sync=True):
         """one DDPG / TD3 update: eager multi-stream enqueue, or -- GRAPHS, single process, no per-launch timing -- the
-        same enqueue captured once per step signature into a HIP graph and replayed"""
+        same enqueue captured once per step signature into a HIP graph and replayed.
+        sync=False: return a PendingStep right after the enqueue.  The host then prepares and enqueues the next step while
+        this one runs (up to engine.HOST_RING - 1 steps ahead): the ~2 ms of launch calls, the uploads and the geometry of
+        step N+1 no longer sit in front of its critical chain, they are queued behind step N on the GPU."""
         ag = self.agent
         policy_step = ag.update_step % ag.policy_update_gap == 0
         use_graph = (GRAPHS and OVERLAP_PASSES and self.dp is None and not engine.SERIAL and not engine.TIMING["enabled"]
                      and batch is not None)
         if not use_graph:
+            slot = self._begin_step(alternate=True)
             self._prestaged = None
             self._ddpg_enqueue(batch, noise_u, policy_step)
-            torch.cuda.current_stream().synchronize()
-            return self.scal_host.numpy()
+            return self._end_step(slot, sync)
+        slot = self._begin_step(0)           # the captured copy nodes read the pinned blocks of set 0
+        sync = True
         # ---- everything the host contributes to this step, before a single launch: inputs, noise draw, Adam scalars
         kind = self._stage_inputs(batch)
         if noise_u is not None:
@@ -317,8 +425,7 @@ class FusedRuntime(object):
                 self.graph_replays += 1
         finally:
             self._prestaged = None
-        torch.cuda.current_stream().synchronize()
-        return self.scal_host.numpy()
+        return self._end_step(slot, sync)
 
     def _stage_inputs(self, batch):
         """graph mode: put the minibatch where the captured step reads it.  Host dict -> the pinned staging buffers (the
@@ -357,13 +464,28 @@ class FusedRuntime(object):
         ag, d, P = self.agent, self.dbuf, self.plans
         B = self.B
         ratio = float(ag.mix_policy_ratio)
-        # staged upload (dict batches): the target chain on the main stream is the critical path of the step, so its
-        # inputs go first and its geometry is enqueued before anything else
-        staged = OVERLAP_PASSES and batch is not None and "replay_gather" not in batch
-        first = ("next_point_state_batch", "time_batch")
-        second = ("point_state_batch", "action_batch")
-        self._copy_in(batch, first if staged else None)
         main = torch.cuda.current_stream()
+        # uploads + geometry of both cloud sets on the prefetch stream, into this step's input / geometry set: ordered only
+        # after the last step that used the set, i.e. they run beside the previous step when the host is ahead of the GPU
+        st = self._sets[self._set]
+        inline = (not OVERLAP_PASSES) or engine.SERIAL or torch.cuda.is_current_stream_capturing()
+        spre = main if inline else engine.side_stream(which=20)
+        if not inline:
+            if st["ev_free"] is not None:
+                spre.wait_event(st["ev_free"])
+            ready = batch.get("ready_event") if batch is not None else None
+            if ready is not None:                       # the producer says when its device tensors are complete
+                spre.wait_event(ready)
+            elif batch is not None and ("replay_gather" in batch or torch.is_tensor(batch["point_state_batch"])):
+                self._ev_pre.record(main)               # device tensors of unknown origin: after everything enqueued so far
+                spre.wait_event(self._ev_pre)
+        with torch.cuda.stream(spre):
+            self._copy_in(batch, None)
+            st["ev_in"].record(spre)
+            self.geo_next.run(d["next_point_state_batch"])      # the target chain (the critical path) needs this one first
+            st["ev_gn"].record(spre)
+            self.geo.run(d["point_state_batch"])
+            st["ev_g"].record(spre)
         idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
         normal_noise = getattr(ag, "noise_type", "uniform") != "uniform"     # core/utils.py:568-569
@@ -398,37 +520,30 @@ class FusedRuntime(object):
                 self._adam(self.enc.flat, ag.state_feat_encoder_optim)
 
         if OVERLAP_PASSES:
-            s1, s2 = engine.side_stream(which=1), engine.side_stream(which=2)
-            self.geo_next.run(d["next_point_state_batch"])
-            if staged:
-                self._copy_in(batch, second)
+            s1, s2, sc = engine.side_stream(which=1), engine.side_stream(which=2), engine.side_stream(which=3)
+            # the side streams share weights and activation scratch with the previous step: they start after it (ev[0] on the
+            # main stream, which every stream of that step was joined into) and after their inputs on the prefetch stream
             self._ev[0].record(main)
-            s1.wait_event(self._ev[0])
-            with torch.cuda.stream(s1):
-                self.geo.run(d["point_state_batch"])
-                self._ev[4].record(s1)                      # geometry of the current state ready (the actor pass needs it)
-            if staged:
-                self._copy_in(batch, tuple(k for k in BATCH_KEYS if k not in first + second))
+            main.wait_event(st["ev_gn"])
+            P["t1"].run()                                           # enqueued FIRST: the host needs ~0.1 ms for the launches below
             # small independent launches (noise draw, result-slot clear, and for data-parallel runs the global mask counts: a
             # 4-double all-reduce) would sit on the critical chain in front of t1: on their own stream they overlap the
             # geometry and t1; the main stream -- and through _ev[2] the actor stream -- waits for them after t1
-            sc = engine.side_stream(which=3)
-            self._ev_in.record(main)                                # after the uploads (noise_u may be copied from the host)
-            P["t1"].run()                                           # enqueued FIRST: the host needs ~0.1 ms for the launches below
-            sc.wait_event(self._ev_in)
+            sc.wait_event(self._ev[0])
+            sc.wait_event(st["ev_in"])
             with torch.cuda.stream(sc):
                 small_inits()
                 if self.dp is not None:
                     self.dp.set_counts(batch)
                 self._ev_counts.record(sc)
             main.wait_event(self._ev_counts)
+            s1.wait_event(self._ev[0])
+            s1.wait_event(st["ev_g"])
             with torch.cuda.stream(s1):
                 P["c_fwd"].run()
         else:
             if self.dp is not None:
                 self.dp.set_counts(batch)
-            self.geo.run(d["point_state_batch"])
-            self.geo_next.run(d["next_point_state_batch"])
             P["c_fwd"].run()
             small_inits()
             P["t1"].run()
@@ -446,7 +561,8 @@ class FusedRuntime(object):
         if OVERLAP_PASSES:
             if P["p_run"] is None:
                 s2.wait_event(self._ev[2])
-            s2.wait_event(self._ev[4])
+            s2.wait_event(self._ev[0])
+            s2.wait_event(st["ev_g"])
             with torch.cuda.stream(s2):
                 P["p_fwd"].run()
                 self._policy_outputs()
@@ -492,6 +608,7 @@ class FusedRuntime(object):
     def bc_step(self, batch):
         ag, d, P = self.agent, self.dbuf, self.plans
         B = self.B
+        self._begin_step()
         self.upload(batch)
         if self.dp is not None:
             self.dp.set_counts(batch)

@@ -247,3 +247,58 @@ def test_prefetched_pinned_batches_feed_the_update():
                     assert np.isfinite(list(out.values())).all()
     for k in res["host"]:
         assert_close(res["prefetch"][k], res["host"][k], 1e-5, 1e-7, k)
+
+
+@pytest.mark.parametrize("source", ["host", "device"])
+def test_run_ahead_steps_equal_synchronous_steps(source):
+    """update_parameters(sync=False) returns before the step has run; the host stages and enqueues the following steps
+    meanwhile (pinned staging sets rotate, engine.HOST_RING).  Same launches in the same order as the synchronous loop:
+    the first steps agree to the atomics' rounding, and after a flush the parameters do too."""
+    from ga_ddpg_amd.core.agent import PendingLog
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.runtime import BATCH_KEYS
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from tests.test_gpu_step import _filled_agent
+    c = load_cfg("ddpg_td3_aux.yaml")
+    mem = BaseMemory(1500, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 1500, seed=5)
+    rng = np.random.default_rng(3)
+    batches = [sample_valid_batch(mem, 32, rng) for _ in range(7)]           # more steps than staging sets
+    noise = [rng.random((32, 6)).astype(np.float32) for _ in batches]
+    if source == "device":
+        batches = [{k: torch.as_tensor(np.ascontiguousarray(b[k], dtype=np.float32)).cuda() for k in BATCH_KEYS} for b in batches]
+    def run(mode, lr):
+        agent, nets = _filled_agent("ddpg_td3_aux.yaml", 11)
+        if lr is not None:
+            for opt in (agent.policy_optim, agent.critic_optim, agent.state_feat_encoder_optim, agent.state_feat_val_encoder_optim):
+                for g in opt.param_groups:
+                    g["lr"] = lr
+        logs = []
+        for b, u in zip(batches, noise):
+            out = agent.update_parameters(b, agent.update_step, 0, noise_u=u, sync=(mode == "sync"))
+            agent.step_scheduler(agent.update_step)
+            logs.append(out)
+        if mode == "ahead":
+            assert all(isinstance(l, PendingLog) for l in logs)
+            assert not logs[-1].done()                                        # nothing was read yet
+            agent.flush()
+        return ([dict(l) for l in logs], {n: p.detach().clone() for nn, net in nets.items() for n, p in
+                                          ((nn + "/" + k, v) for k, v in net.named_parameters())})
+    # (a) the configured learning rates: the first steps agree to the atomics' rounding (later ones are separated float32
+    # trajectories: two synchronous runs differ by 2x in critic_loss at step 5 of these B=32 batches)
+    (la, pa), (lb, pb) = run("sync", None), run("ahead", None)
+    assert set(la[0].keys()) == set(lb[0].keys())
+    for s in range(2):
+        for k in la[s]:
+            assert_close(lb[s][k], la[s][k], 1e-4, 1e-6, "step %d %s" % (s, k))
+    for n in pa:
+        assert float((pa[n] - pb[n]).abs().max()) <= 2.2 * 1e-3 * len(batches), n
+        assert bool(torch.isfinite(pb[n]).all())
+    # (b) learning rate 0: weights stay put (the target networks still move), every step's numbers depend on ITS batch only -- a
+    # step that read another step's inputs, geometry, noise or staging block (sets rotate every 2 / 4 steps) shows up at once
+    (la, _), (lb, _) = run("sync", 0.0), run("ahead", 0.0)
+    for s in range(len(batches)):
+        for k in la[s]:
+            assert_close(lb[s][k], la[s][k], 2e-4, 1e-6, "lr=0 step %d %s" % (s, k))
+    assert abs(la[2]["critic_loss"] - la[3]["critic_loss"]) > 1e-3            # the batches do differ
