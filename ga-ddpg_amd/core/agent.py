@@ -150,6 +150,8 @@ class Agent(object):
 
     def _pending_result(self, pend, has_critic):
         """update_parameters(sync=False): the reference's result dict, filled in on first access (which waits for the step)"""
+        if not hasattr(pend, "wait"):                 # the runtime synchronised anyway (HIP-graph replay)
+            return self._result(pend, has_critic)
         return PendingLog(lambda: self._result(pend.wait(), has_critic))
 
     def flush(self):

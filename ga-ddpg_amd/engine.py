@@ -462,19 +462,38 @@ _SIDE = {}
 SERIAL = False            # bench.py / diagnostics: run the whole step on ONE stream (per-kernel durations without contention)
 
 
+# Logical stream -> physical HIP stream.  MEASURED (MI355X, ROCm 7.2, tests/bisect_bench.sh): ROCm runs the streams of a
+# process on GPU_MAX_HW_QUEUES = 4 hardware queues; a fifth active queue (GPU_MAX_HW_QUEUES >= 5, or one stream created with a
+# priority) drops the step rate from ~265 to ~140 steps/s, and streams beyond the fourth silently SHARE a queue with an earlier
+# one -- which of the step's chains then serialise depends on stream creation order (two extra prefetch streams cost 7 %).
+# So the step uses exactly three side streams besides the caller's, and says which logical lanes ride together:
+#   A: value pass of the critic phase (1) and, later in the step, the critic backward's weight-gradient lane (11)
+#   B: actor pass (2: policy forward, and the whole actor phase on steps without the actor-critic term)
+#   C: the actor backward's weight-gradient lane (12), small initialisations (3), next step's uploads + geometry (20, 21)
+import os as _os
+_PHYS = {1: "A", 11: "A", 2: "B", 12: "C", 3: "C", 20: "C", 21: "C"}
+if _os.environ.get("GAD_STREAM_MAP"):                     # e.g. "1:A,11:A,2:B,12:C,3:C,20:D,21:D"
+    _PHYS = dict((int(kv.split(":")[0]), kv.split(":")[1]) for kv in _os.environ["GAD_STREAM_MAP"].split(","))
+
+
 def side_stream(device=None, which=0):
-    """auxiliary HIP streams (per device, created lazily): 0 = weight-gradient GEMMs forked off the dX chain,
-    1 / 2 = whole encoder passes overlapped by runtime.FusedRuntime"""
+    """auxiliary HIP streams (per device, created lazily): 1 / 2 = whole encoder passes overlapped by runtime.FusedRuntime,
+    3 = small initialisations, 10 + lane = weight-gradient GEMMs forked off a dX chain, 20 / 21 = input / geometry prefetch;
+    several logical streams share a physical one (_PHYS)"""
     dev = torch.cuda.current_device() if device is None else torch.device(device).index
     if SERIAL:                                   # diagnostics: every fork / join degenerates to the caller's stream
         return torch.cuda.current_stream(dev)
-    if (dev, which) not in _SIDE:
-        # (measured: giving the prefetch stream 20 a high priority costs 40 % of the step rate -- 262 -> 147 steps/s)
-        _SIDE[(dev, which)] = torch.cuda.Stream(device=dev)
-    return _SIDE[(dev, which)]
+    key = (dev, _PHYS.get(which, which))
+    if key not in _SIDE:
+        for k in ("A", "B", "C"):                # fixed creation order: the first three side streams get queues of their own
+            if (dev, k) not in _SIDE:
+                _SIDE[(dev, k)] = torch.cuda.Stream(device=dev)
+        if key not in _SIDE:
+            _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
-CONCURRENT_DW = True      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
+CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
 DW_LANES = 1              # number of dW side streams (2 measured no faster: the overlapped kernels already saturate the GPU) the layers alternate between (each with its own partial workspace)
 
 

@@ -28,9 +28,11 @@ OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on 
 # so the captured non-policy actor pass runs its dW GEMMs in line.  Supported and tested (GAD_GRAPH=1), off by default.
 import os as _os
 GRAPHS = _os.environ.get("GAD_GRAPH", "0") == "1"
-# start the actor phase's policy forward right after the geometry, beside t1 and the value pass (three forward passes of
-# latency-bound kernels share the GPU); its BatchNorm running-statistics update is deferred until t1's is in (reference order)
-EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "1") == "1"
+# 1: start the actor phase's policy forward right after the geometry, beside t1 and the value pass (three forward passes
+# share the GPU; its BatchNorm running-statistics update is deferred until t1's is in: reference order); 0: after t1.
+# MEASURED with the stream -> hardware-queue assignment under control (engine._PHYS): 0 is 5 % faster (286 vs 272 steps/s, same
+# box, 3 runs each); the +2 % that 1 showed earlier in the round came with an accidental queue sharing.
+EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "0") == "1"
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
 GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
@@ -470,22 +472,33 @@ class FusedRuntime(object):
         st = self._sets[self._set]
         inline = (not OVERLAP_PASSES) or engine.SERIAL or torch.cuda.is_current_stream_capturing()
         spre = main if inline else engine.side_stream(which=20)
+        spre2 = main if inline else engine.side_stream(which=21)
         if not inline:
-            if st["ev_free"] is not None:
-                spre.wait_event(st["ev_free"])
             ready = batch.get("ready_event") if batch is not None else None
-            if ready is not None:                       # the producer says when its device tensors are complete
-                spre.wait_event(ready)
-            elif batch is not None and ("replay_gather" in batch or torch.is_tensor(batch["point_state_batch"])):
+            if ready is None and batch is not None and ("replay_gather" in batch or torch.is_tensor(batch["point_state_batch"])):
                 self._ev_pre.record(main)               # device tensors of unknown origin: after everything enqueued so far
-                spre.wait_event(self._ev_pre)
+                ready = self._ev_pre
+            for s_ in (spre, spre2):
+                if st["ev_free"] is not None:
+                    s_.wait_event(st["ev_free"])
+                if ready is not None:                   # (a producer's event says when its device tensors are complete)
+                    s_.wait_event(ready)
+        # two prefetch streams: [inputs of the target chain -> geometry of the next state] and [the rest -> geometry of the
+        # current state] run side by side (each geometry is a chain of small latency-bound kernels)
+        whole = batch is not None and "replay_gather" in batch          # one gather launch fills every buffer
+        first = ("next_point_state_batch", "time_batch")
         with torch.cuda.stream(spre):
-            self._copy_in(batch, None)
+            self._copy_in(batch, None if whole else first)
             st["ev_in"].record(spre)
             self.geo_next.run(d["next_point_state_batch"])      # the target chain (the critical path) needs this one first
             st["ev_gn"].record(spre)
+        if whole and not inline:
+            spre2.wait_event(st["ev_in"])
+        with torch.cuda.stream(spre2):
+            if not whole:
+                self._copy_in(batch, tuple(k for k in BATCH_KEYS if k not in first))
             self.geo.run(d["point_state_batch"])
-            st["ev_g"].record(spre)
+            st["ev_g"].record(spre2)                            # ev_g: ALL inputs are in + the geometry of the current state
         idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
         normal_noise = getattr(ag, "noise_type", "uniform") != "uniform"     # core/utils.py:568-569
@@ -530,7 +543,7 @@ class FusedRuntime(object):
             # 4-double all-reduce) would sit on the critical chain in front of t1: on their own stream they overlap the
             # geometry and t1; the main stream -- and through _ev[2] the actor stream -- waits for them after t1
             sc.wait_event(self._ev[0])
-            sc.wait_event(st["ev_in"])
+            sc.wait_event(st["ev_g"])
             with torch.cuda.stream(sc):
                 small_inits()
                 if self.dp is not None:
