@@ -315,7 +315,14 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    def leave_group():
+        # every rank leaves the process group BEFORE rank 0 prints: whatever RCCL writes to stdout while it initialises or
+        # shuts down comes first and the JSON line is the last line of the job's output
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
     if rank != 0:
+        leave_group()
         return
     table_timed = kernel_table(timed_tags, rows, B, args.steps)
     d0 = table_timed.get(dom, table[dom])                           # measured over the timed region itself
@@ -391,7 +398,13 @@ def main():
         res["cpu_baseline"] = cpu_baseline(cfg, host_batches[0], np.random.default_rng(3).random((B, 6)).astype(np.float32))
     else:
         res["cpu_baseline"] = None
-    print(json.dumps(res))
+    try:                                   # libraries' own stdio output (the RCCL banner) first: the JSON line stays the LAST line
+        leave_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

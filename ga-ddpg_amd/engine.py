@@ -406,8 +406,9 @@ def timing_start(tag="*", capacity=2048):
     TIMING.update(enabled=True, tag=tag, slots=slots, next=0, tags=[])
 
 
-def timing_stop():
-    """-> {tag: [milliseconds per launch, ...]} of the launches timed since timing_start()"""
+def timing_stop(spans=False):
+    """-> {tag: [milliseconds per launch, ...]} of the launches timed since timing_start(); spans=True: a list of
+    (tag, start_ms, end_ms) in launch order instead (one clock for every stream: a timeline of the step)"""
     TIMING["enabled"] = False
     torch.cuda.synchronize()
     khz = hip.lib().gad_wall_clock_khz()
@@ -416,7 +417,9 @@ def timing_stop():
     if slots is not None and n:
         t0 = slots[:n, :, 0].min(dim=1).values.cpu().numpy()
         t1 = slots[:n, :, 1].max(dim=1).values.cpu().numpy()
-        for tag, a, b in zip(TIMING["tags"], t0, t1):
+        if spans:
+            out = [(tag, float(a) / float(khz), float(b) / float(khz)) for tag, a, b in zip(TIMING["tags"], t0, t1) if b > 0 and a < b]
+        for tag, a, b in (() if spans else zip(TIMING["tags"], t0, t1)):
             if b > 0 and a < b:
                 out.setdefault(tag, []).append(float(b - a) / float(khz))          # ticks / kHz = ms
     TIMING.update(slots=None, next=0, tags=[])

@@ -24,7 +24,12 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-BUCKETED = os.environ.get("GAD_DP_BUCKETS", "1") == "1"      # 0: one exchange per phase after the whole backward pass
+# 1: two buckets per phase, the first all-reduced under the SA1 backward (below); 0: one exchange per phase after the whole
+# backward pass.  MEASURED at one rank (RCCL, MI355X, same box, tests/bisect_bench.sh): no hooks 288 steps/s, one exchange per
+# phase 287 (0 %), bucketed 262 (-9 %): the asynchronous collective brings a fifth stream into a process whose four hardware
+# queues are all in use (engine._PHYS), and that costs more than the ~0.1 ms an 8 MB ring all-reduce takes over xGMI.  Off by
+# default; kept (and tested bit-identical) for nodes where the exchange is slower than this one.
+BUCKETED = os.environ.get("GAD_DP_BUCKETS", "0") == "1"
 
 
 def mask_counts(batch):

@@ -124,7 +124,9 @@ def _worker_nccl1(rank, port, out_dir):
     dist.init_process_group("nccl", rank=0, world_size=1)
     from ga_ddpg_amd.parallel import DataParallelContext
     res = {}
-    for use_dp in (False, True):
+    import ga_ddpg_amd.parallel as par
+    for use_dp in (False, True, "bucketed"):
+        par.BUCKETED = use_dp == "bucketed"       # off by default (parallel.py): the overlapped two-bucket exchange stays covered
         agent, cfg = _agent()
         batches, u = _batches(cfg, 1)
         rt = agent.runtime(B, batches[0]["point_state_batch"].shape[2])
@@ -146,7 +148,11 @@ def test_single_rank_rccl_equals_plain_step(tmp_path):
     the step unchanged -- this is the stream-ordering contract of RCCL collectives that the gloo tests cannot exercise."""
     mp.spawn(_worker_nccl1, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
     res = torch.load(os.path.join(str(tmp_path), "nccl1.pt"), weights_only=False)
-    a, b = res[False], res[True]
+    for mode in (True, "bucketed"):
+        _compare_with_plain(res[False], res[mode])
+
+
+def _compare_with_plain(a, b):
     for k in a["rets"][0]:
         tol = 2e-2 if k == "actor_critic_loss" else 1e-5
         assert abs(a["rets"][0][k] - b["rets"][0][k]) <= tol * abs(a["rets"][0][k]) + 1e-7, (k, a["rets"][0][k], b["rets"][0][k])
