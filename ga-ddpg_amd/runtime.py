@@ -33,6 +33,10 @@ GRAPHS = _os.environ.get("GAD_GRAPH", "0") == "1"
 # MEASURED with the stream -> hardware-queue assignment under control (engine._PHYS): 0 is 5 % faster (286 vs 272 steps/s, same
 # box, 3 runs each); the +2 % that 1 showed earlier in the round came with an accidental queue sharing.
 EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "0") == "1"
+# 1: the next step's value pass may start under this step's actor backward (its weights are final after the critic's Adam
+# step).  MEASURED: 286.4 vs 287.5 steps/s with the prefetch on the same lane, 288.3 vs 287.2 otherwise -- no gain: the
+# actor backward + its dW lane already fill the GPU and the step is bound by the sum of its kernels' own durations.  Off.
+EARLY_VALUE = _os.environ.get("GAD_EARLY_VALUE", "0") == "1"
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
 GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
@@ -160,6 +164,7 @@ class FusedRuntime(object):
         self._ev_counts = torch.cuda.Event()
         self._ev_in = torch.cuda.Event()
         self._ev_pre = torch.cuda.Event()
+        self._ev_vfree = None
         self.noise_host = self._noise_ring[0]
         self._graphs = {}                # step signature -> torch.cuda.CUDAGraph (None: seen once, capture on the next use)
         self._prestaged = None           # "host" | "dev": the step's inputs were staged before the enqueue (graph mode)
@@ -550,7 +555,11 @@ class FusedRuntime(object):
                     self.dp.set_counts(batch)
                 self._ev_counts.record(sc)
             main.wait_event(self._ev_counts)
-            s1.wait_event(self._ev[0])
+            # the value pass needs the critic / value-encoder weights (final after the previous step's critic Adam) and the
+            # value activation scratch (free after that step's last backward over it): with the host ahead of the GPU it
+            # starts under the previous step's actor backward, which alone cannot fill the GPU
+            early = EARLY_VALUE and self._ev_vfree is not None and not torch.cuda.is_current_stream_capturing()
+            s1.wait_event(self._ev_vfree if early else self._ev[0])
             s1.wait_event(st["ev_g"])
             with torch.cuda.stream(s1):
                 P["c_fwd"].run()
@@ -597,6 +606,8 @@ class FusedRuntime(object):
         hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
         self._adam(self.venc.flat, ag.state_feat_val_encoder_optim)
         self._adam(self.cr.flat, ag.critic_optim, clip=self.clip_sumsq)
+        if not policy_step and OVERLAP_PASSES:
+            self._mark_value_free(main)
         # ---- actor phase
         if OVERLAP_PASSES:
             self._ev[3].record(s2)
@@ -609,6 +620,8 @@ class FusedRuntime(object):
             hip.call("gad_actor_critic_loss", self.hs_cpi.out, d["expert_flag_batch"], d["return_batch"], B, ratio,
                      self.inv_n_actor_critic(), self.hs_cpi.g_out, engine._ptr(self.scal, 8))
             P["v_bwd"].run()
+            if OVERLAP_PASSES:
+                self._mark_value_free(main)
             actor_tail(self.slot_v.daction)
         elif not OVERLAP_PASSES:
             actor_tail(None)
@@ -617,6 +630,16 @@ class FusedRuntime(object):
         self.enc.bump_batches_tracked(2)
         self.venc.bump_batches_tracked(3 if policy_step else 2)
         self._download(sync=False)
+
+    def _mark_value_free(self, stream):
+        """from here on this step neither writes the critic / value-encoder weights nor touches the value pass's activation
+        scratch and head slot: the NEXT step's value pass may start (ddpg_step: EARLY_VALUE)"""
+        if torch.cuda.is_current_stream_capturing():        # (graph replay: the next step orders itself after the whole graph)
+            self._ev_vfree = None
+            return
+        if self._ev_vfree is None:
+            self._ev_vfree = torch.cuda.Event()
+        self._ev_vfree.record(stream)
 
     def bc_step(self, batch):
         ag, d, P = self.agent, self.dbuf, self.plans
