@@ -799,6 +799,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
 }
 
 static int g_opt_dx_slab = 0;    // (see g_opt_fwd_slab)
+static int g_opt_dbg = 0;
 static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
@@ -999,6 +1000,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
     if (!strcmp(name, "dx_slab")) { g_opt_dx_slab = value; return GAD_OK; }
+    if (!strcmp(name, "dbg")) { g_opt_dbg = value; return GAD_OK; }
     if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dw_stream")) { g_opt_dw_stream = value; return GAD_OK; }
     int found = 0;
@@ -1132,6 +1134,7 @@ struct DxEpi {
     const float* zprev; int zprev_pitch; const float* ps; const float* pt; const float* pm; const float* pi;
     double* dbeta; double* dgamma; int stat_stride; int store_masked;
     float* dfeat; int feat_c; const int32_t* row_pt; const int32_t* row_grp; double* daction; int act_c; int gps;
+    int dbg;     // ablation timings (option `dbg`, diagnostics only: results are WRONG with any bit set): 1 no statistics atomics, 2 no stores, 4 no MFMAs, 8 no K-loop global loads
 };
 
 template <int WM, int WN, int TM, int TN, bool VEC, int VM>
@@ -1221,25 +1224,59 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 store_D<BN>(Bs, kk, j, f4sel(ok, rb[it], f4zero()));
             }
         };
-        load_tile(0);
+        if (!(e.dbg & 8)) load_tile(0);
         for (int kt = 0; kt < nk; ++kt) {
             store_tile(kt);
             __syncthreads();
-            if (kt + 1 < nk) load_tile(kt + 1);
-            mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+            if (kt + 1 < nk && !(e.dbg & 8)) load_tile(kt + 1);
+            if (!(e.dbg & 4)) mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
             __syncthreads();
         }
         const int l31 = lane & 31, half = lane >> 5;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int k = k0out + wn * TN * 32 + tn * 32 + l31;
-            const bool kok = k < e.k_valid;
+            const bool kok = k < e.k_valid && !(e.dbg & 2);
             float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
             const bool stats = e.dbeta != nullptr && kok;
             if (stats) { sc = e.ps[goff + k]; sh = e.pt[goff + k]; mu = e.pm[goff + k]; is = e.pi[goff + k]; }
             float sb = 0.f, sg = 0.f;
             int run_smp = -1;
             double run_sum = 0.0;
+            if (e.mode == 0) {
+                // plain layer input: first ALL loads of the previous layer's raw output (clamped rows / column: real, finite
+                // data), then the arithmetic, then the stores.  Written element by element -- load, mask, store, next
+                // load -- the stores, which may alias the loads for all the compiler knows, pin every load behind its
+                // predecessor's store: 16 memory round trips in sequence per workgroup (seen in the ISA: `global_load_dword;
+                // s_waitcnt vmcnt(0); global_store_dword` x 16)
+                const int kc = kok ? k : 0;
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) {
+                    float zp[16];
+                    if (stats) {
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) {
+                            const int rc = min(row0 + wm * TM * 32 + tm * 32 + acc_row(v, half), n_rows - 1);
+                            zp[v] = e.zprev[(size_t)rc * e.zprev_pitch + goff + kc];
+                        }
+                    }
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int r = row0 + wm * TM * 32 + tm * 32 + acc_row(v, half);
+                        const bool live = r < n_rows && kok;
+                        const float gv = acc[tm][tn][v];
+                        float outv = gv;
+                        if (stats) {
+                            const bool act = fmaf(zp[v], sc, sh) > 0.f && live;
+                            const float ga = act ? gv : 0.f;
+                            sb += ga;
+                            sg = fmaf(ga, (zp[v] - mu) * is, sg);
+                            if (e.store_masked) outv = ga;
+                        }
+                        if (live) e.gout[(size_t)r * e.gout_pitch + goff + k] = outv;
+                    }
+                }
+            } else
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1280,7 +1317,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         __syncthreads();
     }
-    if (e.dbeta) {
+    if (e.dbeta && !(e.dbg & 1)) {
         const int rep = blockIdx.x % GAD_STAT_REPLICAS;
         block_column_atomics<WM, WN, TN>(smem, cb, cg, lane, wm, wn, k0out, e.k_valid,
                                          e.dbeta + (size_t)rep * e.stat_stride + goff,
@@ -1746,18 +1783,31 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (stats) { sc = e.ps[goff + kk]; sh = e.pt[goff + kk]; mu = e.pm[goff + kk]; is = e.pi[goff + kk]; }
     float sb = 0.f, sg = 0.f;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int rr = row0 + acc_row(v, half);
-        if (rr >= n_rows || !kok) continue;
-        const float gv = acc[v];
-        float outv = gv;
+    {   // all loads, then the arithmetic, then the stores (see gemm_dx_kernel: interleaved, the stores serialise the loads)
+        float zp[16];
+        const int kc = kok ? kk : 0;
         if (stats) {
-            const float zp = e.zprev[(size_t)rr * e.zprev_pitch + goff + kk];
-            if (fmaf(zp, sc, sh) > 0.f) { sb += gv; sg = fmaf(gv, (zp - mu) * is, sg); }
-            else if (e.store_masked) outv = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int rc = min(row0 + acc_row(v, half), n_rows - 1);
+                zp[v] = e.zprev[(size_t)rc * e.zprev_pitch + goff + kc];
+            }
         }
-        e.gout[(size_t)rr * e.gout_pitch + goff + kk] = outv;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int rr = row0 + acc_row(v, half);
+            const bool live = rr < n_rows && kok;
+            const float gv = acc[v];
+            float outv = gv;
+            if (stats) {
+                const bool act = fmaf(zp[v], sc, sh) > 0.f && live;
+                const float ga = act ? gv : 0.f;
+                sb += ga;
+                sg = fmaf(ga, (zp[v] - mu) * is, sg);
+                if (e.store_masked) outv = ga;
+            }
+            if (live) e.gout[(size_t)rr * e.gout_pitch + goff + kk] = outv;
+        }
     }
     if (e.dbeta) {
         sb += __shfl_xor(sb, 32, 64);
@@ -1783,6 +1833,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     Groups gr = make_groups(a->n_groups, a->dz_off, a->w_off, a->gout_off, a->n_out);
     DxEpi e;
     e.mode = a->epilogue; e.gout = a->gout; e.gout_pitch = a->gout_pitch; e.k_valid = a->k_valid;
+    e.dbg = g_opt_dbg;
     e.zprev = a->zprev; e.zprev_pitch = a->zprev_pitch; e.ps = a->prev_scale; e.pt = a->prev_shift;
     e.pm = a->prev_mean; e.pi = a->prev_istd; e.dbeta = a->prev_dbeta; e.dgamma = a->prev_dgamma;
     e.stat_stride = a->stat_stride;

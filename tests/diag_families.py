@@ -58,7 +58,7 @@ for _ in range(6):
     step(sync=True)
 base = None
 for opts in configs:
-    for k in ("fwd_slab", "dx_slab", "fwd_tile", "dx_tile", "dw_tile"):
+    for k in ("fwd_slab", "dx_slab", "fwd_tile", "dx_tile", "dw_tile", "dbg"):
         try:
             hip.set_option(k, opts.get(k, 0))
         except Exception:
