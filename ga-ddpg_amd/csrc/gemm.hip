@@ -1243,40 +1243,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             float sb = 0.f, sg = 0.f;
             int run_smp = -1;
             double run_sum = 0.0;
-            if (e.mode == 0) {
-                // plain layer input: first ALL loads of the previous layer's raw output (clamped rows / column: real, finite
-                // data), then the arithmetic, then the stores.  Written element by element -- load, mask, store, next
-                // load -- the stores, which may alias the loads for all the compiler knows, pin every load behind its
-                // predecessor's store: 16 memory round trips in sequence per workgroup (seen in the ISA: `global_load_dword;
-                // s_waitcnt vmcnt(0); global_store_dword` x 16)
-                const int kc = kok ? k : 0;
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    float zp[16];
-                    if (stats) {
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) {
-                            const int rc = min(row0 + wm * TM * 32 + tm * 32 + acc_row(v, half), n_rows - 1);
-                            zp[v] = e.zprev[(size_t)rc * e.zprev_pitch + goff + kc];
-                        }
-                    }
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int r = row0 + wm * TM * 32 + tm * 32 + acc_row(v, half);
-                        const bool live = r < n_rows && kok;
-                        const float gv = acc[tm][tn][v];
-                        float outv = gv;
-                        if (stats) {
-                            const bool act = fmaf(zp[v], sc, sh) > 0.f && live;
-                            const float ga = act ? gv : 0.f;
-                            sb += ga;
-                            sg = fmaf(ga, (zp[v] - mu) * is, sg);
-                            if (e.store_masked) outv = ga;
-                        }
-                        if (live) e.gout[(size_t)r * e.gout_pitch + goff + k] = outv;
-                    }
-                }
-            } else
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -1783,31 +1749,18 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
     if (stats) { sc = e.ps[goff + kk]; sh = e.pt[goff + kk]; mu = e.pm[goff + kk]; is = e.pi[goff + kk]; }
     float sb = 0.f, sg = 0.f;
-    {   // all loads, then the arithmetic, then the stores (see gemm_dx_kernel: interleaved, the stores serialise the loads)
-        float zp[16];
-        const int kc = kok ? kk : 0;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int rr = row0 + acc_row(v, half);
+        if (rr >= n_rows || !kok) continue;
+        const float gv = acc[v];
+        float outv = gv;
         if (stats) {
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int rc = min(row0 + acc_row(v, half), n_rows - 1);
-                zp[v] = e.zprev[(size_t)rc * e.zprev_pitch + goff + kc];
-            }
+            const float zp = e.zprev[(size_t)rr * e.zprev_pitch + goff + kk];
+            if (fmaf(zp, sc, sh) > 0.f) { sb += gv; sg = fmaf(gv, (zp - mu) * is, sg); }
+            else if (e.store_masked) outv = 0.f;
         }
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int rr = row0 + acc_row(v, half);
-            const bool live = rr < n_rows && kok;
-            const float gv = acc[v];
-            float outv = gv;
-            if (stats) {
-                const bool act = fmaf(zp[v], sc, sh) > 0.f && live;
-                const float ga = act ? gv : 0.f;
-                sb += ga;
-                sg = fmaf(ga, (zp[v] - mu) * is, sg);
-                if (e.store_masked) outv = ga;
-            }
-            if (live) e.gout[(size_t)rr * e.gout_pitch + goff + kk] = outv;
-        }
+        e.gout[(size_t)rr * e.gout_pitch + goff + kk] = outv;
     }
     if (e.dbeta) {
         sb += __shfl_xor(sb, 32, 64);
