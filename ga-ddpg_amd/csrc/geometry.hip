@@ -115,6 +115,29 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
     for (int j = 1; j < M; ++j) {
         const float x1 = sp[old * 3 + 0], y1 = sp[old * 3 + 1], z1 = sp[old * 3 + 2];
         unsigned long long best = 0ull;
+        if (NPL % 2 == 0) {
+            // two points per instruction: packed FP32 subtract / multiply / add (v_pk_*_f32), each individually rounded like
+            // the scalar gad_sqdist (contraction off: the indices must stay bit-identical to upstream's)
+#pragma clang fp contract(off)
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int s = 0; s + 1 < NPL; s += 2) {
+                const f32x2_t ax = {px[s], px[s + 1]}, ay = {py[s], py[s + 1]}, az = {pz[s], pz[s + 1]};
+                const f32x2_t dx = ax - x1, dy = ay - y1, dz = az - z1;
+                const f32x2_t xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                const f32x2_t dd = (xx + yy) + zz;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (valid & (1u << (s + u))) {
+                        const float d = dd[u];
+                        const float d2 = d < tmp[s + u] ? d : tmp[s + u];
+                        tmp[s + u] = d2;
+                        const unsigned long long c = fps_pack(d2, key[s + u]);
+                        best = c > best ? c : best;
+                    }
+                }
+            }
+        } else {
 #pragma unroll
         for (int s = 0; s < NPL; ++s) {
             if (valid & (1u << s)) {
@@ -124,6 +147,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
                 const unsigned long long c = fps_pack(d2, key[s]);
                 best = c > best ? c : best;
             }
+        }
         }
         best = fps_wave_max(best);
         if (WAVES > 1) {                                           // one barrier per pick: the exchange buffer alternates
@@ -146,6 +170,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
     }
 }
 
+static int g_opt_fps_cfg = 0;     // points per thread x wavefronts for 1024 < N <= 4096: 0 = 16 x 4, 1 = 8 x 8, 2 = 4 x 16 (A/B)
 static int fps_tie_bits(int n) {  // log2 of upstream opt_n_threads(n) = pow2 <= min(n, 512)
     int bits = 0;
     while ((2 << bits) <= n && (2 << bits) <= 512) ++bits;
@@ -165,7 +190,9 @@ extern "C" int gad_furthest_point_sampling(const float* xyz, int B, int N, int M
     } else if (N <= 1024) {
         hipLaunchKernelGGL((fps_kernel<4, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
     } else if (N <= 4096) {
-        hipLaunchKernelGGL((fps_kernel<16, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
+        if (g_opt_fps_cfg == 1) hipLaunchKernelGGL((fps_kernel<8, 8>), dim3(B), dim3(512), lds, st, xyz, N, M, tie, idx, new_xyz);
+        else if (g_opt_fps_cfg == 2) hipLaunchKernelGGL((fps_kernel<4, 16>), dim3(B), dim3(1024), lds, st, xyz, N, M, tie, idx, new_xyz);
+        else hipLaunchKernelGGL((fps_kernel<16, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
     } else {
         hipLaunchKernelGGL((fps_kernel<16, 16>), dim3(B), dim3(1024), lds, st, xyz, N, M, tie, idx, new_xyz);
     }
@@ -709,6 +736,7 @@ __global__ __launch_bounds__(BQC_THREADS) void ball_query_cells_kernel(const flo
 static int g_opt_bq_cells = 1;
 void gad_geometry_set_option(const char* name, int value, int* found) {
     if (!strcmp(name, "bq_cells")) { g_opt_bq_cells = value; *found = 1; }
+    if (!strcmp(name, "fps_cfg")) { g_opt_fps_cfg = value; *found = 1; }
 }
 static bool bq_use_cells(int N, int nsample, float radius) {
     return g_opt_bq_cells && N > 1024 && N <= BQ_MAXN && radius > 0.f && radius < 1.0e18f && nsample <= 128;
