@@ -1134,7 +1134,7 @@ struct DxEpi {
     const float* zprev; int zprev_pitch; const float* ps; const float* pt; const float* pm; const float* pi;
     double* dbeta; double* dgamma; int stat_stride; int store_masked;
     float* dfeat; int feat_c; const int32_t* row_pt; const int32_t* row_grp; double* daction; int act_c; int gps;
-    int dbg;     // ablation timings (option `dbg`, diagnostics only: results are WRONG with any bit set): 1 no statistics atomics, 2 no stores, 4 no MFMAs, 8 no K-loop global loads
+    int dbg;     // ablation timings (option `dbg`, diagnostics only: results are WRONG with any bit set): 1 no statistics atomics, 2 no stores, 4 no MFMAs, 8 no K-loop global loads, 16 no prologue vector staging, 32 no LDS tile stores, 64 no epilogue
 };
 
 template <int WM, int WN, int TM, int TN, bool VEC, int VM>
@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     if ((int)(blockIdx.x * BM) >= n_rows) return;
     const int nk = gad_cdiv_dev(n_out, KT);
-    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    if (VEC && !(e.dbg & 16)) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     const bool need_grp = e.mode == 1 || d.gmode != 0;
 
     float cb[TN], cg[TN];
@@ -1226,13 +1226,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         };
         if (!(e.dbg & 8)) load_tile(0);
         for (int kt = 0; kt < nk; ++kt) {
-            store_tile(kt);
+            if (!(e.dbg & 32)) store_tile(kt);
             __syncthreads();
             if (kt + 1 < nk && !(e.dbg & 8)) load_tile(kt + 1);
             if (!(e.dbg & 4)) mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
             __syncthreads();
         }
         const int l31 = lane & 31, half = lane >> 5;
+        if (e.dbg & 64) continue;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int k = k0out + wn * TN * 32 + tn * 32 + l31;
