@@ -1129,6 +1129,13 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------
 // backward wrt the layer input:  gout[r][k] = sum_n dZ[r][n] * W[n][k]
 // ------------------------------------------------------------------------------------------------
+// ablation hooks of the dX tile kernel: compiled in with -DGAD_ABLATION only (profiles/r02_dx_tile_ablation.txt was measured
+// with such a build; in the shipped build the option `dbg` is accepted and ignored)
+#ifdef GAD_ABLATION
+#define GAD_DBG(bit) (e.dbg & (bit))
+#else
+#define GAD_DBG(bit) false
+#endif
 struct DxEpi {
     int mode; float* gout; int gout_pitch; int k_valid;
     const float* zprev; int zprev_pitch; const float* ps; const float* pt; const float* pm; const float* pi;
@@ -1167,7 +1174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     if ((int)(blockIdx.x * BM) >= n_rows) return;
     const int nk = gad_cdiv_dev(n_out, KT);
-    if (VEC && !(e.dbg & 16)) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    if (VEC && !GAD_DBG(16)) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
     const bool need_grp = e.mode == 1 || d.gmode != 0;
 
     float cb[TN], cg[TN];
@@ -1224,20 +1231,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 store_D<BN>(Bs, kk, j, f4sel(ok, rb[it], f4zero()));
             }
         };
-        if (!(e.dbg & 8)) load_tile(0);
+        if (!GAD_DBG(8)) load_tile(0);
         for (int kt = 0; kt < nk; ++kt) {
-            if (!(e.dbg & 32)) store_tile(kt);
+            if (!GAD_DBG(32)) store_tile(kt);
             __syncthreads();
-            if (kt + 1 < nk && !(e.dbg & 8)) load_tile(kt + 1);
-            if (!(e.dbg & 4)) mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+            if (kt + 1 < nk && !GAD_DBG(8)) load_tile(kt + 1);
+            if (!GAD_DBG(4)) mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
             __syncthreads();
         }
         const int l31 = lane & 31, half = lane >> 5;
-        if (e.dbg & 64) continue;
+        if (GAD_DBG(64)) continue;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int k = k0out + wn * TN * 32 + tn * 32 + l31;
-            const bool kok = k < e.k_valid && !(e.dbg & 2);
+            const bool kok = k < e.k_valid && !GAD_DBG(2);
             float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
             const bool stats = e.dbeta != nullptr && kok;
             if (stats) { sc = e.ps[goff + k]; sh = e.pt[goff + k]; mu = e.pm[goff + k]; is = e.pi[goff + k]; }
@@ -1284,7 +1291,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         __syncthreads();
     }
-    if (e.dbeta && !(e.dbg & 1)) {
+    if (e.dbeta && !GAD_DBG(1)) {
         const int rep = blockIdx.x % GAD_STAT_REPLICAS;
         block_column_atomics<WM, WN, TN>(smem, cb, cg, lane, wm, wn, k0out, e.k_valid,
                                          e.dbeta + (size_t)rep * e.stat_stride + goff,
