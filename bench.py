@@ -367,6 +367,18 @@ def main():
             agent.update_parameters(b, agent.update_step, i)
         torch.cuda.synchronize()
         res["value_host_inclusive"] = n / (time.perf_counter() - t0)
+        # the same, with the sampling on a background thread into pinned staging sets (core/prefetch.PrefetchSampler) and
+        # run-ahead steps: what a training loop over a HOST replay buffer gets
+        from ga_ddpg_amd.core.prefetch import PrefetchSampler
+        with PrefetchSampler(mem, B, depth=3, sample=lambda bs: sample_valid_batch(mem, bs, rng2)) as sampler:
+            for i in range(5):
+                agent.update_parameters(sampler.next(), agent.update_step, i, sync=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                agent.update_parameters(sampler.next(), agent.update_step, i, sync=False)
+            agent.flush()
+            res["value_host_prefetch"] = n / (time.perf_counter() - t0)
         # same loop fed by the GPU-resident replay mirror: indices drawn on the host with the
         # reference's arithmetic, gather in HBM -- the rate a training loop sees without the 17 MB/step host gather
         from ga_ddpg_amd.core.device_replay import DeviceReplay
@@ -374,8 +386,8 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
-            agent.update_parameters(dmem.sample_lazy(B, rng2), agent.update_step, i)
-        torch.cuda.synchronize()
+            agent.update_parameters(dmem.sample_lazy(B, rng2), agent.update_step, i, sync=False)
+        agent.flush()
         res["value_device_replay"] = n / (time.perf_counter() - t0)
     res["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "tags"}
                       for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}

@@ -37,7 +37,7 @@ class PrefetchSampler(object):
         self._free = queue.Queue()
         self._ready = queue.Queue(maxsize=self.depth)
         self._sets = []
-        self._held = None
+        self._held = self._held_item = None
         self._stop = threading.Event()
         self._error = None
         self._thread = threading.Thread(target=self._run, name="gad-prefetch", daemon=True)
@@ -63,6 +63,15 @@ class PrefetchSampler(object):
                 st[k] = t.pin_memory() if self.pin else t
         return st
 
+    @staticmethod
+    def _release(entry):
+        """a staging set comes back with the event after which its host-to-device copies are done (the runtime hangs it on
+        the batch dict as `uploaded_event`; a run-ahead consumer may return the set before those copies have run)"""
+        st, ev = entry
+        if ev is not None:
+            ev.synchronize()
+        return st
+
     def _run(self):
         try:
             while not self._stop.is_set():
@@ -71,7 +80,7 @@ class PrefetchSampler(object):
                     item = batch
                 else:
                     try:
-                        st = self._free.get_nowait()
+                        st = self._release(self._free.get_nowait())
                     except queue.Empty:
                         if len(self._sets) < self.depth + 1:
                             st = self._staging(batch)
@@ -80,7 +89,7 @@ class PrefetchSampler(object):
                             st = None
                             while st is None and not self._stop.is_set():
                                 try:
-                                    st = self._free.get(timeout=0.05)
+                                    st = self._release(self._free.get(timeout=0.05))
                                 except queue.Empty:
                                     pass
                             if st is None:
@@ -104,15 +113,16 @@ class PrefetchSampler(object):
 
     # ------------------------------------------------------------------ consumer
     def next(self):
-        """the next minibatch; the staging set handed out by the PREVIOUS call returns to the pool (its host-to-device
-        copies were enqueued and the update that consumed it has synchronised by then)"""
+        """the next minibatch; the staging set handed out by the PREVIOUS call returns to the pool together with the event
+        that marks its host-to-device copies done (the producer waits for it before overwriting the set)"""
         if self._held is not None:
-            self._free.put(self._held)
-            self._held = None
+            self._free.put((self._held, self._held_item.get("uploaded_event")))
+            self._held = self._held_item = None
         item = self._ready.get()
         if item is None:
             raise RuntimeError("prefetch thread failed") from self._error
         self._held = item.pop("_staging", None) if isinstance(item, dict) else None
+        self._held_item = item if self._held is not None else None
         return item
 
     __call__ = lambda self, batch_size=None: self.next()           # drop-in for memory.sample(batch_size=...)

@@ -135,7 +135,8 @@ class FusedRuntime(object):
                                    slot_p=engine.slot_view(self.slot_p, geo2), slot_v=engine.slot_view(self.slot_v, geo2),
                                    slot_t=engine.slot_view(self.slot_t, geon2)))
         for st in self._sets:
-            st.update(ev_in=torch.cuda.Event(), ev_gn=torch.cuda.Event(), ev_g=torch.cuda.Event(), ev_free=None, plans=None)
+            st.update(ev_in=torch.cuda.Event(), ev_gn=torch.cuda.Event(), ev_g=torch.cuda.Event(), ev_up=torch.cuda.Event(), ev_free=None,
+                      plans=None)
         self._set = 0
         self.scal = torch.zeros(32, **f32)
         self._one = torch.ones(1, **f32)
@@ -480,7 +481,8 @@ class FusedRuntime(object):
         spre2 = main if inline else engine.side_stream(which=21)
         if not inline:
             ready = batch.get("ready_event") if batch is not None else None
-            if ready is None and batch is not None and ("replay_gather" in batch or torch.is_tensor(batch["point_state_batch"])):
+            if ready is None and batch is not None and ("replay_gather" in batch or (
+                    torch.is_tensor(batch["point_state_batch"]) and batch["point_state_batch"].is_cuda)):
                 self._ev_pre.record(main)               # device tensors of unknown origin: after everything enqueued so far
                 ready = self._ev_pre
             for s_ in (spre, spre2):
@@ -502,8 +504,13 @@ class FusedRuntime(object):
         with torch.cuda.stream(spre2):
             if not whole:
                 self._copy_in(batch, tuple(k for k in BATCH_KEYS if k not in first))
+                if not inline:
+                    spre2.wait_event(st["ev_in"])
+            st["ev_up"].record(spre2)                           # every input of the step has left the caller's buffers
             self.geo.run(d["point_state_batch"])
             st["ev_g"].record(spre2)                            # ev_g: ALL inputs are in + the geometry of the current state
+        if isinstance(batch, dict):
+            batch["uploaded_event"] = st["ev_up"]               # a producer may reuse its staging buffers after this one
         idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
         normal_noise = getattr(ag, "noise_type", "uniform") != "uniform"     # core/utils.py:568-569
