@@ -42,11 +42,13 @@ def setup(config_file="ddpg_td3_aux.yaml", policy=None, pretrained=None, model_s
 
 
 def train_off_policy(agent, memory, config, model_output_dir=None, save_model=False, log=None, max_epochs=None,
-                     sample=None):
+                     sample=None, run_ahead=False):
     """The reference's train_off_policy() (:107-161) over an agent and a filled replay memory.
     config = cfg.RL_TRAIN (updates_per_step, batch_size, save_epoch, max_epoch).  `sample(batch_size)` overrides
     memory.sample (device-resident replay, prefetching samplers).  Returns the per-key loss history (deques, as the
-    reference keeps them) and the number of epochs run."""
+    reference keeps them) and the number of epochs run.
+    run_ahead: enqueue the `updates_per_step` updates of an epoch without waiting for each (update_parameters(sync=False));
+    their losses are read at the end of the epoch, the host samples / stages the next minibatch while the GPU works."""
     losses = get_loss_info_dict()
     sample = sample or memory.sample
     epochs = 0
@@ -54,16 +56,23 @@ def train_off_policy(agent, memory, config, model_output_dir=None, save_model=Fa
         start_time = time.time()
         lrs = agent.get_lr()
         data_time, network_time = 0.0, 0.0
+        pending = []
         for i in range(config.updates_per_step):
             batch_data = sample(batch_size=config.batch_size)
             data_time += time.time() - start_time
             start_time = time.time()
-            loss = agent.update_parameters(batch_data, agent.update_step, i)
+            if run_ahead and "sync" in agent.update_parameters.__code__.co_varnames:
+                pending.append(agent.update_parameters(batch_data, agent.update_step, i, sync=False))
+            else:
+                pending.append(agent.update_parameters(batch_data, agent.update_step, i))
             network_time += time.time() - start_time
-            for k, v in loss.items():
-                if k in losses:
-                    losses[k].append(v)
             agent.step_scheduler(agent.update_step)
+            if not run_ahead or i == config.updates_per_step - 1:
+                for loss in pending:                          # (run-ahead: the first read of a PendingLog waits for its step)
+                    for k, v in loss.items():
+                        if k in losses:
+                            losses[k].append(v)
+                pending = []
             start_time = time.time()
             if save_model and epoch % 100 == 0 and i == 0:
                 agent.save_model(agent.update_step, output_dir=model_output_dir)

@@ -156,6 +156,15 @@ def test_offline_loop_checkpoints_resume_and_migrate(golden_dir, tmp_path):
     assert any("updates: 9" in l for l in logs)
     assert os.path.exists(out / "DDPG_actor_PandaYCBEnv_epoch_6") and os.path.exists(out / "DDPG_state_feat_PandaYCBEnv_epoch_6")
     assert torch.load(out / "DDPG_state_feat_PandaYCBEnv_epoch_6", weights_only=False)["step"] == 6
+    # ---- the same loop with run-ahead updates (losses read at the end of each epoch): same bookkeeping, finite losses
+    torch.manual_seed(3)
+    agent_b, _ = make_agent(cfg)
+    np.random.seed(11)
+    losses_b, epochs_b = tto.train_off_policy(agent_b, mem, config, str(tmp_path / "run_b"), save_model=True, run_ahead=True)
+    assert epochs_b == 2 and agent_b.update_step == 9 and len(losses_b["critic_loss"]) == 9
+    assert all(np.isfinite(list(h)).all() for h in losses_b.values())
+    assert abs(list(losses_b["critic_loss"])[1] - list(losses["critic_loss"])[1]) <= 1e-3 * abs(list(losses["critic_loss"])[1]) + 1e-6
+    assert torch.load(tmp_path / "run_b" / "DDPG_state_feat_PandaYCBEnv_epoch_6", weights_only=False)["step"] == 6
     agent.save_model(agent.update_step, output_dir=str(out))
     # ---- resume on a fresh agent BEFORE its first update (the Adam moments must come from the file, not from zero)
     torch.manual_seed(4)
