@@ -101,6 +101,7 @@ class PrefetchSampler(object):
                         if k not in item and k not in ("image_state_batch", "next_image_state_batch"):
                             item[k] = v
                     item["_staging"] = st
+                    item["uploaded_event"] = None                   # the runtime puts the upload's completion event here
                 while not self._stop.is_set():
                     try:
                         self._ready.put(item, timeout=0.05)

@@ -509,8 +509,8 @@ class FusedRuntime(object):
             st["ev_up"].record(spre2)                           # every input of the step has left the caller's buffers
             self.geo.run(d["point_state_batch"])
             st["ev_g"].record(spre2)                            # ev_g: ALL inputs are in + the geometry of the current state
-        if isinstance(batch, dict):
-            batch["uploaded_event"] = st["ev_up"]               # a producer may reuse its staging buffers after this one
+        if isinstance(batch, dict) and "uploaded_event" in batch:   # asked for by the producer (PrefetchSampler): it may
+            batch["uploaded_event"] = st["ev_up"]                   # reuse its staging buffers after this event
         idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
         level = ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)]
         normal_noise = getattr(ag, "noise_type", "uniform") != "uniform"     # core/utils.py:568-569

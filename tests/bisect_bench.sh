@@ -1,5 +1,7 @@
 #!/bin/bash
-# bench rate of the given trees (default: _r01, the bisect worktrees and the working tree), interleaved REPS times on one box
+# bench rate of the given trees, interleaved REPS times on one box.  Trees are git worktrees built in place, e.g.
+#   git worktree add -f _r01 <commit> && (cd _r01 && python -c "import __graft_entry__ as g; g.build()")
+# (_r01/ and _bis/ are git- and gpurun-ignored; remove them from .gpurunignore while they are needed on the GPU box)
 REPS=${REPS:-2}
 STEPS=${STEPS:-100}
 TREES=${TREES:-"_r01 _bis/2e9a10e _bis/7245c40 _bis/48ee1d7 _bis/cebbbed _bis/62dc03d _bis/38bceaf ."}

@@ -258,6 +258,38 @@ def test_prefetched_pinned_batches_feed_the_update():
         assert_close(res["prefetch"][k], res["host"][k], 1e-5, 1e-7, k)
 
 
+def test_prefetch_sampler_under_run_ahead_steps():
+    """run-ahead updates return before their uploads have run: a staging set must not be refilled until the event the
+    runtime hangs on the batch (`uploaded_event`).  Learning rate 0 makes every step a function of ITS minibatch only, so a
+    step that saw a half-overwritten staging set shows up against the synchronous loop over the same minibatches."""
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.prefetch import PrefetchSampler
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle.detfill import fill_module_
+    runs = {}
+    for mode in ("sync", "ahead"):
+        agent, cfg = make_agent("ddpg_td3_aux.yaml")
+        for name in ("policy", "policy_target", "critic", "critic_target", "state_feature_extractor"):
+            fill_module_(getattr(agent, name), name, 5)
+        for opt in (agent.policy_optim, agent.critic_optim, agent.state_feat_encoder_optim, agent.state_feat_val_encoder_optim):
+            for g in opt.param_groups:
+                g["lr"] = 0.0
+        mem = BaseMemory(600, cfg, point_dtype=np.float32)
+        fill_synthetic_buffer(mem, 600, seed=4)
+        rng = np.random.default_rng(2)
+        noise = np.random.default_rng(3).random((10, 32, 6)).astype(np.float32)
+        logs = []
+        with PrefetchSampler(mem, 32, depth=1, sample=lambda n: sample_valid_batch(mem, n, rng)) as s:   # two staging sets circulate
+            for i in range(10):
+                logs.append(agent.update_parameters(s.next(), agent.update_step, i, noise_u=noise[i], sync=(mode == "sync")))
+            agent.flush()
+        runs[mode] = [dict(l) for l in logs]
+    for i, (a, b) in enumerate(zip(runs["sync"], runs["ahead"])):
+        for k in a:
+            assert_close(b[k], a[k], 2e-4, 1e-6, "step %d %s" % (i, k))
+
+
 @pytest.mark.parametrize("source", ["host", "device"])
 def test_run_ahead_steps_equal_synchronous_steps(source):
     """update_parameters(sync=False) returns before the step has run; the host stages and enqueues the following steps
