@@ -800,6 +800,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
 
 static int g_opt_dx_slab = 0;    // (see g_opt_fwd_slab)
 static int g_opt_dbg = 0;
+static int g_opt_dw_direct = 0;   // 1: the tile dW kernel adds its split tiles into the f64 arena with atomics (no partial workspace, no dw_reduce launch)
 static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
@@ -1001,6 +1002,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
     if (!strcmp(name, "dx_slab")) { g_opt_dx_slab = value; return GAD_OK; }
     if (!strcmp(name, "dbg")) { g_opt_dbg = value; return GAD_OK; }
+    if (!strcmp(name, "dw_direct")) { g_opt_dw_direct = value; return GAD_OK; }
     if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dw_stream")) { g_opt_dw_stream = value; return GAD_OK; }
     int found = 0;
@@ -2513,7 +2515,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
             if (splits < 1) splits = 1;                                                                    \
         }                                                                                                  \
         group_stride = (long long)splits * nmax * in.Kp;                                                   \
-        if (part && (splits == 1 || group_stride * gr.n > a->partial_elems)) part = nullptr;               \
+        if (part && (splits == 1 || g_opt_dw_direct || group_stride * gr.n > a->partial_elems)) part = nullptr; \
         if (in.mode == 0) { if (vec) LAUNCH_DW3(WM, WN, TM, TN, 0, true); else LAUNCH_DW3(WM, WN, TM, TN, 0, false); } \
         else              { if (vec) LAUNCH_DW3(WM, WN, TM, TN, 1, true); else LAUNCH_DW3(WM, WN, TM, TN, 1, false); } \
     } while (0)
