@@ -37,6 +37,8 @@ EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "0") == "1"
 # step).  MEASURED: 286.4 vs 287.5 steps/s with the prefetch on the same lane, 288.3 vs 287.2 otherwise -- no gain: the
 # actor backward + its dW lane already fill the GPU and the step is bound by the sum of its kernels' own durations.  Off.
 EARLY_VALUE = _os.environ.get("GAD_EARLY_VALUE", "0") == "1"
+# (measured and removed, same box, 287-288 steps/s for the schedule below: the actor pass after t2, i.e. beside the critic
+# backward only: 275; the value pass after t1, beside t2 and the actor pass: 282; both side passes swapped: 278)
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
 GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
