@@ -35,6 +35,7 @@ __device__ __forceinline__ int gad_cdiv_dev(int a, int b) { return (a + b - 1) /
 void gad_geometry_set_option(const char* name, int value, int* found);
 // the timing slot armed by gad_timing_slot() for the NEXT launch of the calling thread (NULL if none); consumed once
 unsigned long long* gad_take_timing_slot();
+int gad_take_grid_rows();       // rows the caller expects to be live (0: unknown) -- sizes the grid of the next tile launch
 
 #ifdef __HIPCC__
 // squared distance with the evaluation order pinned to the oracle's (oracle/pn2_ref.c sqdist):

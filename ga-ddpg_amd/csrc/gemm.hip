@@ -1050,6 +1050,7 @@ static int check_input(const gad_gemm_fwd_args& a, const char* who) {
 
 extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     unsigned long long* ts = gad_take_timing_slot();
+    const int rows_hint = gad_take_grid_rows();
     GAD_REQUIRE(a && a->W && a->zout, GAD_ERR_NULL, "gemm_fwd: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_fwd: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0 && a->Kp >= 8, GAD_ERR_SHAPE, "gemm_fwd: Kp=%d must be a multiple of 8", a->Kp);
@@ -1067,6 +1068,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     const int nmax = max_nout(gr);
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows;
+    const int grid_rows = (a->n_rows_dev && rows_hint > 0 && rows_hint < rows) ? rows_hint : rows;   // gad_grid_rows_hint
     if (fwd_skinny(*a)) {
         hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(nmax, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
                            gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
@@ -1076,7 +1078,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 #define LAUNCH_FWD2(WM, WN, TM, TN, XM)                                                                    \
     do {                                                                                                   \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                                \
-        int gx = gad_cdiv(rows, BM); if (gx > 2048) gx = 2048;                                             \
+        int gx = gad_cdiv(grid_rows, BM); if (gx > 2048) gx = 2048;                                        \
         hipLaunchKernelGGL((gemm_fwd_kernel<WM, WN, TM, TN, XM>), dim3(gx, gad_cdiv(nmax, BN), gr.n), dim3(256), \
                            0, st, x, gr, a->n_rows_dev, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, \
                            a->stat_sum, a->stat_sq, a->stat_stride, ts);                                       \
@@ -1785,6 +1787,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
 
 extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     unsigned long long* ts = gad_take_timing_slot();
+    const int rows_hint = gad_take_grid_rows();
     GAD_REQUIRE(a && a->W, GAD_ERR_NULL, "gemm_dx: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_dx: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0, GAD_ERR_SHAPE, "gemm_dx: Kp must be a multiple of 8");
@@ -1807,6 +1810,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     GAD_REQUIRE(!e.dbeta || (e.zprev && e.ps && e.pt && e.pm && e.pi && e.dgamma), GAD_ERR_NULL, "gemm_dx: prev BN stats inputs");
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows, kv = a->k_valid;
+    const int grid_rows = (a->n_rows_dev && rows_hint > 0 && rows_hint < rows) ? rows_hint : rows;   // gad_grid_rows_hint
     const bool vec = dz_vectorizable(a->dz, a->dz_off, a->n_out, a->n_groups);
     if (a->dz.bn.dbeta) {
         GAD_REQUIRE(vec && a->n_groups == 1 && a->dz_off[0] == 0, GAD_ERR_SHAPE,
@@ -1857,7 +1861,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
 #define LAUNCH_DX2(WM, WN, TM, TN, V)                                                                    \
     do {                                                                                                 \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                              \
-        int gx = gad_cdiv(rows, BM); if (gx > 2048) gx = 2048;                                           \
+        int gx = gad_cdiv(grid_rows, BM); if (gx > 2048) gx = 2048;                                      \
         if (nmax_dx <= 512)                                                                              \
             hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V, 512>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
                                st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e, ts);                          \

@@ -25,6 +25,18 @@ extern "C" int gad_timing_slot(void* slot) {
     return GAD_OK;
 }
 
+// Grid-size hint for the next tiled gad_gemm_fwd / gad_gemm_dx launch of this thread (see gaddpg.h)
+static thread_local int g_grid_rows = 0;
+int gad_take_grid_rows() {
+    const int r = g_grid_rows;
+    g_grid_rows = 0;
+    return r;
+}
+extern "C" int gad_grid_rows_hint(const int32_t* rows_host, void* /*stream: unused, plan calls pass one*/) {
+    g_grid_rows = rows_host ? *rows_host : 0;
+    return GAD_OK;
+}
+
 extern "C" int gad_wall_clock_khz(void) {
     int dev = 0, khz = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;

@@ -210,6 +210,9 @@ class Geometry(object):
         r3 = self.rows[2]
         hip.call("gad_rows_group_all", B, M2, r3["off"], r3["pt"], r3["grp"], r3["w"], r3["n"])
         self.counts = (float(B * M1 * sa1.nsample), float(B * M2 * sa2.nsample), float(B * M2))
+        # expected live rows of SA1 / SA2 (host ints, 0 = unknown): grid-size hints for the tile launches over de-duplicated
+        # rows (gad_grid_rows_hint); the owner of the geometry keeps them current from the row counts of earlier minibatches
+        self.rows_hint = np.zeros(2, dtype=np.int32)
 
     def run(self, point_state):
         """point_state (B,4,NP) f32 device tensor in the replay layout (gripper points first)."""
@@ -704,6 +707,8 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
             kw["in_bn"] = bn_fin(enc, slot, prev, count_prev, update_running)
         a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(zout), zout_pitch=m.n_out,
                       stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot, **kw)
+        if s < 2:
+            plan.call("gad_grid_rows_hint", hip.Ptr(geo.rows_hint.ctypes.data + 4 * s))
         plan.call_struct("gad_gemm_fwd", a)
         plan.tag_last(tag)
         if not train:
@@ -798,6 +803,9 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.grp_per_sample = 1
         for k, v in epi.items():
             setattr(a, k, v)
+        stage = {"sa1": 0, "sa2": 1}.get(rows_kw.get("name"))
+        if stage is not None:
+            plan.call("gad_grid_rows_hint", hip.Ptr(geo.rows_hint.ctypes.data + 4 * stage))
         plan.call_struct("gad_gemm_dx", a)
         plan.tag_last("dx.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
 

@@ -39,6 +39,7 @@ EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "0") == "1"
 EARLY_VALUE = _os.environ.get("GAD_EARLY_VALUE", "0") == "1"
 # (measured and removed, same box, 287-288 steps/s for the schedule below: the actor pass after t2, i.e. beside the critic
 # backward only: 275; the value pass after t1, beside t2 and the actor pass: 282; both side passes swapped: 278)
+ROW_HINTS = _os.environ.get("GAD_ROW_HINTS", "1") == "1"     # grids of the SA1 / SA2 tile launches sized for the expected live rows
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
 GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
@@ -137,9 +138,11 @@ class FusedRuntime(object):
                                    slot_p=engine.slot_view(self.slot_p, geo2), slot_v=engine.slot_view(self.slot_v, geo2),
                                    slot_t=engine.slot_view(self.slot_t, geon2)))
         for st in self._sets:
+            st["rows_pin"] = torch.zeros(4, dtype=torch.int32).pin_memory()    # live rows of [geo SA1, SA2, geo_next SA1, SA2]
             st.update(ev_in=torch.cuda.Event(), ev_gn=torch.cuda.Event(), ev_g=torch.cuda.Event(), ev_up=torch.cuda.Event(), ev_free=None,
                       plans=None)
         self._set = 0
+        self._rows_seen = [[], []]            # recent live-row counts of SA1 / SA2 (grid-size hints, engine.Geometry.rows_hint)
         self.scal = torch.zeros(32, **f32)
         self._one = torch.ones(1, **f32)
         self._minus_one = -torch.ones(1, **f32)
@@ -358,6 +361,8 @@ class FusedRuntime(object):
             self._ev_done[slot].synchronize()
         self._slot = slot
         self._bind_set((self._set + 1) % len(self._sets) if (alternate and len(self._sets) > 1) else 0)
+        if ROW_HINTS and self.has_critic:
+            self._update_row_hints()
         self.scal_host = self._scal_ring[slot]
         self.noise_host = self._noise_ring[slot]
         if self._hbuf_ring[slot] is None:
@@ -366,6 +371,26 @@ class FusedRuntime(object):
         for net in (self.enc, self.venc, self.pol) + ((self.cr,) if self.has_critic else ()):
             net.flat.hyper_host = net.flat.hyper_ring[slot]
         return slot
+
+    def _update_row_hints(self):
+        """grid-size hints for the tile launches over de-duplicated rows: 1.25 x the largest live-row count among the last
+        minibatches (whatever has arrived in the pinned counters: values of earlier steps, possibly of one still in flight --
+        a hint only, the kernels' grid-stride loops are bounded by the device-side count)"""
+        for st in self._sets:
+            v = st["rows_pin"].numpy()
+            for stage in (0, 1):
+                for x in (int(v[stage]), int(v[2 + stage])):
+                    if x > 0:
+                        seen = self._rows_seen[stage]
+                        seen.append(x)
+                        del seen[:-32]
+        for stage in (0, 1):
+            if self._rows_seen[stage]:
+                h = int(1.25 * max(self._rows_seen[stage])) + 256
+                for st in self._sets:
+                    st["geo"].rows_hint[stage] = h
+                    if st["geo_next"] is not None:
+                        st["geo_next"].rows_hint[stage] = h
 
     def _end_step(self, slot, sync):
         ev = self._ev_done[slot]
@@ -501,6 +526,9 @@ class FusedRuntime(object):
             st["ev_in"].record(spre)
             self.geo_next.run(d["next_point_state_batch"])      # the target chain (the critical path) needs this one first
             st["ev_gn"].record(spre)
+            if ROW_HINTS:
+                st["rows_pin"][2:3].copy_(self.geo_next.rows[0]["n"], non_blocking=True)
+                st["rows_pin"][3:4].copy_(self.geo_next.rows[1]["n"], non_blocking=True)
         if whole and not inline:
             spre2.wait_event(st["ev_in"])
         with torch.cuda.stream(spre2):
@@ -511,6 +539,9 @@ class FusedRuntime(object):
             st["ev_up"].record(spre2)                           # every input of the step has left the caller's buffers
             self.geo.run(d["point_state_batch"])
             st["ev_g"].record(spre2)                            # ev_g: ALL inputs are in + the geometry of the current state
+            if ROW_HINTS:
+                st["rows_pin"][0:1].copy_(self.geo.rows[0]["n"], non_blocking=True)
+                st["rows_pin"][1:2].copy_(self.geo.rows[1]["n"], non_blocking=True)
         if isinstance(batch, dict) and "uploaded_event" in batch:   # asked for by the producer (PrefetchSampler): it may
             batch["uploaded_event"] = st["ev_up"]                   # reuse its staging buffers after this event
         idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)

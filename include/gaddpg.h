@@ -55,6 +55,13 @@ int gad_set_option(const char* name, int value);
 int gad_timing_slot(void* slot);
 int gad_wall_clock_khz(void);              /* rate of that clock (hipDeviceAttributeWallClockRate), 0 if unavailable    */
 
+/* Grid-size hint: the layers of SA1 / SA2 run over de-duplicated rows whose count lives on the device (n_rows_dev); the host
+ * only knows the worst case (n_rows, 20-40x larger), and a grid sized for it is mostly workgroups that exit at once (~1 ns
+ * each: 3-6 us of an SA2 launch).  *rows_host (a HOST int, read at call time) = the number of live rows the caller expects
+ * for the NEXT tiled gad_gemm_fwd / gad_gemm_dx launch of this thread; the grid is sized for it.  It is a hint only: the
+ * kernels walk the rows in a grid-stride loop bounded by the device count, so any value gives the same result.           */
+int gad_grid_rows_hint(const int32_t* rows_host, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * A. pointnet2_ops._ext operator parity (materialising, reference API shapes)
  * ------------------------------------------------------------------------------------------- */

