@@ -800,6 +800,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
 
 static int g_opt_dx_slab = 0;    // (see g_opt_fwd_slab)
 static int g_opt_dbg = 0;
+static int g_opt_gx_cap = 2048;   // most row tiles a tile launch spreads over workgroups (the rest by its grid-stride loop)
 static int g_opt_dw_direct = 0;   // 1: the tile dW kernel adds its split tiles into the f64 arena with atomics (no partial workspace, no dw_reduce launch)
 static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
@@ -1002,6 +1003,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
     if (!strcmp(name, "dx_slab")) { g_opt_dx_slab = value; return GAD_OK; }
     if (!strcmp(name, "dbg")) { g_opt_dbg = value; return GAD_OK; }
+    if (!strcmp(name, "gx_cap")) { g_opt_gx_cap = value > 0 ? value : 2048; return GAD_OK; }
     if (!strcmp(name, "dw_direct")) { g_opt_dw_direct = value; return GAD_OK; }
     if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dw_stream")) { g_opt_dw_stream = value; return GAD_OK; }
@@ -1078,7 +1080,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 #define LAUNCH_FWD2(WM, WN, TM, TN, XM)                                                                    \
     do {                                                                                                   \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                                \
-        int gx = gad_cdiv(grid_rows, BM); if (gx > 2048) gx = 2048;                                        \
+        int gx = gad_cdiv(grid_rows, BM); if (gx > g_opt_gx_cap) gx = g_opt_gx_cap;                                        \
         hipLaunchKernelGGL((gemm_fwd_kernel<WM, WN, TM, TN, XM>), dim3(gx, gad_cdiv(nmax, BN), gr.n), dim3(256), \
                            0, st, x, gr, a->n_rows_dev, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, \
                            a->stat_sum, a->stat_sq, a->stat_stride, ts);                                       \
@@ -1861,7 +1863,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
 #define LAUNCH_DX2(WM, WN, TM, TN, V)                                                                    \
     do {                                                                                                 \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                              \
-        int gx = gad_cdiv(grid_rows, BM); if (gx > 2048) gx = 2048;                                      \
+        int gx = gad_cdiv(grid_rows, BM); if (gx > g_opt_gx_cap) gx = g_opt_gx_cap;                                      \
         if (nmax_dx <= 512)                                                                              \
             hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V, 512>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
                                st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e, ts);                          \
