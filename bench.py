@@ -359,7 +359,7 @@ def main():
     res["step_dense_tflops"] = steps_per_s * world * B * 5.5078e9 / 1e12
     if world == 1 and not args.no_host_rate:
         rng2 = np.random.default_rng(7)
-        n = max(10, args.steps // 10)
+        n = max(40, args.steps // 4)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
