@@ -95,3 +95,64 @@ def test_step_gradients_with_forced_decisions(B, seed, policy_step):
         open(os.path.join(out_dir, "grad_accuracy_forced_B%d%s.txt" % (B, "_policy_step" if policy_step else "")), "w").write("\n".join(lines) + "\n")
     assert len(lines) > (35 if policy_step else 90)
     assert not bad, "\n".join([lines[0]] + bad)
+
+
+def test_bc_step_gradients_with_forced_decisions():
+    """the behaviour-cloning step of BASELINE configs[0] (B = 64): one policy pass forward + backward, same tight criterion"""
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    from tests.kink_forcing import decisions_from_slot, forced_forward
+    from tests.test_gpu_step import _filled_agent
+    B = 64
+    c = load_cfg("bc_dagger_aux.yaml")
+    mem = BaseMemory(2000, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 2000, seed=11)
+    batch = sample_valid_batch(mem, B, np.random.default_rng(4))
+    agent, nets = _filled_agent("bc_dagger_aux.yaml", 3)
+    got = agent.update_parameters(batch, agent.update_step, 0)
+    torch.cuda.synchronize()
+    rt = agent._rt
+    dec = {("policy", 0): decisions_from_slot(rt.enc, rt.slot_p)}
+
+    def oracle(dtype):
+        o = ref_step.OracleAgent(c.RL_TRAIN)
+        for n, net in o.nets().items():
+            fill_module_(net, n, 3)
+        o.to_dtype(dtype)
+        with forced_forward(o.state_feature_extractor.module, dec) as ff:
+            out = o.update_bc(batch)
+        assert ff.calls == {"value": 0, "policy": 1}
+        return out, {nn + "/" + n: p.grad.double() for nn, net in o.nets().items()
+                     for n, p in net.named_parameters() if p.grad is not None}, o
+    out64, g64, o64 = oracle(torch.float64)
+    out32, g32, o32 = oracle(torch.float32)
+    for k in ("bc_loss", "policy_grasp_aux_loss"):
+        assert_close(got[k], out64[k], 2e-5, 1e-7, k)
+    for mine, key in ((agent.pi, "pi"), (agent.aux_pred, "aux_pred")):
+        ref = o64.dbg[key].numpy()
+        scale = np.abs(ref).max()
+        eh = np.abs(mine.cpu().numpy() - ref).max() / scale
+        e32 = np.abs(o32.dbg[key].double().numpy() - ref).max() / scale
+        assert eh <= max(3 * e32, 2e-5), (key, eh, e32)
+    lines = ["%-64s %10s %10s %10s %10s %10s" % ("tensor (BC step, B=64, forced decisions)", "max|f64|", "hip med", "hip max", "f32 med", "f32 max")]
+    bad = []
+    for key, ref in sorted(g64.items()):
+        nn, n = key.split("/", 1)
+        if any(x in n for x in SKIP):
+            continue
+        mine = dict(nets[nn].named_parameters())[n].grad.double().cpu()
+        scale = float(ref.abs().max()) + 1e-300
+        eh, e3 = (mine - ref).abs() / scale, (g32[key] - ref).abs() / scale
+        row = (float(eh.median()), float(eh.max()), float(e3.median()), float(e3.max()))
+        lines.append("%-64s %10.3e %10.2e %10.2e %10.2e %10.2e" % ((key, scale) + row))
+        if row[0] > max(3 * row[2], 2e-6) or row[1] > max(3 * row[3], 1e-4):
+            bad.append(lines[-1])
+    lines.append("violations of  hip med <= max(3 f32 med, 2e-6)  and  hip max <= max(3 f32 max, 1e-4): %d of %d" % (len(bad), len(lines) - 1))
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        open(os.path.join(out_dir, "grad_accuracy_forced_BC_B64.txt"), "w").write("\n".join(lines) + "\n")
+    assert len(lines) > 30
+    assert not bad, "\n".join([lines[0]] + bad)
