@@ -1,6 +1,7 @@
 """bench.py -- DDPG gradient steps / second of the fused MI355X path (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 200 --warmup 50
+    python bench.py --gpus N --steps K --warmup W          # N > 1: launches the N ranks itself (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -208,8 +209,28 @@ def kernel_table(by_tag, rows, B, steps):
     return out
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the driver's invocation form; the reference spreads
+    over GPUs from one process as well: nn.DataParallel, core/utils.py:202): start N ranks of this file under
+    torch.distributed.run -- one process per GPU, rendezvous on 127.0.0.1 -- and relay their output; rank 0's JSON line
+    stays the last line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this driver (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

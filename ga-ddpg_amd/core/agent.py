@@ -244,6 +244,7 @@ class Agent(object):
 
     def save_model(self, step, output_dir="", surfix="latest", actor_path=None, critic_path=None,
                    goal_feat_path=None, state_feat_path=None):
+        self.flush()                        # run-ahead updates (sync=False) still in flight finish before anything is read
         os.makedirs(output_dir, exist_ok=True)
         paths = self._paths(output_dir, surfix)
         actor_path = actor_path or paths["actor"]

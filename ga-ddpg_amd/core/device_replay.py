@@ -68,28 +68,49 @@ class DeviceReplay(object):
             self._ev_refresh = torch.cuda.Event()
         self._ev_refresh.record(torch.cuda.current_stream())      # later handles become ready after this upload
 
-    RING = 8        # index staging sets: a handle stays valid while this many later ones are drawn
+    RING = 8        # index staging sets (a set is reused only after the gather that read it has run: `used` event)
 
     def _stage_set(self, n):
-        """(pinned (3,n) int64, device (3,n) int64, event) of the next handle.  The copies run on a stream of their own and
-        the handle carries the event: a runtime that enqueues steps ahead of the GPU (update_parameters(sync=False)) starts
-        the gather as soon as the indices are on the device, not after everything queued on the caller's stream."""
+        """the next handle's staging set: dict(host = pinned (3,n) int64, dev = device (3,n) int64, copied = event of the
+        host -> device copy, used = event recorded after the LAST gather that read `dev`, or None).  The copies run on a
+        stream of their own and the handle carries `copied`: a runtime that enqueues steps ahead of the GPU
+        (update_parameters(sync=False)) starts the gather as soon as the indices are on the device, not after everything
+        queued on the caller's stream.  Reuse is guarded by BOTH events: the pinned block by the copy that read it, the
+        device block by the gather that read it -- however far ahead handles are drawn (PrefetchSampler depth, host ring),
+        a set never changes under a gather that is still queued; a set whose handle has not been gathered at all yet
+        (`pending`) is skipped, and the ring grows if every set is held that way."""
         key = ("sets", n)
         sets = self._stage.get(key)
         if sets is None:
             sets = self._stage[key] = {"next": 0, "items": [None] * self.RING}
+        items = sets["items"]
         j = sets["next"]
-        sets["next"] = (j + 1) % self.RING
-        it = sets["items"][j]
+        for _ in range(len(items)):              # a set whose handle has not been gathered yet is never handed out again
+            if items[j] is None or not items[j]["pending"]:
+                break
+            j = (j + 1) % len(items)
+        else:                                    # every set is held by a handle drawn ahead of its use: grow the ring
+            if len(items) >= 64:
+                raise RuntimeError("DeviceReplay: 64 sample_lazy() handles are outstanding (drawn but never passed to an "
+                                   "update step); drop-and-redraw loops should use sample() instead")
+            items.append(None)
+            j = len(items) - 1
+        sets["next"] = (j + 1) % len(items)
+        it = items[j]
         if it is None:
-            it = sets["items"][j] = (torch.empty(3, n, dtype=torch.int64).pin_memory(),
-                                     torch.empty(3, n, dtype=torch.int64, device=self.device), torch.cuda.Event())
+            it = items[j] = {"host": torch.empty(3, n, dtype=torch.int64).pin_memory(),
+                             "dev": torch.empty(3, n, dtype=torch.int64, device=self.device),
+                             "copied": torch.cuda.Event(), "used": None, "pending": False}
         else:
-            it[2].synchronize()                  # the copy that last read this pinned block (RING handles ago)
+            it["copied"].synchronize()           # the copy that last read this pinned block
+            if it["used"] is not None:
+                it["used"].synchronize()         # the gather(s) that read the device block
+        it["pending"] = True
         return it
 
     def _indices3(self, idx, nxt, end):
-        host, dev, ev = self._stage_set(idx.shape[0])
+        it = self._stage_set(idx.shape[0])
+        host, dev, ev = it["host"], it["dev"], it["copied"]
         h = host.numpy()
         h[0], h[1], h[2] = idx, nxt, end
         if self._copy_stream is None:
@@ -99,7 +120,7 @@ class DeviceReplay(object):
         with torch.cuda.stream(self._copy_stream):
             dev.copy_(host, non_blocking=True)
             ev.record(self._copy_stream)
-        return dev, ev
+        return dev, ev, it
 
     # ------------------------------------------------------------------ sampling
     def sample_lazy(self, batch_size, rng=None, batch_idx=None):
@@ -113,14 +134,18 @@ class DeviceReplay(object):
         nxt = m.next_indices(batch_idx)
         end = np.asarray(m.episode_map[batch_idx], dtype=np.int64)
         B = batch_idx.shape[0]
-        dev, ev = self._indices3(batch_idx, nxt, end)
-        return {"replay_gather": self, "idx": dev[0], "nxt": dev[1], "end": dev[2], "ready_event": ev,
+        dev, ev, it = self._indices3(batch_idx, nxt, end)
+        return {"replay_gather": self, "idx": dev[0], "nxt": dev[1], "end": dev[2], "ready_event": ev, "_stage_set": it,
                 "batch_idx": np.uint8(batch_idx),
                 "point_state_batch": _Shape((B,) + tuple(self.point_state.shape[1:])),
                 "mask_counts": self._mask_counts(batch_idx)}
 
     def gather_into(self, lazy, dbuf):
-        """fill the runtime's static batch buffers (dict of CUDA float32 tensors) from a sample_lazy() handle"""
+        """fill the runtime's static batch buffers (dict of CUDA float32 tensors) from a sample_lazy() handle.  Ordered on
+        the CURRENT stream after the handle's index upload (which ran on the copy stream), whoever the caller is."""
+        cur = torch.cuda.current_stream()
+        if lazy.get("ready_event") is not None:
+            cur.wait_event(lazy["ready_event"])
         a = hip.ReplayGatherArgs()
         a.B = int(lazy["idx"].shape[0])
         a.cloud_elems = int(self.point_state.shape[1] * self.point_state.shape[2])
@@ -136,6 +161,12 @@ class DeviceReplay(object):
                          ("out_perturb_flag", "perturb_flag_batch")):
             setattr(a, dst, hip.ptr(dbuf[key]))
         hip.call_struct("gad_replay_gather", a)
+        it = lazy.get("_stage_set")
+        if it is not None:                       # the staging set is not rewritten before this gather has run
+            if it["used"] is None:
+                it["used"] = torch.cuda.Event()
+            it["used"].record(cur)
+            it["pending"] = False
 
     def _mask_counts(self, batch_idx):
         m = self.memory
@@ -155,8 +186,9 @@ class DeviceReplay(object):
         batch_idx = np.asarray(batch_idx, dtype=np.int64)
         nxt = m.next_indices(batch_idx)
         end = np.asarray(m.episode_map[batch_idx], dtype=np.int64)
-        dev, ev = self._indices3(batch_idx, nxt, end)
-        torch.cuda.current_stream().wait_event(ev)
+        dev, ev, it = self._indices3(batch_idx, nxt, end)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
         d_idx, d_nxt, d_end = dev[0], dev[1], dev[2]
         out = {"point_state_batch": self.point_state.index_select(0, d_idx),
                "next_point_state_batch": self.point_state.index_select(0, d_nxt)}
@@ -164,6 +196,10 @@ class DeviceReplay(object):
             out[dst] = self.rows[src].index_select(0, d_idx)
         # remaining steps to the end of the episode (post_process_batch)
         out["time_batch"] = self.timestep.index_select(0, d_end) + 1.0 - self.timestep.index_select(0, d_idx)
+        if it["used"] is None:
+            it["used"] = torch.cuda.Event()
+        it["used"].record(cur)                   # the index_selects above read the staging set's device block
+        it["pending"] = False
         out["batch_idx"] = np.uint8(batch_idx)
         out["mask_counts"] = self._mask_counts(batch_idx)
         return out

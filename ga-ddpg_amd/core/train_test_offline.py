@@ -34,9 +34,14 @@ def setup(config_file="ddpg_td3_aux.yaml", policy=None, pretrained=None, model_s
     cfg.RL_TRAIN.batch_size = int(batch_size if batch_size is not None else cfg.OFFLINE_BATCH_SIZE)   # reference :351
     if pretrained:
         src = pretrained
-        if output_dir and os.path.abspath(output_dir) != os.path.abspath(pretrained):
+        # the migration renames BC_* files to DDPG_* (reference utils.py:319-334): only a DDPG agent reads those names
+        if agent.name == "DDPG" and output_dir and os.path.abspath(output_dir) != os.path.abspath(pretrained):
             migrate_model(pretrained, output_dir, model_surfix)
             src = output_dir
+        paths = agent._paths(src, model_surfix)
+        if not (os.path.exists(paths["actor"]) or os.path.exists(paths["state_feat"])):
+            raise FileNotFoundError("--pretrained %s: no %s_* actor / state_feat checkpoint with suffix '%s' found in %s"
+                                    % (pretrained, agent.name, model_surfix, src))
         agent.load_model(src, surfix=model_surfix, set_init_step=True)
     return agent, cfg
 

@@ -37,6 +37,36 @@ void gad_geometry_set_option(const char* name, int value, int* found);
 unsigned long long* gad_take_timing_slot();
 int gad_take_grid_rows();       // rows the caller expects to be live (0: unknown) -- sizes the grid of the next tile launch
 
+// Train-mode BatchNorm finalisation of a layer (internal argument blocks of bn_finalize_kernel / bn_bwd_coef_kernel /
+// the pool finalisation; not part of the C ABI).
+struct gad_bn_fin {
+    const double* stat_sum;    // (GAD_STAT_REPLICAS, stat_stride) accumulators, this layer's first channel
+    const double* stat_sq;
+    int32_t stat_stride;
+    double count;              // rows behind the statistics (padded duplicates included)
+    const float* gamma;
+    const float* beta;
+    float eps;
+    float momentum;
+    float* running_mean;       // nullable (pass overlapped with another pass of the same network)
+    float* running_var;
+    float* scale;              // outputs: scale = gamma*istd, shift = beta - mean*scale
+    float* shift;
+    float* mean;               // nullable
+    float* istd;               // nullable
+};
+struct gad_bn_bwd {
+    const double* dbeta;       // (GAD_STAT_REPLICAS, stat_stride)
+    const double* dgamma;
+    int32_t stat_stride;
+    double count;
+    const float* mean;         // saved by the forward pass
+    const float* istd;
+    double* gacc_gamma;        // nullable
+    double* gacc_beta;
+    int32_t accumulate;
+};
+
 #ifdef __HIPCC__
 // squared distance with the evaluation order pinned to the oracle's (oracle/pn2_ref.c sqdist):
 // every product and sum individually rounded, no FMA contraction.
@@ -94,9 +124,9 @@ struct KTimer {
     }
 };
 
-// Train-mode BatchNorm finalisation of ONE channel from the replicated f64 statistics (gad_bn_finalize's arithmetic;
-// also evaluated in consumer prologues, include/gaddpg.h gad_bn_fin).  `writer` (exactly one thread of the grid per
-// channel) publishes the vectors the backward pass reads and applies the running-statistics momentum update.
+// Train-mode BatchNorm finalisation of ONE channel from the replicated f64 statistics (gad_bn_finalize's arithmetic; also
+// evaluated by the pool finalisation for its channel slice).  `writer` (exactly one thread of the grid per channel)
+// publishes the vectors the backward pass reads and applies the running-statistics momentum update.
 __device__ __forceinline__ void gad_bn_fin_channel(const gad_bn_fin& b, int c, bool writer, float& sc, float& sh) {
     double s1 = 0.0, s2 = 0.0;
 #pragma unroll

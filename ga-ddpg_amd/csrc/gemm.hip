@@ -46,36 +46,24 @@ struct XSrc {   // how a layer's INPUT row r, column c is produced (gad_gemm_fwd
     const float* src_xyz; const float* ctr_xyz; const float* feat; int feat_c;
     const float* action; int act_c; int gps;
     const int32_t* row_pt; const int32_t* row_grp;
-    int affine;          // ACT input: a per-channel affine is applied (given scale / shift, or the deferred BatchNorm `bn`)
-    gad_bn_fin bn;       // deferred BatchNorm finalisation of the input layer (bn.stat_sum == NULL: scale / shift as given)
+    int affine;          // ACT input: a per-channel affine (scale / shift) is applied
 };
 
-static XSrc make_xsrc(const gad_gemm_fwd_args& a, bool with_bn = true) {
+static XSrc make_xsrc(const gad_gemm_fwd_args& a) {
     XSrc x;
     x.mode = a.mode; x.zin = a.zin; x.zin_pitch = a.zin_pitch; x.c_in = a.c_in;
     x.scale = a.scale; x.shift = a.shift; x.relu = a.relu; x.extra = a.extra; x.ones_col = a.ones_col;
     x.src_xyz = a.src_xyz; x.ctr_xyz = a.ctr_xyz; x.feat = a.feat; x.feat_c = a.feat_c;
     x.action = a.action; x.act_c = a.act_c; x.gps = a.grp_per_sample > 0 ? a.grp_per_sample : 1;
     x.row_pt = a.row_pt; x.row_grp = a.row_grp;
-    x.bn = a.in_bn;
-    if (!with_bn || a.mode != 0) x.bn.stat_sum = nullptr;
-    if (x.bn.stat_sum) { x.scale = x.bn.scale; x.shift = x.bn.shift; }
     x.affine = (x.scale && x.shift) ? 1 : 0;
     return x;
 }
 
-// per-channel affine of an ACT input -> LDS: from the given vectors, or finalised here from the BatchNorm statistics
+// per-channel affine of an ACT input -> LDS
 template <int NT>
-__device__ __forceinline__ void stage_affine(float* sv, float* tv, const XSrc& x, int off, int n, bool writer) {
-    if (x.bn.stat_sum) {
-        for (int i = threadIdx.x; i < n; i += NT) {
-            float sc, sh;
-            gad_bn_fin_channel(x.bn, off + i, writer, sc, sh);
-            sv[i] = sc; tv[i] = sh;
-        }
-    } else {
-        for (int i = threadIdx.x; i < n; i += NT) { sv[i] = x.scale[off + i]; tv[i] = x.shift[off + i]; }
-    }
+__device__ __forceinline__ void stage_affine(float* sv, float* tv, const XSrc& x, int off, int n) {
+    for (int i = threadIdx.x; i < n; i += NT) { sv[i] = x.scale[off + i]; tv[i] = x.shift[off + i]; }
 }
 
 struct XRaw { float4 a; float4 s; };     // a: the 16 raw bytes; s: special columns (tail tiles only)
@@ -165,9 +153,8 @@ struct DzSrc {   // gad_dz_src on the device
     const float* P; const float* Q; const float* S; const float* row_w;
     int gmode; const float* G; int g_pitch; const int32_t* argmax; const float* dout;
     const int32_t* row_grp; int c;
-    int coef;            // BatchNorm backward applies (P/Q/S given, or formed from `bn` in the prologue)
+    int coef;            // BatchNorm backward applies (P/Q/S given)
     int premasked;       // the ReLU mask is already in G / dout
-    gad_bn_bwd bn;
 };
 
 static DzSrc make_dzsrc(const gad_dz_src& d) {
@@ -176,16 +163,14 @@ static DzSrc make_dzsrc(const gad_dz_src& d) {
     s.P = d.coefP; s.Q = d.coefQ; s.S = d.coefS; s.row_w = d.row_w;
     s.gmode = d.gmode; s.G = d.G; s.g_pitch = d.g_pitch; s.argmax = d.argmax; s.dout = d.dout;
     s.row_grp = d.row_grp; s.c = d.c;
-    s.bn = d.bn;
     s.premasked = d.premasked;
-    s.coef = (d.coefP != nullptr || d.bn.dbeta != nullptr) ? 1 : 0;
+    s.coef = d.coefP != nullptr ? 1 : 0;
     return s;
 }
 
-// P, Q, S of channel ch: from the given vectors or formed from the deferred BatchNorm-backward sums
-__device__ __forceinline__ void dz_coef(const DzSrc& d, int ch, bool writer, float& P, float& Q, float& S) {
-    if (d.bn.dbeta) gad_bn_bwd_channel(d.bn, d.scale, ch, writer, P, Q, S);
-    else if (d.P) { P = d.P[ch]; Q = d.Q[ch]; S = d.S[ch]; }
+// P, Q, S of channel ch (identity when the layer has no BatchNorm)
+__device__ __forceinline__ void dz_coef(const DzSrc& d, int ch, float& P, float& Q, float& S) {
+    if (d.P) { P = d.P[ch]; Q = d.Q[ch]; S = d.S[ch]; }
     else { P = 1.f; Q = 0.f; S = 0.f; }
 }
 
@@ -272,16 +257,15 @@ __device__ __forceinline__ float4 dz_finish(const DzSrc& d, const DzRaw& raw, in
     return f4sel(valid && inside, g, f4zero());
 }
 
-// writer: exactly one workgroup of the grid (it adds dgamma / dbeta to the gradient arena when d.bn.accumulate)
 template <int VM = VMAX>
-__device__ __forceinline__ void stage_dz_vecs(float* vec, const DzSrc& d, int off, int n, bool writer) {
+__device__ __forceinline__ void stage_dz_vecs(float* vec, const DzSrc& d, int off, int n) {
     if (!d.premasked) {
         stage_vec(vec, d.scale, off, n, 1.f);
         stage_vec(vec + VM, d.shift, off, n, 0.f);
     }
     for (int i = threadIdx.x; i < n; i += 256) {
         float P, Q, S;
-        dz_coef(d, off + i, writer, P, Q, S);
+        dz_coef(d, off + i, P, Q, S);
         vec[2 * VM + i] = P; vec[3 * VM + i] = Q; vec[4 * VM + i] = S;
     }
 }
@@ -349,6 +333,111 @@ __device__ __forceinline__ void mfma_ktile(const float* __restrict__ As, const f
 
 __device__ __forceinline__ int acc_row(int v, int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }
 
+// ------------------------------------------------------------------------------------------------
+// Segment max-pool folded into the epilogue of the pooled layer's GEMM (upstream _PointnetSAModuleBase.forward:
+// F.max_pool2d over the nsample axis of relu(bn(conv)); reference call site core/networks.py:66-81).
+// The pooled quantity is y = relu(scale * z + shift) with scale = gamma * istd: istd > 0, so the SIGN of scale is the sign
+// of gamma -- known before the layer's statistics exist -- and y is monotone in z.  The epilogue therefore reduces the RAW
+// output: max of sgn * z per (group, channel), sgn = +-1 from gamma; gad_pool_finalize applies the affine + ReLU to the
+// winner once the statistics are in (bit-identical to pooling y: a correctly rounded fma is monotone).
+// A group's rows are contiguous (CSR).  The output tile goes through LDS once so that a lane owns ONE column and walks the
+// rows in order: every lane of the wavefront sees the same rows, so the segment structure (where a group ends) is
+// wave-uniform -- scalar branches, group ids read with v_readlane -- and only the running maximum is per-lane work
+// (compare + two selects per row).  A group that lies inside the walked row range is written with ONE plain 8-byte store
+// per channel; only the groups cut by the range's ends (<= 2 per range) need a packed 64-bit atomic maximum --
+// key = (order-preserving bits of the value) << 32 | ~row, so among equal values the smaller row wins (the arg-max trick
+// of fps_kernel).  key 0 = "no row yet".  (First version: per-lane scan of the accumulator registers with an atomic per
+// segment -- 3-4 M atomics per SA1 / SA2 launch cost 20-35 us, profiles/README.md round 3.)
+// Arg-max rule vs the reference ("first maximal y"): identical unless two DIFFERENT raw values of a group round to the
+// same y (then the larger raw value wins here) -- gad_pool_finalize handles y <= 0 (every row ties at 0: first row).
+// ------------------------------------------------------------------------------------------------
+struct PoolEpi {
+    unsigned long long* key;       // (groups, C) packed keys, NULL: no pooling
+    const int32_t* row_grp;        // (rows) group of every row
+    const float* gamma;            // (C) BatchNorm weight of the pooled layer (its sign picks max / min)
+    int C;
+};
+
+__device__ __forceinline__ unsigned pool_ord(float f) {
+    const unsigned u = __float_as_uint(f);
+    return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);
+}
+
+// partial (wave-uniform): the group continues outside the rows this wavefront walks
+__device__ __forceinline__ void pool_put(unsigned long long* keycol, int g, int C, float v, int row, bool partial) {
+    const unsigned long long k = ((unsigned long long)pool_ord(v) << 32) | (unsigned long long)(0xffffffffu - (unsigned)row);
+    if (partial) atomicMax(keycol + (size_t)g * C, k);
+    else keycol[(size_t)g * C] = k;
+}
+
+// running state of one lane's column: the open group (uniform), whether it began before the walked range (uniform), the
+// best value so far and its row
+struct PoolRun { int g; int part; float v; int row; };
+
+// rows [i, e) of the LDS tile belong to the open group: running maximum of sgn * z, strict > (the first maximum stays).
+// i, e, row_base are wave-uniform: the loads of a run are independent of the compares and pipeline freely.
+__device__ __forceinline__ void pool_rows(const float* zt, int pitch, int i, int e, int row_base, float sgn, float& best, int& brow) {
+    int r = i;
+    for (; r + 4 <= e; r += 4) {
+        const float z0 = zt[r * pitch] * sgn, z1 = zt[(r + 1) * pitch] * sgn, z2 = zt[(r + 2) * pitch] * sgn, z3 = zt[(r + 3) * pitch] * sgn;
+        bool t = z0 > best; best = t ? z0 : best; brow = t ? row_base + r : brow;
+        t = z1 > best; best = t ? z1 : best; brow = t ? row_base + r + 1 : brow;
+        t = z2 > best; best = t ? z2 : best; brow = t ? row_base + r + 2 : brow;
+        t = z3 > best; best = t ? z3 : best; brow = t ? row_base + r + 3 : brow;
+    }
+    for (; r < e; ++r) {
+        const float z0 = zt[r * pitch] * sgn;
+        const bool t = z0 > best; best = t ? z0 : best; brow = t ? row_base + r : brow;
+    }
+}
+
+// One wavefront walks 32 consecutive rows (row_base ..) of its LDS tile, lane = column, carrying the open group across
+// calls (streaming kernel: a contiguous range of slabs per wavefront).  gl: lane i < 32 holds the group of row i (-1 past
+// the live rows).  A group that closes here is complete unless c.part says it began before the range.
+__device__ __forceinline__ void pool_scan32(const float* zt, int pitch, int gl, int row_base, float sgn, PoolRun& c,
+                                            unsigned long long* keycol, int C) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(gl, 1, 64);
+    const bool st = lane == 0 ? gl != c.g : gl != prev;
+    const unsigned m = (unsigned)__ballot(st);                  // bit i: row i opens a group (c.g is wave-uniform)
+    int i = 0;
+    while (i < 32) {                                            // wave-uniform control flow throughout
+        if ((m >> i) & 1u) {
+            if (c.g >= 0) pool_put(keycol, c.g, C, c.v, c.row, c.part != 0);
+            c.g = __builtin_amdgcn_readlane(gl, i); c.part = 0; c.v = -INFINITY; c.row = row_base + i;
+        }
+        const unsigned rest = i < 31 ? m >> (i + 1) : 0u;
+        const int e = rest ? i + 1 + __builtin_ctz(rest) : 32;
+        if (c.g >= 0) pool_rows(zt, pitch, i, e, row_base, sgn, c.v, c.row);
+        i = e;
+    }
+}
+
+// A 64-row tile in LDS, lane = column, the tile's groups dealt to the workgroup's wavefronts (piece k -> wavefront k % nw):
+// every piece is closed by the wavefront that walked it; only the pieces cut by the tile's first / last row are partial.
+// gl: lane i holds the group of tile row i (-1 past the live rows); n_live = live rows of the tile (>= 1); g_before /
+// g_after: the groups of the rows just outside the tile (-1: none) -- a piece that shares its group with them is partial.
+__device__ __forceinline__ void pool_tile64(const float* zt, int pitch, int gl, int row0, int n_live, float sgn, int wave,
+                                            int nw, int g_before, int g_after, unsigned long long* keycol, int C) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(gl, 1, 64);
+    const bool st = (lane == 0 || gl != prev) && lane < n_live;
+    unsigned long long m = __ballot(st);
+    int k = 0;
+    while (m) {                                                 // wave-uniform
+        const int i = __builtin_ctzll(m);
+        m &= m - 1;
+        const int e = m ? __builtin_ctzll(m) : n_live;
+        if ((k++ % nw) != wave) continue;
+        const int g = __builtin_amdgcn_readlane(gl, i);
+        float best = -INFINITY;
+        int brow = row0 + i;
+        pool_rows(zt, pitch, i, e, row0, sgn, best, brow);
+        const bool partial = (i == 0 && g == g_before) || (e == n_live && g == g_after);
+        pool_put(keycol, g, C, best, brow, partial);
+    }
+}
+
 struct Groups {
     int n; int aoff[GAD_MAX_GROUPS]; int woff[GAD_MAX_GROUPS]; int ooff[GAD_MAX_GROUPS]; int nout[GAD_MAX_GROUPS];
 };
@@ -384,13 +473,14 @@ __device__ __forceinline__ void block_column_atomics(float* red, const float (&c
 // ------------------------------------------------------------------------------------------------
 // forward:  zout[r][n] = sum_k X[r][k] * W[n][k]      (+ weighted BatchNorm statistics)
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN, int XM>
+template <int WM, int WN, int TM, int TN, int XM, bool POOL>
 __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                         int n_rows_static, const float* __restrict__ row_w,
                                                         const float* __restrict__ W, int Kp,
                                                         float* __restrict__ zout, int zout_pitch,
                                                         double* __restrict__ stat_sum,
-                                                        double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
+                                                        double* __restrict__ stat_sq, int stat_stride, PoolEpi pe,
+                                                        unsigned long long* __restrict__ ts) {
     KTimer kt(ts);
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int PA = PitchT<BM>::v, PB = PitchT<BN>::v;
@@ -463,7 +553,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
     // the three global-load latencies of the prologue (tile, vectors, weights) overlap instead of chaining
     bool preloaded = false;
     if (XM == 0) { load_tile(0); preloaded = true; }
-    if (XM == 0 && x.affine) stage_affine<256>(sv, tv, x, zoff, x.c_in, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    if (XM == 0 && x.affine) stage_affine<256>(sv, tv, x, zoff, x.c_in);
     for (; row0 < n_rows; row0 += gridDim.x * BM) {
         f32x16 acc[TM][TN];
 #pragma unroll
@@ -477,6 +567,17 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             wS[tid] = r < n_rows ? (row_w ? row_w[r] : 1.f) : 0.f;
             if (XM == 1) ptS[tid] = r < n_rows ? x.row_pt[r] : 0;
         }
+        // fused max-pool: the row -> group map of this tile and of its two outside neighbours, the column's sign -- issued
+        // here so that their latency sits under the K loop
+        int pgl = -1, pg_before = -1, pg_after = -1;
+        float psgn = 1.f;
+        if (POOL) {
+            const int r = row0 + lane;
+            pgl = r < n_rows ? pe.row_grp[r] : -1;
+            pg_before = row0 > 0 ? pe.row_grp[row0 - 1] : -1;
+            pg_after = row0 + BM < n_rows ? pe.row_grp[row0 + BM] : -1;
+            psgn = pe.gamma[n0 + lane] < 0.f ? -1.f : 1.f;
+        }
         __syncthreads();                                   // wS / ptS / sv / tv visible
         if (!preloaded) load_tile(0);
         preloaded = false;
@@ -488,6 +589,17 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             __syncthreads();
         }
         const int l31 = lane & 31, half = lane >> 5;
+        if (POOL) {                                          // (64 x 64 tiles, one group, n_out % 64 == 0: the launcher checks)
+            static_assert(!POOL || (BM == 64 && BN == 64 && TM == 1 && TN == 1 && TILE >= 64 * 65), "pooled epilogue: 64 x 64 tiles");
+            float* zt = smem;                                // the operand tiles are done with (barrier at the end of the K loop)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) zt[(wm * 32 + acc_row(v, half)) * 65 + wn * 32 + l31] = acc[0][0][v];
+            __syncthreads();
+            // lane = column; the tile's groups dealt to the four wavefronts
+            pool_tile64(zt + lane, 65, pgl, row0, min(64, n_rows - row0), psgn, __builtin_amdgcn_readfirstlane(wave), 4,
+                        __builtin_amdgcn_readfirstlane(pg_before), __builtin_amdgcn_readfirstlane(pg_after),
+                        pe.key + n0 + lane, pe.C);
+        }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int n = n0 + wn * TN * 32 + tn * 32 + l31;
@@ -499,7 +611,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
                     const int il = wm * TM * 32 + tm * 32 + acc_row(v, half);
                     const int r = row0 + il;
                     const float zv = acc[tm][tn][v];
-                    if (r < n_rows && n < n_out) zout[(size_t)r * zout_pitch + ooff + n] = zv;
+                    if (zout && r < n_rows && n < n_out) zout[(size_t)r * zout_pitch + ooff + n] = zv;
                     const float w = wS[il];
                     s1 = fmaf(w, zv, s1);
                     s2 = fmaf(w * zv, zv, s2);
@@ -536,17 +648,20 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // So the loop below is written for a minimal VALU instruction count: packed (2-wide) f32 math for the BatchNorm
 // affine and the statistics, buffer stores whose row offset lives in an SGPR (no per-store address arithmetic),
 // clamped row indices instead of per-element selects.
-template <int KJ, int TN, int XM>
+template <int KJ, int TN, int XM, bool POOL>
 __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
                                                                   int n_rows_static, const float* __restrict__ row_w,
                                                                   const float* __restrict__ W, float* __restrict__ zout,
                                                                   double* __restrict__ stat_sum,
-                                                                  double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
+                                                                  double* __restrict__ stat_sq, int stat_stride, PoolEpi pe,
+                                                                  unsigned long long* __restrict__ ts) {
     KTimer kt(ts);
     constexpr int KP = 8 * KJ, NO = 32 * TN, PW = KP + 4;
     __shared__ __attribute__((aligned(16))) float Ws[NO * PW];
     __shared__ __attribute__((aligned(16))) float sv[KP], tv[KP];
     __shared__ float red[2 * 8 * NO];
+    __shared__ float pz[POOL ? 8 * 32 * 64 : 1];        // fused max-pool: a 32-row x 64-column tile per wavefront
+    static_assert(!POOL || TN == 4, "pooled epilogue: 128 output columns");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -566,19 +681,45 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
         }
     }
-    if (XM == 0) stage_affine<512>(sv, tv, x, 0, KP, blockIdx.x == 0);
+    if (XM == 0) stage_affine<512>(sv, tv, x, 0, KP);
     __syncthreads();
 
     const int n_slabs = (n_rows + 31) >> 5;
     // 8 wavefronts per workgroup, one workgroup per CU: wavefronts w and w+4 share a SIMD (cyclic placement).  Slabs
     // are dealt wave-major (w * gridDim + block), so the left-over slabs of the last round go to w = 0..3 first and
     // every SIMD ends up with the same slab count +-1 (dealing block-major left whole CUs a round short: -20 %).
-    const int stride = gridDim.x * 8;
+    int stride = gridDim.x * 8;
     int slab = wave * gridDim.x + blockIdx.x;            // wave-uniform (SGPR)
+    int slab_end = n_slabs;
+    if (POOL) {
+        // fused max-pool: every wavefront walks a CONTIGUOUS range of slabs, so a group's running maximum is carried in
+        // registers from slab to slab and only the two groups cut by the range's ends need atomics (same slab count per
+        // wavefront +-1 as the dealing above)
+        const int nw = gridDim.x * 8, base = n_slabs / nw, rem = n_slabs - base * nw;
+        slab_end = slab * base + min(slab, rem) + base + (slab < rem ? 1 : 0);
+        slab = slab * base + min(slab, rem);
+        stride = 1;
+    }
     // output through a buffer descriptor: rows >= n_rows fall outside num_records and are dropped by the hardware
+    const bool store_z = zout != nullptr;                // (a pass that is never back-propagated keeps only the pooled maxima)
     const __amdgpu_buffer_rsrc_t zrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(zout, 0, n_rows * NO * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(store_z ? zout : const_cast<float*>(W), 0, store_z ? n_rows * NO * 4 : 0, 0x00020000);
     const int zlane = (4 * half * NO + l31) * 4;         // byte offset of (row 4*half, column l31)
+    // fused max-pool: in the scan a lane owns columns lane and 64 + lane; +-1 = the sign of their BatchNorm weight
+    float psgn[2];
+    PoolRun prun[2];
+    const int range0 = slab * 32;
+    int g_after = -1;                                    // group of the first row after the range (-1: none)
+    if (POOL && slab < slab_end) {
+        const int g0 = pe.row_grp[range0];               // (range0 < n_rows: the range has rows)
+        const int part0 = range0 > 0 && pe.row_grp[range0 - 1] == g0;
+        if (slab_end * 32 < n_rows) g_after = pe.row_grp[slab_end * 32];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            psgn[p] = pe.gamma[p * 64 + lane] < 0.f ? -1.f : 1.f;
+            prun[p].g = g0; prun[p].part = part0; prun[p].v = -INFINITY; prun[p].row = range0;
+        }
+    }
 
     f32x2 csum[TN], csq[TN];                             // .x/.y: even / odd accumulator rows, summed at the end
 #pragma unroll
@@ -604,7 +745,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         load_slab(slab, pt0, ra);
         pt_nxt = load_pt(slab + stride);
     }
-    for (; slab < n_slabs; slab += stride) {
+    for (; slab < slab_end; slab += stride) {
         load_slab(slab + stride, pt_nxt, rn);
         pt_nxt = load_pt(slab + 2 * stride);
         // the 16 rows this lane owns in the accumulator layout: 4 runs of 4 consecutive rows -> 4 aligned loads
@@ -622,6 +763,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
                 for (int e = 0; e < 4; ++e) wq[e] = (slab * 32 + 8 * q + 4 * half + e < n_rows) ? wq[e] : 0.f;
             }
         }
+        int gl = -1;                                     // fused max-pool: lane i (both halves) holds the group of slab row i
+        if (POOL) { const int rr = slab * 32 + l31; gl = rr < n_rows ? pe.row_grp[rr] : -1; }
         __asm__ volatile("" ::: "memory");        // keep the (loop-invariant) LDS reads of W inside the loop: registers
         f32x16 acc[TN];
 #pragma unroll
@@ -659,6 +802,19 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         // epilogue: raw layer output (SGPR row offset + immediate column offset: no address arithmetic) and the
         // weighted BatchNorm partial sums, two accumulator rows per packed instruction
         const int zrow = slab * 32 * NO * 4;
+        if (POOL) {
+            // 64 columns at a time through this wavefront's LDS tile (in-order LDS: no barrier), then lane = column
+            float* zt = pz + wave * (32 * 64);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    zt[acc_row(v, half) * 64 + l31] = acc[2 * p][v];
+                    zt[acc_row(v, half) * 64 + 32 + l31] = acc[2 * p + 1][v];
+                }
+                pool_scan32(zt + lane, 64, gl, slab * 32, psgn[p], prun[p], pe.key + p * 64 + lane, pe.C);
+            }
+        }
 #pragma unroll
         for (int v = 0; v < 16; v += 2) {
             const int rb = ((v & 3) + 8 * (v >> 2)) * NO * 4;
@@ -666,8 +822,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 const f32x2 zv = f32x2{acc[t][v], acc[t][v + 1]};
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + NO * 4, 0);
+                if (!POOL || store_z) {                  // (rows past n_rows / a NULL zout fall outside num_records: dropped)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + NO * 4, 0);
+                }
                 const f32x2 wz = wr * zv;
                 csum[t] += wz;
                 csq[t] += wz * zv;
@@ -675,6 +833,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         }
 #pragma unroll
         for (int j = 0; j < KJ; ++j) ra[j] = rn[j];
+    }
+    if (POOL && range0 < slab_end * 32) {                // the group still open at the end of the range
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            if (prun[p].g >= 0)
+                pool_put(pe.key + p * 64 + lane, prun[p].g, pe.C, prun[p].v, prun[p].row, prun[p].part != 0 || prun[p].g == g_after);
     }
     if (stat_sum) {
 #pragma unroll
@@ -747,7 +911,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     load_chunk(0, 0);
     // the operand loads above are in flight while the input layer's per-channel affine is staged (or, with a deferred
     // BatchNorm, finalised from its statistics) in LDS
-    if (x.affine) stage_affine<64 * SK_NW>(sv, tv, x, zoff, x.c_in, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    if (x.affine) stage_affine<64 * SK_NW>(sv, tv, x, zoff, x.c_in);
     __syncthreads();
 #pragma unroll
     for (int c = 0; c < SK_MAXCH; ++c) {
@@ -798,213 +962,21 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     }
 }
 
-static int g_opt_dx_slab = 0;    // (see g_opt_fwd_slab)
-static int g_opt_dbg = 0;
-static int g_opt_gx_cap = 2048;   // most row tiles a tile launch spreads over workgroups (the rest by its grid-stride loop)
-static int g_opt_dw_direct = 0;   // 1: the tile dW kernel adds its split tiles into the f64 arena with atomics (no partial workspace, no dw_reduce launch)
+#define GAD_GX_CAP 2048           // most row tiles a tile launch spreads over workgroups (the rest by its grid-stride loop)
 static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
     return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// slab forward for the MID-SIZE layers (SA2 / SA3: 8e3 - 3e4 de-duplicated rows, K 128 - 264, 128 - 512 outputs).
-// The 64x64 tile kernel runs these at 0.2 - 0.35 of the FP32-MFMA peak: every workgroup lives for 4 - 8 K-tiles, so
-// its prologue (index / vector staging, first loads), its 2 barriers per K-tile and its epilogue never overlap anything,
-// and each operand element staged through LDS feeds ONE MFMA per wavefront (9 - 12 vector instructions per MFMA).
-// Here the streaming structure of the SA1 kernel is kept for any K: a workgroup owns a slice of 32*TN output columns
-// whose weights stay in LDS ([n][Kp+4], conflict-free ds_read_b128) for its whole life, every wavefront walks 32-row
-// slabs and feeds the MFMA A operand straight from 16-byte global loads (k = 8j+4h+i order), K is consumed in chunks
-// of 64 with the next chunk (or the next slab's first chunk) in flight during the current chunk's 32*TN MFMAs -- no
-// barrier after the prologue, ~2 vector instructions per MFMA.  Grid = (row groups) x (column slices) ~ one workgroup
-// per CU; the X rows a slab needs are re-read once per column slice (L2).
-// ------------------------------------------------------------------------------------------------
-template <int TN, int XM>
-__global__ __launch_bounds__(512, 2) void gemm_fwd_slab_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
-                                                                int n_rows_static, const float* __restrict__ row_w,
-                                                                const float* __restrict__ W, int Kp, int n_out,
-                                                                float* __restrict__ zout, int zout_pitch,
-                                                                double* __restrict__ stat_sum,
-                                                                double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
-    KTimer kt(ts);
-    constexpr int NO = 32 * TN, CH = 8;
-    extern __shared__ __attribute__((aligned(16))) float slab_smem[];
-    const int PW = Kp + 4;
-    float* Ws = slab_smem;                               // [NO][PW]
-    float* sv = Ws + NO * PW;                            // [Kp]
-    float* tv = sv + Kp;                                 // [Kp]
-    float* red = tv + Kp;                                // [2 * 8 * NO]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    const int n0 = blockIdx.y * NO;
-    {   // this slice's weight rows -> LDS
-        const int upr = Kp >> 2;
-        for (int u = tid; u < NO * upr; u += 512) {
-            const int n = u / upr, c = (u - n * upr) << 2;
-            *reinterpret_cast<float4*>(Ws + n * PW + c) = ldg4(W + (size_t)min(n0 + n, n_out - 1) * Kp + c);
-        }
-    }
-    if (XM == 0) stage_affine<512>(sv, tv, x, 0, Kp, blockIdx.x == 0 && blockIdx.y == 0);
-    __syncthreads();
-
-    const int n_slabs = (n_rows + 31) >> 5;
-    const int stride = gridDim.x * 8;
-    int slab = wave * gridDim.x + blockIdx.x;            // wave-uniform; dealt wave-major like the SA1 kernel
-    const int nj = Kp >> 3, nch = (nj + CH - 1) / CH;
-    const __amdgpu_buffer_rsrc_t zrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(zout, 0, n_rows * zout_pitch * 4, 0x00020000);
-    const int zlane = (4 * half * zout_pitch + n0 + l31) * 4;
-    const int pitch4 = zout_pitch * 4;
-
-    f32x2 csum[TN], csq[TN];
-#pragma unroll
-    for (int t = 0; t < TN; ++t) { csum[t] = f32x2{0.f, 0.f}; csq[t] = f32x2{0.f, 0.f}; }
-
-    // one 8-wide k group of this lane's row: the 16 bytes [8j+4h, 8j+4h+4) of the layer input
-    auto load_group = [&](int r, int pt, int grp, int j) -> float4 {
-        const int c = 8 * j + 4 * half;
-        if (XM == 0) return ldg4(x.zin + (size_t)r * x.zin_pitch + c);
-        if (8 * j < x.feat_c) return ldg4(x.feat + (size_t)pt * x.feat_c + c);            // (feat_c % 8 == 0: wave-uniform)
-        float4 o = f4zero();
-        if (c == x.feat_c) {                                                               // [x - cx, y - cy, z - cz, 0]
-            const float* p = x.src_xyz + (size_t)pt * 3;
-            o.x = p[0]; o.y = p[1]; o.z = p[2];
-            if (x.ctr_xyz) {
-                const float* cp = x.ctr_xyz + (size_t)grp * 3;
-                o.x = __fsub_rn(o.x, cp[0]); o.y = __fsub_rn(o.y, cp[1]); o.z = __fsub_rn(o.z, cp[2]);
-            }
-        }
-        return o;
-    };
-    auto load_chunk = [&](float4 (&dst)[CH], int r, int pt, int grp, int c) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            const int j = min(c * CH + u, nj - 1);       // clamped; groups past nj are skipped at the MFMA
-            dst[u] = load_group(r, pt, grp, j);
-        }
-    };
-    auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
-    int r_cur = row_of(slab);
-    int pt_cur = XM == 1 ? x.row_pt[r_cur] : 0, grp_cur = (XM == 1 && x.ctr_xyz) ? x.row_grp[r_cur] : 0;
-    float4 ra[CH], rn[CH];
-    load_chunk(ra, r_cur, pt_cur, grp_cur, 0);
-    for (; slab < n_slabs; slab += stride) {
-        const int r_nxt = row_of(slab + stride);
-        const int pt_nxt = XM == 1 ? x.row_pt[r_nxt] : 0, grp_nxt = (XM == 1 && x.ctr_xyz) ? x.row_grp[r_nxt] : 0;
-        float4 w4[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r0 = slab * 32 + 8 * q + 4 * half;
-            w4[q] = row_w ? ldg4(row_w + (r0 + 3 < n_rows_static ? r0 : 0)) : make_float4(1.f, 1.f, 1.f, 1.f);
-        }
-        if (slab * 32 + 32 > n_rows) {                   // ragged last slab (wave-uniform): zero the missing rows' weights
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float* wq = &w4[q].x;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) wq[e] = (slab * 32 + 8 * q + 4 * half + e < n_rows) ? wq[e] : 0.f;
-            }
-        }
-        f32x16 acc[TN];
-#pragma unroll
-        for (int t = 0; t < TN; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-        for (int c = 0; c < nch; ++c) {
-            if (c + 1 < nch) load_chunk(rn, r_cur, pt_cur, grp_cur, c + 1);
-            else load_chunk(rn, r_nxt, pt_nxt, grp_nxt, 0);
-            __asm__ volatile("" ::: "memory");           // keep the LDS reads of W inside the loop (registers)
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                const int j = c * CH + u;
-                if (j < nj) {                            // wave-uniform
-                    float4 a4 = ra[u];
-                    if (XM == 0) {
-                        const float4 s4 = *reinterpret_cast<const float4*>(sv + 8 * j + 4 * half);
-                        const float4 t4 = *reinterpret_cast<const float4*>(tv + 8 * j + 4 * half);
-                        a4 = make_float4(__builtin_fmaxf(fmaf(a4.x, s4.x, t4.x), 0.f), __builtin_fmaxf(fmaf(a4.y, s4.y, t4.y), 0.f),
-                                         __builtin_fmaxf(fmaf(a4.z, s4.z, t4.z), 0.f), __builtin_fmaxf(fmaf(a4.w, s4.w, t4.w), 0.f));
-                    }
-                    float4 b4[TN];
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) b4[t] = *reinterpret_cast<const float4*>(Ws + (t * 32 + l31) * PW + 8 * j + 4 * half);
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4[t].x, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4[t].y, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4[t].z, acc[t], 0, 0, 0);
-#pragma unroll
-                    for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < CH; ++u) ra[u] = rn[u];
-        }
-        // epilogue: raw layer output (buffer stores: rows past n_rows fall outside num_records) + weighted statistics
-        const int zrow = slab * 32 * pitch4;
-#pragma unroll
-        for (int v = 0; v < 16; v += 2) {
-            const int rb = ((v & 3) + 8 * (v >> 2)) * pitch4;
-            const f32x2 wr = f32x2{(&w4[v >> 2].x)[v & 3], (&w4[v >> 2].x)[(v & 3) + 1]};
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const f32x2 zv = f32x2{acc[t][v], acc[t][v + 1]};
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, 0);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + pitch4, 0);
-                const f32x2 wz = wr * zv;
-                csum[t] += wz;
-                csq[t] += wz * zv;
-            }
-        }
-        r_cur = r_nxt; pt_cur = pt_nxt; grp_cur = grp_nxt;
-    }
-    if (stat_sum) {
-#pragma unroll
-        for (int t = 0; t < TN; ++t) {
-            const float c0 = csum[t].x + csum[t].y, c1 = csq[t].x + csq[t].y;
-            const float s0 = c0 + __shfl_xor(c0, 32, 64);
-            const float s1 = c1 + __shfl_xor(c1, 32, 64);
-            if (lane < 32) { red[wave * NO + t * 32 + lane] = s0; red[(8 + wave) * NO + t * 32 + lane] = s1; }
-        }
-        __syncthreads();
-        if (tid < NO) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { s0 += red[w * NO + tid]; s1 += red[(8 + w) * NO + tid]; }
-            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
-            atomic_add_f64(stat_sum + (size_t)rep * stat_stride + n0 + tid, (double)s0);
-            atomic_add_f64(stat_sq + (size_t)rep * stat_stride + n0 + tid, (double)s1);
-        }
-    }
-}
-
-static int g_opt_fwd_slab = 0;   // measured neutral-to-slower inside the overlapped step (profiles/README.md round 2): off by default
-// the slab kernel covers: one group, K = the channel count itself (no bias / extra column), outputs a multiple of 64
-static bool fwd_slabable(const gad_gemm_fwd_args& a) {
-    if (!g_opt_fwd_slab || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
-    if (a.n_rows < 2048 || a.n_out[0] % 64 != 0 || a.n_out[0] < 64 || a.Kp > 520) return false;
-    if ((long long)a.n_rows * a.zout_pitch * 4 >= (1ll << 31)) return false;            // buffer-descriptor byte offsets
-    if (a.mode == 0)
-        return a.Kp == a.c_in && a.c_in % 8 == 0 && a.ones_col < 0 && !a.extra && ((a.scale && a.shift) || a.in_bn.stat_sum) && a.relu;
-    return a.feat_c % 8 == 0 && a.act_c == 0 && a.Kp == ((a.feat_c + 3 + 7) & ~7);
-}
-
 static int g_opt_fwd_stream = 1;
+
 extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
-    if (!strcmp(name, "fwd_slab")) { g_opt_fwd_slab = value; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
-    if (!strcmp(name, "dx_slab")) { g_opt_dx_slab = value; return GAD_OK; }
-    if (!strcmp(name, "dbg")) { g_opt_dbg = value; return GAD_OK; }
-    if (!strcmp(name, "gx_cap")) { g_opt_gx_cap = value > 0 ? value : 2048; return GAD_OK; }
-    if (!strcmp(name, "dw_direct")) { g_opt_dw_direct = value; return GAD_OK; }
     if (!strcmp(name, "dw_skinny")) { g_opt_dw_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dw_stream")) { g_opt_dw_stream = value; return GAD_OK; }
     int found = 0;
@@ -1017,10 +989,11 @@ extern "C" int gad_set_option(const char* name, int value) {
 // the streaming kernel covers: one group, no bias / extra column, Kp in {16, 64}, n_out in {64, 128}
 static bool fwd_streamable(const gad_gemm_fwd_args& a) {
     if (!g_opt_fwd_stream) return false;
+    if (a.pool_key && !(a.mode == 0 && a.n_out[0] == 128)) return false;          // pooled instantiation: 64 -> 128 only
     if (a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
-    if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || a.zout_pitch != a.n_out[0]) return false;
+    if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || (a.zout && a.zout_pitch != a.n_out[0])) return false;
     if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
-    if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && ((a.scale && a.shift) || a.in_bn.stat_sum) && a.relu;
+    if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && (a.scale && a.shift) && a.relu;
     return a.Kp == 16 && a.feat_c + 3 + a.act_c <= 16;
 }
 
@@ -1053,79 +1026,61 @@ static int check_input(const gad_gemm_fwd_args& a, const char* who) {
 extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     unsigned long long* ts = gad_take_timing_slot();
     const int rows_hint = gad_take_grid_rows();
-    GAD_REQUIRE(a && a->W && a->zout, GAD_ERR_NULL, "gemm_fwd: null pointer");
+    GAD_REQUIRE(a && a->W && (a->zout || a->pool_key), GAD_ERR_NULL, "gemm_fwd: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_fwd: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0 && a->Kp >= 8, GAD_ERR_SHAPE, "gemm_fwd: Kp=%d must be a multiple of 8", a->Kp);
     if (int e = check_input(*a, "gemm_fwd")) return e;
-    if (a->in_bn.stat_sum) {
-        const gad_bn_fin& b = a->in_bn;
-        GAD_REQUIRE(a->mode == 0 && a->n_groups == 1 && a->zin_off[0] == 0, GAD_ERR_SHAPE,
-                    "gemm_fwd: a deferred BatchNorm needs an ACT input and a single group");
-        GAD_REQUIRE(b.stat_sq && b.gamma && b.beta && b.scale && b.shift && b.count >= 1.0, GAD_ERR_NULL,
-                    "gemm_fwd: incomplete gad_bn_fin");
-    }
     if (a->n_rows <= 0) return GAD_OK;
     XSrc x = make_xsrc(*a);
     Groups gr = make_groups(a->n_groups, a->zin_off, a->w_off, a->out_off, a->n_out);
     const int nmax = max_nout(gr);
     hipStream_t st = (hipStream_t)stream;
     const int rows = a->n_rows;
+    PoolEpi pe;
+    pe.key = reinterpret_cast<unsigned long long*>(a->pool_key); pe.row_grp = a->pool_row_grp; pe.gamma = a->pool_gamma;
+    pe.C = a->n_out[0];
+    if (pe.key) {
+        GAD_REQUIRE(pe.row_grp && pe.gamma, GAD_ERR_NULL, "gemm_fwd: fused max-pool needs pool_row_grp and pool_gamma");
+        GAD_REQUIRE(a->mode == 0 && a->n_groups == 1 && a->out_off[0] == 0 && a->n_out[0] % 64 == 0 && rows % 4 == 0,
+                    GAD_ERR_SHAPE, "gemm_fwd: fused max-pool needs an ACT input, one group, n_out %% 64 == 0, rows %% 4 == 0 (got n_out=%d rows=%d)",
+                    a->n_out[0], rows);
+    }
     const int grid_rows = (a->n_rows_dev && rows_hint > 0 && rows_hint < rows) ? rows_hint : rows;   // gad_grid_rows_hint
-    if (fwd_skinny(*a)) {
+    if (!pe.key && fwd_skinny(*a)) {
         hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(nmax, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
                            gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
         GAD_CHECK_LAUNCH("gemm_fwd(skinny)");
         return GAD_OK;
     }
-#define LAUNCH_FWD2(WM, WN, TM, TN, XM)                                                                    \
+#define LAUNCH_FWD2(WM, WN, TM, TN, XM, POOL)                                                                  \
     do {                                                                                                   \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                                \
-        int gx = gad_cdiv(grid_rows, BM); if (gx > g_opt_gx_cap) gx = g_opt_gx_cap;                                        \
-        hipLaunchKernelGGL((gemm_fwd_kernel<WM, WN, TM, TN, XM>), dim3(gx, gad_cdiv(nmax, BN), gr.n), dim3(256), \
+        int gx = gad_cdiv(grid_rows, BM); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;                                        \
+        hipLaunchKernelGGL((gemm_fwd_kernel<WM, WN, TM, TN, XM, POOL>), dim3(gx, gad_cdiv(nmax, BN), gr.n), dim3(256), \
                            0, st, x, gr, a->n_rows_dev, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, \
-                           a->stat_sum, a->stat_sq, a->stat_stride, ts);                                       \
+                           a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);                               \
     } while (0)
-#define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0); else LAUNCH_FWD2(WM, WN, TM, TN, 1); } while (0)
+#define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0, false); else LAUNCH_FWD2(WM, WN, TM, TN, 1, false); } while (0)
     if (fwd_streamable(*a)) {
         const int slabs = gad_cdiv(rows, 32);
         int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;              // one 8-wavefront workgroup per CU
-#define LAUNCH_STREAM(KJ, TN, XM)                                                                          \
-        hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
-                           a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride, ts)
-        if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0); else LAUNCH_STREAM(8, 4, 0); }
-        else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1); else LAUNCH_STREAM(2, 4, 1); }
+#define LAUNCH_STREAM(KJ, TN, XM, POOL)                                                                    \
+        hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM, POOL>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
+                           a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts)
+        if (pe.key) {
+            LAUNCH_STREAM(8, 4, 0, true);                                  // (fwd_streamable: ACT input, 128 outputs)
+        } else {
+            if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0, false); else LAUNCH_STREAM(8, 4, 0, false); }
+            else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1, false); else LAUNCH_STREAM(2, 4, 1, false); }
+        }
 #undef LAUNCH_STREAM
         GAD_CHECK_LAUNCH("gemm_fwd(stream)");
         return GAD_OK;
     }
-    if (fwd_slabable(*a)) {
-        const int slabs = gad_cdiv(rows, 32), n = a->n_out[0];
-        // 32*TN columns per workgroup: 64 unless that leaves fewer wavefront tasks (slabs x slices) than the chip has slots
-        const int tn = (long long)slabs * (n / 64) >= 1536 ? 2 : 1;
-        const int slices = n / (32 * tn);
-        int gx = 256 / slices; if (gx < 1) gx = 1;
-        if (gx > gad_cdiv(slabs, 8)) gx = gad_cdiv(slabs, 8);
-        const size_t lds = ((size_t)32 * tn * (a->Kp + 4) + 2 * (size_t)a->Kp + 2 * 8 * 32 * tn) * sizeof(float);
-#define LAUNCH_SLAB(TN, XM)                                                                                         \
-        do {                                                                                                        \
-            static bool attr_set = false;                                                                           \
-            if (!attr_set) {                                                                                        \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_fwd_slab_kernel<TN, XM>),            \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
-                attr_set = true;                                                                                    \
-            }                                                                                                       \
-            hipLaunchKernelGGL((gemm_fwd_slab_kernel<TN, XM>), dim3(gx, slices), dim3(512), lds, st, x, a->n_rows_dev, rows, \
-                               a->row_w, a->W, a->Kp, n, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts); \
-        } while (0)
-        if (a->mode == 0) { if (tn == 2) LAUNCH_SLAB(2, 0); else LAUNCH_SLAB(1, 0); }
-        else { if (tn == 2) LAUNCH_SLAB(2, 1); else LAUNCH_SLAB(1, 1); }
-#undef LAUNCH_SLAB
-        GAD_CHECK_LAUNCH("gemm_fwd(slab)");
-        return GAD_OK;
-    }
     // 64 x 64 tiles throughout: with K <= 1024 these launches are prologue/epilogue-bound, more and smaller
     // workgroups win over the 128-wide tiles at every shape of the step (tests/diag_gemm.py)
-    if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);
+    if (pe.key) LAUNCH_FWD2(2, 2, 1, 1, 0, true);
+    else if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);
 #undef LAUNCH_FWD
 #undef LAUNCH_FWD2
     GAD_CHECK_LAUNCH("gemm_fwd");
@@ -1135,19 +1090,11 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 // ------------------------------------------------------------------------------------------------
 // backward wrt the layer input:  gout[r][k] = sum_n dZ[r][n] * W[n][k]
 // ------------------------------------------------------------------------------------------------
-// ablation hooks of the dX tile kernel: compiled in with -DGAD_ABLATION only (profiles/r02_dx_tile_ablation.txt was measured
-// with such a build; in the shipped build the option `dbg` is accepted and ignored)
-#ifdef GAD_ABLATION
-#define GAD_DBG(bit) (e.dbg & (bit))
-#else
-#define GAD_DBG(bit) false
-#endif
 struct DxEpi {
     int mode; float* gout; int gout_pitch; int k_valid;
     const float* zprev; int zprev_pitch; const float* ps; const float* pt; const float* pm; const float* pi;
     double* dbeta; double* dgamma; int stat_stride; int store_masked;
     float* dfeat; int feat_c; const int32_t* row_pt; const int32_t* row_grp; double* daction; int act_c; int gps;
-    int dbg;     // ablation timings (option `dbg`, diagnostics only: results are WRONG with any bit set): 1 no statistics atomics, 2 no stores, 4 no MFMAs, 8 no K-loop global loads, 16 no prologue vector staging, 32 no LDS tile stores, 64 no epilogue
 };
 
 template <int WM, int WN, int TM, int TN, bool VEC, int VM>
@@ -1180,7 +1127,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     if ((int)(blockIdx.x * BM) >= n_rows) return;
     const int nk = gad_cdiv_dev(n_out, KT);
-    if (VEC && !GAD_DBG(16)) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
+    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out);
     const bool need_grp = e.mode == 1 || d.gmode != 0;
 
     float cb[TN], cg[TN];
@@ -1237,20 +1184,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 store_D<BN>(Bs, kk, j, f4sel(ok, rb[it], f4zero()));
             }
         };
-        if (!GAD_DBG(8)) load_tile(0);
+        load_tile(0);
         for (int kt = 0; kt < nk; ++kt) {
-            if (!GAD_DBG(32)) store_tile(kt);
+            store_tile(kt);
             __syncthreads();
-            if (kt + 1 < nk && !GAD_DBG(8)) load_tile(kt + 1);
-            if (!GAD_DBG(4)) mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
+            if (kt + 1 < nk) load_tile(kt + 1);
+            mfma_ktile<TM, TN, PA, PB>(As, Bs, wm * TM * 32, wn * TN * 32, lane, acc);
             __syncthreads();
         }
         const int l31 = lane & 31, half = lane >> 5;
-        if (GAD_DBG(64)) continue;
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
             const int k = k0out + wn * TN * 32 + tn * 32 + l31;
-            const bool kok = k < e.k_valid && !GAD_DBG(2);
+            const bool kok = k < e.k_valid;
             float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
             const bool stats = e.dbeta != nullptr && kok;
             if (stats) { sc = e.ps[goff + k]; sh = e.pt[goff + k]; mu = e.pm[goff + k]; is = e.pi[goff + k]; }
@@ -1297,7 +1243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         }
         __syncthreads();
     }
-    if (e.dbeta && !GAD_DBG(1)) {
+    if (e.dbeta) {
         const int rep = blockIdx.x % GAD_STAT_REPLICAS;
         block_column_atomics<WM, WN, TN>(smem, cb, cg, lane, wm, wn, k0out, e.k_valid,
                                          e.dbeta + (size_t)rep * e.stat_stride + goff,
@@ -1342,7 +1288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
     }
     for (int i = tid; i < NO; i += 512) {
         float P, Q, S;
-        dz_coef(d, i, blockIdx.x == 0, P, Q, S);
+        dz_coef(d, i, P, Q, S);
         vec[i] = P; vec[NO + i] = Q; vec[2 * NO + i] = S;
     }
     __syncthreads();
@@ -1476,206 +1422,13 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// slab dX for the MID-SIZE layers (the backward twin of gemm_fwd_slab_kernel): a workgroup owns 64 input-channel
-// columns of gout; the matching 64-column slice of W (n_out x 64, as stored: no transposition) stays in LDS, the B
-// operand W[8j+4h+i][k] is four conflict-free ds_read_b32 per k group.  Every wavefront walks 32-row slabs; the A operand
-// dZ[r][8j+4h..+3] = P*dY - w*(Q + S*z) is formed in registers from 16-byte loads of z and dY (or of the pooled
-// arg-max / gradient pair) -- the ReLU mask is already in dY (premasked) -- four k groups per register chunk, the next
-// chunk (or the next slab's first) in flight during the current chunk's 32 MFMAs.  Epilogue: dY of the previous layer,
-// masked by that layer's ReLU (store_masked), + its BatchNorm-backward sums.
-// ------------------------------------------------------------------------------------------------
-template <int GM>
-__global__ __launch_bounds__(512, 2) void gemm_dx_slab_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev,
-                                                               int n_rows_static, const float* __restrict__ W, int Kp,
-                                                               int n_out, DxEpi e, unsigned long long* __restrict__ ts) {
-    KTimer kt(ts);
-    extern __shared__ __attribute__((aligned(16))) float slab_smem[];
-    float* Ws = slab_smem;                               // [n_out][64]
-    float* vec = Ws + n_out * 64;                        // P | Q | S   (3 * n_out)
-    float* red = vec + 3 * n_out;                        // [2 * 8 * 64]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, half = lane >> 5;
-    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    const int k0 = blockIdx.y * 64;
-    for (int u = tid; u < n_out * 16; u += 512) {        // W[n][k0 .. k0+63] -> Ws[n][0..63], 16-byte units
-        const int n = u >> 4, c = (u & 15) << 2;
-        *reinterpret_cast<float4*>(Ws + n * 64 + c) = ldg4(W + (size_t)n * Kp + k0 + c);
-    }
-    for (int i = tid; i < n_out; i += 512) {
-        float P, Q, S;
-        dz_coef(d, i, blockIdx.x == 0 && blockIdx.y == 0, P, Q, S);
-        vec[i] = P; vec[n_out + i] = Q; vec[2 * n_out + i] = S;
-    }
-    __syncthreads();
-    const bool stats = e.dbeta != nullptr;
-    float ps[2] = {0.f, 0.f}, pt[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f}, pi[2] = {0.f, 0.f};
-    if (stats) {
-#pragma unroll
-        for (int tk = 0; tk < 2; ++tk) {
-            const int k = k0 + tk * 32 + l31;
-            ps[tk] = e.ps[k]; pt[tk] = e.pt[k]; pm[tk] = e.pm[k]; pi[tk] = e.pi[k];
-        }
-    }
-    const int n_slabs = (n_rows + 31) >> 5;
-    const int stride = gridDim.x * 8;
-    int slab = wave * gridDim.x + blockIdx.x;
-    const int gp4 = e.gout_pitch * 4, zp4 = e.zprev_pitch * 4;
-    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * gp4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(stats ? e.zprev : e.gout), 0, stats ? n_rows_static * zp4 : 4, 0x00020000);
-    const int glane = (4 * half * e.gout_pitch + k0 + l31) * 4;
-    const int zlane = (4 * half * e.zprev_pitch + k0 + l31) * 4;
-    const int nch = n_out >> 5;                          // chunks of four 8-wide k groups
-    const int zpitch = d.z_pitch, gpitch = GM == 0 ? d.g_pitch : d.c;
-
-    float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
-    float4 rz[2][4], rg[2][4];
-    int4 ra[2][4];
-    auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
-    auto load_chunk = [&](int r, int grp, int c, int buf) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int n = 8 * (4 * c + u) + 4 * half;
-            rz[buf][u] = ldg4(d.z + (size_t)r * zpitch + n);
-            if (GM == 0) {
-                rg[buf][u] = ldg4(d.G + (size_t)r * gpitch + n);
-            } else {
-                ra[buf][u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * gpitch + n);
-                rg[buf][u] = ldg4(d.dout + (size_t)grp * gpitch + n);
-            }
-        }
-    };
-    int r_cur = row_of(slab);
-    int grp_cur = GM == 1 ? d.row_grp[r_cur] : 0;
-    load_chunk(r_cur, grp_cur, 0, 0);
-    for (; slab < n_slabs; slab += stride) {
-        const int r_nxt = row_of(slab + stride);
-        const int grp_nxt = GM == 1 ? d.row_grp[r_nxt] : 0;
-        const float wrow = d.row_w ? d.row_w[r_cur] : 1.f;
-        f32x16 acc[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
-        float zp[2][16];
-        const int zrow = slab * 32 * zp4;
-        const int rr = slab * 32 + l31;                  // true row (clamped rows never match an arg-max)
-        for (int c2 = 0; c2 < nch; c2 += 2) {            // two chunks per trip: the register double buffer is static
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int c = c2 + b;
-                if (c >= nch) break;                     // wave-uniform (n_out = 32 * odd)
-                if (c + 1 < nch) load_chunk(r_cur, grp_cur, c + 1, b ^ 1);
-                else {
-                    load_chunk(r_nxt, grp_nxt, 0, 0);    // (nch even: the last chunk is b == 1, buffer 0 is free)
-                    if (stats) {
-#pragma unroll
-                        for (int v = 0; v < 16; ++v)
-#pragma unroll
-                            for (int t = 0; t < 2; ++t)
-                                zp[t][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                                    zrsrc, zlane + t * 128, zrow + ((v & 3) + 8 * (v >> 2)) * zp4, 0));
-                    }
-                }
-                __asm__ volatile("" ::: "memory");
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int n = 8 * (4 * c + u) + 4 * half;
-                    const float4 z = rz[b][u];
-                    float4 g = rg[b][u];
-                    if (GM == 1) {
-                        const int4 a = ra[b][u];
-                        g.x = a.x == rr ? g.x : 0.f; g.y = a.y == rr ? g.y : 0.f;
-                        g.z = a.z == rr ? g.z : 0.f; g.w = a.w == rr ? g.w : 0.f;
-                    }
-                    const float4 P = *reinterpret_cast<const float4*>(vec + n);
-                    const float4 Q = *reinterpret_cast<const float4*>(vec + n_out + n);
-                    const float4 S = *reinterpret_cast<const float4*>(vec + 2 * n_out + n);
-                    float4 a4;
-                    a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
-                    a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
-                    const float* wp = Ws + n * 64 + l31;
-                    float b0[4], b1[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) { b0[i] = wp[i * 64]; b1[i] = wp[i * 64 + 32]; }
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0[0], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1[0], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0[1], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1[1], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0[2], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1[2], acc[1], 0, 0, 0);
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0[3], acc[0], 0, 0, 0);
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1[3], acc[1], 0, 0, 0);
-                }
-            }
-        }
-        const bool full = slab * 32 + 32 <= n_rows;
-        const int grow = slab * 32 * gp4;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int row = acc_row(v, half);
-            const bool live = slab * 32 + row < n_rows;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float gv = acc[t][v];
-                float outv = gv;
-                if (stats) {
-                    const float zv = live ? zp[t][v] : 0.f;       // (see gemm_dx_stream_kernel: no NaN x 0 from unwritten rows)
-                    const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
-                    const float ga = act ? gv : 0.f;
-                    sb[t] += ga;
-                    sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
-                    if (e.store_masked) outv = ga;
-                }
-                if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(outv), grsrc, glane + t * 128,
-                                                                grow + ((v & 3) + 8 * (v >> 2)) * gp4, 0);
-                else if (live) e.gout[(size_t)(slab * 32 + row) * e.gout_pitch + k0 + t * 32 + l31] = outv;
-            }
-        }
-        r_cur = r_nxt;
-        grp_cur = grp_nxt;
-    }
-    if (stats) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const float s0 = sb[t] + __shfl_xor(sb[t], 32, 64);
-            const float s1 = sg[t] + __shfl_xor(sg[t], 32, 64);
-            if (lane < 32) { red[wave * 64 + t * 32 + lane] = s0; red[(8 + wave) * 64 + t * 32 + lane] = s1; }
-        }
-        __syncthreads();
-        if (tid < 64) {
-            float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-            for (int w = 0; w < 8; ++w) { s0 += red[w * 64 + tid]; s1 += red[(8 + w) * 64 + tid]; }
-            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
-            atomic_add_f64(e.dbeta + (size_t)rep * e.stat_stride + k0 + tid, (double)s0);
-            atomic_add_f64(e.dgamma + (size_t)rep * e.stat_stride + k0 + tid, (double)s1);
-        }
-    }
-}
-
-static bool dx_slabable(const gad_gemm_dx_args& a, bool vec) {
-    if (!g_opt_dx_slab || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
-    if (a.dz.gmode != 0 && g_opt_dx_slab < 2) return false;      // pooled source: 57 spilled registers at 256 VGPRs, slower than the tile kernel (option value 2 forces it)
-    if (a.n_rows < 2048 || a.epilogue != 0 || a.k_valid % 64 != 0 || a.k_valid < 64 || a.k_valid > a.Kp) return false;
-    if (a.n_out[0] % 64 != 0 || a.n_out[0] < 64 || a.n_out[0] > 512) return false;    // chunk pairs; W slice <= 128 KB of LDS
-    if (a.prev_dbeta && !(a.zprev && a.prev_scale && a.prev_shift && a.prev_mean && a.prev_istd && a.prev_dgamma)) return false;
-    const gad_dz_src& d = a.dz;
-    const bool coef = (d.coefP && d.coefQ && d.coefS) || d.bn.dbeta;
-    if (!d.z || d.z_pitch % 4 != 0 || !d.scale || !d.relu || !d.premasked || !coef) return false;
-    if (d.gmode == 0 ? (d.g_pitch % 4 != 0 || !d.G) : (d.c % 4 != 0)) return false;
-    return (long long)a.n_rows * (a.gout_pitch > a.zprev_pitch ? a.gout_pitch : a.zprev_pitch) * 4 < (1ll << 31);
-}
-
 static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
     if (!g_opt_dx_stream || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
     if (a.n_rows < 32768 || a.epilogue != 0 || a.k_valid != 64 || a.Kp != 64 || a.gout_pitch != 64) return false;
     if (a.n_out[0] != 64 && a.n_out[0] != 128) return false;
     if (!a.prev_dbeta || a.zprev_pitch != 64 || !a.store_masked) return false;
     const gad_dz_src& d = a.dz;
-    const bool coef = (d.coefP && d.coefQ && d.coefS) || d.bn.dbeta;
+    const bool coef = (d.coefP && d.coefQ && d.coefS);
     if (!d.z || d.z_pitch != a.n_out[0] || !d.scale || !d.relu || !d.premasked || !coef) return false;
     if (d.gmode == 0 ? d.g_pitch != a.n_out[0] : d.c != a.n_out[0]) return false;
     return (long long)a.n_rows * 128 * 4 < (1ll << 31);
@@ -1700,7 +1453,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
         vec[i] = d.scale ? d.scale[doff + i] : 1.f;
         vec[VMAX + i] = d.shift ? d.shift[doff + i] : 0.f;
         float P, Q, S;
-        dz_coef(d, doff + i, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0, P, Q, S);
+        dz_coef(d, doff + i, P, Q, S);
         vec[2 * VMAX + i] = P; vec[3 * VMAX + i] = Q; vec[4 * VMAX + i] = S;
     }
     __syncthreads();
@@ -1801,7 +1554,6 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     Groups gr = make_groups(a->n_groups, a->dz_off, a->w_off, a->gout_off, a->n_out);
     DxEpi e;
     e.mode = a->epilogue; e.gout = a->gout; e.gout_pitch = a->gout_pitch; e.k_valid = a->k_valid;
-    e.dbg = g_opt_dbg;
     e.zprev = a->zprev; e.zprev_pitch = a->zprev_pitch; e.ps = a->prev_scale; e.pt = a->prev_shift;
     e.pm = a->prev_mean; e.pi = a->prev_istd; e.dbeta = a->prev_dbeta; e.dgamma = a->prev_dgamma;
     e.stat_stride = a->stat_stride;
@@ -1814,12 +1566,6 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     const int rows = a->n_rows, kv = a->k_valid;
     const int grid_rows = (a->n_rows_dev && rows_hint > 0 && rows_hint < rows) ? rows_hint : rows;   // gad_grid_rows_hint
     const bool vec = dz_vectorizable(a->dz, a->dz_off, a->n_out, a->n_groups);
-    if (a->dz.bn.dbeta) {
-        GAD_REQUIRE(vec && a->n_groups == 1 && a->dz_off[0] == 0, GAD_ERR_SHAPE,
-                    "gemm_dx: deferred BatchNorm-backward coefficients need 16-byte aligned channels and a single group");
-        GAD_REQUIRE(a->dz.bn.dgamma && a->dz.bn.mean && a->dz.bn.istd && a->dz.scale && a->dz.bn.count >= 1.0, GAD_ERR_NULL,
-                    "gemm_dx: incomplete gad_bn_bwd");
-    }
     if (dx_streamable(*a, vec)) {
         const int slabs = gad_cdiv(rows, 32);
         int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;
@@ -1828,27 +1574,6 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
         else { if (a->dz.gmode == 0) LAUNCH_DXS(8, 0); else LAUNCH_DXS(8, 1); }
 #undef LAUNCH_DXS
         GAD_CHECK_LAUNCH("gemm_dx(stream)");
-        return GAD_OK;
-    }
-    if (dx_slabable(*a, vec)) {
-        const int slabs = gad_cdiv(rows, 32), slices = kv / 64, n = a->n_out[0];
-        int gx = 256 / slices; if (gx < 1) gx = 1;
-        if (gx > gad_cdiv(slabs, 8)) gx = gad_cdiv(slabs, 8);
-        const size_t lds = ((size_t)n * 64 + 3 * (size_t)n + 2 * 8 * 64) * sizeof(float);
-#define LAUNCH_DXSLAB(GM)                                                                                           \
-        do {                                                                                                        \
-            static bool attr_set = false;                                                                           \
-            if (!attr_set) {                                                                                        \
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_dx_slab_kernel<GM>),                  \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                  \
-                attr_set = true;                                                                                    \
-            }                                                                                                       \
-            hipLaunchKernelGGL((gemm_dx_slab_kernel<GM>), dim3(gx, slices), dim3(512), lds, st, d, a->n_rows_dev, rows, \
-                               a->W, a->Kp, n, e, ts);                                                                  \
-        } while (0)
-        if (a->dz.gmode == 0) LAUNCH_DXSLAB(0); else LAUNCH_DXSLAB(1);
-#undef LAUNCH_DXSLAB
-        GAD_CHECK_LAUNCH("gemm_dx(slab)");
         return GAD_OK;
     }
     int nmax_dx = 0;
@@ -1863,7 +1588,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
 #define LAUNCH_DX2(WM, WN, TM, TN, V)                                                                    \
     do {                                                                                                 \
         constexpr int BM = WM * TM * 32, BN = WN * TN * 32;                                              \
-        int gx = gad_cdiv(grid_rows, BM); if (gx > g_opt_gx_cap) gx = g_opt_gx_cap;                                      \
+        int gx = gad_cdiv(grid_rows, BM); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;                                      \
         if (nmax_dx <= 512)                                                                              \
             hipLaunchKernelGGL((gemm_dx_kernel<WM, WN, TM, TN, V, 512>), dim3(gx, gad_cdiv(kv, BN), gr.n), dim3(256), 0, \
                                st, d, gr, a->n_rows_dev, rows, a->W, a->Kp, e, ts);                          \
@@ -1919,8 +1644,8 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
     const int r_begin = blockIdx.y * chunk;
     const int r_end = min(r_begin + chunk, n_rows);
     if (r_begin >= r_end) return;     // the reducer skips the same splits (same chunk arithmetic)
-    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out, blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0);
-    if (XM == 0 && x.affine) stage_affine<256>(sv, tv, x, zoff, x.c_in, false);
+    if (VEC) stage_dz_vecs<VM>(vec, d, doff, n_out);
+    if (XM == 0 && x.affine) stage_affine<256>(sv, tv, x, zoff, x.c_in);
     __syncthreads();
 
     f32x16 acc[TM][TN];
@@ -2065,7 +1790,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSr
     const int ch = doff + (n_ok ? n : 0);
     const float dsc = (d.scale && !d.premasked) ? d.scale[ch] : 1.f, dsh = (d.scale && !d.premasked) ? d.shift[ch] : 0.f;
     float dP, dQ, dS;
-    dz_coef(d, ch, blockIdx.y == 0 && blockIdx.z == 0 && wave == 0 && half == 0 && n_ok, dP, dQ, dS);
+    dz_coef(d, ch, dP, dQ, dS);
     // B side: this lane's input column k: 0 = activation column, 1 = extra column, 2 = bias (ones) column, 3 = padding
     const int k = k0 + l31;
     const int kind = k < x.c_in ? 0 : ((k == x.c_in && x.extra) ? 1 : (k == x.ones_col ? 2 : 3));
@@ -2160,7 +1885,7 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int ch = 64 * cset + 32 * j + l31;
-        dz_coef(d, ch, blockIdx.x == 0 && wr == 0 && half == 0, dP[j], dQ[j], dS[j]);
+        dz_coef(d, ch, dP[j], dQ[j], dS[j]);
         xs[j] = x.scale[32 * j + l31]; xt[j] = x.shift[32 * j + l31];
     }
     // Addressing of the main loop: raw buffer loads whose per-lane byte offset is a CONSTANT (channel block + the
@@ -2302,7 +2027,7 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
     const unsigned lane_n = 2u * l31;
     float dP[2], dQ[2], dS[2];                        // (premasked dY)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dz_coef(d, lane_n + j, blockIdx.x == 0 && wave == 0 && half == 0, dP[j], dQ[j], dS[j]);
+    for (int j = 0; j < 2; ++j) dz_coef(d, lane_n + j, dP[j], dQ[j], dS[j]);
     // B side: what input column k = l31 is made of
     const int k = l31, fc = x.feat_c;
     const int kind = k < fc ? 0 : (k < fc + 3 ? 1 : ((x.action && k < fc + 3 + x.act_c) ? 2 : 3));
@@ -2424,7 +2149,7 @@ static bool dw_gather_streamable(const gad_gemm_dw_args& a, int k_used) {
     const gad_dz_src& d = a.dz;
     if (!g_opt_dw_stream || in.mode != 1 || in.n_groups != 1 || in.Kp > 32 || in.n_out[0] != 64 || k_used > in.Kp) return false;
     if (in.zin_off[0] != 0 || a.dz_off[0] != 0 || in.n_rows < 32768 || d.gmode != 0 || !d.G) return false;
-    if (!d.z || !d.scale || !d.relu || !d.premasked || !((d.coefP && d.coefQ && d.coefS) || d.bn.dbeta)) return false;
+    if (!d.z || !d.scale || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
     if (in.feat_c + 3 + (in.action ? in.act_c : 0) > in.Kp) return false;
     if (!a.partial || 256ll * 64 * in.Kp > a.partial_elems) return false;
     return a.row_splits <= 0;
@@ -2437,7 +2162,7 @@ static bool dw_streamable(const gad_gemm_dw_args& a, int k_used) {
     if (!g_opt_dw_stream || in.mode != 0 || in.n_groups != 1 || in.Kp != 64 || in.c_in != 64 || k_used != 64) return false;
     if (in.zin_off[0] != 0 || a.dz_off[0] != 0 || (in.n_out[0] != 64 && in.n_out[0] != 128)) return false;   // w_off: arena offset, dw_reduce applies it
     if (in.n_rows < 32768 || !in.scale || !in.shift || !in.relu || in.extra || in.ones_col >= 0) return false;
-    if (!d.z || !d.scale || !d.relu || !d.premasked || !((d.coefP && d.coefQ && d.coefS) || d.bn.dbeta)) return false;
+    if (!d.z || !d.scale || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
     if (d.gmode != 0 && d.c != in.n_out[0]) return false;
     if (!a.partial || (long long)DW_STREAM_SPLITS * in.n_out[0] * 64 > a.partial_elems) return false;
     return a.row_splits <= 0;
@@ -2453,7 +2178,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     GAD_REQUIRE(a->dz.gmode == 0 ? a->dz.G != nullptr : (a->dz.argmax && a->dz.dout && a->dz.row_grp), GAD_ERR_NULL,
                 "gemm_dw: gradient source");
     if (in.n_rows <= 0) return GAD_OK;
-    XSrc x = make_xsrc(in, false);          // the input layer's affine was published by the forward pass
+    XSrc x = make_xsrc(in);
     DzSrc d = make_dzsrc(a->dz);
     // group g: dz channel offset dz_off[g], input channel offset zin_off[g], weights at w_off[g]
     Groups gr = make_groups(in.n_groups, a->dz_off, in.w_off, in.zin_off, in.n_out);
@@ -2464,12 +2189,6 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int rows = in.n_rows;
     const bool vec = dz_vectorizable(a->dz, a->dz_off, in.n_out, in.n_groups);
-    if (a->dz.bn.dbeta) {
-        GAD_REQUIRE(vec && in.n_groups == 1 && a->dz_off[0] == 0, GAD_ERR_SHAPE,
-                    "gemm_dw: deferred BatchNorm-backward coefficients need 16-byte aligned channels and a single group");
-        GAD_REQUIRE(a->dz.bn.dgamma && a->dz.bn.mean && a->dz.bn.istd && a->dz.scale && a->dz.bn.count >= 1.0, GAD_ERR_NULL,
-                    "gemm_dw: incomplete gad_bn_bwd");
-    }
     if (g_opt_dw_skinny && in.mode == 0 && a->dz.gmode == 0 && !in.n_rows_dev && rows <= 1024) {
         hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
                            gr, rows, in.Kp, k_used, a->gacc, ts);
@@ -2521,7 +2240,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
             if (splits < 1) splits = 1;                                                                    \
         }                                                                                                  \
         group_stride = (long long)splits * nmax * in.Kp;                                                   \
-        if (part && (splits == 1 || g_opt_dw_direct || group_stride * gr.n > a->partial_elems)) part = nullptr; \
+        if (part && (splits == 1 || group_stride * gr.n > a->partial_elems)) part = nullptr; \
         if (in.mode == 0) { if (vec) LAUNCH_DW3(WM, WN, TM, TN, 0, true); else LAUNCH_DW3(WM, WN, TM, TN, 0, false); } \
         else              { if (vec) LAUNCH_DW3(WM, WN, TM, TN, 1, true); else LAUNCH_DW3(WM, WN, TM, TN, 1, false); } \
     } while (0)

@@ -50,7 +50,7 @@ void gad_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gad_last_error(void) { return g_err; }
-extern "C" int gad_abi_version(void) { return 3; }
+extern "C" int gad_abi_version(void) { return 4; }
 
 // ------------------------------------------------------------------------------------------------
 // furthest point sampling

@@ -82,11 +82,11 @@ extern "C" int gad_bn_running_update(const float* mean, const float* istd, const
 // 16-byte access of consecutive rows; the row phases of a quad are folded with wavefront shuffles
 // (value first, then the smaller row index) -- north_star's "wavefront shuffle reductions for the max-pool".
 // QPR = quads per row handled per lane-row = min(C/4, 64); lanes cover RPW = 64/QPR rows per step and NQ = C/(4*QPR)
-// quads each.  The layer's BatchNorm may be finalised in the prologue (gad_bn_fin).
+// quads each.
 template <int QPR, int NQ>
 __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restrict__ z, int z_pitch,
                                                            const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, gad_bn_fin bn,
+                                                           const float* __restrict__ shift,
                                                            const int32_t* __restrict__ off, int G,
                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
                                                            unsigned long long* __restrict__ ts) {
@@ -95,11 +95,9 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
     __shared__ __attribute__((aligned(16))) float sv[C], tv[C];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool writer = blockIdx.x == 0;
     for (int i = tid; i < C; i += 256) {
         float sc = 1.f, sh = 0.f;
-        if (bn.stat_sum) gad_bn_fin_channel(bn, i, writer, sc, sh);
-        else if (scale) { sc = scale[i]; sh = shift[i]; }
+        if (scale) { sc = scale[i]; sh = shift[i]; }
         sv[i] = sc; tv[i] = sh;
     }
     __syncthreads();
@@ -171,25 +169,17 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
 }
 
 extern "C" int gad_segment_pool(const float* z, int z_pitch, int C, const float* scale, const float* shift,
-                                const gad_bn_fin* host_bn, const int32_t* grp_off, int G, float* out, int32_t* argmax,
-                                void* stream) {
+                                const int32_t* grp_off, int G, float* out, int32_t* argmax, void* stream) {
     unsigned long long* ts = gad_take_timing_slot();
     GAD_REQUIRE(z && grp_off && out, GAD_ERR_NULL, "segment_pool: null pointer");
     GAD_REQUIRE((scale == nullptr) == (shift == nullptr), GAD_ERR_NULL, "segment_pool: scale and shift come together");
     GAD_REQUIRE(z_pitch % 4 == 0, GAD_ERR_SHAPE, "segment_pool: row pitch %d must be a multiple of 4", z_pitch);
     if (G <= 0 || C <= 0) return GAD_OK;
-    gad_bn_fin bn;
-    memset(&bn, 0, sizeof(bn));
-    if (host_bn && host_bn->stat_sum) {
-        bn = *host_bn;
-        GAD_REQUIRE(bn.stat_sq && bn.gamma && bn.beta && bn.scale && bn.shift && bn.count >= 1.0, GAD_ERR_NULL,
-                    "segment_pool: incomplete gad_bn_fin");
-    }
     int gx = gad_cdiv(G, 4);
     if (gx > 2048) gx = 2048;
 #define LAUNCH_POOL(QPR, NQ)                                                                                      \
     hipLaunchKernelGGL((segment_pool_kernel<QPR, NQ>), dim3(gx), dim3(256), 0, (hipStream_t)stream, z, z_pitch, scale, \
-                       shift, bn, grp_off, G, out, argmax, ts)
+                       shift, grp_off, G, out, argmax, ts)
     switch (C) {
         case 8: LAUNCH_POOL(2, 1); break;
         case 16: LAUNCH_POOL(4, 1); break;
@@ -204,6 +194,84 @@ extern "C" int gad_segment_pool(const float* z, int z_pitch, int C, const float*
     }
 #undef LAUNCH_POOL
     GAD_CHECK_LAUNCH("segment_pool");
+    return GAD_OK;
+}
+
+// Finish of the max-pool that gad_gemm_fwd folded into the pooled layer's epilogue (gad_gemm_fwd_args.pool_key): per
+// (group, channel) the packed key holds max over the group's rows of sgn(gamma) * z and the first row attaining it.
+// This kernel (1) finalises the layer's train-mode BatchNorm for its 64-channel slice from the f64 statistics -- the
+// arithmetic of gad_bn_finalize; the workgroups with blockIdx.x == 0 publish scale / shift / mean / istd and apply the
+// running-statistics update -- or takes scale / shift as given (eval mode), (2) decodes the keys: zmax = sgn * value,
+// out = relu(scale * zmax + shift), arg-max = the key's row where out > 0, else the group's FIRST row (every row ties at
+// 0 after the ReLU: torch's max_pool2d keeps the first), and (3) resets the keys to 0 for the next pass.
+// Thread layout: 16 channel quads x 16 groups per step; a group's 64-channel slice is 512 contiguous key bytes.
+__device__ __forceinline__ float pool_unord(unsigned u) {
+    return __uint_as_float((u & 0x80000000u) ? (u ^ 0x80000000u) : ~u);
+}
+
+__global__ __launch_bounds__(256) void pool_finalize_kernel(unsigned long long* __restrict__ key, int C, int G,
+                                                            const int32_t* __restrict__ grp_off, gad_bn_fin bn,
+                                                            float* __restrict__ out, int32_t* __restrict__ argmax,
+                                                            float* __restrict__ zmax) {
+    __shared__ __attribute__((aligned(16))) float sv[64], tv[64], gv[64];
+    const int tid = threadIdx.x, c0 = blockIdx.y * 64;
+    if (tid < 64 && c0 + tid < C) {
+        const int c = c0 + tid;
+        float sc, sh;
+        if (bn.stat_sum) gad_bn_fin_channel(bn, c, blockIdx.x == 0, sc, sh);
+        else { sc = bn.scale[c]; sh = bn.shift[c]; }
+        sv[tid] = sc; tv[tid] = sh; gv[tid] = bn.gamma[c] < 0.f ? -1.f : 1.f;
+    }
+    __syncthreads();
+    const int q = tid & 15, gl = tid >> 4;
+    const int c = c0 + 4 * q;
+    if (c >= C) return;
+    const float4 s4 = *reinterpret_cast<const float4*>(sv + 4 * q), t4 = *reinterpret_cast<const float4*>(tv + 4 * q);
+    const float4 n4 = *reinterpret_cast<const float4*>(gv + 4 * q);
+    const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {t4.x, t4.y, t4.z, t4.w}, sg[4] = {n4.x, n4.y, n4.z, n4.w};
+    for (int g = blockIdx.x * 16 + gl; g < G; g += gridDim.x * 16) {
+        const int r0 = grp_off[g];
+        unsigned long long* kp = key + (size_t)g * C + c;
+        const ulonglong2 k01 = *reinterpret_cast<const ulonglong2*>(kp), k23 = *reinterpret_cast<const ulonglong2*>(kp + 2);
+        const unsigned long long k[4] = {k01.x, k01.y, k23.x, k23.y};
+        float y[4], zm[4];
+        int a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool any = k[e] != 0ull;                       // (a group without rows cannot occur: max(cnt, 1) rows each)
+            const float z = any ? sg[e] * pool_unord((unsigned)(k[e] >> 32)) : 0.f;
+            const float yy = any ? fmaxf(fmaf(z, sc[e], sh[e]), 0.f) : 0.f;
+            y[e] = yy; zm[e] = z;
+            a[e] = (any && yy > 0.f && sc[e] != 0.f) ? (int)(0xffffffffu - (unsigned)(k[e] & 0xffffffffull)) : r0;
+        }
+        const size_t o4 = (size_t)g * C + c;
+        *reinterpret_cast<float4*>(out + o4) = make_float4(y[0], y[1], y[2], y[3]);
+        if (argmax) *reinterpret_cast<int4*>(argmax + o4) = make_int4(a[0], a[1], a[2], a[3]);
+        if (zmax) *reinterpret_cast<float4*>(zmax + o4) = make_float4(zm[0], zm[1], zm[2], zm[3]);
+        const ulonglong2 zero = {0ull, 0ull};
+        *reinterpret_cast<ulonglong2*>(kp) = zero;
+        *reinterpret_cast<ulonglong2*>(kp + 2) = zero;
+    }
+}
+
+extern "C" int gad_pool_finalize(uint64_t* key, int C, int G, const int32_t* grp_off, const double* stat_sum,
+                                 const double* stat_sq, int stat_stride, double count, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                 float* scale, float* shift, float* mean, float* istd, float* out, int32_t* argmax,
+                                 float* zmax, void* stream) {
+    GAD_REQUIRE(key && grp_off && gamma && scale && shift && out, GAD_ERR_NULL, "pool_finalize: null pointer");
+    GAD_REQUIRE(C >= 4 && C % 4 == 0, GAD_ERR_SHAPE, "pool_finalize: C=%d must be a positive multiple of 4", C);
+    GAD_REQUIRE(!stat_sum || (stat_sq && beta && count >= 1.0), GAD_ERR_NULL, "pool_finalize: statistics need stat_sq, beta, count");
+    if (G <= 0) return GAD_OK;
+    gad_bn_fin b;
+    b.stat_sum = stat_sum; b.stat_sq = stat_sq; b.stat_stride = stat_stride; b.count = count; b.gamma = gamma; b.beta = beta;
+    b.eps = eps; b.momentum = momentum; b.running_mean = running_mean; b.running_var = running_var; b.scale = scale;
+    b.shift = shift; b.mean = mean; b.istd = istd;
+    int gx = gad_cdiv(G, 16 * 4);                 // four group steps per workgroup
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(pool_finalize_kernel, dim3(gx, gad_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<unsigned long long*>(key), C, G, grp_off, b, out, argmax, zmax);
+    GAD_CHECK_LAUNCH("pool_finalize");
     return GAD_OK;
 }
 
@@ -240,7 +308,8 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(float* __restrict__
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ istd,
                                                              double* __restrict__ dbeta,
-                                                             double* __restrict__ dgamma, int stride, int mask) {
+                                                             double* __restrict__ dgamma, int stride, int mask,
+                                                             const float* __restrict__ zmax) {
     const int cpb = C < 256 ? C : 256;          // channels per block (C is a multiple of 32)
     const int gl = 256 / cpb;                   // groups processed side by side
     const int c = blockIdx.x * cpb + threadIdx.x % cpb;
@@ -250,8 +319,9 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(float* __restrict__
     float sb = 0.f, sg = 0.f;
     for (int g = blockIdx.y * gl + threadIdx.x / cpb; g < G; g += gstride) {
         const float v = dout[(size_t)g * C + c];
-        const int r = argmax[(size_t)g * C + c];
-        const float zp = z[(size_t)r * z_pitch + c];
+        float zp;
+        if (zmax) zp = zmax[(size_t)g * C + c];              // the winner's raw value, saved by gad_pool_finalize: no gather
+        else zp = z[(size_t)argmax[(size_t)g * C + c] * z_pitch + c];
         if (fmaf(zp, sc, sh) > 0.f) { sb += v; sg = fmaf(v, (zp - mu) * is, sg); }
         else if (mask) dout[(size_t)g * C + c] = 0.f;
     }
@@ -263,8 +333,8 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(float* __restrict__
 extern "C" int gad_pool_bwd_stats(float* dout, const int32_t* argmax, int G, int C, const float* z,
                                   int z_pitch, const float* scale, const float* shift, const float* mean,
                                   const float* istd, double* dbeta, double* dgamma, int stat_stride, int mask_in_place,
-                                  void* stream) {
-    GAD_REQUIRE(dout && argmax && z && scale && shift && mean && istd && dbeta && dgamma, GAD_ERR_NULL,
+                                  const float* zmax, void* stream) {
+    GAD_REQUIRE(dout && (zmax || (argmax && z)) && scale && shift && mean && istd && dbeta && dgamma, GAD_ERR_NULL,
                 "pool_bwd_stats: null pointer");
     GAD_REQUIRE(C % 32 == 0 && (C <= 256 ? 256 % C == 0 : C % 256 == 0), GAD_ERR_SHAPE, "pool_bwd_stats: C=%d", C);
     if (G == 0) return GAD_OK;
@@ -273,7 +343,7 @@ extern "C" int gad_pool_bwd_stats(float* dout, const int32_t* argmax, int G, int
     if (gy > 512) gy = 512;
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(C / cpb, gy), dim3(256), 0, (hipStream_t)stream, dout, argmax, G, C,
-                       z, z_pitch, scale, shift, mean, istd, dbeta, dgamma, stat_stride, mask_in_place);
+                       z, z_pitch, scale, shift, mean, istd, dbeta, dgamma, stat_stride, mask_in_place, zmax);
     GAD_CHECK_LAUNCH("pool_bwd_stats");
     return GAD_OK;
 }

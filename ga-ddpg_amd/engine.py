@@ -3,8 +3,7 @@ layout, per-pass activation workspaces, and the launch plans (sequences of C-ABI
 PointNet++ encoder, the actor/critic heads and their backward passes.
 
 Nothing here computes: every arithmetic step is a libgaddpg kernel (ga-ddpg_amd/hip.py).  torch
-only owns device memory and the stream.  A *plan* is a list of pre-built calls over static buffers,
-so it can be replayed eagerly or captured once into a HIP graph (torch.cuda.CUDAGraph).
+only owns device memory and the stream.  A *plan* is a list of pre-built calls over static buffers.
 
 Reference structure mirrored: core/networks.py:65-92 (base_network = SA1, SA2, SA3, FC head),
 :253-300 (QNetwork), :303-371 (GaussianPolicy); upstream PointnetSAModule.forward.
@@ -16,14 +15,6 @@ from . import hip
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
-# Deferred BatchNorm (include/gaddpg.h gad_bn_fin / gad_bn_bwd): finalise a layer's statistics / backward coefficients in
-# the prologue of the consuming kernels instead of a single-workgroup launch between producer and consumer.  Built,
-# parity-green and MEASURED SLOWER on MI355X (276 -> 223 steps/s, profiles/README.md round 2): every consumer workgroup
-# re-reads the 8 x 2 x C f64 accumulators -- lines that the producer's device-scope atomics left outside the XCD L2s --
-# so ~900 workgroups hammer the same few hundred lines through the fabric; the 77 launches it removes cost less.
-# Default off; GAD_DEFER_BN=1 switches the plans over (both paths satisfy the same tests).
-import os as _os
-DEFER_BN = _os.environ.get("GAD_DEFER_BN", "0") == "1"
 
 
 def round8(k):
@@ -285,16 +276,25 @@ class EncoderSlot(object):
     (every neighbourhood full)."""
 
     def __init__(self, geo, enc, device, with_backward=True):
+        """with_backward=False (a pass that is never back-propagated: the TD-target passes): the pooled layers' raw
+        outputs are not stored at all -- their max-pool is folded into the GEMM epilogue and nothing else reads them"""
         f32 = dict(dtype=torch.float32, device=device)
         B = geo.B
         self.geo, self.B = geo, B
+        self.with_backward = with_backward
         caps = [geo.rows[0]["cap"], geo.rows[1]["cap"], geo.rows[2]["cap"]]
         self.Z = []
         for s, st in enumerate(enc.sa_mats):
-            self.Z.append([torch.empty(caps[s], m.n_out, **f32) for m in st])
+            self.Z.append([torch.empty(caps[s], m.n_out, **f32) if (with_backward or l < 2) else None
+                           for l, m in enumerate(st)])
         self.F = [torch.empty(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, **f32) for s in range(3)]
         self.argmax = [torch.empty(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, dtype=torch.int32, device=device)
                        for s in range(3)]
+        # fused max-pool: packed (value, ~row) keys per (group, channel), 0 between passes (gad_pool_finalize resets them)
+        self.key = [torch.zeros(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, dtype=torch.int64, device=device) for s in range(3)]
+        # raw value of every arg-max row (the pooled layer's BatchNorm-backward sums read it instead of gathering z[argmax])
+        self.zmax = [torch.empty(geo.rows[s]["G"], enc.sa_mats[s][2].n_out, **f32) if with_backward else None
+                     for s in range(3)]
         self.Zfc = [torch.empty(B, m.n_out, **f32) for m in enc.fc_mats]
         tot = enc.bn_total
         R = hip.STAT_REPLICAS
@@ -336,10 +336,7 @@ def _fwd_args(**kw):
     a.ones_col = -1
     a.grp_per_sample = 1
     for k, v in kw.items():
-        if k == "in_bn":
-            if v is not None:
-                a.in_bn = v
-        elif k in ("zin_off", "w_off", "out_off", "n_out"):
+        if k in ("zin_off", "w_off", "out_off", "n_out"):
             arr = getattr(a, k)
             for i, x in enumerate(v):
                 arr[i] = int(x)
@@ -351,50 +348,15 @@ def _fwd_args(**kw):
 def _dz(**kw):
     d = hip.DzSrc()
     for k, v in kw.items():
-        if k == "bn":
-            if v is not None:
-                d.bn = v
-        else:
-            setattr(d, k, v)
+        setattr(d, k, v)
     return d
-
-
-def bn_fin(enc, slot, m, count, update_running=True):
-    """gad_bn_fin of layer m in `slot`: its consumer finalises the BatchNorm in its own prologue (no launch between the
-    producing GEMM and the consumer); workgroup 0 of the consumer publishes scale / shift / mean / istd into the slot
-    and applies the running-statistics update"""
-    o, tot = enc.bn_off[m.bn_index], slot.tot
-    b = hip.BnFin()
-    b.stat_sum, b.stat_sq, b.stat_stride = _ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), 2 * tot
-    b.count = float(count)
-    b.gamma, b.beta = enc.flat.p_gamma(m), enc.flat.p_beta(m)
-    b.eps, b.momentum = BN_EPS, BN_MOMENTUM
-    if update_running:
-        b.running_mean, b.running_var = _ptr(enc.running_mean, o), _ptr(enc.running_var, o)
-    b.scale, b.shift = _ptr(slot.scale, o), _ptr(slot.shift, o)
-    b.mean, b.istd = _ptr(slot.mean, o), _ptr(slot.istd, o)
-    return b
-
-
-def bn_bwd(enc, slot, m, count, want_dw, accumulate):
-    """gad_bn_bwd of layer m: its dX / dW kernels form P, Q, S from the slot's (dbeta, dgamma) sums in their prologue;
-    `accumulate` marks the ONE consumer that also adds dgamma / dbeta to the gradient arena"""
-    o, tot = enc.bn_off[m.bn_index], slot.tot
-    b = hip.BnBwd()
-    b.dbeta, b.dgamma, b.stat_stride = _ptr(slot.bstats, o, 8), _ptr(slot.bstats, tot + o, 8), 2 * tot
-    b.count = float(count)
-    b.mean, b.istd = _ptr(slot.mean, o), _ptr(slot.istd, o)
-    if want_dw and accumulate:
-        b.gacc_gamma, b.gacc_beta = _ptr(enc.flat.gacc, m.g_off, 8), _ptr(enc.flat.gacc, m.b_off, 8)
-        b.accumulate = 1
-    return b
 
 
 # bench.py / diagnostics: durations of tagged launches, stamped by the kernels themselves (gad_timing_slot: first
 # wavefront start -> last wavefront end on the device wall clock -- what a profiler reports as the dispatch duration;
 # HIP events around a 25 us launch inside a five-stream step read 8 - 20 us high: event packets, queue waits)
 TIMING = {"enabled": False, "tag": None, "slots": None, "next": 0, "tags": []}
-_TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_segment_pool")
+_TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_segment_pool")      # (entry points that take a timing slot)
 
 
 TIMING_WAVES = 16384          # include/gaddpg.h GAD_TIMING_WAVES
@@ -561,20 +523,13 @@ class Plan(object):
         for i, t in other.tags.items():
             self.tags[n + i] = t
 
-    def run(self, inline=False):
-        """inline=True: calls marked `side` run on the caller's stream, forks / joins are skipped (a plan replayed on a
-        stream that is itself a fork of a stream under HIP-graph capture: hipStreamEndCapture of ROCm 7.2 crashes on
-        nested forks -- tests/diag_graph.py -- so the captured non-policy actor pass keeps its dW GEMMs in line)"""
+    def run(self):
         import ctypes as C
         main = torch.cuda.current_stream()
         st = hip.stream()
         sides = {}            # lane -> (torch stream, raw handle); dW lanes use side_stream(which = 10 + lane)
         timed = TIMING["enabled"]
         for i, (name, f, args, s, lane) in enumerate(self.calls):
-            if inline:
-                if name in ("fork", "join"):
-                    continue
-                lane = 0
             if name == "fork":
                 if lane not in sides:
                     so = side_stream(which=10 + lane)
@@ -685,55 +640,54 @@ def plan_running_update(enc, slot):
     return plan
 
 
-def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True, finalize_last=False):
-    """SA1 -> SA2 -> SA3 -> FC.  Train mode: no BatchNorm launch at all -- every layer's statistics are finalised in the
-    prologue of its consumer (the next GEMM, the segment pool; gad_bn_fin).  The LAST BatchNorm (fc[1]) is left to the
-    consumer as well: a head's first GEMM takes `bn_fin(enc, slot, enc.fc_mats[1], B, update_running)`;
-    finalize_last=True emits an explicit gad_bn_finalize instead (callers that read slot.scale / shift themselves).
-    That is the DEFER_BN schedule; by default (DEFER_BN off, see the note at the top) every GEMM is followed by its
-    gad_bn_finalize launch and the consumers read the published scale / shift.
+def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True):
+    """SA1 -> SA2 -> SA3 -> FC.  Every GEMM is followed by its gad_bn_finalize launch (train mode) and the consumers read the
+    published scale / shift.  The segment max-pool of each stage is folded into the epilogue of its third GEMM (packed
+    arg-max keys, gad_gemm_fwd_args.pool_key); gad_pool_finalize then finalises that layer's BatchNorm and turns the keys
+    into pooled features, arg-max rows and their raw values.  A slot built with with_backward=False does not store the
+    third layers' outputs at all.
     update_running=False: batch statistics only; the running-statistics momentum update is applied later by
     plan_running_update (for a pass that overlaps another pass of the same network on a second stream)."""
-    import ctypes as C
     geo = slot.geo
     plan = Plan()
     plan.zero(slot.stats)
     tot = slot.tot
 
-    def gemm(m, zout, count_prev, prev, s, l, tag):
+    def gemm(m, zout, s, l, tag, pool=None):
         o = enc.bn_off[m.bn_index]
         kw = _layer_input(enc, slot, geo, s, l, action)
-        if train and prev is not None and DEFER_BN:
-            kw["in_bn"] = bn_fin(enc, slot, prev, count_prev, update_running)
+        if pool is not None:
+            kw.update(pool_key=_ptr(slot.key[s], 0, 8), pool_row_grp=_ptr(geo.rows[s]["grp"]), pool_gamma=enc.flat.p_gamma(m))
         a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(zout), zout_pitch=m.n_out,
                       stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot, **kw)
         if s < 2:
             plan.call("gad_grid_rows_hint", hip.Ptr(geo.rows_hint.ctypes.data + 4 * s))
         plan.call_struct("gad_gemm_fwd", a)
         plan.tag_last(tag)
-        if not train:
-            _finalize(plan, enc, slot, m, 0.0, False)
-        elif not DEFER_BN:
-            _finalize(plan, enc, slot, m, count_self[0], True, update_running)
 
-    count_self = [0.0]
-    for s in range(3):
-        count_self[0] = geo.counts[s]
+    def pool_finalize(s, m, count):
+        o = enc.bn_off[m.bn_index]
         r = geo.rows[s]
-        for l, m in enumerate(enc.sa_mats[s]):
-            gemm(m, slot.Z[s][l], geo.counts[s], enc.sa_mats[s][l - 1] if l > 0 else None, s, l,
-                 "fwd.sa%d.l%d" % (s + 1, l + 1))
-        m = enc.sa_mats[s][2]
-        b = bn_fin(enc, slot, m, geo.counts[s], update_running) if (train and DEFER_BN) else None
-        plan.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, _bn_vec(slot, enc, m, "scale"),
-                  _bn_vec(slot, enc, m, "shift"), C.byref(b) if b is not None else None, r["off"], r["G"], slot.F[s],
-                  slot.argmax[s])
+        if train:
+            stats = (_ptr(slot.stats, o, 8), _ptr(slot.stats, tot + o, 8), 2 * tot, hip.Dbl(count))
+            run = (_ptr(enc.running_mean, o), _ptr(enc.running_var, o)) if update_running else (None, None)
+        else:           # eval mode: scale / shift from the running statistics, computed before the keys are decoded
+            _finalize(plan, enc, slot, m, 0.0, False)
+            stats, run = (None, None, 0, hip.Dbl(1.0)), (None, None)
+        plan.call("gad_pool_finalize", _ptr(slot.key[s], 0, 8), m.n_out, r["G"], r["off"], *stats, enc.flat.p_gamma(m),
+                  enc.flat.p_beta(m), BN_EPS, BN_MOMENTUM, *run, _bn_vec(slot, enc, m, "scale"), _bn_vec(slot, enc, m, "shift"),
+                  _bn_vec(slot, enc, m, "mean"), _bn_vec(slot, enc, m, "istd"), slot.F[s], slot.argmax[s], slot.zmax[s])
         plan.tag_last("pool.sa%d" % (s + 1))
-    count_self[0] = float(slot.B)
+
+    for s in range(3):
+        for l, m in enumerate(enc.sa_mats[s]):
+            gemm(m, slot.Z[s][l], s, l, "fwd.sa%d.l%d" % (s + 1, l + 1), pool=(s if l == 2 else None))
+            if l < 2:
+                _finalize(plan, enc, slot, m, geo.counts[s], train, update_running)
+        pool_finalize(s, enc.sa_mats[s][2], geo.counts[s])
     for l, m in enumerate(enc.fc_mats):
-        gemm(m, slot.Zfc[l], float(slot.B), enc.fc_mats[0] if l > 0 else None, 3, l, "fwd.fc%d" % (l + 1))
-    if finalize_last and train and DEFER_BN:
-        _finalize(plan, enc, slot, enc.fc_mats[1], float(slot.B), True, update_running)
+        gemm(m, slot.Zfc[l], 3, l, "fwd.fc%d" % (l + 1))
+        _finalize(plan, enc, slot, m, float(slot.B), train, update_running)
     return plan
 
 
@@ -780,10 +734,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     def bn_dz(m, z, count, accumulate, G=None, pooled=None, row_w=None):
         d = dict(z=_ptr(z), z_pitch=m.n_out, scale=_bn_vec(slot, enc, m, "scale"),
                  shift=_bn_vec(slot, enc, m, "shift"), relu=1, premasked=1, row_w=row_w, c=m.n_out)
-        if DEFER_BN:
-            d["bn"] = bn_bwd(enc, slot, m, count, want_dw, accumulate)
-        else:
-            d["coefP"], d["coefQ"], d["coefS"] = _coef_ptrs(slot, enc, m)
+        d["coefP"], d["coefQ"], d["coefS"] = _coef_ptrs(slot, enc, m)
         if pooled is None:
             d.update(gmode=0, G=_ptr(G), g_pitch=m.n_out)
         else:
@@ -830,8 +781,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     def layer(s, l, m, z, count, has_dx, **src):
         """(dz for the dW, dz for the dX) of one layer: the dX carries the arena accumulation of dgamma / dbeta when
         there is one, else the dW does"""
-        if not DEFER_BN:
-            _bn_coef(plan, enc, slot, m, count, want_dw)
+        _bn_coef(plan, enc, slot, m, count, want_dw)
         d_dw = bn_dz(m, z, count, not has_dx, **src)
         dw(s, l, d_dw, m, action)
         return bn_dz(m, z, count, True, **src) if has_dx else None
@@ -859,7 +809,8 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         # dbeta / dgamma of the pooled layer; the pooled gradient is ReLU-masked in place for its consumers
         plan.call("gad_pool_bwd_stats", slot.dF[s], slot.argmax[s], r["G"], m3.n_out, slot.Z[s][2], m3.n_out,
                   _bn_vec(slot, enc, m3, "scale"), _bn_vec(slot, enc, m3, "shift"), _bn_vec(slot, enc, m3, "mean"),
-                  _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8), 2 * tot, 1)
+                  _bn_vec(slot, enc, m3, "istd"), _ptr(slot.bstats, o3, 8), _ptr(slot.bstats, tot + o3, 8), 2 * tot, 1,
+                  slot.zmax[s])
         d = layer(s, 2, m3, slot.Z[s][2], cnt, True, pooled=(slot.argmax[s], slot.dF[s], r["grp"]), row_w=_ptr(r["w"]))
         dx(dict(rows_kw, layer=3), d, m3, m2.n_out, epilogue=0, gout=_ptr(gbuf[0]), gout_pitch=m2.n_out,
            **prev_stats(m2, slot.Z[s][1]))

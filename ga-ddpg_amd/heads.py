@@ -65,14 +65,13 @@ class HeadSlot(object):
         self.g_feat = torch.empty(B, 512, **f32)
 
 
-def _feat_input(enc, eslot, time, bn=None):
+def _feat_input(enc, eslot, time):
     """heads' layer-1 input: [relu(bn(Zfc2)) (512), time, 1]; a plain feature tensor (runtime._FeatureSource:
-    `input_relu` 0, identity scale / shift) is taken as it is.  bn: engine.bn_fin(...) of the encoder's last BatchNorm
-    when this GEMM is its (first) consumer -- the statistics are then finalised in this kernel's prologue."""
+    `input_relu` 0, identity scale / shift) is taken as it is."""
     fc2 = enc.fc_mats[1]
     return dict(n_rows=eslot.B, mode=0, zin=_ptr(eslot.Zfc[1]), zin_pitch=fc2.n_out, c_in=fc2.n_out,
                 scale=_bn_vec(eslot, enc, fc2, "scale"), shift=_bn_vec(eslot, enc, fc2, "shift"),
-                relu=getattr(enc, "input_relu", 1), extra=_ptr(time), ones_col=fc2.n_out + 1, in_bn=bn)
+                relu=getattr(enc, "input_relu", 1), extra=_ptr(time), ones_col=fc2.n_out + 1)
 
 
 def _hidden_input(B, z, pitch, hidden, offs):
@@ -80,13 +79,13 @@ def _hidden_input(B, z, pitch, hidden, offs):
                 zin_off=offs)
 
 
-def plan_critic_forward(cr, hs, enc, eslot, time, bn=None):
+def plan_critic_forward(cr, hs, enc, eslot, time):
     plan = Plan()
     B, H, ng = hs.B, cr.hidden, cr.ng
     fl = cr.flat
     offs = [i * H for i in range(ng)]
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=fl.p_w(cr.l1[0]), Kp=cr.l1[0].Kp, n_out=[cr.width], zout=_ptr(hs.Z1),
-                                               zout_pitch=cr.width, **_feat_input(enc, eslot, time, bn)))
+                                               zout_pitch=cr.width, **_feat_input(enc, eslot, time)))
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=_ptr(fl.packed), Kp=cr.l2[0].Kp, n_groups=ng,
                                                w_off=[m.w_off for m in cr.l2], n_out=[H] * ng, out_off=offs,
                                                zout=_ptr(hs.Z2), zout_pitch=cr.width,
@@ -176,14 +175,14 @@ class _Cat(object):
             assert b.w_off == a.w_off + a.n_out * a.Kp and a.Kp == b.Kp
 
 
-def plan_policy_forward(po, hs, enc, eslot, time, with_log_std=False, bn=None):
+def plan_policy_forward(po, hs, enc, eslot, time, with_log_std=False):
     """hs.out (B, 6 + extra) = [mean | extra]; with_log_std: (B, 6 + extra + 6) = [mean | extra | log_std] (the
     three output matrices are consecutive in the packed layout: one GEMM either way)"""
     plan = Plan()
     B, H = hs.B, po.hidden
     fl = po.flat
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=fl.p_w(po.l1), Kp=po.l1.Kp, n_out=[H], zout=_ptr(hs.Z1), zout_pitch=H,
-                                               **_feat_input(enc, eslot, time, bn)))
+                                               **_feat_input(enc, eslot, time)))
     plan.call_struct("gad_gemm_fwd", _fwd_args(W=fl.p_w(po.l2), Kp=po.l2.Kp, n_out=[H], zout=_ptr(hs.Z2), zout_pitch=H,
                                                **_hidden_input(B, hs.Z1, H, H, [0])))
     cat = _Cat([po.mean, po.extra] + ([po.log_std] if with_log_std else []))

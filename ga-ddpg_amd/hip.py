@@ -14,17 +14,6 @@ STAT_REPLICAS = 8
 _i32, _f32, _f64, _vp = C.c_int32, C.c_float, C.c_double, C.c_void_p
 
 
-class BnFin(C.Structure):
-    _fields_ = [("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32), ("count", _f64), ("gamma", _vp), ("beta", _vp),
-                ("eps", _f32), ("momentum", _f32), ("running_mean", _vp), ("running_var", _vp), ("scale", _vp),
-                ("shift", _vp), ("mean", _vp), ("istd", _vp)]
-
-
-class BnBwd(C.Structure):
-    _fields_ = [("dbeta", _vp), ("dgamma", _vp), ("stat_stride", _i32), ("count", _f64), ("mean", _vp), ("istd", _vp),
-                ("gacc_gamma", _vp), ("gacc_beta", _vp), ("accumulate", _i32)]
-
-
 class GemmFwdArgs(C.Structure):
     _fields_ = [("n_rows_dev", _vp), ("n_rows", _i32), ("row_w", _vp), ("mode", _i32),
                 ("zin", _vp), ("zin_pitch", _i32), ("c_in", _i32), ("scale", _vp), ("shift", _vp),
@@ -35,14 +24,15 @@ class GemmFwdArgs(C.Structure):
                 ("n_groups", _i32), ("zin_off", _i32 * MAX_GROUPS), ("w_off", _i32 * MAX_GROUPS),
                 ("out_off", _i32 * MAX_GROUPS), ("n_out", _i32 * MAX_GROUPS),
                 ("W", _vp), ("Kp", _i32), ("zout", _vp), ("zout_pitch", _i32),
-                ("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32), ("in_bn", BnFin)]
+                ("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32),
+                ("pool_key", _vp), ("pool_row_grp", _vp), ("pool_gamma", _vp)]
 
 
 class DzSrc(C.Structure):
     _fields_ = [("z", _vp), ("z_pitch", _i32), ("scale", _vp), ("shift", _vp), ("relu", _i32),
                 ("coefP", _vp), ("coefQ", _vp), ("coefS", _vp), ("row_w", _vp), ("gmode", _i32),
                 ("G", _vp), ("g_pitch", _i32), ("argmax", _vp), ("dout", _vp), ("row_grp", _vp),
-                ("c", _i32), ("bn", BnBwd), ("premasked", _i32)]
+                ("c", _i32), ("premasked", _i32)]
 
 
 class GemmDxArgs(C.Structure):
@@ -95,7 +85,7 @@ EXPORTS = (
     "gad_abi_version", "gad_last_error", "gad_set_option", "gad_timing_slot", "gad_wall_clock_khz", "gad_grid_rows_hint", "gad_bn_running_update", "gad_replay_gather", "gad_zero_buffers", "gad_furthest_point_sampling", "gad_gather_points",
     "gad_gather_points_grad", "gad_ball_query", "gad_group_points", "gad_group_points_grad",
     "gad_query_and_group", "gad_prep_points", "gad_rows_from_ball_query", "gad_rows_group_all",
-    "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_affine_act",
+    "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_pool_finalize", "gad_affine_act",
     "gad_pool_bwd_stats", "gad_bn_bwd_coef", "gad_gemm_dx", "gad_gemm_dw", "gad_critic_loss",
     "gad_policy_outputs", "gad_policy_sample", "gad_actor_loss", "gad_actor_critic_loss", "gad_mask_counts", "gad_target_noise",
     "gad_grad_from_arena", "gad_sumsq", "gad_absmax_segments", "gad_adam_step", "gad_polyak",

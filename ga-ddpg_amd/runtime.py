@@ -18,30 +18,13 @@ BATCH_KEYS = ("point_state_batch", "next_point_state_batch", "action_batch", "ex
 
 
 OVERLAP_PASSES = True      # run independent encoder passes of the DDPG step on side streams
-# Replay the DDPG step from a HIP graph (torch.cuda.CUDAGraph over the multi-stream schedule): the ~330 launches of a step
-# cost the host 1.9 - 2.7 ms to enqueue, and on steps without the actor-critic term the critic backward -- the critical
-# chain -- used to start 0.4 - 0.6 ms late because the host was still enqueueing the actor pass (tests/diag_phases.py).
-# A graph is captured per (policy step?, hard target update?, noise level, mix ratio, batch source) on the second step that
-# needs it; per-step scalars (Adam bias corrections, learning rates) travel through pinned blocks that graph nodes read.
-# MEASURED (MI355X, ROCm 7.2, profiles/README.md round 2): replay == eager within noise (269 - 274 vs 276 steps/s) -- with
-# the enqueue order of round 1 the step is GPU-bound, and hipStreamEndCapture crashes on forks taken from a forked stream,
-# so the captured non-policy actor pass runs its dW GEMMs in line.  Supported and tested (GAD_GRAPH=1), off by default.
 import os as _os
-GRAPHS = _os.environ.get("GAD_GRAPH", "0") == "1"
-# 1: start the actor phase's policy forward right after the geometry, beside t1 and the value pass (three forward passes
-# share the GPU; its BatchNorm running-statistics update is deferred until t1's is in: reference order); 0: after t1.
-# MEASURED with the stream -> hardware-queue assignment under control (engine._PHYS): 0 is 5 % faster (286 vs 272 steps/s, same
-# box, 3 runs each); the +2 % that 1 showed earlier in the round came with an accidental queue sharing.
-EARLY_ACTOR = _os.environ.get("GAD_EARLY_ACTOR", "0") == "1"
-# 1: the next step's value pass may start under this step's actor backward (its weights are final after the critic's Adam
-# step).  MEASURED: 286.4 vs 287.5 steps/s with the prefetch on the same lane, 288.3 vs 287.2 otherwise -- no gain: the
-# actor backward + its dW lane already fill the GPU and the step is bound by the sum of its kernels' own durations.  Off.
-EARLY_VALUE = _os.environ.get("GAD_EARLY_VALUE", "0") == "1"
-# (measured and removed, same box, 287-288 steps/s for the schedule below: the actor pass after t2, i.e. beside the critic
-# backward only: 275; the value pass after t1, beside t2 and the actor pass: 282; both side passes swapped: 278)
+# (measured and removed, same box, 287-288 steps/s for the schedule below: HIP-graph replay of the step 240; the actor pass
+# started beside t1 272; the next step's value pass under this step's actor backward: no gain; the actor pass after t2, i.e.
+# beside the critic backward only: 275; the value pass after t1, beside t2 and the actor pass: 282; both side passes
+# swapped: 278 -- profiles/README.md round 2)
 ROW_HINTS = _os.environ.get("GAD_ROW_HINTS", "1") == "1"     # grids of the SA1 / SA2 tile launches sized for the expected live rows
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
-GRAPH_EAGER_FIRST = True   # the first step of a signature runs eagerly (lazy workspaces, kernel attributes), the second captures
 
 
 def _dev_f32(x, dev):
@@ -170,11 +153,7 @@ class FusedRuntime(object):
         self._ev_counts = torch.cuda.Event()
         self._ev_in = torch.cuda.Event()
         self._ev_pre = torch.cuda.Event()
-        self._ev_vfree = None
         self.noise_host = self._noise_ring[0]
-        self._graphs = {}                # step signature -> torch.cuda.CUDAGraph (None: seen once, capture on the next use)
-        self._prestaged = None           # "host" | "dev": the step's inputs were staged before the enqueue (graph mode)
-        self.graph_replays = 0
 
     # ------------------------------------------------------------------ plans over static buffers
     def enable_bucketed_reduce(self):
@@ -234,16 +213,8 @@ class FusedRuntime(object):
         d = self.dbuf
         enc, pol = self.enc, self.pol
         P = self.plans = {}
-        P["geo"] = None
-        def last_bn(e, slot, update_running=True):
-            """engine.DEFER_BN: the encoder's last BatchNorm is finalised by the head's first GEMM (its consumer)"""
-            return engine.bn_fin(e, slot, e.fc_mats[1], float(self.B), update_running) if engine.DEFER_BN else None
-        fl = not engine.DEFER_BN                                   # explicit gad_bn_finalize for fc[1] otherwise
-        early = EARLY_ACTOR and OVERLAP_PASSES and self.has_critic
-        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None, finalize_last=fl, update_running=not early)
-        P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"],
-                                                    bn=last_bn(enc, self.slot_p, not early)))
-        P["p_run"] = engine.plan_running_update(enc, self.slot_p) if early else None
+        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None)
+        P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
         bw = Plan()
         bw.zero_multi([pol.flat.gacc, enc.flat.gacc, self.slot_p.bstats, self.slot_p.dF[0], self.slot_p.dF[1]])
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
@@ -254,16 +225,14 @@ class FusedRuntime(object):
         if not self.has_critic:
             return
         venc, cr = self.venc, self.cr
-        c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"], finalize_last=fl)
-        c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"], bn=last_bn(venc, self.slot_v)))
-        t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None, finalize_last=fl)
-        t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"], bn=last_bn(enc, self.slot_t)))
+        c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"])
+        c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
+        t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
         t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.pi_t, None)
-        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES,
-                                         finalize_last=fl)
+        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES)
         P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
-        t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"],
-                                            bn=last_bn(venc, self.slot_t, not OVERLAP_PASSES)))
+        t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
         P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
         cb = Plan()
         cb.zero_multi([cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1]])
@@ -273,8 +242,8 @@ class FusedRuntime(object):
         self._grad_tail(cb, cr, venc, "c", True)
         P["c_bwd"] = cb
         # actor-critic term: Q(s, pi(s)) through the freshly updated critic, gradient back to pi
-        v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi, finalize_last=fl)
-        v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"], bn=last_bn(venc, self.slot_v)))
+        v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi)
+        v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
         P["v_fwd"] = v
         vb = Plan()
         vb.zero_multi([cr.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.slot_v.daction])
@@ -327,8 +296,7 @@ class FusedRuntime(object):
         flat.set_adam_hyper(g["lr"], g["betas"], g["eps"], g["weight_decay"], upload=False)
 
     def _adam(self, flat, optim, clip=None):
-        if self._prestaged is None:
-            self._adam_host(flat, optim)
+        self._adam_host(flat, optim)
         flat.hyper.copy_(flat.hyper_host, non_blocking=True)
         hip.call("gad_adam_step", flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq, flat.active, flat.m2p,
                  flat.packed, flat.n, flat.hyper, clip, float(self.agent.clip_grad) if clip is not None else 0.0)
@@ -412,90 +380,19 @@ class FusedRuntime(object):
         torch.cuda.current_stream().synchronize()
 
     def ddpg_step(self, batch, noise_u=None, sync=True):
-        """one DDPG / TD3 update: eager multi-stream enqueue, or -- GRAPHS, single process, no per-launch timing -- the
-        same enqueue captured once per step signature into a HIP graph and replayed.
+        """one DDPG / TD3 update: eager multi-stream enqueue.
         sync=False: return a PendingStep right after the enqueue.  The host then prepares and enqueues the next step while
         this one runs (up to engine.HOST_RING - 1 steps ahead): the ~2 ms of launch calls, the uploads and the geometry of
         step N+1 no longer sit in front of its critical chain, they are queued behind step N on the GPU."""
         ag = self.agent
         policy_step = ag.update_step % ag.policy_update_gap == 0
-        use_graph = (GRAPHS and OVERLAP_PASSES and self.dp is None and not engine.SERIAL and not engine.TIMING["enabled"]
-                     and batch is not None)
-        if not use_graph:
-            slot = self._begin_step(alternate=True)
-            self._prestaged = None
-            self._ddpg_enqueue(batch, noise_u, policy_step)
-            return self._end_step(slot, sync)
-        slot = self._begin_step(0)           # the captured copy nodes read the pinned blocks of set 0
-        sync = True
-        # ---- everything the host contributes to this step, before a single launch: inputs, noise draw, Adam scalars
-        kind = self._stage_inputs(batch)
-        if noise_u is not None:
-            np.copyto(self.noise_host.numpy(), np.asarray(noise_u, dtype=np.float32).reshape(self.B, 6))
-        self._adam_host(self.venc.flat, ag.state_feat_val_encoder_optim)
-        self._adam_host(self.cr.flat, ag.critic_optim)
-        self._adam_host(self.pol.flat, ag.policy_optim)
-        if ag.train_feature:
-            self._adam_host(self.enc.flat, ag.state_feat_encoder_optim)
-        idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
-        key = (policy_step, int(ag.update_step % ag.target_update_interval == 0), idx, float(ag.mix_policy_ratio),
-               getattr(ag, "noise_type", "uniform"), noise_u is not None, kind, bool(ag.train_feature))
-        self._prestaged = kind
-        try:
-            g = self._graphs.get(key, False)
-            if g is False and GRAPH_EAGER_FIRST:  # first step with this signature: eager (lazy allocations, attribute calls)
-                self._graphs[key] = None
-                self._ddpg_enqueue(batch, noise_u, policy_step)
-            else:
-                if g is None or g is False:
-                    g = torch.cuda.CUDAGraph()
-                    cur = torch.cuda.current_stream()
-                    cap = engine.side_stream(which=9)
-                    cap.wait_stream(cur)
-                    with torch.cuda.graph(g, stream=cap, capture_error_mode="thread_local"):
-                        self._ddpg_enqueue(batch, noise_u, policy_step)
-                    cur.wait_stream(cap)
-                    self._graphs[key] = g
-                g.replay()
-                self.graph_replays += 1
-        finally:
-            self._prestaged = None
+        slot = self._begin_step(alternate=True)
+        self._ddpg_enqueue(batch, noise_u, policy_step)
         return self._end_step(slot, sync)
 
-    def _stage_inputs(self, batch):
-        """graph mode: put the minibatch where the captured step reads it.  Host dict -> the pinned staging buffers (the
-        graph's copy nodes move them to the device); device-resident dict / replay-gather handle -> straight into the
-        static device buffers, eagerly on the current stream, ahead of the replay."""
-        if "replay_gather" in batch or torch.is_tensor(batch["point_state_batch"]):
-            self.upload(batch)
-            return "dev"
-        B = self.B
-        for k in BATCH_KEYS:
-            if k not in batch:
-                continue
-            a = np.asarray(batch[k])
-            if a.shape[0] != B:
-                raise RuntimeError("batch size changed: runtime was built for B=%d, got %d" % (B, a.shape[0]))
-            h = self.hbuf[k]
-            np.copyto(h.numpy(), a.reshape(h.shape), casting="same_kind")
-        np.subtract(self.hbuf["time_batch"].numpy(), 1.0, out=self.hbuf["time_m1"].numpy())
-        return "host"
-
-    def _copy_in(self, batch, keys):
-        """the enqueue's view of the upload: staged already (graph mode: pinned -> device copies only, or nothing for
-        device-resident batches), or the eager staged upload"""
-        if self._prestaged is None:
-            return self.upload(batch, keys)
-        if self._prestaged == "host":
-            for k in (BATCH_KEYS if keys is None else keys):
-                if k in batch:
-                    self.dbuf[k].copy_(self.hbuf[k], non_blocking=True)
-                    if k == "time_batch":
-                        self.dbuf["time_m1"].copy_(self.hbuf["time_m1"], non_blocking=True)
-
     def _ddpg_enqueue(self, batch, noise_u, policy_step):
-        """enqueue one update step on the current stream + the side streams (no host synchronisation inside: this is
-        what a graph capture records); ends with the 32-float result block on its way to the pinned host buffer"""
+        """enqueue one update step on the current stream + the side streams (no host synchronisation inside); ends with the
+        32-float result block on its way to the pinned host buffer"""
         ag, d, P = self.agent, self.dbuf, self.plans
         B = self.B
         ratio = float(ag.mix_policy_ratio)
@@ -503,7 +400,7 @@ class FusedRuntime(object):
         # uploads + geometry of both cloud sets on the prefetch stream, into this step's input / geometry set: ordered only
         # after the last step that used the set, i.e. they run beside the previous step when the host is ahead of the GPU
         st = self._sets[self._set]
-        inline = (not OVERLAP_PASSES) or engine.SERIAL or torch.cuda.is_current_stream_capturing()
+        inline = (not OVERLAP_PASSES) or engine.SERIAL
         spre = main if inline else engine.side_stream(which=20)
         spre2 = main if inline else engine.side_stream(which=21)
         if not inline:
@@ -522,7 +419,7 @@ class FusedRuntime(object):
         whole = batch is not None and "replay_gather" in batch          # one gather launch fills every buffer
         first = ("next_point_state_batch", "time_batch")
         with torch.cuda.stream(spre):
-            self._copy_in(batch, None if whole else first)
+            self.upload(batch, None if whole else first)
             st["ev_in"].record(spre)
             self.geo_next.run(d["next_point_state_batch"])      # the target chain (the critical path) needs this one first
             st["ev_gn"].record(spre)
@@ -533,7 +430,7 @@ class FusedRuntime(object):
             spre2.wait_event(st["ev_in"])
         with torch.cuda.stream(spre2):
             if not whole:
-                self._copy_in(batch, tuple(k for k in BATCH_KEYS if k not in first))
+                self.upload(batch, tuple(k for k in BATCH_KEYS if k not in first))
                 if not inline:
                     spre2.wait_event(st["ev_in"])
             st["ev_up"].record(spre2)                           # every input of the step has left the caller's buffers
@@ -555,8 +452,6 @@ class FusedRuntime(object):
                     self.noise_u.normal_()                              # torch.randn_like (core/utils.py:573)
                 else:
                     self.noise_u.uniform_(0.0, 1.0)                     # torch.rand_like (core/utils.py:575)
-            elif self._prestaged is not None:
-                self.noise_u.copy_(self.noise_host, non_blocking=True)  # staged in the pinned block by ddpg_step
             else:
                 self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
             self.scal.zero_()
@@ -570,8 +465,7 @@ class FusedRuntime(object):
                      d["return_batch"], d["goal_batch"], B, self.pol.n_heads, 1.0 - ratio, int(bool(ag.policy_aux)),
                      self.action_scale, g_pi,
                      self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
-            # under graph capture the non-policy actor tail runs on a forked stream: no nested dW forks there
-            P["p_bwd"].run(inline=(g_pi is None and OVERLAP_PASSES and torch.cuda.is_current_stream_capturing()))
+            P["p_bwd"].run()
             self._reduce([self.pol.flat, self.enc.flat], "a")
             self._adam(self.pol.flat, ag.policy_optim)
             if ag.train_feature:
@@ -595,11 +489,7 @@ class FusedRuntime(object):
                     self.dp.set_counts(batch)
                 self._ev_counts.record(sc)
             main.wait_event(self._ev_counts)
-            # the value pass needs the critic / value-encoder weights (final after the previous step's critic Adam) and the
-            # value activation scratch (free after that step's last backward over it): with the host ahead of the GPU it
-            # starts under the previous step's actor backward, which alone cannot fill the GPU
-            early = EARLY_VALUE and self._ev_vfree is not None and not torch.cuda.is_current_stream_capturing()
-            s1.wait_event(self._ev_vfree if early else self._ev[0])
+            s1.wait_event(self._ev[0])
             s1.wait_event(st["ev_g"])
             with torch.cuda.stream(s1):
                 P["c_fwd"].run()
@@ -621,16 +511,12 @@ class FusedRuntime(object):
         hip.call("gad_target_noise", self.pi_t, self.noise_u, B, float(level), int(normal_noise), self.a_next)
         P["t2"].run()
         if OVERLAP_PASSES:
-            if P["p_run"] is None:
-                s2.wait_event(self._ev[2])
+            s2.wait_event(self._ev[2])
             s2.wait_event(self._ev[0])
             s2.wait_event(st["ev_g"])
             with torch.cuda.stream(s2):
                 P["p_fwd"].run()
                 self._policy_outputs()
-                if P["p_run"] is not None:                  # the encoder's running statistics: t1's update first
-                    s2.wait_event(self._ev[2])
-                    P["p_run"].run()
                 if not policy_step:
                     actor_tail(None)
         if OVERLAP_PASSES:
@@ -646,8 +532,6 @@ class FusedRuntime(object):
         hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
         self._adam(self.venc.flat, ag.state_feat_val_encoder_optim)
         self._adam(self.cr.flat, ag.critic_optim, clip=self.clip_sumsq)
-        if not policy_step and OVERLAP_PASSES:
-            self._mark_value_free(main)
         # ---- actor phase
         if OVERLAP_PASSES:
             self._ev[3].record(s2)
@@ -660,8 +544,6 @@ class FusedRuntime(object):
             hip.call("gad_actor_critic_loss", self.hs_cpi.out, d["expert_flag_batch"], d["return_batch"], B, ratio,
                      self.inv_n_actor_critic(), self.hs_cpi.g_out, engine._ptr(self.scal, 8))
             P["v_bwd"].run()
-            if OVERLAP_PASSES:
-                self._mark_value_free(main)
             actor_tail(self.slot_v.daction)
         elif not OVERLAP_PASSES:
             actor_tail(None)
@@ -670,16 +552,6 @@ class FusedRuntime(object):
         self.enc.bump_batches_tracked(2)
         self.venc.bump_batches_tracked(3 if policy_step else 2)
         self._download(sync=False)
-
-    def _mark_value_free(self, stream):
-        """from here on this step neither writes the critic / value-encoder weights nor touches the value pass's activation
-        scratch and head slot: the NEXT step's value pass may start (ddpg_step: EARLY_VALUE)"""
-        if torch.cuda.is_current_stream_capturing():        # (graph replay: the next step orders itself after the whole graph)
-            self._ev_vfree = None
-            return
-        if self._ev_vfree is None:
-            self._ev_vfree = torch.cuda.Event()
-        self._ev_vfree.record(stream)
 
     def bc_step(self, batch):
         ag, d, P = self.agent, self.dbuf, self.plans
@@ -696,7 +568,7 @@ class FusedRuntime(object):
                  d["return_batch"], d["goal_batch"], B, self.pol.n_heads, 1.0, int(bool(ag.policy_aux)), self.action_scale, None,
                  self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
         P["p_bwd"].run()
-        self._reduce([self.pol.flat, self.enc.flat])
+        self._reduce([self.pol.flat, self.enc.flat], "a")      # (bucketed: the early bucket left from the plan's hook)
         self._adam(self.pol.flat, ag.policy_optim)
         if ag.train_feature:
             self._adam(self.enc.flat, ag.state_feat_encoder_optim)
@@ -810,7 +682,7 @@ def feature_forward(fe, pc, value=False):
                               engine.SAConfig(32, 0.04, 128), dev)
         slot = engine.EncoderSlot(geo, encs[False], dev, with_backward=False)
         act = torch.zeros(B, 6, device=dev)
-        plans = {(v, t): engine.plan_encoder_forward(encs[v], slot, action=act if v else None, train=t, finalize_last=True)
+        plans = {(v, t): engine.plan_encoder_forward(encs[v], slot, action=act if v else None, train=t)
                  for v in (False, True) for t in (False, True)}
         return dict(geo=geo, slot=slot, action=act, out=torch.empty(B, 512, device=dev), plans=plans)
     rt = _module_runtime(fe, ("shape", B, NP), build_b)

@@ -126,13 +126,11 @@ class _StageRun(object):
         for l, m in enumerate(net.mats):
             o = net.bn_off[l]
             kw = self._input(net, mod, l)
-            if train and l > 0 and engine.DEFER_BN:      # the previous layer's BatchNorm finalised in this GEMM's prologue
-                kw["in_bn"] = engine.bn_fin(net, self, net.mats[l - 1], self.count)
             a = _fwd_args(W=net.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(self.Z[l]), zout_pitch=m.n_out,
                           stat_sum=_ptr(self.stats, o, 8) if train else None,
                           stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot, **kw)
             plan.call_struct("gad_gemm_fwd", a)
-            if train and not engine.DEFER_BN:
+            if train:
                 plan.call("gad_bn_finalize", _ptr(self.stats, o, 8), _ptr(self.stats, tot + o, 8), 2 * tot,
                           net.flat.p_gamma(m), net.flat.p_beta(m), m.n_out, hip.Dbl(self.count), BN_EPS, BN_MOMENTUM,
                           _ptr(net.running_mean, o), _ptr(net.running_var, o), _ptr(self.scale, o), _ptr(self.shift, o),
@@ -142,9 +140,10 @@ class _StageRun(object):
                           _ptr(net.running_var, o), m.n_out, BN_EPS, _ptr(self.scale, o), _ptr(self.shift, o))
         m = net.mats[2]
         o = net.bn_off[2]
-        b = engine.bn_fin(net, self, m, self.count) if (train and engine.DEFER_BN) else None
+        # the stand-alone module keeps the separate segment max-pool operator (gad_segment_pool: exactly torch's "first
+        # maximal activation" arg-max); the fused update step folds the pool into the GEMM epilogue (engine.plan_encoder_forward)
         plan.call("gad_segment_pool", self.Z[2], m.n_out, m.n_out, _ptr(self.scale, o), _ptr(self.shift, o),
-                  C.byref(b) if b is not None else None, r["off"], r["G"], self.F, self.argmax)
+                  r["off"], r["G"], self.F, self.argmax)
         return plan
 
     def _plan_backward(self, net):
@@ -163,15 +162,12 @@ class _StageRun(object):
         def bn_dz(m, o, z, accumulate, G=None, pooled=False):
             d = dict(z=_ptr(z), z_pitch=m.n_out, scale=vec("scale", o), shift=vec("shift", o), relu=1, premasked=1,
                      row_w=_ptr(r["w"]), c=m.n_out)
-            if engine.DEFER_BN:
-                d["bn"] = engine.bn_bwd(net, self, m, self.count, True, accumulate)
-            else:
-                if not accumulate:            # first use of the layer's coefficients (the dW precedes the dX below)
-                    plan.call("gad_bn_bwd_coef", _ptr(self.bstats, o, 8), _ptr(self.bstats, tot + o, 8), 2 * tot,
-                              vec("scale", o), vec("mean", o), vec("istd", o), m.n_out, hip.Dbl(self.count),
-                              _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o),
-                              _ptr(fl.gacc, m.g_off, 8), _ptr(fl.gacc, m.b_off, 8))
-                d["coefP"], d["coefQ"], d["coefS"] = _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o)
+            if not accumulate:            # first use of the layer's coefficients (the dW precedes the dX below)
+                plan.call("gad_bn_bwd_coef", _ptr(self.bstats, o, 8), _ptr(self.bstats, tot + o, 8), 2 * tot,
+                          vec("scale", o), vec("mean", o), vec("istd", o), m.n_out, hip.Dbl(self.count),
+                          _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o),
+                          _ptr(fl.gacc, m.g_off, 8), _ptr(fl.gacc, m.b_off, 8))
+            d["coefP"], d["coefQ"], d["coefS"] = _ptr(self.coef, o), _ptr(self.coef, tot + o), _ptr(self.coef, 2 * tot + o)
             if pooled:
                 d.update(gmode=1, argmax=_ptr(self.argmax), dout=_ptr(self.dF), row_grp=_ptr(r["grp"]))
             else:
@@ -206,10 +202,10 @@ class _StageRun(object):
                         prev_mean=vec("mean", po), prev_istd=vec("istd", po), prev_dbeta=_ptr(self.bstats, po, 8),
                         prev_dgamma=_ptr(self.bstats, tot + po, 8), stat_stride=2 * tot, store_masked=1)
 
-        # no BatchNorm launches: P, Q, S are formed in the dX / dW prologues (gad_bn_bwd), gradients travel ReLU-masked
+        # gradients travel ReLU-masked between the layers (store_masked / premasked)
         plan.call("gad_pool_bwd_stats", self.dF, self.argmax, r["G"], m3.n_out, self.Z[2], m3.n_out, vec("scale", o3),
                   vec("shift", o3), vec("mean", o3), vec("istd", o3), _ptr(self.bstats, o3, 8),
-                  _ptr(self.bstats, tot + o3, 8), 2 * tot, 1)
+                  _ptr(self.bstats, tot + o3, 8), 2 * tot, 1, None)
         dw(2, bn_dz(m3, o3, self.Z[2], False, pooled=True), m3)
         dx(bn_dz(m3, o3, self.Z[2], True, pooled=True), m3, m2.n_out, epilogue=0, gout=_ptr(self.G[0]), gout_pitch=m2.n_out,
            **prev_stats(m2, o2, self.Z[1]))

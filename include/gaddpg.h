@@ -37,8 +37,10 @@ typedef enum {
 
 int gad_abi_version(void);                 /* bumped on any signature change or new entry point (2: gad_set_option,
                                             * gad_bn_running_update, gad_replay_gather; 3: head pitch in gad_policy_outputs /
-                                            * gad_actor_loss, noise type in gad_target_noise, gad_policy_sample, the
-                                            * fused BatchNorm finalisation fields, gad_segment_pool via wave shuffles) */
+                                            * gad_actor_loss, noise type in gad_target_noise, gad_policy_sample;
+                                            * 4: max-pool fused into the pooled layer's GEMM (pool_key fields, nullable
+                                            * zout, gad_pool_finalize, zmax in gad_pool_bwd_stats); the deferred-BatchNorm
+                                            * fields and the slab / graph switches of version 3 are gone)              */
 const char* gad_last_error(void);          /* thread-local description of the last <0   */
 /* Kernel-selection switches for A/B diagnostics (defaults in brackets).  "fwd_stream" [1]: route the wide and
  * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route
@@ -130,43 +132,6 @@ int gad_rows_group_all(int G, int pts_per_group, int32_t* grp_off, int32_t* row_
  * same-address atomic contention); gad_bn_finalize / gad_bn_bwd_coef sum the replicas.               */
 #define GAD_STAT_REPLICAS 8
 
-/* Deferred train-mode BatchNorm finalisation: a layer's consumer (the next GEMM, the segment pool, a head's first
- * GEMM) turns the f64 statistics of the producing GEMM into the per-channel affine in its own prologue -- every
- * workgroup for the channels it needs, identical arithmetic to gad_bn_finalize -- instead of a single-workgroup launch
- * on the dependency chain between the two kernels.  Workgroup 0 also publishes scale / shift / mean / istd (read by the
- * backward pass, a later launch) and applies the running-statistics momentum update.  stat_sum == NULL: not used.   */
-typedef struct {
-    const double* stat_sum;    /* (GAD_STAT_REPLICAS, stat_stride) accumulators, this layer's first channel      */
-    const double* stat_sq;
-    int32_t stat_stride;
-    double count;              /* rows behind the statistics (padded duplicates included)                       */
-    const float* gamma;
-    const float* beta;
-    float eps;
-    float momentum;
-    float* running_mean;       /* nullable (pass overlapped with another pass of the same network)              */
-    float* running_var;
-    float* scale;              /* outputs, written by workgroup 0: scale = gamma*istd, shift = beta - mean*scale */
-    float* shift;
-    float* mean;               /* nullable */
-    float* istd;               /* nullable */
-} gad_bn_fin;
-
-/* Deferred BatchNorm-backward coefficients: the dX / dW kernels of a layer form P, Q, S (gad_bn_bwd_coef) from the
- * f64 sums (dbeta, dgamma) in their prologue.  `accumulate`: workgroup 0 of THIS launch also adds dgamma / dbeta to
- * the gradient arena (set on exactly one consumer per layer).  dbeta == NULL: not used (coefP/Q/S as given).     */
-typedef struct {
-    const double* dbeta;       /* (GAD_STAT_REPLICAS, stat_stride)                                              */
-    const double* dgamma;
-    int32_t stat_stride;
-    double count;
-    const float* mean;         /* saved by the forward pass                                                     */
-    const float* istd;
-    double* gacc_gamma;        /* nullable                                                                      */
-    double* gacc_beta;
-    int32_t accumulate;
-} gad_bn_bwd;
-
 typedef struct {
     /* rows */
     const int32_t* n_rows_dev; /* device scalar with the live row count, or NULL -> n_rows       */
@@ -204,13 +169,18 @@ typedef struct {
     const float* W;
     int32_t Kp;
     /* outputs */
-    float* zout;               /* (rows, zout_pitch) raw pre-activation output (bias included)   */
+    float* zout;               /* (rows, zout_pitch) raw pre-activation output (bias included); nullable when the max-pool
+                                * is fused (pool_key): a pass that is never back-propagated keeps only the pooled maxima */
     int32_t zout_pitch;
     double* stat_sum;          /* per output channel sum_r w*z and sum_r w*z^2 (f64 atomics),    */
     double* stat_sq;           /*   NULL -> no statistics                                        */
     int32_t stat_stride;       /* elements between the GAD_STAT_REPLICAS replicas of the sums     */
-    gad_bn_fin in_bn;          /* ACT input: finalise the input layer's BatchNorm here (scale/shift above are then
-                                * ignored; in_bn.scale / .shift receive the affine).  One group only.          */
+    /* segment max-pool fused into the epilogue (the pooled layer of a set-abstraction stage): per (group, channel) the
+     * packed maximum of sgn(gamma) * z over the group's rows, finished by gad_pool_finalize (which also resets the keys).
+     * One group, n_out a multiple of 64, rows a multiple of 4.  pool_key == NULL: not used.                            */
+    uint64_t* pool_key;        /* (groups, n_out) keys, all 0 before the launch                   */
+    const int32_t* pool_row_grp; /* (rows) group index of every row (contiguous runs: CSR order)  */
+    const float* pool_gamma;   /* (n_out) BatchNorm weight of THIS layer                          */
 } gad_gemm_fwd_args;
 
 int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);
@@ -237,8 +207,19 @@ int gad_bn_eval_affine(const float* gamma, const float* beta, const float* runni
 /* segment max-pool over each group's rows of act(scale*z+shift): out (G,C) point-major,
  * argmax (G,C) = global row index of the first maximum.                                          */
 int gad_segment_pool(const float* z, int z_pitch, int C, const float* scale, const float* shift,
-                     const gad_bn_fin* host_bn /*nullable: finalise the layer's BatchNorm in the prologue*/,
                      const int32_t* grp_off, int G, float* out, int32_t* argmax, void* stream);
+
+/* Finish of the max-pool folded into the pooled layer's GEMM epilogue (gad_gemm_fwd_args.pool_key): finalises that
+ * layer's train-mode BatchNorm from its f64 statistics (stat_sum != NULL: same arithmetic and outputs as gad_bn_finalize;
+ * running_mean / running_var nullable) or takes scale / shift as given (stat_sum == NULL: eval mode), then per (group,
+ * channel): zmax = the winning raw value, out = relu(scale * zmax + shift), argmax = the winner's global row where
+ * out > 0, else the group's first row (grp_off[g]); the keys are reset to 0.  argmax / zmax nullable.
+ * Replaces upstream's F.max_pool2d over the nsample axis (reference call site core/networks.py:66-81).              */
+int gad_pool_finalize(uint64_t* key, int C, int G, const int32_t* grp_off, const double* stat_sum /*nullable*/,
+                      const double* stat_sq, int stat_stride, double count, const float* gamma, const float* beta,
+                      float eps, float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                      float* mean /*nullable*/, float* istd /*nullable*/, float* out, int32_t* argmax, float* zmax,
+                      void* stream);
 
 /* apply act(scale*z+shift) elementwise -> out (rows,C) (used at API boundaries only)            */
 int gad_affine_act(const float* z, int z_pitch, int rows, int C, const float* scale,
@@ -262,7 +243,6 @@ typedef struct {
     const float* dout;         /* pooled: (groups, C)                                            */
     const int32_t* row_grp;    /* pooled: (rows)                                                 */
     int32_t c;                 /* channels of this layer (n_out)                                 */
-    gad_bn_bwd bn;             /* deferred coefficients (coefP/Q/S ignored when bn.dbeta != NULL) */
     int32_t premasked;         /* the ReLU mask is already applied to G / dout (dX epilogue with store_masked,
                                 * gad_pool_bwd_stats with mask_in_place): `relu`, scale and shift are not needed   */
 } gad_dz_src;
@@ -270,10 +250,12 @@ typedef struct {
 /* pooled-gradient statistics for the BN that feeds a segment pool: dbeta/dgamma f64 sums        */
 /* mask_in_place != 0: dout[g][c] is also overwritten with its ReLU-masked value (0 where the arg-max row's
  * activation is not positive), so that the layer's dX / dW can take it as `premasked`.             */
+/* zmax (nullable): (G,C) raw value of every arg-max row as saved by gad_pool_finalize -- read instead of gathering
+ * z[argmax] (argmax / z may then be NULL).                                                          */
 int gad_pool_bwd_stats(float* dout, const int32_t* argmax, int G, int C, const float* z,
                        int z_pitch, const float* scale, const float* shift, const float* mean,
                        const float* istd, double* dbeta, double* dgamma, int stat_stride,
-                       int mask_in_place, void* stream);
+                       int mask_in_place, const float* zmax, void* stream);
 
 /* BN backward coefficients from (dbeta,dgamma): P,Q,S above; also accumulates dgamma/dbeta into
  * the f64 gradient arena slots gacc_gamma/gacc_beta (nullable).                                 */

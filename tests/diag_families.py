@@ -50,7 +50,7 @@ def probe(serial, n=6):
     return {k: 1e3 * float(np.mean(v)) for k, v in acc.items()}, {k: len(v) / n for k, v in acc.items()}
 
 
-configs = [dict(), dict(fwd_slab=1), dict(dx_slab=1), dict(dx_slab=2)]
+configs = [dict()]            # CONFIGS="fwd_stream=0;dx_stream=0,dw_stream=0": kernel-family switches (gad_set_option), default 1
 extra = os.environ.get("CONFIGS")
 if extra:
     configs = [dict()] + [dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in cfg.split(",")) for cfg in extra.split(";")]
@@ -58,18 +58,15 @@ for _ in range(6):
     step(sync=True)
 base = None
 for opts in configs:
-    for k in ("fwd_slab", "dx_slab", "fwd_tile", "dx_tile", "dw_tile", "dbg"):
-        try:
-            hip.set_option(k, opts.get(k, 0))
-        except Exception:
-            pass
+    for k in ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny"):
+        hip.set_option(k, opts.get(k, 1))
     for _ in range(4):
         step(sync=True)
     alone, cnt = probe(True)
     inside, _ = probe(False)
     r = rate()
     print("==== options", opts, " steps/s %.1f" % r)
-    tags = sorted(t for t in alone if any(t.startswith(p) for p in ("fwd.sa2", "fwd.sa3", "dx.sa2", "dx.sa3", "dw.sa2", "dw.sa3")))
+    tags = sorted(t for t in alone if any(t.startswith(p) for p in ("fwd.sa2", "fwd.sa3", "dx.sa2", "dx.sa3", "dw.sa2", "dw.sa3", "bwd.sa2", "bwd.sa3")))
     tot_a = tot_i = 0.0
     for t in tags:
         tot_a += alone[t] * cnt[t]

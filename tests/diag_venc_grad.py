@@ -5,10 +5,8 @@ import numpy as np, torch
 from tests.helpers import golden_batch, grad_accuracy_rows
 from tests.test_gpu_step import _filled_agent, SEED, SKIP
 
-def run(label, serial=False, early=None, opts=()):
+def run(label, serial=False, opts=()):
     from ga_ddpg_amd import engine, runtime, hip
-    if early is not None:
-        runtime.EARLY_ACTOR = early
     for k, v in opts:
         hip.set_option(k, v)
     engine.SERIAL = serial
@@ -27,7 +25,7 @@ def run(label, serial=False, early=None, opts=()):
     print("%-28s value_encoder: median of medians %.2e worst %.2e | encoder: %.2e worst %.2e" % (
         label, np.median([r[2] for r in ve]), max(r[2] for r in ve), np.median([r[2] for r in pe]), max(r[2] for r in pe)))
     for k, v in opts:
-        hip.set_option(k, 1 if k not in ("fwd_slab", "dx_slab") else 0)
+        hip.set_option(k, 1)
 
 if __name__ == "__main__":
     run("default")

@@ -160,3 +160,24 @@ def _compare_with_plain(a, b):
     assert float((a["pi"] - b["pi"]).abs().max()) <= 5e-2 * float(a["pi"].abs().max())   # after two Adam steps: sanity bound
     for n in a["state"]:
         assert bool(torch.isfinite(b["state"][n]).all()), n
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (the driver's invocation form, no launcher around it) starts two ranks itself and rank 0
+    prints ONE JSON line with n_gpus == 2.  gloo carries the tensors here: both ranks share the box's single GPU, which
+    RCCL refuses -- a plumbing check of the N > 1 path, not a measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, GAD_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                          "--batch", "32", "--buffer", "1500", "--probe-steps", "2", "--no-cpu-baseline", "--no-host-rate",
+                          "--no-sa-kernel"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 4 and res["scaling"] == "weak"
+    assert res["config"]["parallelism"] == "dp2" and res["config"]["global_batch"] == 64
+    assert res["value"] > 0 and np.isfinite(res["losses"]["critic_loss"])

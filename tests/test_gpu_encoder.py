@@ -35,7 +35,7 @@ def _geometry(B):
 
 def _run_encoder(enc, slot, action, probe, want_daction):
     from ga_ddpg_amd import engine, hip
-    engine.plan_encoder_forward(enc, slot, action=action, finalize_last=True).run()   # no head here: finalise fc[1] explicitly
+    engine.plan_encoder_forward(enc, slot, action=action).run()
     fc2 = enc.fc_mats[1]
     o = enc.bn_off[fc2.bn_index]
     sc, sh = slot.scale[o:o + 512], slot.shift[o:o + 512]

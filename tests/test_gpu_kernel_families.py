@@ -1,6 +1,8 @@
-"""Kernel families of the layer GEMMs against each other: the slab kernels of the mid-size layers (SA2 / SA3) and the
-64x64 tile kernels compute the same layers (gad_set_option switches the routing); both orders of summation must agree
-to float32 rounding on every activation, statistic and gradient of an encoder forward + backward."""
+"""Kernel families of the layer GEMMs against each other: the specialised kernels (streaming SA1 forward / dX / dW, skinny
+split-K kernels of the FC head) and the generic 64x64 tile kernels compute the same layers (gad_set_option switches the
+routing); both orders of summation must agree to float32 rounding on every activation, statistic and gradient of an
+encoder forward + backward.  Also here: the max-pool folded into the pooled layers' GEMM epilogue against the stand-alone
+segment max-pool operator on the same raw activations."""
 import numpy as np
 import pytest
 import torch
@@ -8,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(B, value, options):
+def _run(B, value, options, keep_slot=False):
     from ga_ddpg_amd import engine, hip
     from ga_ddpg_amd.core.replay_memory import BaseMemory
     from ga_ddpg_amd.experiments.config import load_cfg
@@ -38,12 +40,16 @@ def _run(B, value, options):
                 out["Z%d%d" % (s + 1, l + 1)] = slot.Z[s][l][:n[s]].clone()
             out["F%d" % (s + 1)] = slot.F[s].clone()
             out["dF%d" % (s + 1)] = slot.dF[s].clone()
+            out["A%d" % (s + 1)] = slot.argmax[s].clone()
+            out["zmax%d" % (s + 1)] = slot.zmax[s].clone()
         if value:
             out["daction"] = slot.daction.clone()
         out["rows"] = n
+        if keep_slot:
+            out.update(slot=slot, enc=enc, geo=geo)
     finally:
         for k in options:
-            hip.set_option(k, 0)                       # library defaults of the two slab switches
+            hip.set_option(k, 1)                       # library defaults of the family switches
     return out
 
 
@@ -58,22 +64,63 @@ def _compare(a, b, keys, tol, mtol, what):
     return bad
 
 
+FAMILIES = ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny")
+
+
 @pytest.mark.parametrize("value", [False, True])
-def test_slab_and_tile_kernels_agree(value):
-    """forward: slab vs tile kernels on identical inputs -> every activation, pooled feature and BatchNorm statistic agrees
-    to float32 summation-order rounding.  backward: with the SAME forward kernels (identical activations, hence identical
-    arg-max routing and ReLU masks) the slab dX kernels -- pooled-gradient source included -- reproduce the tile kernels'
+def test_specialised_and_tile_kernels_agree(value):
+    """forward: streaming / skinny kernels vs the tile kernels on identical inputs -> every activation, pooled feature and
+    BatchNorm statistic agrees to float32 summation-order rounding.  backward: with the SAME forward kernels (identical
+    activations, hence identical arg-max routing and ReLU masks) the specialised dX / dW kernels reproduce the tile kernels'
     gradients to rounding; across different forward kernels gradients may differ in the few entries whose max-pool /
     ReLU decision sits within rounding of a tie, so that pairing is only held to the norm-wise median."""
-    B = 96                                             # SA2 ~ 1e4 rows, SA3 3072 rows: both above the slab threshold
-    tile = _run(B, value, {"fwd_slab": 0, "dx_slab": 0})
-    fwd = _run(B, value, {"fwd_slab": 1, "dx_slab": 0})
-    dx = _run(B, value, {"fwd_slab": 0, "dx_slab": 2})
-    assert tile["rows"] == fwd["rows"] == dx["rows"] and tile["rows"][2] >= 2048
+    B = 96                                             # SA1 ~ 8e4 rows: above the streaming threshold
+    default = _run(B, value, {})
+    tile = _run(B, value, {k: 0 for k in FAMILIES})
+    fwd_tile = _run(B, value, {"fwd_stream": 0, "fwd_skinny": 0})
+    bwd_tile = _run(B, value, {k: 0 for k in FAMILIES if not k.startswith("fwd")})
+    assert default["rows"] == tile["rows"] == fwd_tile["rows"] and default["rows"][0] >= 32768
     acts = [k for k in tile if k[0] in "ZFzmir" and k != "rows"]
     grads = [k for k in tile if k not in acts and k != "rows"]
-    bad = _compare(fwd, tile, acts, 2e-5, 2e-6, "forward slab vs tile:")
-    bad += _compare(dx, tile, acts, 1e-6, 1e-7, "same forward kernels:")       # (BatchNorm sums: f64 atomics, order varies)
-    bad += _compare(dx, tile, grads, 2e-4, 1e-5, "dX slab vs tile:")
-    bad += _compare(fwd, tile, grads, 1.0, 2e-4, "forward slab vs tile (gradients, median):")
+    bad = _compare(fwd_tile, default, acts, 2e-5, 2e-6, "forward tile vs specialised:")
+    bad += _compare(bwd_tile, default, acts, 1e-6, 1e-7, "same forward kernels:")       # (BatchNorm sums: f64 atomics, order varies)
+    bad += _compare(bwd_tile, default, grads, 2e-4, 1e-5, "backward tile vs specialised:")
+    bad += _compare(tile, default, grads, 1.0, 2e-4, "all tile vs specialised (gradients, median):")
     assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("value", [False, True])
+def test_fused_pool_equals_segment_pool_operator(value):
+    """the max-pool folded into the third GEMM of every stage (packed arg-max keys + gad_pool_finalize) against
+    gad_segment_pool run on the SAME stored raw activations with the same published scale / shift: pooled features
+    bit-equal (a rounded fma is monotone, so relu(fma(max z)) == max relu(fma(z))); arg-max rows identical except where two
+    different raw values of a group round to the same activation (the fused pool then keeps the larger raw value, torch
+    the first row) -- such positions must carry bit-equal activations; zmax is the raw value at the reported row."""
+    from ga_ddpg_amd import hip
+    for B in (24, 96):
+        out = _run(B, value, {}, keep_slot=True)
+        slot, enc, geo = out["slot"], out["enc"], out["geo"]
+        for s in range(3):
+            m = enc.sa_mats[s][2]
+            o = enc.bn_off[m.bn_index]
+            r = geo.rows[s]
+            F = torch.empty_like(slot.F[s])
+            A = torch.empty_like(slot.argmax[s])
+            hip.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, slot.scale[o:o + m.n_out], slot.shift[o:o + m.n_out],
+                     r["off"], r["G"], F, A)
+            torch.cuda.synchronize()
+            assert torch.equal(F, out["F%d" % (s + 1)]), "stage %d: pooled features differ" % (s + 1)
+            Af = out["A%d" % (s + 1)]
+            diff = (A != Af)
+            z = slot.Z[s][2]
+            cols = torch.arange(m.n_out, device=z.device).expand_as(A)
+            sc, sh = slot.scale[o:o + m.n_out], slot.shift[o:o + m.n_out]
+            ya = torch.relu(torch.addcmul(sh.double(), z[A.long(), cols].double(), sc.double()).float())
+            yf = torch.relu(torch.addcmul(sh.double(), z[Af.long(), cols].double(), sc.double()).float())
+            assert float(diff.float().mean()) <= 1e-4, "stage %d: %d arg-max rows differ" % (s + 1, int(diff.sum()))
+            if bool(diff.any()):
+                assert torch.equal(ya[diff], yf[diff]), "stage %d: a differing arg-max row does not tie" % (s + 1)
+            assert bool((slot.key[s] == 0).all()), "stage %d: keys not reset" % (s + 1)
+            zm = out["zmax%d" % (s + 1)]
+            live = out["F%d" % (s + 1)] > 0
+            assert torch.equal(zm[live], z[Af.long(), cols][live]), "stage %d: zmax is not the raw value at the arg-max row" % (s + 1)

@@ -426,62 +426,3 @@ def test_overlapped_schedule_equals_serial_schedule():
             # value_encoder sees a third pass AFTER the critic's Adam step on steps with the actor-critic term
             tol = 2e-3 if (start == 2 and n in venc) else 1e-5
             assert_close(b0[n], b1[n], tol, tol * max(1.0, float(np.abs(b1[n]).max())), n)
-
-
-def test_graph_replay_equals_eager_enqueue():
-    """the update step replayed from a HIP graph (ga_ddpg_amd.runtime.GRAPHS; per-step Adam scalars and the minibatch
-    travel through pinned blocks that graph nodes read) against the same steps enqueued eagerly, from identical
-    parameters: the FIRST step of each kind (captured at once here: GRAPH_EAGER_FIRST off) must agree to the atomics'
-    summation-order noise; follow-up steps (capture reused: replay) inherit Adam's +-lr noise like any two runs.
-    Host dict batches and device-resident batches, injected noise."""
-    from ga_ddpg_amd import runtime
-    from ga_ddpg_amd.core.replay_memory import BaseMemory
-    from ga_ddpg_amd.experiments.config import load_cfg
-    from ga_ddpg_amd.runtime import BATCH_KEYS
-    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
-    c = load_cfg("ddpg_td3_aux.yaml")
-    mem = BaseMemory(1500, c, point_dtype=np.float32)
-    fill_synthetic_buffer(mem, 1500, seed=6)
-    rng = np.random.default_rng(21)
-    batches = [sample_valid_batch(mem, 48, rng) for _ in range(4)]
-    noise = [rng.random((48, 6)).astype(np.float32) for _ in range(4)]
-    warm, _ = _filled_agent("ddpg_td3_aux.yaml", 92)          # lazy workspaces / kernel attributes exist before any capture
-    for i in range(2):
-        warm.update_parameters(batches[i], warm.update_step, i, noise_u=noise[i])
-    for device_batches in (False, True):
-        out = {}
-        for graphs in (False, True):
-            agent, nets = _filled_agent("ddpg_td3_aux.yaml", 92)
-            old = (runtime.GRAPHS, runtime.GRAPH_EAGER_FIRST)
-            runtime.GRAPHS, runtime.GRAPH_EAGER_FIRST = graphs, False
-            try:
-                res = []
-                for i, (b, u) in enumerate(zip(batches, noise)):
-                    if device_batches:
-                        b = {k: torch.as_tensor(np.ascontiguousarray(b[k], dtype=np.float32)).cuda() for k in BATCH_KEYS}
-                    r = agent.update_parameters(b, agent.update_step, i, noise_u=u)
-                    agent.step_scheduler()
-                    res.append((r, agent.qf1.cpu().numpy().copy(), agent.pi.cpu().numpy().copy()))
-                torch.cuda.synchronize()
-            finally:
-                runtime.GRAPHS, runtime.GRAPH_EAGER_FIRST = old
-            rt = agent._rt
-            out[graphs] = (res, {n: getattr(rt, n).flat.master.cpu().numpy().copy() for n in ("pol", "cr", "enc", "venc")},
-                           [getattr(rt, n).flat.step_count for n in ("pol", "cr", "enc", "venc")], rt.graph_replays)
-        (r0, p0, c0, n0), (r1, p1, c1, n1) = out[False], out[True]
-        assert n0 == 0 and n1 == 4, (n0, n1)          # steps 1, 2: capture + replay; 3, 4: replay
-        assert c0 == c1 == [4, 4, 4, 4]
-        for i, ((ra, qa, pa), (rb, qb, pb)) in enumerate(zip(r0, r1)):
-            for k in ra:
-                # the very first step from identical parameters is tight; everything after an Adam step carries the
-                # +-lr noise of analytically-zero gradient entries (tests/diag_determinism.py), so does actor_critic_loss
-                # of step 2 (it looks through the critic updated in that same step)
-                loose = i > 0 or k in ("actor_critic_loss", "critic_grad")
-                chaotic = i > 0 and k in ("actor_critic_loss", "critic_grad")     # through a critic that took noisy Adam steps
-                assert_close(rb[k], ra[k], 5e-1 if chaotic else (1e-1 if loose else 1e-5), 1e-2 if loose else 1e-6, "step %d %s" % (i, k))
-            assert_close(qb, qa, 0.0, (1e-5 if i == 0 else 1e-1) * np.abs(qa).max(), "q1 step %d" % i)
-            assert_close(pb, pa, 0.0, (1e-5 if i == 0 else 1e-1) * np.abs(pa).max(), "pi step %d" % i)
-        for n in p0:
-            # four Adam steps: every parameter within 4 x lr (1e-3 encoders) of the eager run, the bulk much closer
-            d = np.abs(p1[n] - p0[n])
-            assert d.max() <= 4.4e-3 and np.median(d) <= 2e-4, (n, d.max(), np.median(d))
