@@ -97,11 +97,13 @@ def plan_critic_forward(cr, hs, enc, eslot, time):
     return plan
 
 
-def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True, dw_lane=1):
+def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True, dw_lane=1, join_dw=False):
     """consumes hs.g_out (B,9); leaves dLoss/dfeature in hs.g_feat (B,512) and the BN-backward sums
     of the encoder's last BatchNorm in eslot.bstats (which the caller must have zeroed).
-    dw_lane: the split-K workspace of the head's weight-gradient GEMMs (the lane of the encoder backward that
-    follows on the same stream: critic 1, actor 2 -- the two backward passes may run concurrently)."""
+    dw_lane: the side stream the head's weight-gradient GEMMs are forked onto (they feed nothing but the optimiser: off the
+    dX chain, like the encoder's) = the lane of the encoder backward that follows (critic 1, actor 2 -- the two backward
+    passes may run concurrently); that plan's final join covers them.  join_dw: join here instead (a caller that reads the
+    gradient arena right after the head)."""
     plan = Plan()
     B, H, ng = hs.B, cr.hidden, cr.ng
     fl = cr.flat
@@ -120,7 +122,10 @@ def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True, dw_lane=1):
         a.gacc = _ptr(fl.gacc)
         ws = dw_workspace(fl.device, lane=100 + dw_lane)     # never shared with a forked encoder dW (lanes 1, 2)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
-        plan.call_struct("gad_gemm_dw", a)
+        lane = dw_lane if CONCURRENT_DW_HEADS() else 0
+        if lane:
+            plan.fork(lane)
+        plan.call_struct("gad_gemm_dw", a, side=lane)
 
     def dx(dz, dz_off, mats, k_valid, gout, gout_off, **epi):
         a = hip.GemmDxArgs()
@@ -162,7 +167,14 @@ def plan_critic_backward(cr, hs, enc, eslot, time, want_dw=True, dw_lane=1):
        prev_mean=_bn_vec(eslot, enc, fc2, "mean"), prev_istd=_bn_vec(eslot, enc, fc2, "istd"),
        prev_dbeta=_ptr(eslot.bstats, o, 8), prev_dgamma=_ptr(eslot.bstats, tot + o, 8), stat_stride=2 * tot,
        store_masked=1)          # g_feat carries the encoder's last ReLU mask (engine.plan_encoder_backward: premasked)
+    if join_dw and want_dw and CONCURRENT_DW_HEADS():
+        plan.join(dw_lane)
     return plan
+
+
+def CONCURRENT_DW_HEADS():
+    from . import engine
+    return engine.CONCURRENT_DW            # (measured: 299 vs 296 steps/s with the heads' dW GEMMs in line on the main stream)
 
 
 class _Cat(object):
@@ -209,7 +221,10 @@ def plan_policy_backward(po, hs, enc, eslot, time, dw_lane=2):
         a.gacc = _ptr(fl.gacc)
         ws = dw_workspace(fl.device, lane=100 + dw_lane)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
-        plan.call_struct("gad_gemm_dw", a)
+        lane = dw_lane if CONCURRENT_DW_HEADS() else 0
+        if lane:
+            plan.fork(lane)                       # weight gradients off the dX chain (the encoder backward's final join covers them)
+        plan.call_struct("gad_gemm_dw", a, side=lane)
 
     def dx(dz, m, k_valid, gout, **epi):
         a = hip.GemmDxArgs()

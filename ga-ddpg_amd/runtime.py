@@ -248,10 +248,13 @@ class FusedRuntime(object):
         vb = Plan()
         vb.zero_multi([cr.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.slot_v.daction])
         vb.extend(heads.plan_critic_backward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
-        # the reference's backward also leaves the actor-loss gradient in critic.grad (logged as critic_grad)
-        vb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 1)
+        # the reference's backward also leaves the actor-loss gradient in critic.grad (logged as critic_grad): converted on the
+        # weight-gradient lane, behind the head's dW GEMMs, off the dX chain (v_bwd's closing join covers it)
+        vb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 1, side=1 if heads.CONCURRENT_DW_HEADS() else 0)
         vb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_cpi.g_feat, action=self.pi, want_dw=False,
                                                want_daction=True, zero_scatter=False))
+        if heads.CONCURRENT_DW_HEADS():
+            vb.join(1)                   # (no encoder weight gradients in this pass: nothing else joins the head's lane)
         P["v_bwd"] = vb
 
     # ------------------------------------------------------------------ host -> device
@@ -548,6 +551,8 @@ class FusedRuntime(object):
         elif not OVERLAP_PASSES:
             actor_tail(None)
         self._target_updates()
+        # (measured and not kept: the bookkeeping below on the small-launch lane instead of the main stream: 287 vs 297
+        # steps/s -- that lane also carries the next step's uploads and geometry)
         self._stats()
         self.enc.bump_batches_tracked(2)
         self.venc.bump_batches_tracked(3 if policy_step else 2)
