@@ -374,20 +374,29 @@ __device__ __forceinline__ void pool_put(unsigned long long* keycol, int g, int 
 // best value so far and its row
 struct PoolRun { int g; int part; float v; int row; };
 
-// rows [i, e) of the LDS tile belong to the open group: running maximum of sgn * z, strict > (the first maximum stays).
-// i, e, row_base are wave-uniform: the loads of a run are independent of the compares and pipeline freely.
-__device__ __forceinline__ void pool_rows(const float* zt, int pitch, int i, int e, int row_base, float sgn, float& best, int& brow) {
+// rows [i, e) of the LDS tile belong to the open group: running maximum of sgn * z, strict > (the first maximum stays),
+// for NC columns per lane (zt + c * cstride).  i, e, row_base are wave-uniform: the loads of a run are independent of the
+// compares and pipeline freely.
+template <int NC>
+__device__ __forceinline__ void pool_rows(const float* zt, int pitch, int cstride, int i, int e, int row_base, const float (&sgn)[NC],
+                                          float (&best)[NC], int (&brow)[NC]) {
     int r = i;
-    for (; r + 4 <= e; r += 4) {
-        const float z0 = zt[r * pitch] * sgn, z1 = zt[(r + 1) * pitch] * sgn, z2 = zt[(r + 2) * pitch] * sgn, z3 = zt[(r + 3) * pitch] * sgn;
-        bool t = z0 > best; best = t ? z0 : best; brow = t ? row_base + r : brow;
-        t = z1 > best; best = t ? z1 : best; brow = t ? row_base + r + 1 : brow;
-        t = z2 > best; best = t ? z2 : best; brow = t ? row_base + r + 2 : brow;
-        t = z3 > best; best = t ? z3 : best; brow = t ? row_base + r + 3 : brow;
+    for (; r + 2 <= e; r += 2) {
+        float z0[NC], z1[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { z0[c] = zt[r * pitch + c * cstride] * sgn[c]; z1[c] = zt[(r + 1) * pitch + c * cstride] * sgn[c]; }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            bool t = z0[c] > best[c]; best[c] = t ? z0[c] : best[c]; brow[c] = t ? row_base + r : brow[c];
+            t = z1[c] > best[c]; best[c] = t ? z1[c] : best[c]; brow[c] = t ? row_base + r + 1 : brow[c];
+        }
     }
-    for (; r < e; ++r) {
-        const float z0 = zt[r * pitch] * sgn;
-        const bool t = z0 > best; best = t ? z0 : best; brow = t ? row_base + r : brow;
+    if (r < e) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float z0 = zt[r * pitch + c * cstride] * sgn[c];
+            const bool t = z0 > best[c]; best[c] = t ? z0 : best[c]; brow[c] = t ? row_base + r : brow[c];
+        }
     }
 }
 
@@ -408,17 +417,26 @@ __device__ __forceinline__ void pool_scan32(const float* zt, int pitch, int gl, 
         }
         const unsigned rest = i < 31 ? m >> (i + 1) : 0u;
         const int e = rest ? i + 1 + __builtin_ctz(rest) : 32;
-        if (c.g >= 0) pool_rows(zt, pitch, i, e, row_base, sgn, c.v, c.row);
+        if (c.g >= 0) {
+            const float sg1[1] = {sgn};
+            float bv[1] = {c.v};
+            int br[1] = {c.row};
+            pool_rows<1>(zt, pitch, 0, i, e, row_base, sg1, bv, br);
+            c.v = bv[0]; c.row = br[0];
+        }
         i = e;
     }
 }
 
-// A 64-row tile in LDS, lane = column, the tile's groups dealt to the workgroup's wavefronts (piece k -> wavefront k % nw):
-// every piece is closed by the wavefront that walked it; only the pieces cut by the tile's first / last row are partial.
+// A 64-row tile in LDS, lane = column (NC columns per lane, cstride apart), the tile's groups dealt to the workgroup's
+// wavefronts (piece k -> wavefront k % nw): every piece is closed by the wavefront that walked it; only the pieces cut by
+// the tile's first / last row are partial.
 // gl: lane i holds the group of tile row i (-1 past the live rows); n_live = live rows of the tile (>= 1); g_before /
 // g_after: the groups of the rows just outside the tile (-1: none) -- a piece that shares its group with them is partial.
-__device__ __forceinline__ void pool_tile64(const float* zt, int pitch, int gl, int row0, int n_live, float sgn, int wave,
-                                            int nw, int g_before, int g_after, unsigned long long* keycol, int C) {
+template <int NC>
+__device__ __forceinline__ void pool_tile64(const float* zt, int pitch, int cstride, int gl, int row0, int n_live,
+                                            const float (&sgn)[NC], int wave, int nw, int g_before, int g_after,
+                                            unsigned long long* keycol, int C) {
     const int lane = threadIdx.x & 63;
     const int prev = __shfl_up(gl, 1, 64);
     const bool st = (lane == 0 || gl != prev) && lane < n_live;
@@ -430,11 +448,14 @@ __device__ __forceinline__ void pool_tile64(const float* zt, int pitch, int gl, 
         const int e = m ? __builtin_ctzll(m) : n_live;
         if ((k++ % nw) != wave) continue;
         const int g = __builtin_amdgcn_readlane(gl, i);
-        float best = -INFINITY;
-        int brow = row0 + i;
-        pool_rows(zt, pitch, i, e, row0, sgn, best, brow);
+        float best[NC];
+        int brow[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { best[c] = -INFINITY; brow[c] = row0 + i; }
+        pool_rows<NC>(zt, pitch, cstride, i, e, row0, sgn, best, brow);
         const bool partial = (i == 0 && g == g_before) || (e == n_live && g == g_after);
-        pool_put(keycol, g, C, best, brow, partial);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) pool_put(keycol + c * cstride, g, C, best[c], brow[c], partial);
     }
 }
 
@@ -596,9 +617,12 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
             for (int v = 0; v < 16; ++v) zt[(wm * 32 + acc_row(v, half)) * 65 + wn * 32 + l31] = acc[0][0][v];
             __syncthreads();
             // lane = column; the tile's groups dealt to the four wavefronts
-            pool_tile64(zt + lane, 65, pgl, row0, min(64, n_rows - row0), psgn, __builtin_amdgcn_readfirstlane(wave), 4,
-                        __builtin_amdgcn_readfirstlane(pg_before), __builtin_amdgcn_readfirstlane(pg_after),
-                        pe.key + n0 + lane, pe.C);
+            {
+                const float sg1[1] = {psgn};
+                pool_tile64<1>(zt + lane, 65, 0, pgl, row0, min(64, n_rows - row0), sg1, __builtin_amdgcn_readfirstlane(wave), 4,
+                               __builtin_amdgcn_readfirstlane(pg_before), __builtin_amdgcn_readfirstlane(pg_after),
+                               pe.key + n0 + lane, pe.C);
+            }
         }
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
@@ -627,6 +651,166 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
                                          stat_sum + (size_t)rep * stat_stride + ooff,
                                          stat_sq + (size_t)rep * stat_stride + ooff);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wide-tile forward for the MID-SIZE layers (SA2 / SA3 layers 2 and 3: 8e3 - 3e4 rows, K 128 - 256, 128 - 512 outputs).
+// The 64 x 64 kernel above gives every wavefront ONE 32 x 32 accumulator: 16 MFMAs (0.45 us) per K-tile against ~1 us of
+// global-load latency, a transposing LDS store of four ds_write_b32 per staged float4 and ~10 vector instructions per MFMA.
+// Here a workgroup owns 64 rows x 128 columns, a wavefront 32 x 64 (two accumulators sharing the A fragment):
+//   * 32 MFMAs (0.85 us) per K-tile and wavefront cover the load latency of the next tile (register-staged, issued right
+//     after the previous LDS write), LDS is double-buffered: ONE barrier per K-tile;
+//   * operands sit row-major in LDS, [row][32 + 4] floats: the staged float4 goes out as one ds_write_b128 (eight lanes
+//     fill one row: conflict-free), fragments come in as one ds_read_b128 per four MFMA steps (k visited as 8j + 4h + i, the
+//     streaming kernels' order: the 36-float pitch spreads 16 rows over all 64 banks);
+//   * relu(scale * z + shift) is applied once per staged element, not per fragment read.
+// Measured alone (tests/diag_gemm.py, B = 256 shapes): see profiles/README.md round 3.
+// ------------------------------------------------------------------------------------------------
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
+                                                               const float* __restrict__ row_w, const float* __restrict__ W,
+                                                               int Kp, int n_out, float* __restrict__ zout, int zout_pitch,
+                                                               double* __restrict__ stat_sum, double* __restrict__ stat_sq,
+                                                               int stat_stride, PoolEpi pe, unsigned long long* __restrict__ ts) {
+    KTimer kt_(ts);
+    constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = (BM + BN) * P, VM = 512;
+    static_assert(2 * STAGE >= 64 * 129, "the pooled epilogue's tile lives in the operand buffers");
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * VM + BM];
+    float* sv = smem + 2 * STAGE;
+    float* tv = sv + VM;
+    float* wS = tv + VM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = blockIdx.y * BN;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    if ((int)(blockIdx.x * BM) >= n_rows) return;
+    const int nk = Kp / KT;
+    const int c4 = (tid & 7) * 4;                        // this thread's 16-byte column chunk inside a K-tile
+    const int ur = tid >> 3;                             // ... and row (A: rows ur, ur + 32; B: ur, +32, +64, +96)
+    stage_affine<256>(sv, tv, x, 0, Kp);
+
+    float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
+    for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        int pgl = -1, pg_before = -1, pg_after = -1;
+        float psgn[2] = {1.f, 1.f};
+        if (POOL) {
+            const int r = row0 + lane;
+            pgl = r < n_rows ? pe.row_grp[r] : -1;
+            pg_before = row0 > 0 ? pe.row_grp[row0 - 1] : -1;
+            pg_after = row0 + BM < n_rows ? pe.row_grp[row0 + BM] : -1;
+            psgn[0] = pe.gamma[n0 + lane] < 0.f ? -1.f : 1.f;
+            psgn[1] = pe.gamma[n0 + 64 + lane] < 0.f ? -1.f : 1.f;
+        }
+        // rows past the live count are clamped to the last live row (never stored, weight 0 in the statistics)
+        const float* ap0 = x.zin + (size_t)min(row0 + ur, n_rows - 1) * x.zin_pitch + c4;
+        const float* ap1 = x.zin + (size_t)min(row0 + ur + 32, n_rows - 1) * x.zin_pitch + c4;
+        const float* bp = W + (size_t)(n0 + ur) * Kp + c4;
+        float4 ra[2], rb[4];
+        auto load_regs = [&](int kt) {
+            const int k0 = kt * KT;
+            ra[0] = ldg4(ap0 + k0); ra[1] = ldg4(ap1 + k0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rb[u] = ldg4(bp + (size_t)u * 32 * Kp + k0);
+        };
+        auto write_lds = [&](int kt) {
+            float* As = smem + (kt & 1) * STAGE;
+            float* Bs = As + BM * P;
+            const float4 s4 = *reinterpret_cast<const float4*>(sv + kt * KT + c4);
+            const float4 t4 = *reinterpret_cast<const float4*>(tv + kt * KT + c4);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float4 v = ra[u];
+                v.x = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f);
+                v.z = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f);
+                *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(Bs + (ur + 32 * u) * P + c4) = rb[u];
+        };
+        load_regs(0);
+        __syncthreads();                                 // sv / tv visible; the previous row tile's LDS reads (wS, zt) are done
+        if (tid < BM) { const int r = row0 + tid; wS[tid] = r < n_rows ? (row_w ? row_w[r] : 1.f) : 0.f; }
+        write_lds(0);
+        if (nk > 1) load_regs(1);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* As = smem + (kt & 1) * STAGE + (wm * 32 + l31) * P + 4 * half;
+            const float* Bs = smem + (kt & 1) * STAGE + BM * P + (wn * 64 + l31) * P + 4 * half;
+            float4 a4 = *reinterpret_cast<const float4*>(As);
+            float4 b0 = *reinterpret_cast<const float4*>(Bs), b1 = *reinterpret_cast<const float4*>(Bs + 32 * P);
+#pragma unroll
+            for (int j = 0; j < KT / 8; ++j) {
+                float4 an = a4, bn0 = b0, bn1 = b1;
+                if (j + 1 < KT / 8) {                    // next k group's fragments land under this group's MFMAs
+                    an = *reinterpret_cast<const float4*>(As + 8 * (j + 1));
+                    bn0 = *reinterpret_cast<const float4*>(Bs + 8 * (j + 1));
+                    bn1 = *reinterpret_cast<const float4*>(Bs + 32 * P + 8 * (j + 1));
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
+                a4 = an; b0 = bn0; b1 = bn1;
+            }
+            if (kt + 1 < nk) write_lds(kt + 1);          // the other buffer: its readers passed the previous barrier
+            if (kt + 2 < nk) load_regs(kt + 2);
+            __syncthreads();
+        }
+        if (POOL) {
+            float* zt = smem;                            // [64][129]: every wavefront is past the K loop's last barrier
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) zt[(wm * 32 + acc_row(v, half)) * 129 + wn * 64 + t * 32 + l31] = acc[t][v];
+            __syncthreads();
+            const int gb = __builtin_amdgcn_readfirstlane(pg_before), ga = __builtin_amdgcn_readfirstlane(pg_after);
+            pool_tile64<2>(zt + lane, 129, 64, pgl, row0, min(64, n_rows - row0), psgn, wave, 4, gb, ga, pe.key + n0 + lane, pe.C);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n = n0 + wn * 64 + t * 32 + l31;
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int il = wm * 32 + acc_row(v, half);
+                const int r = row0 + il;
+                const float zv = acc[t][v];
+                if (zout && r < n_rows) zout[(size_t)r * zout_pitch + n] = zv;
+                const float w = wS[il];
+                s1 = fmaf(w, zv, s1);
+                s2 = fmaf(w * zv, zv, s2);
+            }
+            csum[t] += s1;
+            csq[t] += s2;
+        }
+        // (the next row tile's first barrier orders these wS / zt reads before its writes)
+    }
+    if (stat_sum) {
+        const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+        block_column_atomics<2, 2, 2>(smem, csum, csq, lane, wm, wn, n0, n_out, stat_sum + (size_t)rep * stat_stride,
+                                      stat_sq + (size_t)rep * stat_stride);
+    }
+}
+
+static int g_opt_fwd_wide = 1;
+static int g_opt_dx_wide = 1, g_opt_dw_wide = 1;
+// the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
+// column), outputs a multiple of 128
+static bool fwd_wideable(const gad_gemm_fwd_args& a) {
+    if (!g_opt_fwd_wide || a.mode != 0 || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
+    if (a.n_rows < 2048 || a.n_out[0] % 128 != 0 || a.Kp % 32 != 0 || a.Kp > 512 || a.Kp != a.c_in) return false;
+    return a.ones_col < 0 && !a.extra && a.scale && a.shift && a.relu;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -974,6 +1158,9 @@ static int g_opt_fwd_stream = 1;
 extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
+    if (!strcmp(name, "fwd_wide")) { g_opt_fwd_wide = value; return GAD_OK; }
+    if (!strcmp(name, "dx_wide")) { g_opt_dx_wide = value; return GAD_OK; }
+    if (!strcmp(name, "dw_wide")) { g_opt_dw_wide = value; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
@@ -1075,6 +1262,18 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         }
 #undef LAUNCH_STREAM
         GAD_CHECK_LAUNCH("gemm_fwd(stream)");
+        return GAD_OK;
+    }
+    if (fwd_wideable(*a)) {
+        int gx = gad_cdiv(grid_rows, 64); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;
+        const dim3 grid(gx, a->n_out[0] / 128);
+        if (pe.key)
+            hipLaunchKernelGGL((gemm_fwd_wide_kernel<true>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
+                               a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
+        else
+            hipLaunchKernelGGL((gemm_fwd_wide_kernel<false>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
+                               a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
+        GAD_CHECK_LAUNCH("gemm_fwd(wide)");
         return GAD_OK;
     }
     // 64 x 64 tiles throughout: with K <= 1024 these launches are prologue/epilogue-bound, more and smaller
@@ -1422,6 +1621,184 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// wide-tile dX for the MID-SIZE layers (the backward twin of gemm_fwd_wide_kernel): a workgroup owns 64 rows x 128 input
+// channels of gout, a wavefront 32 x 64.  A operand: dZ[r][n] = P*dY - w*(Q + S*z) formed once per staged element from
+// 16-byte loads of z and dY (or of the pooled arg-max / gradient pair; the ReLU mask is already in dY: premasked), stored
+// row-major ([row][32 + 4]); B operand: W[n][k] as stored, written TRANSPOSED into LDS ([k][32 + 4], four ds_write_b32 per
+// staged float4: 16 per thread and K-tile against 32 MFMAs) so that both fragments are one ds_read_b128 per four MFMA steps.
+// Epilogue: dY of the previous layer masked by its ReLU (store_masked) + that layer's BatchNorm-backward sums.
+// ------------------------------------------------------------------------------------------------
+template <int GM>
+__global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
+                                                              const float* __restrict__ W, int Kp, int n_out, DxEpi e,
+                                                              unsigned long long* __restrict__ ts) {
+    KTimer kt_(ts);
+    constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = (BM + BN) * P, VM = 512;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 3 * VM + BM];
+    float* vP = smem + 2 * STAGE;                        // P | Q | S of this layer's channels
+    float* wS = vP + 3 * VM;
+    int32_t* grS = reinterpret_cast<int32_t*>(wS);       // (pooled source: the rows' groups share the slot with the weights: see below)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int k0out = blockIdx.y * BN;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    if ((int)(blockIdx.x * BM) >= n_rows) return;
+    const int nk = n_out / KT;
+    const int c4 = (tid & 7) * 4, ur = tid >> 3;         // A staging: 16-byte chunk of the K-tile, row (ur, ur + 32)
+    const int bk4 = (tid & 31) * 4, bn = tid >> 5;       // B staging: W rows bn, +8, +16, +24 of the K-tile, k chunk bk4
+    for (int i = tid; i < n_out; i += 256) {
+        float Pc, Qc, Sc;
+        dz_coef(d, i, Pc, Qc, Sc);
+        vP[i] = Pc; vP[VM + i] = Qc; vP[2 * VM + i] = Sc;
+    }
+    (void)grS;
+    // previous layer's BatchNorm vectors of this lane's two output columns
+    float ps[2], pt[2], pm[2], pi[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int k = k0out + wn * 64 + t * 32 + l31;
+        ps[t] = e.ps[k]; pt[t] = e.pt[k]; pm[t] = e.pm[k]; pi[t] = e.pi[k];
+    }
+    float cb[2] = {0.f, 0.f}, cg[2] = {0.f, 0.f};
+    for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
+        f32x16 acc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+        // this thread's two staged rows (clamped past the live count: their dZ is zeroed through the weight / validity)
+        int rr[2], grp[2];
+        float wrow[2];
+        bool live[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int r = row0 + ur + 32 * u;
+            live[u] = r < n_rows;
+            rr[u] = live[u] ? r : n_rows - 1;
+            wrow[u] = d.row_w ? d.row_w[rr[u]] : 1.f;
+            grp[u] = GM == 1 ? d.row_grp[rr[u]] : 0;
+        }
+        const int gpitch = GM == 0 ? d.g_pitch : d.c;
+        float4 rz[2], rg[2], rb[4];
+        int4 ra[2];
+        auto load_regs = [&](int kt) {
+            const int nb = kt * KT + c4;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                rz[u] = ldg4(d.z + (size_t)rr[u] * d.z_pitch + nb);
+                if (GM == 0) {
+                    rg[u] = ldg4(d.G + (size_t)rr[u] * gpitch + nb);
+                } else {
+                    ra[u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp[u] * gpitch + nb);
+                    rg[u] = ldg4(d.dout + (size_t)grp[u] * gpitch + nb);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rb[u] = ldg4(W + (size_t)(kt * KT + bn + 8 * u) * Kp + k0out + bk4);
+        };
+        auto write_lds = [&](int kt) {
+            float* As = smem + (kt & 1) * STAGE;
+            float* Bs = As + BM * P;
+            const int nb = kt * KT + c4;
+            const float4 P4 = *reinterpret_cast<const float4*>(vP + nb), Q4 = *reinterpret_cast<const float4*>(vP + VM + nb);
+            const float4 S4 = *reinterpret_cast<const float4*>(vP + 2 * VM + nb);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float4 g = rg[u];
+                const float4 z = rz[u];
+                if (GM == 1) {
+                    const int r = row0 + ur + 32 * u;        // the true row (a clamped row never matches an arg-max)
+                    g.x = ra[u].x == r ? g.x : 0.f; g.y = ra[u].y == r ? g.y : 0.f;
+                    g.z = ra[u].z == r ? g.z : 0.f; g.w = ra[u].w == r ? g.w : 0.f;
+                }
+                const float w = wrow[u];
+                float4 v;
+                v.x = P4.x * g.x - w * fmaf(S4.x, z.x, Q4.x); v.y = P4.y * g.y - w * fmaf(S4.y, z.y, Q4.y);
+                v.z = P4.z * g.z - w * fmaf(S4.z, z.z, Q4.z); v.w = P4.w * g.w - w * fmaf(S4.w, z.w, Q4.w);
+                if (!live[u]) v = f4zero();
+                *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                    // W[n][k..k+3] -> Bs[k + i][n]
+                float* bp = Bs + bk4 * P + bn + 8 * u;
+                bp[0] = rb[u].x; bp[P] = rb[u].y; bp[2 * P] = rb[u].z; bp[3 * P] = rb[u].w;
+            }
+        };
+        load_regs(0);
+        __syncthreads();                                 // vP visible; the previous row tile's LDS reads are done
+        write_lds(0);
+        if (nk > 1) load_regs(1);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const float* As = smem + (kt & 1) * STAGE + (wm * 32 + l31) * P + 4 * half;
+            const float* Bs = smem + (kt & 1) * STAGE + BM * P + (wn * 64 + l31) * P + 4 * half;
+            float4 a4 = *reinterpret_cast<const float4*>(As);
+            float4 b0 = *reinterpret_cast<const float4*>(Bs), b1 = *reinterpret_cast<const float4*>(Bs + 32 * P);
+#pragma unroll
+            for (int j = 0; j < KT / 8; ++j) {
+                float4 an = a4, bn0 = b0, bn1 = b1;
+                if (j + 1 < KT / 8) {
+                    an = *reinterpret_cast<const float4*>(As + 8 * (j + 1));
+                    bn0 = *reinterpret_cast<const float4*>(Bs + 8 * (j + 1));
+                    bn1 = *reinterpret_cast<const float4*>(Bs + 32 * P + 8 * (j + 1));
+                }
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1.y, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0.z, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1.z, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
+                a4 = an; b0 = bn0; b1 = bn1;
+            }
+            if (kt + 1 < nk) write_lds(kt + 1);
+            if (kt + 2 < nk) load_regs(kt + 2);
+            __syncthreads();
+        }
+        // epilogue: dY of the previous layer (ReLU-masked) + its BatchNorm-backward sums; all z_prev loads first
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int k = k0out + wn * 64 + t * 32 + l31;
+            float zp[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = min(row0 + wm * 32 + acc_row(v, half), n_rows - 1);
+                zp[v] = e.zprev[(size_t)r * e.zprev_pitch + k];
+            }
+            float sb = 0.f, sg = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = row0 + wm * 32 + acc_row(v, half);
+                const bool ok = r < n_rows;
+                const float gv = acc[t][v];
+                const bool act = ok && fmaf(zp[v], ps[t], pt[t]) > 0.f;
+                const float ga = act ? gv : 0.f;
+                if (ok) e.gout[(size_t)r * e.gout_pitch + k] = ga;
+                sb += ga;
+                sg = fmaf(ga, act ? (zp[v] - pm[t]) * pi[t] : 0.f, sg);
+            }
+            cb[t] += sb; cg[t] += sg;
+        }
+    }
+    const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+    block_column_atomics<2, 2, 2>(smem, cb, cg, lane, wm, wn, k0out, e.k_valid, e.dbeta + (size_t)rep * e.stat_stride,
+                                  e.dgamma + (size_t)rep * e.stat_stride);
+}
+
+static bool dx_wideable(const gad_gemm_dx_args& a, bool vec) {
+    if (!g_opt_dx_wide || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
+    if (a.n_rows < 2048 || a.epilogue != 0 || a.k_valid % 128 != 0 || a.k_valid > a.Kp) return false;
+    if (a.n_out[0] % 32 != 0 || a.n_out[0] < 32 || a.n_out[0] > 512) return false;
+    if (!a.prev_dbeta || !a.store_masked || !(a.zprev && a.prev_scale && a.prev_shift && a.prev_mean && a.prev_istd && a.prev_dgamma)) return false;
+    const gad_dz_src& d = a.dz;
+    if (!d.z || d.z_pitch % 4 != 0 || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
+    return d.gmode == 0 ? (d.g_pitch % 4 == 0 && d.G) : (d.c % 4 == 0);
+}
+
 static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
     if (!g_opt_dx_stream || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
     if (a.n_rows < 32768 || a.epilogue != 0 || a.k_valid != 64 || a.Kp != 64 || a.gout_pitch != 64) return false;
@@ -1574,6 +1951,16 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
         else { if (a->dz.gmode == 0) LAUNCH_DXS(8, 0); else LAUNCH_DXS(8, 1); }
 #undef LAUNCH_DXS
         GAD_CHECK_LAUNCH("gemm_dx(stream)");
+        return GAD_OK;
+    }
+    if (dx_wideable(*a, vec)) {
+        int gx = gad_cdiv(grid_rows, 64); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;
+        const dim3 grid(gx, kv / 128);
+        if (a->dz.gmode == 0)
+            hipLaunchKernelGGL((gemm_dx_wide_kernel<0>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
+        else
+            hipLaunchKernelGGL((gemm_dx_wide_kernel<1>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
+        GAD_CHECK_LAUNCH("gemm_dx(wide)");
         return GAD_OK;
     }
     int nmax_dx = 0;

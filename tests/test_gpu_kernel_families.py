@@ -1,5 +1,5 @@
 """Kernel families of the layer GEMMs against each other: the specialised kernels (streaming SA1 forward / dX / dW, skinny
-split-K kernels of the FC head) and the generic 64x64 tile kernels compute the same layers (gad_set_option switches the
+split-K kernels of the FC head, wide-tile kernels of the mid-size layers) and the generic 64x64 tile kernels compute the same layers (gad_set_option switches the
 routing); both orders of summation must agree to float32 rounding on every activation, statistic and gradient of an
 encoder forward + backward.  Also here: the max-pool folded into the pooled layers' GEMM epilogue against the stand-alone
 segment max-pool operator on the same raw activations."""
@@ -64,7 +64,7 @@ def _compare(a, b, keys, tol, mtol, what):
     return bad
 
 
-FAMILIES = ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny")
+FAMILIES = ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny", "fwd_wide", "dx_wide", "dw_wide")
 
 
 @pytest.mark.parametrize("value", [False, True])
@@ -77,7 +77,7 @@ def test_specialised_and_tile_kernels_agree(value):
     B = 96                                             # SA1 ~ 8e4 rows: above the streaming threshold
     default = _run(B, value, {})
     tile = _run(B, value, {k: 0 for k in FAMILIES})
-    fwd_tile = _run(B, value, {"fwd_stream": 0, "fwd_skinny": 0})
+    fwd_tile = _run(B, value, {"fwd_stream": 0, "fwd_skinny": 0, "fwd_wide": 0})
     bwd_tile = _run(B, value, {k: 0 for k in FAMILIES if not k.startswith("fwd")})
     assert default["rows"] == tile["rows"] == fwd_tile["rows"] and default["rows"][0] >= 32768
     acts = [k for k in tile if k[0] in "ZFzmir" and k != "rows"]
