@@ -138,6 +138,111 @@ extern "C" int gad_polyak(float* target, const float* source, const uint8_t* sel
     return GAD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch for an optimiser phase: up to GAD_MAX_OPTIM_JOBS flat buffers (blockIdx.y = job), each optionally
+//   gradient arena (f64, packed order) -> .grad (f32, master order)           [gad_grad_from_arena]
+//   Adam step with in-kernel clip_grad_norm_ scaling, packed mirror            [gad_adam_step]
+//   polyak / hard update of a target network FROM THE UPDATED value, mirror    [gad_polyak]
+//   max |parameter| / max |gradient| into log slots (non-negative float bits)  [gad_absmax_segments]
+//   a BatchNorm num_batches_tracked bump.
+// The step used to end in ~12 launches of 5-10 us each on its critical chain (core/agent.py:192-259: optimize, target
+// updates, log_stat); the arithmetic per element is unchanged.
+// ------------------------------------------------------------------------------------------------
+struct OptimJobs { gad_optim_job j[GAD_MAX_OPTIM_JOBS]; };
+
+__global__ __launch_bounds__(256) void optim_jobs_kernel(OptimJobs jobs) {
+    const gad_optim_job& J = jobs.j[blockIdx.y];
+    const int n = J.n;
+    if (blockIdx.x == 0 && threadIdx.x < J.counter_n && J.counter) J.counter[threadIdx.x] += J.counter_add;
+    float lr = 0.f, b1 = 0.f, b2 = 0.f, eps = 0.f, wd = 0.f, bc1 = 1.f, sbc2 = 1.f, coef = 1.f;
+    const bool adam = J.hyper != nullptr;
+    if (adam) {
+        lr = J.hyper[0]; b1 = J.hyper[1]; b2 = J.hyper[2]; eps = J.hyper[3]; wd = J.hyper[4]; bc1 = J.hyper[5]; sbc2 = J.hyper[6];
+        coef = J.hyper[7];
+        if (J.clip_sumsq) {
+            const float c = J.clip_max / ((float)sqrt(*J.clip_sumsq) + 1e-6f);     // torch clip_grad_norm_
+            coef *= c < 1.f ? c : 1.f;
+        }
+    }
+    float amax_p = 0.f, amax_g = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int jm = J.m2p ? J.m2p[i] : -1;
+        float g = J.grad ? J.grad[i] : 0.f;
+        if (J.gacc) {
+            const float ga = jm >= 0 ? (float)J.gacc[jm] : 0.f;
+            g = J.accumulate ? g + ga : ga;
+            J.grad[i] = g;
+        }
+        float pv = J.p ? J.p[i] : 0.f;
+        if (adam && !(J.active && !J.active[i])) {
+            g *= coef;
+            if (J.clip_sumsq) J.grad[i] = g;                                       // torch scales .grad in place
+            float gw = fmaf(wd, pv, g);
+            const float mi = b1 * J.exp_avg[i] + (1.f - b1) * gw;
+            const float vi = b2 * J.exp_avg_sq[i] + (1.f - b2) * gw * gw;
+            J.exp_avg[i] = mi;
+            J.exp_avg_sq[i] = vi;
+            const float denom = sqrtf(vi) / sbc2 + eps;
+            pv = pv - (lr / bc1) * (mi / denom);
+            J.p[i] = pv;
+            if (J.packed && jm >= 0) J.packed[jm] = pv;
+        }
+        if (J.target) {
+            const int k = J.target_sel ? J.target_sel[i] : 1;
+            float nv = 0.f;
+            bool wr = false;
+            if (k == 1) { nv = J.target[i] * (1.f - J.tau) + pv * J.tau; wr = true; }
+            else if (k == 2 && J.hard_enable) { nv = pv; wr = true; }
+            if (wr) {
+                J.target[i] = nv;
+                if (J.target_packed) { const int jt = J.target_m2p[i]; if (jt >= 0) J.target_packed[jt] = nv; }
+            }
+        }
+        amax_p = fmaxf(amax_p, fabsf(pv));
+        amax_g = fmaxf(amax_g, fabsf(g));
+    }
+    // statistics: one atomic per workgroup that had elements, spread over GAD_ABSMAX_SLOTS addresses (a same-address
+    // device atomic costs ~25 ns: 4096 wavefronts on one slot were 0.1 ms)
+    if ((J.absmax_p || J.absmax_grad) && (int)(blockIdx.x * 256) < n) {
+        __shared__ float red[2][4];
+        amax_p = wave_max(amax_p);
+        amax_g = wave_max(amax_g);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = amax_p; red[1][threadIdx.x >> 6] = amax_g; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int slot = blockIdx.x % GAD_ABSMAX_SLOTS;
+            if (J.absmax_p)
+                atomicMax(reinterpret_cast<unsigned int*>(J.absmax_p) + slot,
+                          __float_as_uint(fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]))));
+            if (J.absmax_grad)
+                atomicMax(reinterpret_cast<unsigned int*>(J.absmax_grad) + slot,
+                          __float_as_uint(fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]))));
+        }
+    }
+}
+
+extern "C" int gad_optim_jobs(const gad_optim_job* host_jobs, int n_jobs, void* stream) {
+    GAD_REQUIRE(host_jobs && n_jobs >= 1 && n_jobs <= GAD_MAX_OPTIM_JOBS, GAD_ERR_SHAPE, "optim_jobs: 1..%d jobs", GAD_MAX_OPTIM_JOBS);
+    OptimJobs jobs;
+    int nmax = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const gad_optim_job& J = host_jobs[k];
+        GAD_REQUIRE(J.n >= 0, GAD_ERR_SHAPE, "optim_jobs: job %d: n", k);
+        GAD_REQUIRE(!J.hyper || (J.p && J.grad && J.exp_avg && J.exp_avg_sq), GAD_ERR_NULL, "optim_jobs: job %d: Adam buffers", k);
+        GAD_REQUIRE(!J.gacc || (J.m2p && J.grad), GAD_ERR_NULL, "optim_jobs: job %d: arena conversion needs m2p and grad", k);
+        GAD_REQUIRE(!J.packed || J.m2p, GAD_ERR_NULL, "optim_jobs: job %d: packed mirror needs m2p", k);
+        GAD_REQUIRE(!J.target || (J.p && (!J.target_packed || J.target_m2p)), GAD_ERR_NULL, "optim_jobs: job %d: target update", k);
+        GAD_REQUIRE(!J.counter || (J.counter_n >= 0 && J.counter_n <= 256), GAD_ERR_SHAPE, "optim_jobs: job %d: counters", k);
+        jobs.j[k] = J;
+        nmax = J.n > nmax ? J.n : nmax;
+    }
+    int gx = gad_cdiv(nmax, 256 * 4);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(optim_jobs_kernel, dim3(gx, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    GAD_CHECK_LAUNCH("optim_jobs");
+    return GAD_OK;
+}
+
 __global__ __launch_bounds__(256) void pack_params_kernel(const float* __restrict__ p, const int32_t* __restrict__ m2p,
                                                           int n, float* __restrict__ packed) {
     const int i = blockIdx.x * 256 + threadIdx.x;

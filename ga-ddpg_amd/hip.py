@@ -60,6 +60,14 @@ class ReplayGatherArgs(C.Structure):
                 ("out_time_m1", _vp), ("out_expert_flag", _vp), ("out_perturb_flag", _vp)]
 
 
+class OptimJob(C.Structure):
+    _fields_ = [("n", _i32), ("p", _vp), ("grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("active", _vp), ("m2p", _vp),
+                ("packed", _vp), ("gacc", _vp), ("accumulate", _i32), ("hyper", _vp), ("clip_sumsq", _vp), ("clip_max", _f32),
+                ("target", _vp), ("target_sel", _vp), ("target_m2p", _vp), ("target_packed", _vp), ("tau", _f32),
+                ("hard_enable", _i32), ("absmax_p", _vp), ("absmax_grad", _vp), ("counter", _vp), ("counter_n", _i32),
+                ("counter_add", _i32)]
+
+
 _lib = None
 
 
@@ -88,7 +96,7 @@ EXPORTS = (
     "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_pool_finalize", "gad_affine_act",
     "gad_pool_bwd_stats", "gad_bn_bwd_coef", "gad_gemm_dx", "gad_gemm_dw", "gad_critic_loss",
     "gad_policy_outputs", "gad_policy_sample", "gad_actor_loss", "gad_actor_critic_loss", "gad_mask_counts", "gad_target_noise",
-    "gad_grad_from_arena", "gad_sumsq", "gad_absmax_segments", "gad_adam_step", "gad_polyak",
+    "gad_grad_from_arena", "gad_optim_jobs", "gad_sumsq", "gad_absmax_segments", "gad_adam_step", "gad_polyak",
     "gad_pack_params")
 
 

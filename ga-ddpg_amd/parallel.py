@@ -70,6 +70,8 @@ class DataParallelContext(object):
         rt.world_size = self.world
         rt.dp = self
         rt.allreduce = self.allreduce_grads
+        if hasattr(rt, "set_fused_optim"):
+            rt.set_fused_optim(False)               # the gradient exchange sits between the arena conversion and the Adam step
         rt.inv_n = torch.zeros(8, dtype=torch.float32, device=rt.dev)
         self._counts = torch.zeros(4, dtype=torch.float64, device=rt.dev)
         from . import engine

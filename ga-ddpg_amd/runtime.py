@@ -35,12 +35,20 @@ def _dev_f32(x, dev):
     return torch.as_tensor(np.asarray(x, dtype=np.float32)).to(dev)
 
 
+def _fold_stats(s, fused):
+    """private copy of a step's result block; the max-abs statistics of a fused optimiser launch arrive spread over 8 slots"""
+    s = s.copy()
+    if fused:
+        s[10], s[11], s[12] = s[32:40].max(), s[40:48].max(), s[48:56].max()
+    return s
+
+
 class PendingStep(object):
     """result block of a step that was enqueued without waiting for it (ddpg_step(sync=False)); wait() blocks until the
     step has run and returns a private copy of the 32 floats"""
 
-    def __init__(self, event, view):
-        self.event, self._view, self._value = event, view, None
+    def __init__(self, event, view, fused=False):
+        self.event, self._view, self._value, self._fused = event, view, None, fused
 
     def done(self):
         return self._value is not None or self.event.query()
@@ -48,7 +56,7 @@ class PendingStep(object):
     def wait(self):
         if self._value is None:
             self.event.synchronize()
-            self._value = self._view.copy()
+            self._value = _fold_stats(self._view, self._fused)
             self._view = None
         return self._value
 
@@ -126,12 +134,12 @@ class FusedRuntime(object):
                       plans=None)
         self._set = 0
         self._rows_seen = [[], []]            # recent live-row counts of SA1 / SA2 (grid-size hints, engine.Geometry.rows_hint)
-        self.scal = torch.zeros(32, **f32)
+        self.scal = torch.zeros(64, **f32)          # [0, 32): the step's result block; [32, 56): 3 x 8 spread max-abs slots
         self._one = torch.ones(1, **f32)
         self._minus_one = -torch.ones(1, **f32)
         # host-side staging, one set per in-flight step (ddpg_step(sync=False) lets the host run ahead of the GPU)
         R = engine.HOST_RING
-        self._scal_ring = torch.zeros(R, 32, dtype=torch.float32).pin_memory()
+        self._scal_ring = torch.zeros(R, 64, dtype=torch.float32).pin_memory()
         self._noise_ring = torch.zeros(R, B, 6, dtype=torch.float32).pin_memory()
         self._hbuf_ring = [self.hbuf] + [None] * (R - 1)       # further sets are allocated when a host batch needs them
         self._ev_done = [None] * R
@@ -140,6 +148,16 @@ class FusedRuntime(object):
         self._slot = 0
         self.scal_host = self._scal_ring[0]
         self.bucketed = False
+        # One launch per optimiser phase (gad_optim_jobs: arena -> .grad, Adam, target update, log statistics, BatchNorm
+        # counters) instead of ~6 / ~12 small ones; a data-parallel run exchanges gradients between the conversion and the
+        # Adam step and keeps the separate launches (DataParallelContext.attach -> set_fused_optim(False)).
+        self.fused_optim = self.has_critic and _os.environ.get("GAD_FUSED_OPTIM", "1") == "1"
+        # this step's Adam scalars of every network: one pinned block per in-flight step, ONE upload
+        self._opt_nets = [self.pol, self.enc] + ([self.venc, self.cr] if self.has_critic else [])
+        self.hyper_all = torch.zeros(len(self._opt_nets), 8, **f32)
+        self._hyper_ring = torch.zeros(R, len(self._opt_nets), 8, dtype=torch.float32).pin_memory()
+        for k, net in enumerate(self._opt_nets):
+            net.flat.hyper = self.hyper_all[k]
         self.seg = {}
         for nm, fl in (("pol", self.pol.flat),) + ((("cr", self.cr.flat),) if self.has_critic else ()):
             self.seg[nm] = torch.tensor([0, fl.n], dtype=torch.int32, device=dev)
@@ -156,6 +174,14 @@ class FusedRuntime(object):
         self.noise_host = self._noise_ring[0]
 
     # ------------------------------------------------------------------ plans over static buffers
+    def set_fused_optim(self, on):
+        """switch between one optimiser launch per phase and the separate conversion / Adam / target / statistics launches
+        (rebuilds the backward plans: the fused launch takes over their arena -> .grad tail)"""
+        on = bool(on) and self.has_critic
+        if on != self.fused_optim:
+            self.fused_optim = on
+            self._build_all_plans()
+
     def enable_bucketed_reduce(self):
         """data-parallel runs: rebuild the backward plans so that each optimiser phase's gradients leave in two buckets --
         [head | encoder FC + SA3 + SA2] as soon as the SA2 backward is done (99 % of the bytes, all-reduced under the SA1
@@ -166,6 +192,11 @@ class FusedRuntime(object):
     def _grad_tail(self, plan, head, enc, tag, early):
         """arena (f64, packed) -> flat .grad (f32, master order) at the end of a backward plan; bucketed: only what the
         early hook has not converted yet (the encoder's SA1 parameters, which lead its flat buffer)"""
+        if self.fused_optim and self.has_critic:
+            # the optimiser launch converts (gad_optim_jobs); only the critic's gradient is needed before it: clip_grad_norm_
+            if tag == "c":
+                plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
+            return
         if not (self.bucketed and early):
             plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
             plan.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, enc.flat.n, enc.flat.grad, 0)
@@ -235,7 +266,7 @@ class FusedRuntime(object):
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
         P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
         cb = Plan()
-        cb.zero_multi([cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1]])
+        cb.zero_multi([cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.clip_sumsq])
         cb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
         cb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=d["action_batch"], want_dw=True,
                                                zero_scatter=False, early_hook=self._early_hook(cr, venc, "c")))
@@ -294,6 +325,59 @@ class FusedRuntime(object):
                 np.subtract(self.hbuf["time_batch"].numpy(), 1.0, out=h.numpy())
                 self.dbuf["time_m1"].copy_(h, non_blocking=True)
 
+    def _optim_job(self, flat, adam=True, arena=True, clip=None, target=None, sel=None, absmax_p=None, absmax_grad=None,
+                   counter=None):
+        j = hip.OptimJob()
+        j.n = flat.n
+        j.p, j.grad, j.exp_avg, j.exp_avg_sq = (hip.ptr(t) for t in (flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq))
+        j.active, j.m2p, j.packed = hip.ptr(flat.active), hip.ptr(flat.m2p), hip.ptr(flat.packed)
+        if arena:
+            j.gacc = hip.ptr(flat.gacc)
+        if adam:
+            j.hyper = hip.ptr(flat.hyper)
+        if clip is not None:
+            j.clip_sumsq, j.clip_max = hip.ptr(clip), float(self.agent.clip_grad)
+        if target is not None:
+            j.target, j.target_m2p, j.target_packed = hip.ptr(target.master), hip.ptr(target.m2p), hip.ptr(target.packed)
+            j.target_sel = hip.ptr(sel)
+            j.tau = float(self.agent.tau)
+        j.absmax_p, j.absmax_grad = hip.ptr(absmax_p), hip.ptr(absmax_grad)
+        if counter is not None:
+            j.counter, j.counter_n = hip.ptr(counter), int(counter.numel())
+        return j
+
+    def _optim_phase(self, which, policy_step):
+        """gad_optim_jobs for the critic phase ("c"), the actor phase ("a") or the end of the step ("end": what has to
+        wait for both phases -- max |critic.grad| as the reference logs it after the actor backward, the value encoder's
+        BatchNorm counters)"""
+        import ctypes as C
+        ag = self.agent
+        jobs = getattr(self, "_optim_jobs_cache", None)
+        if jobs is None or jobs["key"] != (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature)):
+            sc = self.scal
+            arr = lambda js: (hip.OptimJob * len(js))(*js)
+            jobs = self._optim_jobs_cache = {
+                "key": (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature)),
+                # value encoder: arena -> grad + Adam; critic: Adam with the clip (its .grad is converted already) + target
+                # update from the updated parameters (nothing reads critic_target before the next step) + max |parameter|
+                "c": arr([self._optim_job(self.venc.flat),
+                          self._optim_job(self.cr.flat, arena=False, clip=self.clip_sumsq, target=self.cr_t.flat, sel=self.critic_sel,
+                                          absmax_p=engine._ptr(sc, 48))]),
+                "a": arr([self._optim_job(self.pol.flat, target=self.pol_t.flat, absmax_p=engine._ptr(sc, 32)),
+                          self._optim_job(self.enc.flat, adam=bool(ag.train_feature), counter=self.enc.batches_tracked)]),
+                "end": arr([self._optim_job(self.cr.flat, adam=False, arena=False, absmax_grad=engine._ptr(sc, 40),
+                                            counter=self.venc.batches_tracked)])}
+        js = jobs[which]
+        if which == "c":
+            js[1].hard_enable = int(ag.update_step % ag.target_update_interval == 0)
+            js[1].tau = float(ag.tau)
+        elif which == "a":
+            js[0].tau = float(ag.tau)
+            js[1].counter_add = 2
+        else:
+            js[0].counter_add = 3 if policy_step else 2
+        hip.check(hip.lib().gad_optim_jobs(js, len(js), hip.stream()), "gad_optim_jobs")
+
     def _adam_host(self, flat, optim):
         g = optim.param_groups[0]
         flat.set_adam_hyper(g["lr"], g["betas"], g["eps"], g["weight_decay"], upload=False)
@@ -339,8 +423,8 @@ class FusedRuntime(object):
         if self._hbuf_ring[slot] is None:
             self._hbuf_ring[slot] = {k: torch.zeros(*shp, dtype=torch.float32).pin_memory() for k, shp in self._hshapes.items()}
         self.hbuf = self._hbuf_ring[slot]
-        for net in (self.enc, self.venc, self.pol) + ((self.cr,) if self.has_critic else ()):
-            net.flat.hyper_host = net.flat.hyper_ring[slot]
+        for k, net in enumerate(self._opt_nets):
+            net.flat.hyper_host = self._hyper_ring[slot][k]
         return slot
 
     def _update_row_hints(self):
@@ -369,10 +453,11 @@ class FusedRuntime(object):
             ev = self._ev_done[slot] = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self._sets[self._set]["ev_free"] = ev        # every stream of the step has been joined into this one by now
+        fused = self.fused_optim and self.has_critic
         if sync:
             ev.synchronize()
-            return self.scal_host.numpy()
-        pend = self._pending[slot] = PendingStep(ev, self.scal_host.numpy())
+            return _fold_stats(self.scal_host.numpy(), fused)
+        pend = self._pending[slot] = PendingStep(ev, self.scal_host.numpy(), fused)
         return pend
 
     def flush(self):
@@ -458,6 +543,13 @@ class FusedRuntime(object):
             else:
                 self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
             self.scal.zero_()
+            if self.fused_optim:                    # this step's Adam scalars of all four networks: one upload
+                self._adam_host(self.venc.flat, ag.state_feat_val_encoder_optim)
+                self._adam_host(self.cr.flat, ag.critic_optim)
+                self._adam_host(self.pol.flat, ag.policy_optim)
+                if ag.train_feature:
+                    self._adam_host(self.enc.flat, ag.state_feat_encoder_optim)
+                self.hyper_all.copy_(self._hyper_ring[self._slot], non_blocking=True)
         # ---- critic phase.  The TD target chain (encoder(next) -> target policy -> value encoder(next, a') -> target
         # critic) and the value pass on the current state are independent: the latter runs on a second stream.
         # Both go through value_encoder's BatchNorms; the reference runs the current-state pass first
@@ -469,6 +561,9 @@ class FusedRuntime(object):
                      self.action_scale, g_pi,
                      self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
             P["p_bwd"].run()
+            if self.fused_optim:
+                self._optim_phase("a", policy_step)
+                return
             self._reduce([self.pol.flat, self.enc.flat], "a")
             self._adam(self.pol.flat, ag.policy_optim)
             if ag.train_feature:
@@ -529,12 +624,15 @@ class FusedRuntime(object):
         hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
                  d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
                  self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
-        P["c_bwd"].run()
-        self._reduce([self.cr.flat, self.venc.flat], "c")
-        self.clip_sumsq.zero_()
-        hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
-        self._adam(self.venc.flat, ag.state_feat_val_encoder_optim)
-        self._adam(self.cr.flat, ag.critic_optim, clip=self.clip_sumsq)
+        P["c_bwd"].run()                            # (clears clip_sumsq with its other buffers)
+        if self.fused_optim:
+            hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
+            self._optim_phase("c", policy_step)
+        else:
+            self._reduce([self.cr.flat, self.venc.flat], "c")
+            hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
+            self._adam(self.venc.flat, ag.state_feat_val_encoder_optim)
+            self._adam(self.cr.flat, ag.critic_optim, clip=self.clip_sumsq)
         # ---- actor phase
         if OVERLAP_PASSES:
             self._ev[3].record(s2)
@@ -550,6 +648,10 @@ class FusedRuntime(object):
             actor_tail(self.slot_v.daction)
         elif not OVERLAP_PASSES:
             actor_tail(None)
+        if self.fused_optim:
+            self._optim_phase("end", policy_step)
+            self._download(sync=False)
+            return
         self._target_updates()
         # (measured and not kept: the bookkeeping below on the small-launch lane instead of the main stream: 287 vs 297
         # steps/s -- that lane also carries the next step's uploads and geometry)

@@ -385,6 +385,25 @@ int gad_adam_step(float* p, const float* grad, float* exp_avg, float* exp_avg_sq
 /* target <- (1-tau)*target + tau*source where sel[i]==1, target <- source where sel[i]==2        */
 int gad_polyak(float* target, const float* source, const uint8_t* sel, const int32_t* m2p,
                float* target_packed, int n, float tau, int hard_enable, void* stream);
+/* One launch for a whole optimiser phase: each job is one flat buffer and, optionally and in this order per element:
+ * .grad <- gradient arena (gad_grad_from_arena), Adam step with clip scaling and packed mirror (gad_adam_step; hyper ==
+ * NULL: none), target-network update FROM THE UPDATED parameter (gad_polyak; target == NULL: none), max |p| / max |grad|
+ * atomically maximised into absmax_p / absmax_grad (GAD_ABSMAX_SLOTS floats each, float bits, zeroed by the caller,
+ * who takes the maximum of the slots), and counter[0..counter_n) += counter_add (BatchNorm num_batches_tracked).
+ * Same arithmetic as the single-purpose entry points.                                                               */
+#define GAD_MAX_OPTIM_JOBS 4
+#define GAD_ABSMAX_SLOTS 8
+typedef struct {
+    int32_t n;
+    float* p; float* grad; float* exp_avg; float* exp_avg_sq; const uint8_t* active; const int32_t* m2p; float* packed;
+    const double* gacc; int32_t accumulate;
+    const float* hyper; const double* clip_sumsq; float clip_max;
+    float* target; const uint8_t* target_sel; const int32_t* target_m2p; float* target_packed; float tau; int32_t hard_enable;
+    float* absmax_p; float* absmax_grad;
+    int64_t* counter; int32_t counter_n; int32_t counter_add;
+} gad_optim_job;
+int gad_optim_jobs(const gad_optim_job* host_jobs, int n_jobs, void* stream);
+
 /* packed[m2p[i]] = p[i] (refresh the compute layout after an external parameter change)          */
 int gad_pack_params(const float* p, const int32_t* m2p, int n, float* packed, void* stream);
 
