@@ -537,6 +537,40 @@ def gen_replay_io():
     np.savez_compressed(os.path.join(OUT, "replay_io.npz"), **out)
 
 
+def _manifest(obj):
+    """key / shape / dtype structure of a checkpoint object (tensors -> [shape, dtype]; scalars -> type name)"""
+    if torch.is_tensor(obj):
+        return {"tensor": list(obj.shape), "dtype": str(obj.dtype).replace("torch.", "")}
+    if isinstance(obj, dict):
+        return {"dict": {str(k): _manifest(v) for k, v in obj.items()}, "int_keys": all(isinstance(k, int) for k in obj) and len(obj) > 0}
+    if isinstance(obj, (list, tuple)):
+        return {"list": [_manifest(v) for v in obj]}
+    return {"scalar": type(obj).__name__}
+
+
+def gen_checkpoint(B=8):
+    """A checkpoint set WRITTEN BY THE REFERENCE's own Agent.save_model (core/agent.py:282-346) after one DDPG update (so the
+    Adam states exist): file names, dict keys, state-dict keys, tensor shapes / dtypes, optimiser-state structure.  Only the
+    manifest is kept (the files themselves are 40 MB of det-filled weights): tests/test_oracle_golden.py checks that our
+    save_model writes exactly this structure and that load_model accepts a file set built from it."""
+    import tempfile
+    agent, cfg = _make_agent("DDPG", "td3_critic_aux_policy_aux.yaml")
+    _fill_agent(agent, SEED)
+    agent.update_step = 2
+    torch.manual_seed(SEED)
+    batch = make_batch("ddpg_td3_aux.yaml", B, 600, 77)
+    agent.update_parameters(batch, agent.update_step, 0)
+    agent.step_scheduler(agent.update_step)
+    out = {"files": {}, "step_saved": 7, "agent_name": agent.name, "env_name": agent.env_name}
+    with tempfile.TemporaryDirectory() as d:
+        agent.save_model(7, output_dir=d, surfix="latest")
+        for f in sorted(os.listdir(d)):
+            out["files"][f] = _manifest(torch.load(os.path.join(d, f), weights_only=False))
+    with open(os.path.join(OUT, "checkpoint_manifest.json"), "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+    return sorted(out["files"])
+
+
 def main():
     """python -m oracle.make_golden [name ...]: regenerate all fixtures, or only the named generators
     (config losses heads replay replay_io encoder bc ddpg ...)"""
@@ -545,7 +579,7 @@ def main():
     torch.set_num_threads(8)
     gens = [("config", gen_config), ("losses", gen_losses), ("heads", gen_heads), ("replay", gen_replay),
             ("replay_io", gen_replay_io), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg),
-            ("ddpg_f64", gen_ddpg_f64)]
+            ("ddpg_f64", gen_ddpg_f64), ("checkpoint", gen_checkpoint)]
     if sys.argv[1:] == ["seeds"]:
         print(find_ddpg_seeds())
         return

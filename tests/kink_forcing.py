@@ -39,7 +39,7 @@ def decisions_from_slot(enc, slot):
         C = enc.sa_mats[s][2].n_out
         win = slot.argmax[s].long().cpu() - off[:-1, None]                                      # (G,C): winner's slot
         assert int(win.min()) >= 0 and bool((win < cnt[:, None]).all())
-        dec["sa"].append({"relu": relu, "pool": win.reshape(B, M, C).permute(0, 2, 1).contiguous()})
+        dec["sa"].append({"relu": relu, "pool": win.reshape(B, M, C).permute(0, 2, 1).contiguous(), "cnt": cnt.reshape(B, M)})
     for l, m in enumerate(enc.fc_mats):
         o = enc.bn_off[m.bn_index]
         y = slot.Zfc[l].double() * slot.scale[o:o + m.n_out].double() + slot.shift[o:o + m.n_out].double()
@@ -94,3 +94,110 @@ class forced_forward(object):
 
     def __exit__(self, *a):
         self.fe.forward = self.orig
+
+
+def _forward_recording(fe, pc, value, rec):
+    """the same forward, free-running: every ReLU / max-pool takes its own decision, which is recorded together with the
+    quantity it was taken on (post-BatchNorm pre-activation y; pooled activations) -> rec = decisions + "y" / "pooled" """
+    x = pc[..., 6:] if pc.shape[-1] != 1024 else pc
+    c = fe.critic_input_dim if value else fe.policy_input_dim
+    feats = x[:, :c].contiguous()
+    xyz = feats.transpose(1, -1)[..., :3].contiguous()
+    enc = fe.value_encoder if value else fe.encoder
+    rec["sa"], rec["fc"], rec["y_sa"], rec["y_fc"], rec["pooled"] = [], [], [], [], []
+    for s, sa in enumerate(enc[0]):
+        new_xyz = None
+        if sa.npoint is not None:
+            fps_idx = pu.furthest_point_sample(xyz, sa.npoint)
+            new_xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), fps_idx).transpose(1, 2).contiguous()
+        h = sa.groupers[0](xyz, new_xyz, feats)
+        seq = sa.mlps[0]
+        relu, ys = [], []
+        for l in range(3):
+            y = seq[3 * l + 1](seq[3 * l](h))
+            ys.append(y.detach())
+            relu.append((y > 0).detach())
+            h = torch.relu(y)
+        win = h.argmax(dim=3)                                       # first maximum (torch.max_pool2d's rule on CPU)
+        rec["sa"].append({"relu": relu, "pool": win.detach()})
+        rec["y_sa"].append(ys)
+        rec["pooled"].append(h.detach())
+        feats = h.max(dim=3).values
+        xyz = new_xyz
+    fc = enc[1]
+    y1 = fc[1](fc[0](feats.squeeze(-1)))
+    y2 = fc[4](fc[3](torch.relu(y1)))
+    rec["fc"] = [(y1 > 0).detach(), (y2 > 0).detach()]
+    rec["y_fc"] = [y1.detach(), y2.detach()]
+    return torch.relu(y2)
+
+
+class recording_forward(object):
+    """context manager: every call of the oracle's feature extractor runs free and leaves its decisions in
+    self.records[("value" | "policy", call index)]"""
+
+    def __init__(self, fe):
+        self.fe, self.records = fe, {}
+
+    def __enter__(self):
+        fe, calls = self.fe, {"value": 0, "policy": 0}
+        self.orig = fe.forward
+
+        def fwd(pc, value=False):
+            tag = "value" if value else "policy"
+            k = calls[tag]
+            calls[tag] += 1
+            rec = self.records[(tag, k)] = {}
+            return _forward_recording(fe, pc, value, rec)
+        fe.forward = fwd
+        return self
+
+    def __exit__(self, *a):
+        self.fe.forward = self.orig
+
+
+def decision_differences(hip_dec, rec):
+    """compare the HIP pass's decisions with a free-running oracle pass's own: -> dict(n, n_diff, worst) for the ReLU
+    masks (worst = largest |pre-activation| / channel scale among the differing entries, measured in the oracle) and for
+    the pool winners (worst = largest relative gap between the oracle's maximum and its activation at the HIP winner)"""
+    n = n_diff = 0
+    worst = 0.0
+    for s in range(3):
+        for l in range(3):
+            a, b, y = hip_dec["sa"][s]["relu"][l], rec["sa"][s]["relu"][l], rec["y_sa"][s][l]
+            d = a != b
+            n += d.numel()
+            n_diff += int(d.sum())
+            if bool(d.any()):
+                scale = y.abs().amax(dim=(0, 2, 3), keepdim=True).expand_as(y)
+                worst = max(worst, float((y.abs() / scale)[d].max()))
+    for l in range(2):
+        a, b, y = hip_dec["fc"][l], rec["fc"][l], rec["y_fc"][l]
+        d = a != b
+        n += d.numel()
+        n_diff += int(d.sum())
+        if bool(d.any()):
+            scale = y.abs().amax(dim=0, keepdim=True).expand_as(y)
+            worst = max(worst, float((y.abs() / scale)[d].max()))
+    pn = pn_diff = 0
+    pworst = 0.0
+    detail = []
+    for s in range(3):
+        a, b, h = hip_dec["sa"][s]["pool"], rec["sa"][s]["pool"], rec["pooled"][s]
+        # upstream pads a group to nsample slots with copies of its first hit: a winner among the copies IS slot 0 (the
+        # float64 convolution is not bitwise identical across the copies, its arg-max lands on one of them now and then)
+        b = torch.where(b >= hip_dec["sa"][s]["cnt"][:, None, :], torch.zeros_like(b), b)
+        d = a != b
+        pn += d.numel()
+        pn_diff += int(d.sum())
+        if bool(d.any()):
+            top = h.max(dim=3).values
+            at = h.gather(3, a.unsqueeze(-1)).squeeze(-1)
+            gap = (top - at) / (top.abs() + 1e-30)
+            # all-zero groups (every activation clipped by the ReLU): any winner is the reference's "first" only by index
+            live = d & (top > 0)
+            exact = d & (top == at)
+            detail.append("stage %d: %d differ, %d with a positive maximum, %d exactly tied in float64" % (s + 1, int(d.sum()), int(live.sum()), int(exact.sum())))
+            if bool(live.any()):
+                pworst = max(pworst, float(gap[live].max()))
+    return dict(relu=dict(n=n, n_diff=n_diff, worst=worst), pool=dict(n=pn, n_diff=pn_diff, worst=pworst, detail="; ".join(detail)))

@@ -156,3 +156,51 @@ def test_bc_step_gradients_with_forced_decisions():
         open(os.path.join(out_dir, "grad_accuracy_forced_BC_B64.txt"), "w").write("\n".join(lines) + "\n")
     assert len(lines) > 30
     assert not bad, "\n".join([lines[0]] + bad)
+
+
+@pytest.mark.parametrize("B,seed", [(32, 1), (64, 2)])
+def test_hip_decisions_agree_with_the_free_running_oracle(B, seed):
+    """The forced-decision gate above takes its ReLU masks and max-pool winners FROM the HIP pass, so a wrong mask or a
+    non-maximal winner would be followed, not caught.  Here the float64 oracle runs FREE on the same step and takes its own
+    decisions: the two may differ only where the pre-activation (winner's margin) sits within rounding of the kink --
+    fraction of differing decisions <= 1e-5 (ReLU) / 1e-4 (pool), every differing pre-activation within 1e-5 of zero on its
+    channel's scale, every differing winner within 1e-5 (relative) of the oracle's maximum."""
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    from tests.kink_forcing import decision_differences, decisions_from_slot, recording_forward
+    from tests.test_gpu_step import _filled_agent
+    c = load_cfg("ddpg_td3_aux.yaml")
+    mem = BaseMemory(2000, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 2000, seed=5 + seed)
+    rng = np.random.default_rng(seed)
+    batch = sample_valid_batch(mem, B, rng)
+    u = rng.random((B, 6)).astype(np.float32)
+    agent, nets = _filled_agent("ddpg_td3_aux.yaml", 3)
+    agent.update_step = 1
+    agent.update_parameters(batch, agent.update_step, 0, noise_u=u)
+    torch.cuda.synchronize()
+    rt = agent._rt
+    dec = {("value", 0): decisions_from_slot(rt.venc, rt.slot_v), ("policy", 1): decisions_from_slot(rt.enc, rt.slot_p)}
+    o = ref_step.OracleAgent(c.RL_TRAIN)
+    for n, net in o.nets().items():
+        fill_module_(net, n, 3)
+    o.to_dtype(torch.float64)
+    o.update_step = 1
+    with recording_forward(o.state_feature_extractor.module) as rf:
+        o.update_ddpg(batch, noise_u=u)
+    lines = []
+    for key in dec:
+        r = decision_differences(dec[key], rf.records[key])
+        lines.append("%s pass %d: ReLU %d of %d decisions differ (largest |pre-activation| / scale %.2e); pool %d of %d winners "
+                     "differ (largest relative gap %.2e) [%s]" % (key[0], key[1], r["relu"]["n_diff"], r["relu"]["n"], r["relu"]["worst"],
+                                                              r["pool"]["n_diff"], r["pool"]["n"], r["pool"]["worst"], r["pool"]["detail"]))
+        assert r["relu"]["n_diff"] <= 1e-5 * r["relu"]["n"] and r["relu"]["worst"] <= 1e-5, lines[-1]
+        assert r["pool"]["n_diff"] <= 1e-4 * r["pool"]["n"] and r["pool"]["worst"] <= 1e-5, lines[-1]
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "decision_differences_B%d.txt" % B), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))

@@ -189,3 +189,110 @@ def test_device_replay_matches_host_sampling():
     dmem.refresh(100, 110)
     got = dmem.sample(10, batch_idx=np.arange(100, 110))
     assert float((got["action_batch"] - 0.25).abs().max()) == 0.0
+
+
+def _manifest(obj):
+    """structure of a checkpoint object, as oracle/make_golden.py records it for the reference's files"""
+    if torch.is_tensor(obj):
+        return {"tensor": list(obj.shape), "dtype": str(obj.dtype).replace("torch.", "")}
+    if isinstance(obj, dict):
+        return {"dict": {str(k): _manifest(v) for k, v in obj.items()}, "int_keys": all(isinstance(k, int) for k in obj) and len(obj) > 0}
+    if isinstance(obj, (list, tuple)):
+        return {"list": [_manifest(v) for v in obj]}
+    return {"scalar": type(obj).__name__}
+
+
+def _from_manifest(m, rng):
+    """a checkpoint object with the manifest's structure and random contents"""
+    if "tensor" in m:
+        dt = getattr(torch, m["dtype"])
+        if dt.is_floating_point:
+            return (torch.as_tensor(np.asarray(rng.standard_normal(m["tensor"]), dtype=np.float32)).reshape(m["tensor"]) * 0.05).to(dt)
+        return torch.full(m["tensor"], 3, dtype=dt)
+    if "dict" in m:
+        return {(int(k) if m.get("int_keys") else k): _from_manifest(v, rng) for k, v in m["dict"].items()}
+    if "list" in m:
+        return [_from_manifest(v, rng) for v in m["list"]]
+    return {"int": 3, "float": 0.5, "bool": False, "str": "x", "NoneType": None}[m["scalar"]]
+
+
+def _diff(a, b, path=""):
+    """structural differences between two manifests (scalar types int / float are interchangeable: torch versions differ)"""
+    if set(a) - {"int_keys"} != set(b) - {"int_keys"}:
+        return ["%s: %s vs %s" % (path, sorted(a), sorted(b))]
+    if "tensor" in a:
+        return [] if (a["tensor"] == b["tensor"] and a["dtype"] == b["dtype"]) else ["%s: %s %s vs %s %s" % (path, a["tensor"], a["dtype"], b["tensor"], b["dtype"])]
+    if "dict" in a:
+        out = []
+        if set(a["dict"]) != set(b["dict"]):
+            out.append("%s: keys differ: only ours %s, only reference %s" % (path, sorted(set(a["dict"]) - set(b["dict"]))[:6], sorted(set(b["dict"]) - set(a["dict"]))[:6]))
+        for k in set(a["dict"]) & set(b["dict"]):
+            out += _diff(a["dict"][k], b["dict"][k], path + "/" + k)
+        return out
+    if "list" in a:
+        if len(a["list"]) != len(b["list"]):
+            return ["%s: list length %d vs %d" % (path, len(a["list"]), len(b["list"]))]
+        return [d for i, (x, y) in enumerate(zip(a["list"], b["list"])) for d in _diff(x, y, path + "[%d]" % i)]
+    return []
+
+
+def test_checkpoints_have_the_reference_writers_structure(tmp_path, golden_dir):
+    """tests/golden/checkpoint_manifest.json = file names, dict keys, state-dict keys, tensor shapes / dtypes and optimiser
+    state structure of a checkpoint set WRITTEN BY THE REFERENCE's Agent.save_model (core/agent.py:282-346) after one update
+    (oracle/make_golden.py gen_checkpoint).  (1) our save_model writes exactly that structure; (2) a file set built from the
+    manifest -- what a reference run leaves on disk -- is accepted by our load_model: every tensor arrives, the schedulers
+    and Adam states are restored, update_step comes from the file."""
+    import json
+    import os
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    man = json.load(open(os.path.join(golden_dir, "checkpoint_manifest.json")))
+    torch.manual_seed(5)
+    a1, cfg = make_agent("ddpg_td3_aux.yaml")
+    assert (a1.name, a1.env_name) == (man["agent_name"], man["env_name"])
+    mem = BaseMemory(600, cfg, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 600, seed=4)
+    rng = np.random.default_rng(2)
+    a1.update_step = 2
+    a1.update_parameters(sample_valid_batch(mem, 8, rng), a1.update_step, 0)
+    a1.step_scheduler()
+    ours_dir = os.path.join(str(tmp_path), "ours")
+    a1.save_model(7, output_dir=ours_dir)
+    assert sorted(os.listdir(ours_dir)) == sorted(man["files"])
+    bad = []
+    for f in man["files"]:
+        bad += _diff(_manifest(torch.load(os.path.join(ours_dir, f), weights_only=False)), man["files"][f], f)
+    assert not bad, "\n".join(bad[:20])
+    # (2) a file set as the reference leaves it -> load_model
+    ref_dir = os.path.join(str(tmp_path), "ref")
+    os.makedirs(ref_dir)
+    objs = {}
+    for f, m in man["files"].items():
+        objs[f] = _from_manifest(m, rng)
+        for part in ("opt", "encoder_opt", "val_encoder_opt"):           # valid optimiser hyper-parameters, positive second moments
+            if part in objs[f]:
+                for st in objs[f][part]["state"].values():
+                    st["exp_avg_sq"] = st["exp_avg_sq"].abs()
+                first = 0
+                for g in objs[f][part]["param_groups"]:
+                    g.update(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
+                             params=list(range(first, first + len(g["params"]))))
+                    first += len(g["params"])
+        for k, v in objs[f]["net"].items():
+            if k.endswith("running_var"):
+                objs[f]["net"][k] = v.abs() + 0.5
+        for part in ("sch", "encoder_sch", "val_encoder_sch"):
+            if part in objs[f]:
+                objs[f][part] = a1.policy_scheduler.state_dict()          # a well-formed MultiStepLR state
+        torch.save(objs[f], os.path.join(ref_dir, f))
+    a2, _ = make_agent("ddpg_td3_aux.yaml")
+    assert a2.load_model(ref_dir) == 3                                     # `step` of the state_feat file (the manifest's int -> 3)
+    for f, attr in (("DDPG_actor_PandaYCBEnv_latest", "policy"), ("DDPG_critic_PandaYCBEnv_latest", "critic"),
+                    ("DDPG_state_feat_PandaYCBEnv_latest", "state_feature_extractor")):
+        sd = getattr(a2, attr).state_dict()
+        for k, v in objs[f]["net"].items():
+            assert torch.equal(sd[k].cpu().to(v.dtype), v), (f, k)
+    st = a2.policy_optim.state_dict()["state"]
+    ref_st = objs["DDPG_actor_PandaYCBEnv_latest"]["opt"]["state"]
+    assert set(st) == set(ref_st) and all(torch.equal(st[i]["exp_avg"].cpu(), ref_st[i]["exp_avg"]) for i in st)

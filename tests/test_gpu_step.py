@@ -381,6 +381,61 @@ def test_ragged_batch_and_cloud_sizes_vs_oracle(B, NP):
     assert_close(agent.qf1.cpu().numpy(), q_ref, 0.0, tol * np.abs(q_ref).max() + 2e-6, "q1")
 
 
+def test_ddpg_step_B256_vs_oracle():
+    """The benchmark's own size (BASELINE configs[1]: B = 256, N = 1024): one DDPG update from identical parameters against the
+    CPU oracle on the same minibatch and target noise, a step with the actor-critic term (all 4.5 encoder passes and both
+    critic evaluations take part).  Losses to the north star's 1e-4 against the float32 oracle; Q1 / Q2, the TD target,
+    actions and the aux pose against the oracle evaluated in FLOAT64, with the float32 oracle's own distance from it as the
+    yardstick: ours <= max(1e-4, 2 x torch-float32) of the tensor's scale (the TD target runs through four chained
+    train-mode BatchNorm networks; two float32 evaluations of it sit ~1e-4 apart at this size).
+    (An oracle step takes ~20 s on the box's host cores; bench.py times the same call as its cpu_baseline.)"""
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from oracle import ref_step
+    from oracle.detfill import fill_module_
+    B = 256
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))
+    c = load_cfg("ddpg_td3_aux.yaml")
+    mem = BaseMemory(3000, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 3000, seed=6)
+    rng = np.random.default_rng(12)
+    batch = sample_valid_batch(mem, B, rng)
+    u = rng.random((B, 6)).astype(np.float32)
+    agent, nets = _filled_agent("ddpg_td3_aux.yaml", 29)
+    agent.update_step = 2                                  # policy_update_gap 2: the actor-critic term is on
+    got = agent.update_parameters(batch, agent.update_step, 0, noise_u=u)
+    torch.cuda.synchronize()
+
+    def run(dtype):
+        o = ref_step.OracleAgent(c.RL_TRAIN)
+        for name, net in o.nets().items():
+            fill_module_(net, name, 29)
+        o.to_dtype(dtype)
+        o.update_step = 2
+        return o.update_ddpg(batch, noise_u=u), {k: o.dbg[k].double().numpy() for k in ("q1", "q2", "y", "pi", "aux_pred")}
+    want, t32 = run(torch.float32)
+    _, t64 = run(torch.float64)
+    for k in ("critic_loss", "critic_grasp_aux_loss", "bc_loss", "policy_grasp_aux_loss"):
+        assert_close(got[k], want[k], 1e-4, 1e-6, k)
+    # evaluated through the critic AFTER its Adam step of the same update (sign-like first step: DESIGN.md 6)
+    assert_close(got["actor_critic_loss"], want["actor_critic_loss"], 5e-2, 1e-4, "actor_critic_loss")
+    lines = []
+    for name, ours, k in (("q1", agent.qf1, "q1"), ("q2", agent.qf2, "q2"), ("td target", agent.next_q_value, "y"),
+                          ("pi", agent.pi, "pi"), ("aux_pred", agent.aux_pred, "aux_pred")):
+        ref = t64[k]
+        scale = np.abs(ref).max()
+        e_hip = np.abs(ours.cpu().double().numpy().reshape(ref.shape) - ref).max() / scale
+        e_f32 = np.abs(t32[k] - ref).max() / scale
+        lines.append("%-10s max error / scale vs float64: hip %.2e   torch-float32 %.2e" % (name, e_hip, e_f32))
+        assert e_hip <= max(1e-4, 2.0 * e_f32), lines[-1]
+    print("\n".join(lines))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "step_B256_vs_oracle.txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
 def test_overlapped_schedule_equals_serial_schedule():
     """the step runs on five HIP streams (value pass, target chain, actor pass, two weight-gradient lanes) with a host
     enqueue order chosen for the critical path; with every fork folded onto one stream (engine.SERIAL) the same plans run
