@@ -22,6 +22,11 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// cache policy of the streaming kernels' big output stores (buffer-store aux bits: 0 plain, 2 nt, 16 sc1 = write-through)
+#ifndef GAD_STREAM_STORE_AUX
+#define GAD_STREAM_STORE_AUX 0
+#endif
+
 #define KT 32   // reduction tile
 
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -664,9 +669,13 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
 //     fill one row: conflict-free), fragments come in as one ds_read_b128 per four MFMA steps (k visited as 8j + 4h + i, the
 //     streaming kernels' order: the 36-float pitch spreads 16 rows over all 64 banks);
 //   * relu(scale * z + shift) is applied once per staged element, not per fragment read.
+// XM = 1: the first layer of SA2 / SA3, whose input rows are GATHERED ([feat[pt] | src_xyz[pt] - ctr_xyz[grp]], features a
+// multiple of 32 wide, already activated): the K loop runs over the feature columns only, the three coordinate columns
+// are a rank-3 update of the accumulators in the epilogue (z += dx . W[n][feat_c .. feat_c + 2]) instead of a fifth,
+// almost empty K-tile.
 // Measured alone (tests/diag_gemm.py, B = 256 shapes): see profiles/README.md round 3.
 // ------------------------------------------------------------------------------------------------
-template <bool POOL>
+template <int XM, bool POOL>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
                                                                const float* __restrict__ row_w, const float* __restrict__ W,
                                                                int Kp, int n_out, float* __restrict__ zout, int zout_pitch,
@@ -675,10 +684,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
     KTimer kt_(ts);
     constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = (BM + BN) * P, VM = 512;
     static_assert(2 * STAGE >= 64 * 129, "the pooled epilogue's tile lives in the operand buffers");
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * VM + BM];
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * VM + BM + 4 * BM];
     float* sv = smem + 2 * STAGE;
     float* tv = sv + VM;
     float* wS = tv + VM;
+    float* dxS = wS + BM;                                // XM = 1: [row][4] = src_xyz[pt] - ctr_xyz[grp]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -686,10 +696,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
     const int n0 = blockIdx.y * BN;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     if ((int)(blockIdx.x * BM) >= n_rows) return;
-    const int nk = Kp / KT;
+    const int nk = (XM == 0 ? Kp : x.feat_c) / KT;
     const int c4 = (tid & 7) * 4;                        // this thread's 16-byte column chunk inside a K-tile
     const int ur = tid >> 3;                             // ... and row (A: rows ur, ur + 32; B: ur, +32, +64, +96)
-    stage_affine<256>(sv, tv, x, 0, Kp);
+    if (XM == 0) stage_affine<256>(sv, tv, x, 0, Kp);
 
     float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
     for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
@@ -709,8 +719,9 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
             psgn[1] = pe.gamma[n0 + 64 + lane] < 0.f ? -1.f : 1.f;
         }
         // rows past the live count are clamped to the last live row (never stored, weight 0 in the statistics)
-        const float* ap0 = x.zin + (size_t)min(row0 + ur, n_rows - 1) * x.zin_pitch + c4;
-        const float* ap1 = x.zin + (size_t)min(row0 + ur + 32, n_rows - 1) * x.zin_pitch + c4;
+        const int ra0 = min(row0 + ur, n_rows - 1), ra1 = min(row0 + ur + 32, n_rows - 1);
+        const float* ap0 = XM == 0 ? x.zin + (size_t)ra0 * x.zin_pitch + c4 : x.feat + (size_t)x.row_pt[ra0] * x.feat_c + c4;
+        const float* ap1 = XM == 0 ? x.zin + (size_t)ra1 * x.zin_pitch + c4 : x.feat + (size_t)x.row_pt[ra1] * x.feat_c + c4;
         const float* bp = W + (size_t)(n0 + ur) * Kp + c4;
         float4 ra[2], rb[4];
         auto load_regs = [&](int kt) {
@@ -722,13 +733,18 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         auto write_lds = [&](int kt) {
             float* As = smem + (kt & 1) * STAGE;
             float* Bs = As + BM * P;
-            const float4 s4 = *reinterpret_cast<const float4*>(sv + kt * KT + c4);
-            const float4 t4 = *reinterpret_cast<const float4*>(tv + kt * KT + c4);
+            float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = f4zero();
+            if (XM == 0) {
+                s4 = *reinterpret_cast<const float4*>(sv + kt * KT + c4);
+                t4 = *reinterpret_cast<const float4*>(tv + kt * KT + c4);
+            }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 float4 v = ra[u];
-                v.x = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f);
-                v.z = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f);
+                if (XM == 0) {
+                    v.x = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f);
+                    v.z = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f);
+                }
                 *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
             }
 #pragma unroll
@@ -736,7 +752,20 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         };
         load_regs(0);
         __syncthreads();                                 // sv / tv visible; the previous row tile's LDS reads (wS, zt) are done
-        if (tid < BM) { const int r = row0 + tid; wS[tid] = r < n_rows ? (row_w ? row_w[r] : 1.f) : 0.f; }
+        if (tid < BM) {
+            const int r = row0 + tid;
+            wS[tid] = r < n_rows ? (row_w ? row_w[r] : 1.f) : 0.f;
+            if (XM == 1) {                               // the row's recentred coordinates (rounded as the oracle rounds them)
+                const int rr = min(r, n_rows - 1);
+                const float* p = x.src_xyz + (size_t)x.row_pt[rr] * 3;
+                float q0 = p[0], q1 = p[1], q2 = p[2];
+                if (x.ctr_xyz) {
+                    const float* cp = x.ctr_xyz + (size_t)x.row_grp[rr] * 3;
+                    q0 = __fsub_rn(q0, cp[0]); q1 = __fsub_rn(q1, cp[1]); q2 = __fsub_rn(q2, cp[2]);
+                }
+                *reinterpret_cast<float4*>(dxS + 4 * tid) = make_float4(q0, q1, q2, 0.f);
+            }
+        }
         write_lds(0);
         if (nk > 1) load_regs(1);
         __syncthreads();
@@ -766,6 +795,18 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
             if (kt + 1 < nk) write_lds(kt + 1);          // the other buffer: its readers passed the previous barrier
             if (kt + 2 < nk) load_regs(kt + 2);
             __syncthreads();
+        }
+        if (XM == 1) {                                   // the three coordinate columns: z += dx . W[n][feat_c .. feat_c + 2]
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float* wx = W + (size_t)(n0 + wn * 64 + t * 32 + l31) * Kp + x.feat_c;
+                const float w0 = wx[0], w1 = wx[1], w2 = wx[2];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float4 q = *reinterpret_cast<const float4*>(dxS + 4 * (wm * 32 + acc_row(v, half)));
+                    acc[t][v] = fmaf(q.x, w0, fmaf(q.y, w1, fmaf(q.z, w2, acc[t][v])));
+                }
+            }
         }
         if (POOL) {
             float* zt = smem;                            // [64][129]: every wavefront is past the K loop's last barrier
@@ -808,9 +849,13 @@ static int g_opt_dx_wide = 1, g_opt_dw_wide = 1;
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
 static bool fwd_wideable(const gad_gemm_fwd_args& a) {
-    if (!g_opt_fwd_wide || a.mode != 0 || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
-    if (a.n_rows < 2048 || a.n_out[0] % 128 != 0 || a.Kp % 32 != 0 || a.Kp > 512 || a.Kp != a.c_in) return false;
-    return a.ones_col < 0 && !a.extra && a.scale && a.shift && a.relu;
+    if (!g_opt_fwd_wide || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
+    if (a.n_rows < 2048 || a.n_out[0] % 128 != 0 || a.ones_col >= 0) return false;
+    if (a.mode == 1)                                     // gathered first layer: features a multiple of 32, + 3 coordinates
+        return g_opt_fwd_wide != 2 && !a.pool_key && a.act_c == 0 && a.feat_c % 32 == 0 && a.feat_c >= 32 && a.feat_c <= 512 &&
+               a.Kp == ((a.feat_c + 3 + 7) & ~7);
+    if (a.Kp % 32 != 0 || a.Kp > 512 || a.Kp != a.c_in) return false;
+    return !a.extra && a.scale && a.shift && a.relu;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1007,8 +1052,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             for (int t = 0; t < TN; ++t) {
                 const f32x2 zv = f32x2{acc[t][v], acc[t][v + 1]};
                 if (!POOL || store_z) {                  // (rows past n_rows / a NULL zout fall outside num_records: dropped)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, 0);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + NO * 4, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, GAD_STREAM_STORE_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + NO * 4, GAD_STREAM_STORE_AUX);
                 }
                 const f32x2 wz = wr * zv;
                 csum[t] += wz;
@@ -1267,11 +1312,14 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     if (fwd_wideable(*a)) {
         int gx = gad_cdiv(grid_rows, 64); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;
         const dim3 grid(gx, a->n_out[0] / 128);
-        if (pe.key)
-            hipLaunchKernelGGL((gemm_fwd_wide_kernel<true>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
+        if (a->mode == 1)
+            hipLaunchKernelGGL((gemm_fwd_wide_kernel<1, false>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
+                               a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
+        else if (pe.key)
+            hipLaunchKernelGGL((gemm_fwd_wide_kernel<0, true>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
                                a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
         else
-            hipLaunchKernelGGL((gemm_fwd_wide_kernel<false>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
+            hipLaunchKernelGGL((gemm_fwd_wide_kernel<0, false>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
                                a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
         GAD_CHECK_LAUNCH("gemm_fwd(wide)");
         return GAD_OK;
@@ -1594,7 +1642,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
                 const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
                 const float ga = act ? gv : 0.f;
                 // the previous layer's consumers take dY with its ReLU mask applied (premasked)
-                if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), grsrc, glane + t * 128, rb, 0);
+                if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), grsrc, glane + t * 128, rb, GAD_STREAM_STORE_AUX);
                 else if (live) e.gout[(size_t)(slab * 32 + row) * 64 + t * 32 + l31] = ga;
                 sb[t] += ga;
                 sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
@@ -2129,10 +2177,12 @@ __global__ __launch_bounds__(256) void gemm_dw_kernel(DzSrc d, XSrc x, Groups gr
 }
 
 #define DW_RED_CHUNK 16
+// all_active: every split wrote its partial tile (the streaming kernels deal row units to the splits round-robin); else the
+// splits are contiguous row chunks and those past the live rows were not written
 __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict__ partial, long long group_stride,
                                                         Groups gr, const int32_t* __restrict__ n_rows_dev,
                                                         int n_rows_static, int splits, int Kp, int k_used,
-                                                        double* __restrict__ gacc) {
+                                                        double* __restrict__ gacc, int all_active = 0) {
     const int g = blockIdx.z;
     const int n_out = gr.nout[g];
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -2142,7 +2192,7 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     int chunk = (n_rows + splits - 1) / splits;
     chunk = (chunk + KT - 1) / KT * KT;
-    const int active = chunk > 0 ? (n_rows + chunk - 1) / chunk : 0;
+    const int active = all_active ? splits : (chunk > 0 ? (n_rows + chunk - 1) / chunk : 0);
     const int s0 = blockIdx.y * DW_RED_CHUNK, s1 = min(s0 + DW_RED_CHUNK, active);
     if (s0 >= s1) return;
     const float* p = partial + (size_t)g * group_stride + e;
@@ -2262,10 +2312,13 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
     const int l31 = lane & 31, half = lane >> 5;
     const int cset = wave / RW, wr = wave % RW;                    // column set, rank among the wavefronts of that set
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    int chunk = (n_rows + splits - 1) / splits;
-    chunk = (chunk + KT - 1) / KT * KT;                            // == dw_reduce_kernel's split geometry
-    const int r_begin = blockIdx.x * chunk, r_end = min(n_rows, r_begin + chunk);
-    if (r_begin >= n_rows) return;                                 // inactive split: dw_reduce does not read it
+    // 8-row units are dealt to the workgroups ROUND-ROBIN (unit = (k * gridDim.x + blockIdx.x) * RW + rank): at any time
+    // the whole grid reads one contiguous window of rows and that window sweeps the arrays front to back -- the order in
+    // which the dX kernel of the same layer, running beside this one on the main stream, walks them too, so the second
+    // reader of z / dY finds the lines in the L2 / Infinity Cache instead of HBM (contiguous chunks per workgroup touched
+    // all of the array at once).  Every workgroup writes its partial tile (zeros without rows): dw_reduce all_active.
+    const int r_begin = 0, r_end = n_rows;
+    (void)splits;
 
     // per-lane constants: A side (dZ) output channels n = 64 cset + 32 j + l31, B side (X) input channels k = 32 b + l31
     float dP[2], dQ[2], dS[2], xs[2], xt[2];          // (the ReLU mask is already in dY: premasked)
@@ -2352,20 +2405,21 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
     };
     const std::integral_constant<bool, false> full;
     const std::integral_constant<bool, true> part;
-    const int nfull = (r_end - r_begin) >> 3;                      // units with all eight rows inside the split
+    const int nfull = (r_end - r_begin) >> 3;                      // units with all eight rows live
+    const int ustep = gridDim.x * RW;
     Unit u0, u1;
-    int un = wr;                                                   // units are dealt round-robin to the set's wavefronts
+    int un = blockIdx.x * RW + wr;
     if (un < nfull) load(u0, un);
     while (un < nfull) {
-        if (un + RW < nfull) load(u1, un + RW);
+        if (un + ustep < nfull) load(u1, un + ustep);
         compute(u0, un, full);
-        un += RW;
+        un += ustep;
         if (un >= nfull) break;
-        if (un + RW < nfull) load(u0, un + RW);
+        if (un + ustep < nfull) load(u0, un + ustep);
         compute(u1, un, full);
-        un += RW;
+        un += ustep;
     }
-    if (((r_end - r_begin) & 7) != 0 && wr == nfull % RW) {        // the ragged last unit of the last split
+    if (((r_end - r_begin) & 7) != 0 && (nfull / RW) % gridDim.x == blockIdx.x && wr == nfull % RW) {   // the ragged last unit
         load_tail(u0, nfull);
         compute(u0, nfull, part);
     }
@@ -2406,10 +2460,8 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    int chunk = (n_rows + splits - 1) / splits;
-    chunk = (chunk + KT - 1) / KT * KT;
-    const int r_begin = blockIdx.x * chunk, r_end = min(n_rows, r_begin + chunk);
-    if (r_begin >= n_rows) return;
+    const int r_begin = 0, r_end = n_rows;         // units dealt round-robin over the grid (see gemm_dw_stream_kernel)
+    (void)splits;
 
     const unsigned lane_n = 2u * l31;
     float dP[2], dQ[2], dS[2];                        // (premasked dY)
@@ -2494,19 +2546,20 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
     const std::integral_constant<bool, false> full;
     const std::integral_constant<bool, true> part;
     const int nfull = (r_end - r_begin) >> 3;
+    const int ustep = gridDim.x * RW;
     Unit u0, u1;
-    int un = wave;
+    int un = blockIdx.x * RW + wave;
     if (un < nfull) load(u0, un);
     while (un < nfull) {
-        if (un + RW < nfull) load(u1, un + RW);
+        if (un + ustep < nfull) load(u1, un + ustep);
         compute(u0, un, full);
-        un += RW;
+        un += ustep;
         if (un >= nfull) break;
-        if (un + RW < nfull) load(u0, un + RW);
+        if (un + ustep < nfull) load(u0, un + ustep);
         compute(u1, un, full);
-        un += RW;
+        un += ustep;
     }
-    if (((r_end - r_begin) & 7) != 0 && wave == nfull % RW) {
+    if (((r_end - r_begin) & 7) != 0 && (nfull / RW) % gridDim.x == blockIdx.x && wave == nfull % RW) {
         load_tail(u0, nfull);
         compute(u0, nfull, part);
     }
@@ -2589,7 +2642,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
                            1.0f / (float)gps, a->partial, ts);
         GAD_CHECK_LAUNCH("gemm_dw(gather stream)");
         hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256), 0,
-                           st, a->partial, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
+                           st, a->partial, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc, 1);
         GAD_CHECK_LAUNCH("dw_reduce");
         return GAD_OK;
     }
@@ -2605,7 +2658,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         }
         GAD_CHECK_LAUNCH("gemm_dw(stream)");
         hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256), 0,
-                           st, part, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
+                           st, part, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc, 1);
         GAD_CHECK_LAUNCH("dw_reduce");
         return GAD_OK;
     }

@@ -24,6 +24,7 @@ import os as _os
 # beside the critic backward only: 275; the value pass after t1, beside t2 and the actor pass: 282; both side passes
 # swapped: 278 -- profiles/README.md round 2)
 ROW_HINTS = _os.environ.get("GAD_ROW_HINTS", "1") == "1"     # grids of the SA1 / SA2 tile launches sized for the expected live rows
+EARLY_ZERO = _os.environ.get("GAD_EARLY_ZERO", "1") == "1"   # backward buffers cleared at the end of the forward plans; t2's running update on the value stream
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
 
 
@@ -171,6 +172,7 @@ class FusedRuntime(object):
         self._ev_counts = torch.cuda.Event()
         self._ev_in = torch.cuda.Event()
         self._ev_pre = torch.cuda.Event()
+        self._ev_run = torch.cuda.Event()
         self.noise_host = self._noise_ring[0]
 
     # ------------------------------------------------------------------ plans over static buffers
@@ -246,8 +248,11 @@ class FusedRuntime(object):
         P = self.plans = {}
         P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None)
         P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
+        # the backward pass's buffers are cleared at the END of the forward plan (the actor stream, long before the backward
+        # starts) instead of at the head of the backward plan, one launch in front of its critical chain
+        zp = [pol.flat.gacc, enc.flat.gacc, self.slot_p.bstats, self.slot_p.dF[0], self.slot_p.dF[1]]
         bw = Plan()
-        bw.zero_multi([pol.flat.gacc, enc.flat.gacc, self.slot_p.bstats, self.slot_p.dF[0], self.slot_p.dF[1]])
+        (P["p_fwd"] if EARLY_ZERO else bw).zero_multi(zp)
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
         bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True, dw_lane=2,
                                                zero_scatter=False, early_hook=self._early_hook(pol, enc, "a")))
@@ -258,6 +263,9 @@ class FusedRuntime(object):
         venc, cr = self.venc, self.cr
         c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"])
         c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
+        zc = [cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.clip_sumsq]
+        if EARLY_ZERO:
+            c.zero_multi(zc)
         t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
         t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
         t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.pi_t, None)
@@ -265,8 +273,9 @@ class FusedRuntime(object):
         P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
         P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
-        cb = Plan()
-        cb.zero_multi([cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.clip_sumsq])
+        cb = Plan()                                 # (its buffers were cleared at the end of the value pass)
+        if not EARLY_ZERO:
+            cb.zero_multi(zc)
         cb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
         cb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=d["action_batch"], want_dw=True,
                                                zero_scatter=False, early_hook=self._early_hook(cr, venc, "c")))
@@ -620,11 +629,20 @@ class FusedRuntime(object):
         if OVERLAP_PASSES:
             self._ev[1].record(s1)
             main.wait_event(self._ev[1])
-            P["t2_run"].run()
+            # the target chain's deferred running-statistics update: on the value stream, behind the value pass's own
+            # updates (the reference's order) and the target pass (event), off the main stream's chain; the main stream picks
+            # it up again before the next writer of those statistics
+            self._ev[4].record(main)
+            s1.wait_event(self._ev[4])
+            with torch.cuda.stream(s1 if EARLY_ZERO else main):
+                P["t2_run"].run()
+                self._ev_run.record(s1 if EARLY_ZERO else main)
         hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
                  d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
                  self.inv_n_critic(), self.y, self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0))
-        P["c_bwd"].run()                            # (clears clip_sumsq with its other buffers)
+        P["c_bwd"].run()
+        if OVERLAP_PASSES:
+            main.wait_event(self._ev_run)           # (long done; orders the running statistics before the next value pass)
         if self.fused_optim:
             hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
             self._optim_phase("c", policy_step)

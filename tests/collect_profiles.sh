@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence on the GPU box: bench line, rocprofv3 kernel stats, PMC traffic (FETCH / WRITE in separate passes) and the
 # MFMA / VALU instruction counters.  Writes gpurun_out/rNN_*; copy what is to be judged into profiles/.
-R=${1:-r02}
+R=${1:-r03}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -14,6 +14,8 @@ timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/prof_write -o r --
 python tests/prof_traffic.py /tmp/prof_fetch /tmp/prof_write $OUT/${R}_traffic.json > $OUT/${R}_traffic.txt 2>&1
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVE_CYCLES -d /tmp/prof_mfma -o r -- $BENCH --steps 6 --warmup 4 --probe-steps 2 > /dev/null 2>&1
 python tests/prof_pmc.py /tmp/prof_mfma 140 > $OUT/${R}_rocprofv3_pmc_SQ_mfma.txt 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES -d /tmp/prof_waits -o r -- $BENCH --steps 6 --warmup 4 --probe-steps 2 > /dev/null 2>&1
+python tests/prof_pmc.py /tmp/prof_waits 200 > $OUT/${R}_rocprofv3_pmc_SQ_waits.txt 2>&1
 cp $OUT/${R}_traffic.json profiles/${R}_traffic.json 2>/dev/null     # bench.py reads roofline.traffic from here
 python bench.py --steps 200 --warmup 50 > $OUT/${R}_bench_B256.json 2> $OUT/${R}_bench_B256.err
 tail -c 600 $OUT/${R}_bench_B256.json
