@@ -2584,6 +2584,144 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wide-tile dW for the MID-SIZE layers: dW[n][k] = sum_r dZ[r][n] * X[r][k] is a tiny output (128 x 128 ... 512 x 256)
+// behind a long reduction (8e3 - 3e4 rows).  The 64 x 64 kernel re-reads every row of dZ and X once per output tile (4 - 32
+// times through L2: 112 MB of traffic for 42 MB of operands) and keeps one accumulator per wavefront.  Here a workgroup owns
+// a 128 x 128 block of dW for its chunk of rows -- the whole matrix for the 128-wide layers -- a wavefront 64 x 64 (four
+// accumulators: each staged operand value feeds two MFMAs), K-tile = 32 rows, LDS double-buffered with one barrier per
+// K-tile, operands stored as loaded ([row][128 + 4]: one ds_write_b128 per staged float4, fragments are conflict-free
+// ds_read_b32 of consecutive channels).  dZ = P*dY - w*(Q + S*z) and X = relu(scale*z_in + shift) are formed once per
+// staged element.  Partial tiles go to the caller's workspace, dw_reduce sums the row chunks in f64.
+// ------------------------------------------------------------------------------------------------
+template <int GM>
+__global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                              int n_rows_static, int Kp, int n_out, int tiles_k,
+                                                              float* __restrict__ partial, unsigned long long* __restrict__ ts) {
+    KTimer kt_(ts);
+    constexpr int BT = 128, P = BT + 4, STAGE = 2 * KT * P, VM = 512;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 5 * VM];
+    float* vP = smem + 2 * STAGE;                        // P | Q | S of the dZ channels, scale | shift of the input channels
+    float* sv = vP + 3 * VM;
+    float* tv = sv + VM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = (blockIdx.x / tiles_k) * BT, k0 = (blockIdx.x % tiles_k) * BT;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    int chunk = gad_cdiv_dev(n_rows, (int)gridDim.y);
+    chunk = (chunk + KT - 1) / KT * KT;                  // == dw_reduce_kernel's split geometry
+    const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, n_rows);
+    if (r_begin >= r_end) return;                        // the reducer skips the same splits
+    for (int i = tid; i < BT; i += 256) {
+        float Pc, Qc, Sc;
+        dz_coef(d, n0 + i, Pc, Qc, Sc);
+        vP[i] = Pc; vP[VM + i] = Qc; vP[2 * VM + i] = Sc;
+        sv[i] = x.scale[k0 + i]; tv[i] = x.shift[k0 + i];
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    // staging: a K-tile is 32 rows x 128 channels per side = 1024 float4: thread -> rows sr + 8 u (u < 4), channels c4 .. c4 + 3
+    const int c4 = (tid & 31) * 4, sr = tid >> 5;
+    const int gpitch = GM == 0 ? d.g_pitch : d.c;
+    float4 rz[4], rg[4], rx[4];
+    int4 ra[4];
+    float rw[4];
+    auto load_regs = [&](int rb0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb0 + sr + 8 * u;
+            const int rr = r < r_end ? r : r_end - 1;
+            rw[u] = d.row_w ? d.row_w[rr] : 1.f;
+            rz[u] = ldg4(d.z + (size_t)rr * d.z_pitch + n0 + c4);
+            if (GM == 0) {
+                rg[u] = ldg4(d.G + (size_t)rr * gpitch + n0 + c4);
+            } else {
+                const int grp = d.row_grp[rr];
+                ra[u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * gpitch + n0 + c4);
+                rg[u] = ldg4(d.dout + (size_t)grp * gpitch + n0 + c4);
+            }
+            rx[u] = ldg4(x.zin + (size_t)rr * x.zin_pitch + k0 + c4);
+        }
+    };
+    auto write_lds = [&](int it, int rb0) {
+        float* As = smem + (it & 1) * STAGE;
+        float* Bs = As + KT * P;
+        const float4 Pv = *reinterpret_cast<const float4*>(vP + c4), Qv = *reinterpret_cast<const float4*>(vP + VM + c4);
+        const float4 Sv = *reinterpret_cast<const float4*>(vP + 2 * VM + c4);
+        const float4 s4 = *reinterpret_cast<const float4*>(sv + c4), t4 = *reinterpret_cast<const float4*>(tv + c4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb0 + sr + 8 * u;
+            float4 g = rg[u];
+            const float4 z = rz[u];
+            if (GM == 1) {
+                g.x = ra[u].x == r ? g.x : 0.f; g.y = ra[u].y == r ? g.y : 0.f;
+                g.z = ra[u].z == r ? g.z : 0.f; g.w = ra[u].w == r ? g.w : 0.f;
+            }
+            const float w = rw[u];
+            float4 a, b;
+            a.x = Pv.x * g.x - w * fmaf(Sv.x, z.x, Qv.x); a.y = Pv.y * g.y - w * fmaf(Sv.y, z.y, Qv.y);
+            a.z = Pv.z * g.z - w * fmaf(Sv.z, z.z, Qv.z); a.w = Pv.w * g.w - w * fmaf(Sv.w, z.w, Qv.w);
+            b.x = fmaxf(fmaf(rx[u].x, s4.x, t4.x), 0.f); b.y = fmaxf(fmaf(rx[u].y, s4.y, t4.y), 0.f);
+            b.z = fmaxf(fmaf(rx[u].z, s4.z, t4.z), 0.f); b.w = fmaxf(fmaf(rx[u].w, s4.w, t4.w), 0.f);
+            if (r >= r_end) { a = f4zero(); b = f4zero(); }
+            *reinterpret_cast<float4*>(As + (sr + 8 * u) * P + c4) = a;
+            *reinterpret_cast<float4*>(Bs + (sr + 8 * u) * P + c4) = b;
+        }
+    };
+    load_regs(r_begin);
+    __syncthreads();                                     // vP / sv / tv visible
+    write_lds(0, r_begin);
+    if (r_begin + KT < r_end) load_regs(r_begin + KT);
+    __syncthreads();
+    int it = 0;
+    for (int rb0 = r_begin; rb0 < r_end; rb0 += KT, ++it) {
+        const float* As = smem + (it & 1) * STAGE + half * P + wm * 64 + l31;
+        const float* Bs = smem + (it & 1) * STAGE + KT * P + half * P + wn * 64 + l31;
+#pragma unroll
+        for (int s = 0; s < KT / 2; ++s) {
+            const float a0 = As[2 * s * P], a1 = As[2 * s * P + 32];
+            const float b0 = Bs[2 * s * P], b1 = Bs[2 * s * P + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (rb0 + KT < r_end) write_lds(it + 1, rb0 + KT);
+        if (rb0 + 2 * KT < r_end) load_regs(rb0 + 2 * KT);
+        __syncthreads();
+    }
+    float* pout = partial + (size_t)blockIdx.y * n_out * Kp;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int n = n0 + wm * 64 + a * 32 + acc_row(v, half), k = k0 + wn * 64 + b * 32 + l31;
+                pout[(size_t)n * Kp + k] = acc[a][b][v];
+            }
+}
+
+// the wide-tile dW covers: ACT input with BatchNorm + ReLU in front, one group, 128-multiples on both sides, no bias / extra column
+static bool dw_wideable(const gad_gemm_dw_args& a, int k_used, bool vec) {
+    const gad_gemm_fwd_args& in = a.in;
+    const gad_dz_src& d = a.dz;
+    if (!g_opt_dw_wide || !vec || in.mode != 0 || in.n_groups != 1 || in.zin_off[0] != 0 || a.dz_off[0] != 0) return false;
+    if (in.n_rows < 2048 || in.n_out[0] % 128 != 0 || in.n_out[0] > 512 || in.Kp % 128 != 0 || in.Kp > 512 || k_used != in.Kp) return false;
+    if (in.c_in != in.Kp || !in.scale || !in.shift || !in.relu || in.extra || in.ones_col >= 0) return false;
+    if (!d.z || d.z_pitch % 4 != 0 || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
+    if (d.gmode == 0 ? (d.g_pitch % 4 != 0 || !d.G) : (d.c % 4 != 0)) return false;
+    return a.partial != nullptr && a.row_splits <= 0;
+}
+
 static bool dw_gather_streamable(const gad_gemm_dw_args& a, int k_used) {
     const gad_gemm_fwd_args& in = a.in;
     const gad_dz_src& d = a.dz;
@@ -2661,6 +2799,26 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
                            st, part, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc, 1);
         GAD_CHECK_LAUNCH("dw_reduce");
         return GAD_OK;
+    }
+    if (dw_wideable(*a, k_used, vec)) {
+        const int tn_ = in.n_out[0] / 128, tk_ = in.Kp / 128;
+        int splits = gad_cdiv(256, tn_ * tk_);                          // ~one workgroup per CU
+        const int by_rows = gad_cdiv(rows, 4 * KT);
+        if (splits > by_rows) splits = by_rows;
+        if (splits < 1) splits = 1;
+        if ((long long)splits * in.n_out[0] * in.Kp <= a->partial_elems) {
+            if (a->dz.gmode == 0)
+                hipLaunchKernelGGL((gemm_dw_wide_kernel<0>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,
+                                   in.n_out[0], tk_, a->partial, ts);
+            else
+                hipLaunchKernelGGL((gemm_dw_wide_kernel<1>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,
+                                   in.n_out[0], tk_, a->partial, ts);
+            GAD_CHECK_LAUNCH("gemm_dw(wide)");
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256),
+                               0, st, a->partial, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
+            GAD_CHECK_LAUNCH("dw_reduce");
+            return GAD_OK;
+        }
     }
     long long group_stride = 0;
 #define LAUNCH_DW4(WM, WN, TM, TN, XM, V, VM)                                                              \
