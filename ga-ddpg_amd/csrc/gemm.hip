@@ -2593,8 +2593,11 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
 // K-tile, operands stored as loaded ([row][128 + 4]: one ds_write_b128 per staged float4, fragments are conflict-free
 // ds_read_b32 of consecutive channels).  dZ = P*dY - w*(Q + S*z) and X = relu(scale*z_in + shift) are formed once per
 // staged element.  Partial tiles go to the caller's workspace, dw_reduce sums the row chunks in f64.
+// XM = 1 (first layer of SA2 / SA3: gathered input [feat[pt] | src_xyz[pt] - ctr_xyz[grp]]): the X side is feat[pt] as
+// stored (row -> point indices fetched one K-tile ahead of the rows they address); the three coordinate columns of dW are
+// sums of dZ * dx accumulated with vector FMAs while dZ is staged (12 per float4) by the workgroups of the first k block.
 // ------------------------------------------------------------------------------------------------
-template <int GM>
+template <int XM, int GM>
 __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
                                                               int n_rows_static, int Kp, int n_out, int tiles_k,
                                                               float* __restrict__ partial, unsigned long long* __restrict__ ts) {
@@ -2618,8 +2621,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
         float Pc, Qc, Sc;
         dz_coef(d, n0 + i, Pc, Qc, Sc);
         vP[i] = Pc; vP[VM + i] = Qc; vP[2 * VM + i] = Sc;
-        sv[i] = x.scale[k0 + i]; tv[i] = x.shift[k0 + i];
+        if (XM == 0) { sv[i] = x.scale[k0 + i]; tv[i] = x.shift[k0 + i]; }
     }
+    const bool coords = XM == 1 && k0 == 0;              // this workgroup also forms dW[n][feat_c .. feat_c + 2]
+    float wx[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wx[j][0] = 0.f; wx[j][1] = 0.f; wx[j][2] = 0.f; }
     f32x16 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -2632,7 +2639,17 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
     const int gpitch = GM == 0 ? d.g_pitch : d.c;
     float4 rz[4], rg[4], rx[4];
     int4 ra[4];
-    float rw[4];
+    float rw[4], rd[4][3];
+    int pq[4], gq[4];                                    // XM = 1: point / group of the NEXT tile's rows
+    auto load_idx = [&](int rb0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb0 + sr + 8 * u;
+            const int rr = r < r_end ? r : r_end - 1;
+            pq[u] = XM == 1 ? x.row_pt[rr] : 0;
+            gq[u] = (XM == 1 && x.ctr_xyz) ? x.row_grp[rr] : 0;
+        }
+    };
     auto load_regs = [&](int rb0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -2647,15 +2664,30 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
                 ra[u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * gpitch + n0 + c4);
                 rg[u] = ldg4(d.dout + (size_t)grp * gpitch + n0 + c4);
             }
-            rx[u] = ldg4(x.zin + (size_t)rr * x.zin_pitch + k0 + c4);
+            if (XM == 0) {
+                rx[u] = ldg4(x.zin + (size_t)rr * x.zin_pitch + k0 + c4);
+            } else {
+                rx[u] = ldg4(x.feat + (size_t)pq[u] * x.feat_c + k0 + c4);
+                if (coords) {
+                    const float* p = x.src_xyz + (size_t)pq[u] * 3;
+                    float q0 = p[0], q1 = p[1], q2 = p[2];
+                    if (x.ctr_xyz) {
+                        const float* cp = x.ctr_xyz + (size_t)gq[u] * 3;
+                        q0 = __fsub_rn(q0, cp[0]); q1 = __fsub_rn(q1, cp[1]); q2 = __fsub_rn(q2, cp[2]);
+                    }
+                    rd[u][0] = q0; rd[u][1] = q1; rd[u][2] = q2;
+                }
+            }
         }
+        if (XM == 1) load_idx(rb0 + KT);
     };
     auto write_lds = [&](int it, int rb0) {
         float* As = smem + (it & 1) * STAGE;
         float* Bs = As + KT * P;
         const float4 Pv = *reinterpret_cast<const float4*>(vP + c4), Qv = *reinterpret_cast<const float4*>(vP + VM + c4);
         const float4 Sv = *reinterpret_cast<const float4*>(vP + 2 * VM + c4);
-        const float4 s4 = *reinterpret_cast<const float4*>(sv + c4), t4 = *reinterpret_cast<const float4*>(tv + c4);
+        float4 s4 = f4zero(), t4 = f4zero();
+        if (XM == 0) { s4 = *reinterpret_cast<const float4*>(sv + c4); t4 = *reinterpret_cast<const float4*>(tv + c4); }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = rb0 + sr + 8 * u;
@@ -2669,13 +2701,25 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
             float4 a, b;
             a.x = Pv.x * g.x - w * fmaf(Sv.x, z.x, Qv.x); a.y = Pv.y * g.y - w * fmaf(Sv.y, z.y, Qv.y);
             a.z = Pv.z * g.z - w * fmaf(Sv.z, z.z, Qv.z); a.w = Pv.w * g.w - w * fmaf(Sv.w, z.w, Qv.w);
-            b.x = fmaxf(fmaf(rx[u].x, s4.x, t4.x), 0.f); b.y = fmaxf(fmaf(rx[u].y, s4.y, t4.y), 0.f);
-            b.z = fmaxf(fmaf(rx[u].z, s4.z, t4.z), 0.f); b.w = fmaxf(fmaf(rx[u].w, s4.w, t4.w), 0.f);
+            if (XM == 0) {
+                b.x = fmaxf(fmaf(rx[u].x, s4.x, t4.x), 0.f); b.y = fmaxf(fmaf(rx[u].y, s4.y, t4.y), 0.f);
+                b.z = fmaxf(fmaf(rx[u].z, s4.z, t4.z), 0.f); b.w = fmaxf(fmaf(rx[u].w, s4.w, t4.w), 0.f);
+            } else {
+                b = rx[u];
+            }
             if (r >= r_end) { a = f4zero(); b = f4zero(); }
+            if (coords) {
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+                    wx[0][dd] = fmaf(a.x, rd[u][dd], wx[0][dd]); wx[1][dd] = fmaf(a.y, rd[u][dd], wx[1][dd]);
+                    wx[2][dd] = fmaf(a.z, rd[u][dd], wx[2][dd]); wx[3][dd] = fmaf(a.w, rd[u][dd], wx[3][dd]);
+                }
+            }
             *reinterpret_cast<float4*>(As + (sr + 8 * u) * P + c4) = a;
             *reinterpret_cast<float4*>(Bs + (sr + 8 * u) * P + c4) = b;
         }
     };
+    if (XM == 1) load_idx(r_begin);
     load_regs(r_begin);
     __syncthreads();                                     // vP / sv / tv visible
     write_lds(0, r_begin);
@@ -2708,15 +2752,35 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
                 const int n = n0 + wm * 64 + a * 32 + acc_row(v, half), k = k0 + wn * 64 + b * 32 + l31;
                 pout[(size_t)n * Kp + k] = acc[a][b][v];
             }
+    if (coords) {                                        // eight staging rows per channel quad -> one sum (the tile LDS is free)
+        float* red = smem;                               // [8][128][3]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) red[(sr * BT + c4 + j) * 3 + dd] = wx[j][dd];
+        __syncthreads();
+        for (int i = tid; i < BT * 3; i += 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += red[q * BT * 3 + i];
+            pout[(size_t)(n0 + i / 3) * Kp + x.feat_c + i % 3] = sum;
+        }
+    }
 }
 
 // the wide-tile dW covers: ACT input with BatchNorm + ReLU in front, one group, 128-multiples on both sides, no bias / extra column
 static bool dw_wideable(const gad_gemm_dw_args& a, int k_used, bool vec) {
     const gad_gemm_fwd_args& in = a.in;
     const gad_dz_src& d = a.dz;
-    if (!g_opt_dw_wide || !vec || in.mode != 0 || in.n_groups != 1 || in.zin_off[0] != 0 || a.dz_off[0] != 0) return false;
-    if (in.n_rows < 2048 || in.n_out[0] % 128 != 0 || in.n_out[0] > 512 || in.Kp % 128 != 0 || in.Kp > 512 || k_used != in.Kp) return false;
-    if (in.c_in != in.Kp || !in.scale || !in.shift || !in.relu || in.extra || in.ones_col >= 0) return false;
+    if (!g_opt_dw_wide || !vec || in.n_groups != 1 || in.zin_off[0] != 0 || a.dz_off[0] != 0) return false;
+    if (in.n_rows < 2048 || in.n_out[0] % 128 != 0 || in.n_out[0] > 512 || in.ones_col >= 0) return false;
+    if (in.mode == 1) {                                  // gathered first layer: features a multiple of 128, + 3 coordinates
+        if (g_opt_dw_wide == 2 || d.gmode != 0 || in.act_c != 0 || in.feat_c % 128 != 0 || in.feat_c > 512) return false;
+        if (in.Kp != ((in.feat_c + 3 + 7) & ~7) || k_used != in.feat_c + 3) return false;
+    } else {
+        if (in.Kp % 128 != 0 || in.Kp > 512 || k_used != in.Kp) return false;
+        if (in.c_in != in.Kp || !in.scale || !in.shift || !in.relu || in.extra) return false;
+    }
     if (!d.z || d.z_pitch % 4 != 0 || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
     if (d.gmode == 0 ? (d.g_pitch % 4 != 0 || !d.G) : (d.c % 4 != 0)) return false;
     return a.partial != nullptr && a.row_splits <= 0;
@@ -2801,17 +2865,20 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         return GAD_OK;
     }
     if (dw_wideable(*a, k_used, vec)) {
-        const int tn_ = in.n_out[0] / 128, tk_ = in.Kp / 128;
+        const int tn_ = in.n_out[0] / 128, tk_ = (in.mode == 1 ? in.feat_c : in.Kp) / 128;
         int splits = gad_cdiv(256, tn_ * tk_);                          // ~one workgroup per CU
         const int by_rows = gad_cdiv(rows, 4 * KT);
         if (splits > by_rows) splits = by_rows;
         if (splits < 1) splits = 1;
         if ((long long)splits * in.n_out[0] * in.Kp <= a->partial_elems) {
-            if (a->dz.gmode == 0)
-                hipLaunchKernelGGL((gemm_dw_wide_kernel<0>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,
+            if (in.mode == 1)
+                hipLaunchKernelGGL((gemm_dw_wide_kernel<1, 0>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,
+                                   in.n_out[0], tk_, a->partial, ts);
+            else if (a->dz.gmode == 0)
+                hipLaunchKernelGGL((gemm_dw_wide_kernel<0, 0>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,
                                    in.n_out[0], tk_, a->partial, ts);
             else
-                hipLaunchKernelGGL((gemm_dw_wide_kernel<1>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,
+                hipLaunchKernelGGL((gemm_dw_wide_kernel<0, 1>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,
                                    in.n_out[0], tk_, a->partial, ts);
             GAD_CHECK_LAUNCH("gemm_dw(wide)");
             hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256),
