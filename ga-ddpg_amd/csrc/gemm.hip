@@ -846,6 +846,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
 
 static int g_opt_fwd_wide = 1;
 static int g_opt_dx_wide = 1, g_opt_dw_wide = 1;
+static int g_opt_bwd_fused = 1;
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
 static bool fwd_wideable(const gad_gemm_fwd_args& a) {
@@ -1206,6 +1207,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "fwd_wide")) { g_opt_fwd_wide = value; return GAD_OK; }
     if (!strcmp(name, "dx_wide")) { g_opt_dx_wide = value; return GAD_OK; }
     if (!strcmp(name, "dw_wide")) { g_opt_dw_wide = value; return GAD_OK; }
+    if (!strcmp(name, "bwd_fused")) { g_opt_bwd_fused = value; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
@@ -1668,6 +1670,247 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fused backward of an SA1 layer (rows ~ 2e5, 64 input channels, 64 / 128 output channels): dX AND dW in one pass over
+// z / dY / z_prev.  The two streaming kernels above read the same 55 - 110 MB tensors from two streams at once and slow each
+// other down far below what either reaches alone (layer 3: 67 + 83 us alone, 119 + 168 us side by side).  Here a workgroup
+// of 8 wavefronts splits into 4 PRODUCERS and 4 CONSUMERS (one of each per SIMD, so the MFMA pipe of a SIMD alternates
+// between them) and walks quads of four 32-row slabs:
+//   producer p takes slab 4*quad + p exactly as gemm_dx_stream_kernel does (16-byte loads of z and dY, dZ in registers,
+//     W^T fragments from LDS -> dY_prev, ReLU-masked, stored; the previous layer's BatchNorm-backward sums) and ALSO
+//     writes its dZ values, row-major, into an LDS exchange buffer: the first half of the output channels, barrier, the
+//     second half, barrier (two buffers: while one half is being written the consumers read the other);
+//   consumer q owns one 32 x 32 tile of dW per channel half -- (channel tile, input half) -- in persistent accumulators
+//     (2 x 16 VGPRs) and adds dZ^T . relu(bn(z_prev)) of the quad's slabs to it: dZ^T fragments are 4-byte LDS reads of
+//     the exchange buffer (lane = channel: conflict-free), the activation fragments are rebuilt from z_prev (L1 / L2 hits:
+//     the producers read the same rows).  n_out = 64 has one tile per half and input half, so two consumers share a tile
+//     and take two slabs each.
+// No dW traffic leaves the workgroup before its end: each consumer then stores its tiles into the workgroup's partial
+// block(s); dw_reduce sums the blocks (f64).  A first version that had every wavefront do both products on its own slab
+// and add 32 x 32 tiles into a dW block in LDS (ds_add_f32) ran at 365 us for layer 3: LDS float atomics retire ~1 lane
+// per clock, and re-reading dZ in the accumulator layout cost another 130 us.
+// ------------------------------------------------------------------------------------------------
+template <int NJ, int GM>
+__global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
+                                                                  const float* __restrict__ W, DxEpi e, float* __restrict__ partial,
+                                                                  unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
+    constexpr int NO = 8 * NJ, PW = NO + 4, NCH = NJ / 4, HCH = NCH / 2;    // chunks of 32 channels; per half
+    constexpr int HC = NO / 2, HP = HC + 4;                                 // channels per half, exchange-buffer pitch
+    constexpr int NCT = HC / 32;                                            // dW channel tiles per half (2 or 1)
+    __shared__ __attribute__((aligned(16))) float Wt[64 * PW];
+    __shared__ __attribute__((aligned(16))) float vec[3 * NO];          // P | Q | S
+    __shared__ float red[2 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float dzb[2 * 4 * 32 * HP];  // [half][slab of the quad][row][channel of the half]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    {   // W (n_out x 64, row-major) -> W^T in LDS
+        constexpr int UW = NO * 16 / 512;
+        float4 wr[UW];
+#pragma unroll
+        for (int it = 0; it < UW; ++it) wr[it] = ldg4(W + (size_t)(it * 512 + tid) * 4);
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 512 + tid;
+            const int n = u >> 4, k4 = (u & 15) * 4;
+            Wt[(k4 + 0) * PW + n] = wr[it].x; Wt[(k4 + 1) * PW + n] = wr[it].y;
+            Wt[(k4 + 2) * PW + n] = wr[it].z; Wt[(k4 + 3) * PW + n] = wr[it].w;
+        }
+    }
+    for (int i = tid; i < NO; i += 512) {
+        float P, Q, S;
+        dz_coef(d, i, P, Q, S);
+        vec[i] = P; vec[NO + i] = Q; vec[2 * NO + i] = S;
+    }
+    __syncthreads();
+    const int n_slabs = (n_rows + 31) >> 5;
+    const int n_quads = (n_slabs + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t zrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, n_rows * 64 * 4, 0x00020000);   // rows past n_rows read as 0
+    const int glane = (4 * half * 64 + l31) * 4;
+
+    if (wave < 4) {
+        // ---------------------------------------------------------------- producer: dX of slab 4 * quad + wave
+        float ps[2], pt[2], pm[2], pi[2];
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk) {
+            const int k = tk * 32 + l31;
+            ps[tk] = e.ps[k]; pt[tk] = e.pt[k]; pm[tk] = e.pm[k]; pi[tk] = e.pi[k];
+        }
+        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * 64 * 4, 0x00020000);
+        float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
+        float4 rz[2][4], rg[2][4];
+        int4 ra[2][4];
+        auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+        auto load_chunk = [&](int r, int grp, int c, int buf) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned n = 8 * (4 * c + u) + 4 * half;
+                rz[buf][u] = ldg4(d.z + ((unsigned)r * NO + n));
+                if (GM == 0) {
+                    rg[buf][u] = ldg4(d.G + ((unsigned)r * NO + n));
+                } else {
+                    ra[buf][u] = *reinterpret_cast<const int4*>(d.argmax + ((unsigned)grp * NO + n));
+                    rg[buf][u] = ldg4(d.dout + ((unsigned)grp * NO + n));
+                }
+            }
+        };
+        int quad = blockIdx.x;
+        int slab = quad * 4 + wave;
+        int r_cur = row_of(slab);
+        int grp_cur = GM == 1 ? d.row_grp[r_cur] : 0;
+        load_chunk(r_cur, grp_cur, 0, 0);
+        float* const mybuf = dzb + (wave * 32 + l31) * HP + 4 * half;
+        for (; quad < n_quads; quad += gridDim.x) {
+            slab = quad * 4 + wave;
+            const int slab_nxt = slab + 4 * gridDim.x;
+            const int r_nxt = row_of(slab_nxt);
+            const int grp_nxt = GM == 1 ? d.row_grp[r_nxt] : 0;
+            const bool row_live = slab * 32 + l31 < n_rows;
+            const float wrow = d.row_w ? d.row_w[r_cur] : 1.f;
+            f32x16 acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+            float zp[2][16];
+            const int zrow = (slab < n_slabs ? slab : 0) * 32 * 64 * 4;     // (a slab past the end: nothing is kept of it)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                if (c + 1 < NCH) load_chunk(r_cur, grp_cur, c + 1, (c + 1) & 1);
+                else {
+                    load_chunk(r_nxt, grp_nxt, 0, 0);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            zp[t][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                zrsrc, glane + t * 128, zrow + ((v & 3) + 8 * (v >> 2)) * 256, 0));
+                }
+                float* const hb = mybuf + (c / HCH) * (4 * 32 * HP) + (c % HCH) * 32;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int n = 8 * (4 * c + u) + 4 * half;
+                    const float4 z = rz[c & 1][u];
+                    float4 g = rg[c & 1][u];
+                    if (GM == 1) {
+                        const int4 a = ra[c & 1][u];
+                        const int rr = slab * 32 + l31;
+                        g.x = a.x == rr ? g.x : 0.f; g.y = a.y == rr ? g.y : 0.f;
+                        g.z = a.z == rr ? g.z : 0.f; g.w = a.w == rr ? g.w : 0.f;
+                    }
+                    const float4 P = *reinterpret_cast<const float4*>(vec + n);
+                    const float4 Q = *reinterpret_cast<const float4*>(vec + NO + n);
+                    const float4 S = *reinterpret_cast<const float4*>(vec + 2 * NO + n);
+                    float4 a4;
+                    a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
+                    a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
+                    if (!row_live) a4 = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end add nothing to dW
+                    *reinterpret_cast<float4*>(hb + 8 * u) = a4;
+                    const float4 b0 = *reinterpret_cast<const float4*>(Wt + l31 * PW + n);
+                    const float4 b1 = *reinterpret_cast<const float4*>(Wt + (32 + l31) * PW + n);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1.y, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b0.z, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b1.z, acc[1], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
+                }
+                if ((c + 1) % HCH == 0) __syncthreads();                   // this half of the quad's dZ is in the buffer
+            }
+            // epilogue: dY of the previous layer (ReLU-masked) + its BatchNorm-backward sums (the consumers are at work
+            // on the second half meanwhile)
+            const bool full = slab * 32 + 32 <= n_rows;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = acc_row(v, half);
+                const bool live = slab * 32 + row < n_rows;
+                const int rb = zrow + ((v & 3) + 8 * (v >> 2)) * 256;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float gv = acc[t][v];
+                    const float zv = zp[t][v];
+                    const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
+                    const float ga = act ? gv : 0.f;
+                    if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), grsrc, glane + t * 128, rb, GAD_STREAM_STORE_AUX);
+                    else if (live) e.gout[(size_t)(slab * 32 + row) * 64 + t * 32 + l31] = ga;
+                    sb[t] += ga;
+                    sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
+                }
+            }
+            r_cur = r_nxt;
+            grp_cur = grp_nxt;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float s0 = sb[t] + __shfl_xor(sb[t], 32, 64);
+            const float s1 = sg[t] + __shfl_xor(sg[t], 32, 64);
+            if (lane < 32) { red[wave * 64 + t * 32 + lane] = s0; red[(4 + wave) * 64 + t * 32 + lane] = s1; }
+        }
+    } else {
+        // ---------------------------------------------------------------- consumer: dW tiles (channel tile, input half b)
+        const int q = wave - 4;
+        const int b = q & 1;
+        const int tcl = NCT == 2 ? (q >> 1) : 0;                            // channel tile within the half
+        const int s0 = NCT == 2 ? 0 : 2 * (q >> 1);                         // slabs of the quad this wavefront takes
+        constexpr int NS = NCT == 2 ? 4 : 2;
+        const float psb = e.ps[32 * b + l31], ptb = e.pt[32 * b + l31];
+        f32x16 aw[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) aw[h][v] = 0.f;
+        float yv[2][16];
+        auto load_y = [&](int slab, int buf) {                              // z_prev rows of `slab`, accumulator layout
+            const int zrow = (slab < n_slabs ? slab : 0) * 32 * 64 * 4;     // (past the end: the producers wrote dZ = 0)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                yv[buf][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zrsrc, glane + b * 128, zrow + ((v & 3) + 8 * (v >> 2)) * 256, 0));
+        };
+        const float* const rbase = dzb + (4 * half) * HP + 32 * tcl + l31;
+        for (int quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+            const int slab0 = quad * 4 + s0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                load_y(slab0, 0);
+                __syncthreads();                                            // half h of this quad is in buffer h
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (s + 1 < NS) load_y(slab0 + s + 1, (s + 1) & 1);
+                    const float* rb = rbase + (h * 4 + s0 + s) * (32 * HP);
+                    float dz[16];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) dz[v] = rb[((v & 3) + 8 * (v >> 2)) * HP];
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const float y = fmaxf(fmaf(yv[s & 1][v], psb, ptb), 0.f);
+                        aw[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[v], y, aw[h], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // the workgroup's partial dW block(s): n_out = 64 -> two consumers share a tile, each writes its own block
+        float* pout = partial + (size_t)(NCT == 2 ? blockIdx.x : 2 * blockIdx.x + (q >> 1)) * NO * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) pout[(32 * (NCT * h + tcl) + acc_row(v, half)) * 64 + 32 * b + l31] = aw[h][v];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { s0 += red[w * 64 + tid]; s1 += red[(4 + w) * 64 + tid]; }
+        const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+        atomic_add_f64(e.dbeta + (size_t)rep * e.stat_stride + tid, (double)s0);
+        atomic_add_f64(e.dgamma + (size_t)rep * e.stat_stride + tid, (double)s1);
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // wide-tile dX for the MID-SIZE layers (the backward twin of gemm_fwd_wide_kernel): a workgroup owns 64 rows x 128 input
@@ -2929,5 +3172,54 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
                            group_stride, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
         GAD_CHECK_LAUNCH("dw_reduce");
     }
+    return GAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// dX and dW of one layer in one call.  The SA1 layers the two streaming kernels cover take the fused kernel
+// (gemm_bwd_stream_kernel); everything else runs gad_gemm_dw then gad_gemm_dx on the same stream.
+// ------------------------------------------------------------------------------------------------
+extern "C" int gad_gemm_bwd(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* aw, void* stream) {
+    GAD_REQUIRE(ax && aw, GAD_ERR_NULL, "gemm_bwd: null pointer");
+    const gad_gemm_fwd_args& in = aw->in;
+    bool fused = g_opt_bwd_fused != 0;
+    if (fused) {
+        const bool vec = dz_vectorizable(ax->dz, ax->dz_off, ax->n_out, ax->n_groups);
+        int k_used = in.mode == 0 ? in.c_in + (in.extra ? 1 : 0) : in.feat_c + 3 + in.act_c;
+        fused = dx_streamable(*ax, vec) && dw_streamable(*aw, k_used);
+        // the two descriptions must be of the same layer: same dZ source, and dW's input = the layer dX feeds
+        fused = fused && ax->dz.z == aw->dz.z && ax->dz.gmode == aw->dz.gmode && ax->dz.G == aw->dz.G && ax->dz.dout == aw->dz.dout &&
+                ax->dz.argmax == aw->dz.argmax && ax->dz.row_w == aw->dz.row_w && ax->n_rows == in.n_rows && ax->n_rows_dev == in.n_rows_dev &&
+                ax->n_out[0] == in.n_out[0] && in.zin == ax->zprev && in.scale == ax->prev_scale && in.shift == ax->prev_shift &&
+                in.zin_pitch == 64 && ax->gout && ax->prev_dgamma;
+    }
+    if (!fused) {
+        if (int e = gad_gemm_dw(aw, stream)) return e;
+        return gad_gemm_dx(ax, stream);
+    }
+    unsigned long long* ts = gad_take_timing_slot();
+    (void)gad_take_grid_rows();
+    GAD_REQUIRE(aw->gacc && ax->W, GAD_ERR_NULL, "gemm_bwd: null pointer");
+    if (ax->n_rows <= 0) return GAD_OK;
+    DzSrc d = make_dzsrc(ax->dz);
+    DxEpi e;
+    e.mode = 0; e.gout = ax->gout; e.gout_pitch = ax->gout_pitch; e.k_valid = ax->k_valid;
+    e.zprev = ax->zprev; e.zprev_pitch = ax->zprev_pitch; e.ps = ax->prev_scale; e.pt = ax->prev_shift;
+    e.pm = ax->prev_mean; e.pi = ax->prev_istd; e.dbeta = ax->prev_dbeta; e.dgamma = ax->prev_dgamma;
+    e.stat_stride = ax->stat_stride; e.store_masked = 1;
+    e.dfeat = nullptr; e.feat_c = 0; e.row_pt = nullptr; e.row_grp = nullptr; e.daction = nullptr; e.act_c = 0; e.gps = 1;
+    hipStream_t st = (hipStream_t)stream;
+    const int rows = ax->n_rows, wgs = DW_STREAM_SPLITS;
+    const int splits = ax->n_out[0] == 64 ? 2 * wgs : wgs;            // partial dW blocks the kernel writes (see its header)
+    GAD_REQUIRE((long long)splits * in.n_out[0] * 64 <= aw->partial_elems, GAD_ERR_SHAPE, "gemm_bwd: partial workspace too small");
+#define LAUNCH_BWS(NJ, GM) hipLaunchKernelGGL((gemm_bwd_stream_kernel<NJ, GM>), dim3(wgs), dim3(512), 0, st, d, ax->n_rows_dev, rows, ax->W, e, aw->partial, ts)
+    if (ax->n_out[0] == 128) { if (ax->dz.gmode == 0) LAUNCH_BWS(16, 0); else LAUNCH_BWS(16, 1); }
+    else { if (ax->dz.gmode == 0) LAUNCH_BWS(8, 0); else LAUNCH_BWS(8, 1); }
+#undef LAUNCH_BWS
+    GAD_CHECK_LAUNCH("gemm_bwd(stream)");
+    Groups gr = make_groups(1, aw->dz_off, in.w_off, in.zin_off, in.n_out);
+    hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)in.n_out[0] * 64, 256), gad_cdiv(splits, DW_RED_CHUNK), 1), dim3(256), 0, st,
+                       aw->partial, (long long)splits * in.n_out[0] * 64, gr, in.n_rows_dev, rows, splits, 64, 64, aw->gacc, 1);
+    GAD_CHECK_LAUNCH("dw_reduce");
     return GAD_OK;
 }

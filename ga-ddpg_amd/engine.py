@@ -356,7 +356,7 @@ def _dz(**kw):
 # wavefront start -> last wavefront end on the device wall clock -- what a profiler reports as the dispatch duration;
 # HIP events around a 25 us launch inside a five-stream step read 8 - 20 us high: event packets, queue waits)
 TIMING = {"enabled": False, "tag": None, "slots": None, "next": 0, "tags": []}
-_TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_segment_pool")      # (entry points that take a timing slot)
+_TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_bwd", "gad_segment_pool")      # (entry points that take a timing slot)
 
 
 TIMING_WAVES = 16384          # include/gaddpg.h GAD_TIMING_WAVES
@@ -462,6 +462,7 @@ def side_stream(device=None, which=0):
 
 
 CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
+FUSED_SA1_BWD = _os.environ.get("GAD_FUSED_SA1_BWD", "1") == "1"     # SA1 l3 / l2 backward: dX + dW in one kernel (gad_gemm_bwd)
 DW_LANES = 1              # number of dW side streams (2 measured no faster: the overlapped kernels already saturate the GPU) the layers alternate between (each with its own partial workspace)
 
 
@@ -757,10 +758,18 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         stage = {"sa1": 0, "sa2": 1}.get(rows_kw.get("name"))
         if stage is not None:
             plan.call("gad_grid_rows_hint", hip.Ptr(geo.rows_hint.ctypes.data + 4 * stage))
+        if fused_dw:                       # SA1 l3 / l2: dX and dW in one streaming pass on this stream (gad_gemm_bwd)
+            aw = fused_dw.pop()
+            import ctypes as C
+            plan.keep.extend([a, aw])
+            plan.call("gad_gemm_bwd", C.byref(a), C.byref(aw))
+            plan.tag_last("bwd.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
+            return
         plan.call_struct("gad_gemm_dx", a)
         plan.tag_last("dx.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
 
     dw_lanes = []
+    fused_dw = []
 
     def dw(s, l, dz, m, action):
         if not want_dw:
@@ -769,6 +778,14 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **_layer_input(enc, slot, geo, s, l, action))
         a.dz = dz
         a.gacc = _ptr(enc.flat.gacc)
+        if FUSED_SA1_BWD and s == 0 and l > 0:
+            # the two SA1 layers whose dX and dW both stream the same ~1e5-row tensors: side by side on two streams they
+            # slow each other down to 2x their stand-alone durations; one kernel reads the tensors once for both
+            # (workspace per backward pass: the critic's and the actor's may run at the same time)
+            ws = dw_workspace(enc.flat.device, elems=256 * 128 * 64, lane=200 + dw_lane)
+            a.partial, a.partial_elems = _ptr(ws), ws.numel()
+            fused_dw.append(a)
+            return
         lane = dw_lane + (len(dw_lanes) % DW_LANES) if CONCURRENT_DW else 0
         dw_lanes.append(lane)
         ws = dw_workspace(enc.flat.device, lane=lane)

@@ -308,6 +308,13 @@ typedef struct {
 
 int gad_gemm_dw(const gad_gemm_dw_args* host_args, void* stream);
 
+/* dX and dW of ONE layer in one call: `dx` and `dw` describe the same layer (same gradient source; dw->in = the layer
+ * dx writes the gradient of).  The SA1 layers of the update step (>= 32768 rows, 64 input channels, 64 / 128 outputs,
+ * BatchNorm+ReLU on both sides: reference core/networks.py:29-51 through pointnet2's SharedMLP) run as one streaming
+ * pass that reads z / dY / z_prev once for both products; any other layer runs gad_gemm_dw then gad_gemm_dx on
+ * `stream`.  Results are those of the two separate calls (dW: f32 partial sums per workgroup, f64 across them).      */
+int gad_gemm_bwd(const gad_gemm_dx_args* dx, const gad_gemm_dw_args* dw, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * D. heads' losses (forward value + gradient wrt head outputs in one pass)
  * ------------------------------------------------------------------------------------------- */

@@ -58,7 +58,7 @@ for _ in range(6):
     step(sync=True)
 base = None
 for opts in configs:
-    for k in ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny", "fwd_wide", "dx_wide", "dw_wide"):
+    for k in ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny", "fwd_wide", "dx_wide", "dw_wide", "bwd_fused"):
         hip.set_option(k, opts.get(k, 1))
     for _ in range(4):
         step(sync=True)
@@ -66,7 +66,7 @@ for opts in configs:
     inside, _ = probe(False)
     r = rate()
     print("==== options", opts, " steps/s %.1f" % r)
-    tags = sorted(t for t in alone if any(t.startswith(p) for p in ("fwd.sa2", "fwd.sa3", "dx.sa2", "dx.sa3", "dw.sa2", "dw.sa3", "bwd.sa2", "bwd.sa3")))
+    tags = sorted(t for t in alone if any(t.startswith(p) for p in ("fwd.sa2", "fwd.sa3", "dx.sa2", "dx.sa3", "dw.sa2", "dw.sa3", "bwd.sa2", "bwd.sa3", "bwd.sa1", "dx.sa1", "dw.sa1")))
     tot_a = tot_i = 0.0
     for t in tags:
         tot_a += alone[t] * cnt[t]

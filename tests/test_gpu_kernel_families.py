@@ -64,7 +64,7 @@ def _compare(a, b, keys, tol, mtol, what):
     return bad
 
 
-FAMILIES = ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny", "fwd_wide", "dx_wide", "dw_wide")
+FAMILIES = ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny", "fwd_wide", "dx_wide", "dw_wide", "bwd_fused")
 
 
 @pytest.mark.parametrize("value", [False, True])
@@ -86,6 +86,10 @@ def test_specialised_and_tile_kernels_agree(value):
     bad += _compare(bwd_tile, default, acts, 1e-6, 1e-7, "same forward kernels:")       # (BatchNorm sums: f64 atomics, order varies)
     bad += _compare(bwd_tile, default, grads, 2e-4, 1e-5, "backward tile vs specialised:")
     bad += _compare(tile, default, grads, 1.0, 2e-4, "all tile vs specialised (gradients, median):")
+    # the fused SA1 dX + dW kernel (gad_gemm_bwd) against the two separate streaming kernels: same forward, same sums
+    unfused = _run(B, value, {"bwd_fused": 0})
+    bad += _compare(unfused, default, acts, 1e-6, 1e-7, "same forward kernels (unfused backward):")
+    bad += _compare(unfused, default, grads, 2e-4, 1e-5, "separate dX / dW vs fused SA1 backward:")
     assert not bad, "\n".join(bad)
 
 
