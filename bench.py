@@ -138,13 +138,21 @@ def cpu_baseline(cfg, batch, noise):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-# kernel table: tag -> (kernel symbol, bound, executed FLOPs, algorithmic bytes) per launch.  Mirrors the routing of
-# gad_gemm_fwd / _dx / _dw (csrc/gemm.hip): SA1 (>= 32768 rows, 64-wide) -> streaming kernels (HBM-bound), SA2 / SA3 ->
-# 64x64 tile kernels (FP32 MFMA-bound), FC / heads (<= 1024 rows) -> skinny split-K kernels (latency-bound).
+# kernel table: tag -> (kernel symbol, bound, executed FLOPs, algorithmic bytes) per launch.  The symbol is the one the
+# library REPORTS for the tagged call (gad_last_kernel -> engine.timing_routes(): csrc/gemm.hip routes SA1 (>= 32768 rows,
+# 64-wide) to the streaming kernels (HBM-bound; SA1 layers 3 / 2 backward with weight gradients: the fused dX + dW
+# kernel), SA2 / SA3 to the wide-tile kernels (FP32 MFMA-bound; generic 64x64 tiles where a shape does not fit), FC / heads
+# (<= 1024 rows) to the skinny split-K kernels (latency-bound)); the prices are per layer.
 # ----------------------------------------------------------------------------------------------------------------------
 SA_DIMS = {"sa1": [(None, 64), (64, 64), (64, 128)], "sa2": [(131, 128), (128, 128), (128, 256)],
            "sa3": [(259, 256), (256, 256), (256, 512)], "fc": [(512, 1024), (1024, 512)]}
 DENSE_ROWS = {"sa1": 32 * 64, "sa2": 32 * 128, "sa3": 32, "fc": 1}
+ROUTE_SYMBOL = {"gemm_fwd(stream)": "gemm_fwd_stream_kernel", "gemm_fwd(wide)": "gemm_fwd_wide_kernel", "gemm_fwd(skinny)": "gemm_fwd_skinny_kernel",
+                "gemm_fwd": "gemm_fwd_kernel", "gemm_dx(stream)": "gemm_dx_stream_kernel", "gemm_dx(wide)": "gemm_dx_wide_kernel",
+                "gemm_dx(skinny)": "gemm_dx_skinny_kernel", "gemm_dx": "gemm_dx_kernel", "gemm_dw(stream)": "gemm_dw_stream_kernel",
+                "gemm_dw(gather stream)": "gemm_dw_gather_stream_kernel", "gemm_dw(wide)": "gemm_dw_wide_kernel",
+                "gemm_dw(skinny)": "gemm_dw_skinny_kernel", "gemm_dw": "gemm_dw_kernel", "gemm_bwd(stream)": "gemm_bwd_stream_kernel"}
+ROUTES = {}                 # tag -> routed kernel family, filled from engine.timing_routes() after each probe
 
 
 def tag_info(tag, rows, B):
@@ -152,10 +160,8 @@ def tag_info(tag, rows, B):
     per stage"""
     parts = tag.split(".")
     kind, stage = parts[0], parts[1]
-    if kind == "pool":
-        c = {"sa1": 128, "sa2": 256, "sa3": 512}[stage]
-        r = rows[stage]
-        return "segment_pool_kernel", "hbm", 0.0, r * c * 4.0 + 2.0 * (B * (32 if stage != "sa3" else 1)) * c * 4, 0.0
+    if kind == "pool" or tag not in ROUTES:
+        return None
     layer = int(parts[2][1:]) if len(parts) > 2 else 0
     if stage.startswith("fc"):                      # fwd.fc1 / fwd.fc2 carry the layer in the stage name
         layer, stage = (int(stage[2:]) if len(stage) > 2 else layer), "fc"
@@ -167,19 +173,21 @@ def tag_info(tag, rows, B):
     r = float(rows[stage])
     flops = 2.0 * r * k * n
     dense = 2.0 * B * DENSE_ROWS[stage] * k * n
-    stream = stage == "sa1"
-    skinny = stage == "fc"
+    route = ROUTES[tag]
+    sym = ROUTE_SYMBOL.get(route, route)
+    stream = "stream" in route
     if kind == "fwd":
-        sym = "gemm_fwd_stream_kernel" if stream else ("gemm_fwd_skinny_kernel" if skinny else "gemm_fwd_kernel")
         nbytes = r * (min(k, 16 if stream and layer == 1 else k) + n) * 4.0
+        if layer == 3 and stage != "fc":            # pooled layers: the keys of the fused max-pool are per group, not per row
+            nbytes += 2.0 * (B * (32 if stage != "sa3" else 1)) * n * 4
     elif kind == "dx":
-        sym = "gemm_dx_stream_kernel" if (stream and layer > 1) else ("gemm_dx_skinny_kernel" if skinny else "gemm_dx_kernel")
         nbytes = r * (2 * n + 2 * k) * 4.0           # z and dY of this layer in, dY of the previous layer out, its z for the sums
+    elif kind == "bwd":                              # dX + dW in one pass: the dX kernel's traffic, twice the FLOPs
+        nbytes = r * (2 * n + 2 * k) * 4.0
+        flops, dense = 2.0 * flops, 2.0 * dense
     else:
-        sym = ("gemm_dw_gather_stream_kernel" if layer == 1 else "gemm_dw_stream_kernel") if stream else \
-            ("gemm_dw_skinny_kernel" if skinny else "gemm_dw_kernel")
         nbytes = r * (2 * n + k) * 4.0               # z, dY of this layer and the layer input
-    bound = "hbm" if stream else ("latency" if skinny else "mfma")
+    bound = "hbm" if stream else ("latency" if "skinny" in route else "mfma")
     return sym, bound, flops, nbytes, dense
 
 
@@ -301,6 +309,7 @@ def main():
         for i in range(n):
             step(args.warmup + i)
         acc = engine.timing_stop()
+        ROUTES.update(engine.timing_routes())
         engine.SERIAL = False
         return acc
     probe_n = args.probe_steps + args.probe_steps % 2            # policy and non-policy steps in equal number
@@ -421,7 +430,7 @@ def main():
         # 0.5-1 KB moved per row) from the table above -- inside the overlapped step and alone -- plus the materialising
         # configs[3] kernel behind pointnet2_utils.query_and_group
         sa = {}
-        for sym in ("gemm_fwd_stream_kernel", "gemm_dx_stream_kernel", "gemm_dw_stream_kernel"):
+        for sym in ("gemm_fwd_stream_kernel", "gemm_bwd_stream_kernel", "gemm_dx_stream_kernel", "gemm_dw_gather_stream_kernel", "gemm_dw_stream_kernel"):
             if sym in table:
                 t, a1 = table[sym], table_alone.get(sym, {})
                 sa[sym] = {"bound": "hbm", "kernel_avg_us": t["kernel_avg_us"], "achieved": t["algorithmic_gbps"], "peak": 8000.0,

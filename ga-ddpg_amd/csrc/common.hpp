@@ -18,8 +18,10 @@ void gad_set_error(const char* fmt, ...);
         }                                \
     } while (0)
 
+extern const char* g_gad_last_kernel;     // geometry.hip: name of the kernel family the last GEMM entry point launched
 #define GAD_CHECK_LAUNCH(name)                                                          \
     do {                                                                                \
+        if ((name)[0] == 'g' && (name)[4] == '_') g_gad_last_kernel = name;             \
         hipError_t e__ = hipGetLastError();                                             \
         if (e__ != hipSuccess) {                                                        \
             gad_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));       \

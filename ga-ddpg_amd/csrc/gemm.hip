@@ -1686,6 +1686,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
 //     the exchange buffer (lane = channel: conflict-free), the activation fragments are rebuilt from z_prev (L1 / L2 hits:
 //     the producers read the same rows).  n_out = 64 has one tile per half and input half, so two consumers share a tile
 //     and take two slabs each.
+// The producers' global operands come through a ring of 8 steps (8 channels each) filled 7 steps ahead, across slab
+// boundaries (one producer per SIMD: nothing else hides the HBM latency; a scheduling barrier per step keeps the compiler
+// from sinking the loads to their uses), their per-row metadata a whole slab ahead, their LDS operands one step ahead.
 // No dW traffic leaves the workgroup before its end: each consumer then stores its tiles into the workgroup's partial
 // block(s); dw_reduce sums the blocks (f64).  A first version that had every wavefront do both products on its own slab
 // and add 32 x 32 tiles into a dW block in LDS (ds_add_f32) ran at 365 us for layer 3: LDS float atomics retire ~1 lane
@@ -1742,35 +1745,50 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
         }
         const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * 64 * 4, 0x00020000);
         float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
-        float4 rz[2][4], rg[2][4];
-        int4 ra[2][4];
+        // operand ring: 8 steps of 8 output channels each (z, dY [, arg-max] of this lane's row: 16-byte loads), filled 7
+        // steps ahead of their use and across slab boundaries -- with one producer per SIMD nothing else hides the HBM
+        // latency of these loads (a two-chunk double buffer left ~2 us of stall per 32-channel chunk)
+        constexpr int NU = NO / 8, RING = 8, AHEAD = RING - 1;
+        float4 rz[RING], rg[RING];
+        int4 ra[RING];
         auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
-        auto load_chunk = [&](int r, int grp, int c, int buf) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const unsigned n = 8 * (4 * c + u) + 4 * half;
-                rz[buf][u] = ldg4(d.z + ((unsigned)r * NO + n));
-                if (GM == 0) {
-                    rg[buf][u] = ldg4(d.G + ((unsigned)r * NO + n));
-                } else {
-                    ra[buf][u] = *reinterpret_cast<const int4*>(d.argmax + ((unsigned)grp * NO + n));
-                    rg[buf][u] = ldg4(d.dout + ((unsigned)grp * NO + n));
-                }
+        auto load_u = [&](int r, int grp, int uu, int buf) {
+            const unsigned n = 8 * uu + 4 * half;
+            rz[buf] = ldg4(d.z + ((unsigned)r * NO + n));
+            if (GM == 0) {
+                rg[buf] = ldg4(d.G + ((unsigned)r * NO + n));
+            } else {
+                ra[buf] = *reinterpret_cast<const int4*>(d.argmax + ((unsigned)grp * NO + n));
+                rg[buf] = ldg4(d.dout + ((unsigned)grp * NO + n));
             }
         };
         int quad = blockIdx.x;
         int slab = quad * 4 + wave;
-        int r_cur = row_of(slab);
-        int grp_cur = GM == 1 ? d.row_grp[r_cur] : 0;
-        load_chunk(r_cur, grp_cur, 0, 0);
+        // row index / group / weight of this lane's row: fetched one slab (two for the group, which the ring's addresses
+        // need mid-slab) before their use -- loads return in order, so waiting for a young load drains the whole ring
+        int r_cur = row_of(slab), r_nxt = row_of(slab + 4 * gridDim.x);
+        int grp_cur = GM == 1 ? d.row_grp[r_cur] : 0, grp_nxt = GM == 1 ? d.row_grp[r_nxt] : 0;
+        float wrow = d.row_w ? d.row_w[r_cur] : 1.f;
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) load_u(r_cur, grp_cur, i, i);
         float* const mybuf = dzb + (wave * 32 + l31) * HP + 4 * half;
+        // LDS operands of a step (dZ coefficients of its 4 channels, W^T fragments): read one step ahead
+        float4 P, Q, S, nb0, nb1;
+        auto lds_operands = [&](int uu) {
+            const int n = 8 * uu + 4 * half;
+            P = *reinterpret_cast<const float4*>(vec + n);
+            Q = *reinterpret_cast<const float4*>(vec + NO + n);
+            S = *reinterpret_cast<const float4*>(vec + 2 * NO + n);
+            nb0 = *reinterpret_cast<const float4*>(Wt + l31 * PW + n);
+            nb1 = *reinterpret_cast<const float4*>(Wt + (32 + l31) * PW + n);
+        };
+        lds_operands(0);
         for (; quad < n_quads; quad += gridDim.x) {
             slab = quad * 4 + wave;
-            const int slab_nxt = slab + 4 * gridDim.x;
-            const int r_nxt = row_of(slab_nxt);
-            const int grp_nxt = GM == 1 ? d.row_grp[r_nxt] : 0;
+            const int r_nn = row_of(slab + 8 * gridDim.x);
+            const int grp_nn = GM == 1 ? d.row_grp[r_nn] : 0;
+            const float w_nxt = d.row_w ? d.row_w[r_nxt] : 1.f;
             const bool row_live = slab * 32 + l31 < n_rows;
-            const float wrow = d.row_w ? d.row_w[r_cur] : 1.f;
             f32x16 acc[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1779,10 +1797,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
             float zp[2][16];
             const int zrow = (slab < n_slabs ? slab : 0) * 32 * 64 * 4;     // (a slab past the end: nothing is kept of it)
 #pragma unroll
-            for (int c = 0; c < NCH; ++c) {
-                if (c + 1 < NCH) load_chunk(r_cur, grp_cur, c + 1, (c + 1) & 1);
-                else {
-                    load_chunk(r_nxt, grp_nxt, 0, 0);
+            for (int uu = 0; uu < NU; ++uu) {
+                if (uu + AHEAD < NU) load_u(r_cur, grp_cur, uu + AHEAD, (uu + AHEAD) % RING);
+                else load_u(r_nxt, grp_nxt, uu + AHEAD - NU, (uu + AHEAD) % RING);
+                if (uu == 0) {                                             // z_prev for the epilogue: a whole slab ahead of its use
 #pragma unroll
                     for (int v = 0; v < 16; ++v)
 #pragma unroll
@@ -1790,28 +1808,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
                             zp[t][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
                                 zrsrc, glane + t * 128, zrow + ((v & 3) + 8 * (v >> 2)) * 256, 0));
                 }
-                float* const hb = mybuf + (c / HCH) * (4 * 32 * HP) + (c % HCH) * 32;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int n = 8 * (4 * c + u) + 4 * half;
-                    const float4 z = rz[c & 1][u];
-                    float4 g = rg[c & 1][u];
+                __builtin_amdgcn_sched_barrier(0);                         // (the scheduler would sink the loads to their uses)
+                float* const hb = mybuf + (uu / (NU / 2)) * (4 * 32 * HP) + (uu % (NU / 2)) * 8;
+                {
+                    const float4 z = rz[uu % RING];
+                    float4 g = rg[uu % RING];
                     if (GM == 1) {
-                        const int4 a = ra[c & 1][u];
+                        const int4 a = ra[uu % RING];
                         const int rr = slab * 32 + l31;
                         g.x = a.x == rr ? g.x : 0.f; g.y = a.y == rr ? g.y : 0.f;
                         g.z = a.z == rr ? g.z : 0.f; g.w = a.w == rr ? g.w : 0.f;
                     }
-                    const float4 P = *reinterpret_cast<const float4*>(vec + n);
-                    const float4 Q = *reinterpret_cast<const float4*>(vec + NO + n);
-                    const float4 S = *reinterpret_cast<const float4*>(vec + 2 * NO + n);
                     float4 a4;
                     a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
                     a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
                     if (!row_live) a4 = make_float4(0.f, 0.f, 0.f, 0.f);          // rows past the end add nothing to dW
-                    *reinterpret_cast<float4*>(hb + 8 * u) = a4;
-                    const float4 b0 = *reinterpret_cast<const float4*>(Wt + l31 * PW + n);
-                    const float4 b1 = *reinterpret_cast<const float4*>(Wt + (32 + l31) * PW + n);
+                    *reinterpret_cast<float4*>(hb) = a4;
+                    const float4 b0 = nb0, b1 = nb1;
+                    lds_operands((uu + 1) % NU);                           // the next step's, in flight under this step's MFMAs
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b0.y, acc[0], 0, 0, 0);
@@ -1821,7 +1835,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b0.w, acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
                 }
-                if ((c + 1) % HCH == 0) __syncthreads();                   // this half of the quad's dZ is in the buffer
+                if ((uu + 1) % (NU / 2) == 0) __syncthreads();             // this half of the quad's dZ is in the buffer
             }
             // epilogue: dY of the previous layer (ReLU-masked) + its BatchNorm-backward sums (the consumers are at work
             // on the second half meanwhile)
@@ -1843,8 +1857,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
                     sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
                 }
             }
-            r_cur = r_nxt;
-            grp_cur = grp_nxt;
+            r_cur = r_nxt; r_nxt = r_nn;
+            grp_cur = grp_nxt; grp_nxt = grp_nn;
+            wrow = w_nxt;
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -1865,32 +1880,35 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int v = 0; v < 16; ++v) aw[h][v] = 0.f;
-        float yv[2][16];
-        auto load_y = [&](int slab, int buf) {                              // z_prev rows of `slab`, accumulator layout
+        // relu(bn(z_prev)) of the quad's slabs in the accumulator layout, kept for both channel halves; the next quad's
+        // rows are requested as soon as the second half has used a slab's values (a whole exchange phase ahead)
+        float yq[NS][16];
+        auto load_y = [&](int slab, int s) {
             const int zrow = (slab < n_slabs ? slab : 0) * 32 * 64 * 4;     // (past the end: the producers wrote dZ = 0)
 #pragma unroll
             for (int v = 0; v < 16; ++v)
-                yv[buf][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zrsrc, glane + b * 128, zrow + ((v & 3) + 8 * (v >> 2)) * 256, 0));
+                yq[s][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zrsrc, glane + b * 128, zrow + ((v & 3) + 8 * (v >> 2)) * 256, 0));
         };
         const float* const rbase = dzb + (4 * half) * HP + 32 * tcl + l31;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) load_y(blockIdx.x * 4 + s0 + s, s);
         for (int quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
-            const int slab0 = quad * 4 + s0;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                load_y(slab0, 0);
                 __syncthreads();                                            // half h of this quad is in buffer h
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    if (s + 1 < NS) load_y(slab0 + s + 1, (s + 1) & 1);
                     const float* rb = rbase + (h * 4 + s0 + s) * (32 * HP);
                     float dz[16];
 #pragma unroll
                     for (int v = 0; v < 16; ++v) dz[v] = rb[((v & 3) + 8 * (v >> 2)) * HP];
+                    if (h == 0) {
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const float y = fmaxf(fmaf(yv[s & 1][v], psb, ptb), 0.f);
-                        aw[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[v], y, aw[h], 0, 0, 0);
+                        for (int v = 0; v < 16; ++v) yq[s][v] = fmaxf(fmaf(yq[s][v], psb, ptb), 0.f);
                     }
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) aw[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(dz[v], yq[s][v], aw[h], 0, 0, 0);
+                    if (h == 1) load_y((quad + gridDim.x) * 4 + s0 + s, s);
                 }
             }
         }

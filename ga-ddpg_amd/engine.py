@@ -355,7 +355,7 @@ def _dz(**kw):
 # bench.py / diagnostics: durations of tagged launches, stamped by the kernels themselves (gad_timing_slot: first
 # wavefront start -> last wavefront end on the device wall clock -- what a profiler reports as the dispatch duration;
 # HIP events around a 25 us launch inside a five-stream step read 8 - 20 us high: event packets, queue waits)
-TIMING = {"enabled": False, "tag": None, "slots": None, "next": 0, "tags": []}
+TIMING = {"enabled": False, "tag": None, "slots": None, "next": 0, "tags": [], "routed": {}}
 _TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_bwd", "gad_segment_pool")      # (entry points that take a timing slot)
 
 
@@ -368,7 +368,7 @@ def timing_start(tag="*", capacity=2048):
     dev = torch.device("cuda", torch.cuda.current_device())
     slots = torch.zeros(capacity, TIMING_WAVES, 2, dtype=torch.int64, device=dev)
     slots[:, :, 0] = torch.iinfo(torch.int64).max
-    TIMING.update(enabled=True, tag=tag, slots=slots, next=0, tags=[])
+    TIMING.update(enabled=True, tag=tag, slots=slots, next=0, tags=[], routed={})
 
 
 def timing_stop(spans=False):
@@ -544,6 +544,7 @@ class Plan(object):
                     main.wait_event(args)
                 continue
             lane = int(lane)
+            took_slot = False
             if timed and name in _TIMED_CALLS and i in self.tags and TIMING["next"] < TIMING["slots"].shape[0] and (
                     TIMING["tag"] == "*" or self.tags[i] == TIMING["tag"] or
                     (isinstance(TIMING["tag"], (set, frozenset, tuple, list)) and self.tags[i] in TIMING["tag"])):
@@ -551,6 +552,7 @@ class Plan(object):
                 TIMING["next"] = k + 1
                 TIMING["tags"].append(self.tags[i])
                 hip.lib().gad_timing_slot(C.c_void_p(TIMING["slots"].data_ptr() + 16 * TIMING_WAVES * k))   # consumed by the call below
+                took_slot = True
             q = sides[lane][1] if lane else st
             if name == "zero":
                 args.zero_()
@@ -564,6 +566,13 @@ class Plan(object):
                 hip.check(f(C.byref(s), q), name)
             else:
                 hip.check(f(*(args + [q])), name)
+            if took_slot:
+                TIMING["routed"][self.tags[i]] = hip.lib().gad_last_kernel().decode()      # kernel family the call routed to
+
+
+def timing_routes():
+    """{tag: kernel family} of the launches timed since the last timing_start() (gad_last_kernel after each)"""
+    return dict(TIMING["routed"])
 
 
 # ----------------------------------------------------------------------------------------------

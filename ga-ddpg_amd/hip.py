@@ -82,6 +82,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.gad_last_error.restype = C.c_char_p
         L.gad_abi_version.restype = C.c_int
+        L.gad_last_kernel.restype = C.c_char_p
         _lib = L
         for k, v in os.environ.items():          # GAD_OPT_<name>=<int>: kernel-selection switches for A/B diagnostics
             if k.startswith("GAD_OPT_"):
@@ -90,7 +91,7 @@ def lib():
 
 
 EXPORTS = (
-    "gad_abi_version", "gad_last_error", "gad_set_option", "gad_timing_slot", "gad_wall_clock_khz", "gad_grid_rows_hint", "gad_bn_running_update", "gad_replay_gather", "gad_zero_buffers", "gad_furthest_point_sampling", "gad_gather_points",
+    "gad_abi_version", "gad_last_kernel", "gad_last_error", "gad_set_option", "gad_timing_slot", "gad_wall_clock_khz", "gad_grid_rows_hint", "gad_bn_running_update", "gad_replay_gather", "gad_zero_buffers", "gad_furthest_point_sampling", "gad_gather_points",
     "gad_gather_points_grad", "gad_ball_query", "gad_group_points", "gad_group_points_grad",
     "gad_query_and_group", "gad_prep_points", "gad_rows_from_ball_query", "gad_rows_group_all",
     "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_pool_finalize", "gad_affine_act",

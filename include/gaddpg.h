@@ -40,7 +40,12 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * gad_actor_loss, noise type in gad_target_noise, gad_policy_sample;
                                             * 4: max-pool fused into the pooled layer's GEMM (pool_key fields, nullable
                                             * zout, gad_pool_finalize, zmax in gad_pool_bwd_stats); the deferred-BatchNorm
-                                            * fields and the slab / graph switches of version 3 are gone)              */
+                                            * fields and the slab / graph switches of version 3 are gone;
+                                            * 5: gad_gemm_bwd, gad_optim_jobs, gad_last_kernel)                       */
+/* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
+ * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
+ * with it instead of restating the routing rules.                                                  */
+const char* gad_last_kernel(void);
 const char* gad_last_error(void);          /* thread-local description of the last <0   */
 /* Kernel-selection switches for A/B diagnostics (defaults in brackets).  "fwd_stream" [1]: route the wide and
  * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route

@@ -18,6 +18,26 @@ def assert_close(a, b, rtol, atol, what=""):
                                                    tol.ravel()[i], err.max()))
 
 
+def assert_close_rows(a, b, rtol, atol, what="", stray_rows=1, stray_factor=20.0):
+    """Entry-wise rtol / atol for per-sample tensors (one row per sample), except that `stray_rows` rows may be off by
+    up to `stray_factor` x the tolerance: two float32 evaluations of the step resolve the odd ReLU / max-pool tie
+    differently (tests/test_gpu_forced_decisions.py counts them: 0-4 decisions in 8e5), which moves the outputs of the
+    sample it sits in by ~1e-5 and nothing else."""
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, "%s: shape %s vs %s" % (what, a.shape, b.shape)
+    if a.ndim < 1 or a.shape[0] < 4:
+        return assert_close(a, b, rtol, atol, what)
+    err = np.abs(a - b).reshape(a.shape[0], -1)
+    tol = (atol + rtol * np.abs(b)).reshape(a.shape[0], -1)
+    over = (err / tol).max(axis=1)
+    stray = np.nonzero(over > 1.0)[0]
+    if len(stray) > stray_rows or (len(stray) and over.max() > stray_factor):
+        i = int(np.argmax(over))
+        raise AssertionError("%s: %d rows beyond tolerance (allowed: %d within %gx); worst row %d at %.3g x tol, max abs err %.3g"
+                             % (what, len(stray), stray_rows, stray_factor, i, over[i], err.max()))
+
+
 def check_summaries(golden, prefix, named_tensors, rtol, atol, skip=(), normwise=False, l2_rtol=2e-2, max_rtol=5e-2):
     """Compare tensors against fingerprints written by oracle.detfill.summarize_named.
     The tolerance on the aggregate stats is scaled by the tensor's abs-sum / l2.

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests.helpers import assert_close, check_summaries, golden_batch
+from tests.helpers import assert_close, assert_close_rows, check_summaries, golden_batch
 
 pytestmark = pytest.mark.gpu
 SEED = 1234
@@ -65,7 +65,7 @@ def _check_step(agent, nets, g, p, kind, s, tight):
         # tight steps: entry-wise rt + at; follow-up steps (after an Adam step the float32 trajectories of ANY two
         # implementations separate: torch-f32 vs torch-f64 differ by 1.25e-2 in pi at BC step 1): norm-wise
         if tight:
-            assert_close(a, b, rt, extra * at, what)
+            assert_close_rows(a, b, rt, extra * at, what)
         else:
             assert_close(a, b, 0.0, rt * np.abs(b).max() + at, what)
     nclose(agent.pi.cpu().numpy(), g[p + "t/pi"], p + "pi")
