@@ -24,12 +24,18 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-# 1: two buckets per phase, the first all-reduced under the SA1 backward (below); 0: one exchange per phase after the whole
-# backward pass.  MEASURED at one rank (RCCL, MI355X, same box, tests/bisect_bench.sh): no hooks 288 steps/s, one exchange per
-# phase 287 (0 %), bucketed 262 (-9 %): the asynchronous collective brings a fifth stream into a process whose four hardware
-# queues are all in use (engine._PHYS), and that costs more than the ~0.1 ms an 8 MB ring all-reduce takes over xGMI.  Off by
-# default; kept (and tested bit-identical) for nodes where the exchange is slower than this one.
-BUCKETED = os.environ.get("GAD_DP_BUCKETS", "0") == "1"
+# Two buckets per phase, the first all-reduced under the SA1 backward (above); "0": one exchange per phase after the whole
+# backward pass.  Round 2 measured the bucketed exchange at -9 % at one rank because torch.distributed runs an asynchronous
+# collective on a stream of its own -- a fifth active queue in a process that keeps four busy (engine._PHYS).  With the
+# collectives issued through RCCL's C API on the weight-gradient lane itself (rccl.Communicator, DIRECT below) there is no
+# extra stream.  MEASURED, round 3, one rank, same box (tests/ab_dp2.sh; GAD_BENCH_FORCE_DP=1): no hooks 320.0 steps/s, one
+# exchange per phase 318.7 (direct) / 316.8 (torch.distributed), bucketed 319.4 (direct) / 288.8 (torch.distributed).  So
+# buckets are the default wherever the direct path is available (backend 'nccl', world > 1); over gloo / torch.distributed
+# the default stays one exchange per phase.
+BUCKETED = {None: None, "0": False, "1": True}[os.environ.get("GAD_DP_BUCKETS")]        # None: decided in attach()
+# gradient / count exchanges of CUDA tensors through rccl.Communicator on the caller's stream (backend 'nccl' only: gloo
+# groups -- the CPU tests, two test ranks sharing one GPU -- keep torch.distributed)
+DIRECT = os.environ.get("GAD_DP_DIRECT_RCCL", "1") != "0"
 
 
 def mask_counts(batch):
@@ -64,14 +70,39 @@ class DataParallelContext(object):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.rt = None
+        self._comm = None
+        self._direct = DIRECT and dist.get_backend(group) == "nccl" and torch.cuda.is_available()
+
+    @property
+    def comm(self):
+        """rccl.Communicator of this group, created at first use"""
+        if self._direct and self._comm is None:
+            from . import engine, rccl
+            # HIP binds a stream to one of the process's four hardware queues at the stream's FIRST LAUNCH, and
+            # ncclCommInitRank launches on streams of its own: created before the step's streams have run anything, the
+            # communicator takes queues and the step's chains end up sharing one (measured: 318 -> 260 steps/s at one
+            # rank).  So every stream of the step launches something first.
+            dev = torch.cuda.current_device()
+            streams = [torch.cuda.current_stream(dev)] + [engine.side_stream(dev, w) for w in (1, 2, 3)]
+            for st in streams:
+                with torch.cuda.stream(st):
+                    torch.zeros(64, device="cuda").add_(1.0)
+            torch.cuda.synchronize(dev)
+            self._comm = rccl.Communicator(self.group)
+        return self._comm
+
+    def _sum(self, t):
+        """in-place SUM over the ranks, ordered on the CURRENT stream"""
+        if self.comm is not None and t.is_cuda:
+            self.comm.all_reduce_(t)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
     def attach(self, rt):
         self.rt = rt
         rt.world_size = self.world
         rt.dp = self
         rt.allreduce = self.allreduce_grads
-        if hasattr(rt, "set_fused_optim"):
-            rt.set_fused_optim(False)               # the gradient exchange sits between the arena conversion and the Adam step
         rt.inv_n = torch.zeros(8, dtype=torch.float32, device=rt.dev)
         self._counts = torch.zeros(4, dtype=torch.float64, device=rt.dev)
         from . import engine
@@ -82,27 +113,43 @@ class DataParallelContext(object):
         self._numer = torch.tensor([1.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0, 1.0], dtype=torch.float64, device=rt.dev)
         self._pick = torch.tensor([0, 1, 2, 1, 3], dtype=torch.int64, device=rt.dev)
         self._inflight = {}
-        if BUCKETED and hasattr(rt, "enable_bucketed_reduce"):
+        bucketed = BUCKETED if BUCKETED is not None else (self._direct and self.world > 1)
+        if bucketed and hasattr(rt, "enable_bucketed_reduce"):
             rt.enable_bucketed_reduce()
+        elif hasattr(rt, "_build_all_plans"):
+            rt._build_all_plans()                   # the backward plans end differently once an exchange follows them
 
     def reduce_early(self, tag, tensors):
-        """start the exchange of a bucket whose gradients are complete (asynchronous: the collective runs on the backend's
-        own stream, ordered after the launches enqueued so far on the current stream)"""
+        """start the exchange of a bucket whose gradients are complete, ordered after the launches enqueued so far on the
+        current stream (the weight-gradient lane that produced the bucket).  Direct RCCL: the collective is a kernel of
+        that very stream and an event marks its end; torch.distributed: asynchronous on the backend's own stream."""
         self._inflight.setdefault(tag, [])
         for t in tensors:
-            self._inflight[tag].append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.comm is not None and t.is_cuda:
+                self.comm.all_reduce_(t)
+                ev = torch.cuda.Event()
+                ev.record()
+                self._inflight[tag].append(ev)
+            else:
+                self._inflight[tag].append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def reduce_finish(self, tag, tensors):
         """exchange the rest of the phase's gradients and make the current stream wait for every bucket of the phase"""
         works = self._inflight.pop(tag, [])
         for t in tensors:
-            works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.comm is not None and t.is_cuda:
+                self.comm.all_reduce_(t)
+            else:
+                works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
-            w.wait()
+            if isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(w)
+            else:
+                w.wait()
 
     def allreduce_grads(self, tensors):
         for t in tensors:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            self._sum(t)
 
     def set_counts(self, batch):
         """global mask counts -> rt.inv_n: one 4-double all-reduce per step, stream-ordered (no host sync: counts and
@@ -116,7 +163,7 @@ class DataParallelContext(object):
             h = self._counts_host[getattr(self.rt, "_slot", 0)]
             h.numpy()[:] = mask_counts(batch)
             self._counts.copy_(h, non_blocking=True)
-        dist.all_reduce(self._counts, op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(self._counts)
         self.rt.inv_n[0:5] = (self._numer / self._counts.index_select(0, self._pick)).float()
 
     def global_counts(self, local, device):
@@ -126,9 +173,12 @@ class DataParallelContext(object):
 
     def reduce_scalars(self, scal):
         """losses / counts are partial sums per rank (already divided by the global counts)"""
-        dist.all_reduce(scal[0:10], op=dist.ReduceOp.SUM, group=self.group)
+        self._sum(scal[0:10])
 
     def broadcast_parameters(self, flats):
         for f in flats:
-            dist.broadcast(f.master, src=0, group=self.group)
+            if self.comm is not None and f.master.is_cuda:
+                self.comm.broadcast_(f.master, root=0)
+            else:
+                dist.broadcast(f.master, src=0, group=self.group)
             f.sync_packed()

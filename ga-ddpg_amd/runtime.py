@@ -149,9 +149,11 @@ class FusedRuntime(object):
         self._slot = 0
         self.scal_host = self._scal_ring[0]
         self.bucketed = False
+        self.dp = None                   # parallel.DataParallelContext (set by its attach())
+        self.allreduce = None            # callable(list of flat grad tensors)
         # One launch per optimiser phase (gad_optim_jobs: arena -> .grad, Adam, target update, log statistics, BatchNorm
         # counters) instead of ~6 / ~12 small ones; a data-parallel run exchanges gradients between the conversion and the
-        # Adam step and keeps the separate launches (DataParallelContext.attach -> set_fused_optim(False)).
+        # Adam step: the backward plans then convert arena -> .grad themselves and the launch starts from .grad.
         self.fused_optim = self.has_critic and _os.environ.get("GAD_FUSED_OPTIM", "1") == "1"
         # this step's Adam scalars of every network: one pinned block per in-flight step, ONE upload
         self._opt_nets = [self.pol, self.enc] + ([self.venc, self.cr] if self.has_critic else [])
@@ -164,8 +166,6 @@ class FusedRuntime(object):
             self.seg[nm] = torch.tensor([0, fl.n], dtype=torch.int32, device=dev)
         self._build_all_plans()
         self.world_size = 1
-        self.dp = None                   # parallel.DataParallelContext (set by its attach())
-        self.allreduce = None            # callable(list of flat grad tensors)
         self.inv_n = None
         self.resident = False            # True: the static batch buffers were filled on the device
         self._ev = [torch.cuda.Event() for _ in range(5)]
@@ -194,8 +194,9 @@ class FusedRuntime(object):
     def _grad_tail(self, plan, head, enc, tag, early):
         """arena (f64, packed) -> flat .grad (f32, master order) at the end of a backward plan; bucketed: only what the
         early hook has not converted yet (the encoder's SA1 parameters, which lead its flat buffer)"""
-        if self.fused_optim and self.has_critic:
+        if self.fused_optim and self.has_critic and self.dp is None:
             # the optimiser launch converts (gad_optim_jobs); only the critic's gradient is needed before it: clip_grad_norm_
+            # (data-parallel runs convert here instead: the exchange sits between the conversion and the optimiser launch)
             if tag == "c":
                 plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
             return
@@ -362,18 +363,19 @@ class FusedRuntime(object):
         import ctypes as C
         ag = self.agent
         jobs = getattr(self, "_optim_jobs_cache", None)
-        if jobs is None or jobs["key"] != (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature)):
+        ar = self.dp is None          # data-parallel: the .grad buffers hold the converted, all-reduced gradients already
+        if jobs is None or jobs["key"] != (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar):
             sc = self.scal
             arr = lambda js: (hip.OptimJob * len(js))(*js)
             jobs = self._optim_jobs_cache = {
-                "key": (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature)),
+                "key": (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar),
                 # value encoder: arena -> grad + Adam; critic: Adam with the clip (its .grad is converted already) + target
                 # update from the updated parameters (nothing reads critic_target before the next step) + max |parameter|
-                "c": arr([self._optim_job(self.venc.flat),
+                "c": arr([self._optim_job(self.venc.flat, arena=ar),
                           self._optim_job(self.cr.flat, arena=False, clip=self.clip_sumsq, target=self.cr_t.flat, sel=self.critic_sel,
                                           absmax_p=engine._ptr(sc, 48))]),
-                "a": arr([self._optim_job(self.pol.flat, target=self.pol_t.flat, absmax_p=engine._ptr(sc, 32)),
-                          self._optim_job(self.enc.flat, adam=bool(ag.train_feature), counter=self.enc.batches_tracked)]),
+                "a": arr([self._optim_job(self.pol.flat, arena=ar, target=self.pol_t.flat, absmax_p=engine._ptr(sc, 32)),
+                          self._optim_job(self.enc.flat, arena=ar, adam=bool(ag.train_feature), counter=self.enc.batches_tracked)]),
                 "end": arr([self._optim_job(self.cr.flat, adam=False, arena=False, absmax_grad=engine._ptr(sc, 40),
                                             counter=self.venc.batches_tracked)])}
         js = jobs[which]
@@ -571,6 +573,7 @@ class FusedRuntime(object):
                      self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4))
             P["p_bwd"].run()
             if self.fused_optim:
+                self._reduce([self.pol.flat, self.enc.flat], "a")          # (no-op outside data-parallel runs)
                 self._optim_phase("a", policy_step)
                 return
             self._reduce([self.pol.flat, self.enc.flat], "a")
@@ -644,6 +647,7 @@ class FusedRuntime(object):
         if OVERLAP_PASSES:
             main.wait_event(self._ev_run)           # (long done; orders the running statistics before the next value pass)
         if self.fused_optim:
+            self._reduce([self.cr.flat, self.venc.flat], "c")
             hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
             self._optim_phase("c", policy_step)
         else:

@@ -132,14 +132,49 @@ def _worker_nccl1(rank, port, out_dir):
         rt = agent.runtime(B, batches[0]["point_state_batch"].shape[2])
         if use_dp:
             dp = DataParallelContext()
+            assert dp.comm is not None                 # backend nccl: the exchanges go through rccl.Communicator on the caller's stream
             agent._dp = dp
             dp.attach(rt)
+            assert rt.bucketed == (use_dp == "bucketed")
         rets = [agent.update_parameters(batches[0], agent.update_step, s, noise_u=u) for s in range(2)]
         torch.cuda.synchronize()
         res[use_dp] = {"rets": rets, "pi": agent.pi.cpu().clone(), "state": _state(agent)}
     torch.save(res, os.path.join(out_dir, "nccl1.pt"))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _worker_rccl_direct(rank, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)          # the bootstrap needs a group, not this backend
+    from ga_ddpg_amd import rccl
+    comm = rccl.Communicator()
+    side = torch.cuda.Stream()
+    x = torch.arange(1 << 20, dtype=torch.float32, device="cuda")
+    d = torch.arange(1000, dtype=torch.float64, device="cuda")
+    ref, refd = x.clone(), d.clone()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        x.mul_(2.0)                                    # stream-ordered before ...
+        comm.all_reduce_(x)                            # ... the collective on the SAME stream ...
+        x.add_(1.0)                                    # ... and after it
+        comm.all_reduce_(d[10:20])                     # a slice (contiguous view at an offset)
+        comm.broadcast_(d)
+    torch.cuda.current_stream().wait_stream(side)
+    ok = bool(torch.equal(x, ref * 2.0 + 1.0)) and bool(torch.equal(d, refd))
+    comm.destroy()
+    torch.save({"ok": ok, "world": comm.world}, os.path.join(out_dir, "rccl_direct.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_communicator_runs_on_the_callers_stream(tmp_path):
+    """rccl.Communicator (RCCL's C API through ctypes, bootstrapped over a torch.distributed group): one-rank all-reduce /
+    broadcast enqueued on a side stream between two kernels of that stream leave the values of a sum over one rank, in
+    order -- the property the bucketed gradient exchange relies on (no stream of its own, no fifth hardware queue)."""
+    mp.spawn(_worker_rccl_direct, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "rccl_direct.pt"), weights_only=False)
+    assert res["ok"] and res["world"] == 1
 
 
 def test_single_rank_rccl_equals_plain_step(tmp_path):
