@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 // the partial tiles are summed through LDS.  256 rows x 1024 -> 512: 37.8 us -> see tests/diag_gemm.py.
 // ------------------------------------------------------------------------------------------------
 #define SK_NW 8          // wavefronts per workgroup (K split); 16 -> 128-VGPR budget -> spills, 2x slower
-#define SK_CH 6          // 8-wide k groups per register chunk
+#define SK_CH 6          // 8-wide k groups per register chunk (17 x 1 = the whole K share in one round of loads: measured 2 % slower)
 #define SK_MAXCH 3       // chunks per wavefront: K <= 8 * SK_NW * SK_CH * SK_MAXCH = 1152
 __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Groups gr, int n_rows,
                                                                      const float* __restrict__ row_w,
@@ -1116,7 +1116,9 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     const int l31 = lane & 31, half = lane >> 5;
     const int g = blockIdx.z;
     const int zoff = gr.aoff[g], n_out = gr.nout[g], ooff = gr.ooff[g];
-    const int n0 = blockIdx.y * 32, row0 = blockIdx.x * 32;
+    // x = column tile, y = row tile: workgroups go to the 8 XCDs round-robin in x-fastest order, so the workgroups that read
+    // one 32-column slice of W share an L2 (each XCD pulls 1/8 of the weights instead of all of them)
+    const int n0 = blockIdx.x * 32, row0 = blockIdx.y * 32;
     if (n0 >= n_out) return;                                  // workgroup-uniform
     const float* Wg = W + gr.woff[g] + (size_t)min(n0 + l31, n_out - 1) * Kp + 4 * half;   // clamped: extra columns unused
     const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are neither stored nor counted
@@ -1185,7 +1187,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (lane < 32 && n < n_out) {
-            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+            const int rep = blockIdx.y % GAD_STAT_REPLICAS;
             atomic_add_f64(stat_sum + (size_t)rep * stat_stride + ooff + n, (double)s1);
             atomic_add_f64(stat_sq + (size_t)rep * stat_stride + ooff + n, (double)s2);
         }
@@ -1281,7 +1283,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     }
     const int grid_rows = (a->n_rows_dev && rows_hint > 0 && rows_hint < rows) ? rows_hint : rows;   // gad_grid_rows_hint
     if (!pe.key && fwd_skinny(*a)) {
-        hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(nmax, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
+        hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
                            gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
         GAD_CHECK_LAUNCH("gemm_fwd(skinny)");
         return GAD_OK;
@@ -2134,7 +2136,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     const int l31 = lane & 31, half = lane >> 5;
     const int g = blockIdx.z;
     const int doff = gr.aoff[g], n_out = gr.nout[g], goff = gr.ooff[g];
-    const int k0 = blockIdx.y * 32, row0 = blockIdx.x * 32;
+    const int k0 = blockIdx.x * 32, row0 = blockIdx.y * 32;      // (x = column tile: see gemm_fwd_skinny_kernel)
     for (int i = tid; i < n_out; i += 64 * SK_NW) {
         vec[i] = d.scale ? d.scale[doff + i] : 1.f;
         vec[VMAX + i] = d.shift ? d.shift[doff + i] : 0.f;
@@ -2219,7 +2221,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
         sb += __shfl_xor(sb, 32, 64);
         sg += __shfl_xor(sg, 32, 64);
         if (lane < 32 && kok) {
-            const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+            const int rep = blockIdx.y % GAD_STAT_REPLICAS;
             atomic_add_f64(e.dbeta + (size_t)rep * e.stat_stride + goff + kk, (double)sb);
             atomic_add_f64(e.dgamma + (size_t)rep * e.stat_stride + goff + kk, (double)sg);
         }
@@ -2276,7 +2278,7 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     for (int i = 0; i < a->n_groups; ++i) nmax_dx = a->n_out[i] > nmax_dx ? a->n_out[i] : nmax_dx;
     if (g_opt_dx_skinny && vec && e.mode == 0 && a->dz.gmode == 0 && !a->n_rows_dev && rows <= 1024 &&
         nmax_dx <= 8 * SK_NW * SK_CH * SK_MAXCH && nmax_dx <= VMAX) {
-        hipLaunchKernelGGL(gemm_dx_skinny_kernel, dim3(gad_cdiv(rows, 32), gad_cdiv(kv, 32), gr.n), dim3(64 * SK_NW), 0, st, d, gr,
+        hipLaunchKernelGGL(gemm_dx_skinny_kernel, dim3(gad_cdiv(kv, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, d, gr,
                            rows, a->W, a->Kp, e, ts);
         GAD_CHECK_LAUNCH("gemm_dx(skinny)");
         return GAD_OK;
