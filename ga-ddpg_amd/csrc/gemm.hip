@@ -1101,6 +1101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 // ------------------------------------------------------------------------------------------------
 #define SK_NW 8          // wavefronts per workgroup (K split); 16 -> 128-VGPR budget -> spills, 2x slower
 #define SK_CH 6          // 8-wide k groups per register chunk (17 x 1 = the whole K share in one round of loads: measured 2 % slower)
+#define SK_SP 36         // pitch (floats) of the wavefront-private operand stage of the skinny forward kernel
 #define SK_MAXCH 3       // chunks per wavefront: K <= 8 * SK_NW * SK_CH * SK_MAXCH = 1152
 __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Groups gr, int n_rows,
                                                                      const float* __restrict__ row_w,
@@ -1110,6 +1111,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
                                                                      double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
     KTimer kt(ts);
     __shared__ float part[SK_NW * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float stA[SK_NW * 32 * SK_SP], stW[SK_NW * 32 * SK_SP];
     __shared__ __attribute__((aligned(16))) float sv[8 * SK_NW * SK_CH * SK_MAXCH], tv[8 * SK_NW * SK_CH * SK_MAXCH];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1129,32 +1131,73 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-    XRaw ra[SK_MAXCH > 1 ? 2 : 1][SK_CH];
-    float4 rb[SK_MAXCH > 1 ? 2 : 1][SK_CH];
-    auto load_chunk = [&](int c, int buf) {
+    // Operand blocks of four k groups (32 columns) go through a wavefront-private LDS stage: loaded COALESCED (8 lanes per
+    // 128-byte row segment, 8 rows per instruction: 8-16 cache lines instead of the 32 a lane-per-row 16-byte load touches
+    // -- these launches were bound by the texture path, not by the number of load rounds), written row-major with pitch 36
+    // and read back as the MFMA fragments.  Blocks that reach beyond the bulk columns (bias / extra column) or the
+    // wavefront's last groups take the lane-per-row loads.
+    float* const myA = stA + wave * (32 * SK_SP);
+    float* const myW = stW + wave * (32 * SK_SP);
+    const int rsub = lane >> 3, chunk = lane & 7;
+    const float* pa[4];
+    const float* pw[4];
 #pragma unroll
-        for (int u = 0; u < SK_CH; ++u) {
-            const int j = min(j0 + c * SK_CH + u, nj - 1);    // clamped; masked out at the MFMA
-            const int col = 8 * j + 4 * half;
-            ra[buf][u] = x_raw<0>(x, r, true, zoff, col, col + 4 > x.c_in, 0);
-            rb[buf][u] = ldg4(Wg + 8 * j);
-        }
+    for (int i = 0; i < 4; ++i) {
+        pa[i] = x.zin + (size_t)min(row0 + rsub + 8 * i, n_rows - 1) * x.zin_pitch + zoff + 4 * chunk;
+        pw[i] = W + gr.woff[g] + (size_t)min(n0 + rsub + 8 * i, n_out - 1) * Kp + 4 * chunk;
+    }
+    auto staged = [&](int jb) { return jb + 4 <= j1 && 8 * (jb + 4) <= x.c_in; };       // wave-uniform
+    float4 ga[4], gw[4];
+    auto load_blk = [&](int jb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ga[i] = ldg4(pa[i] + 8 * jb); gw[i] = ldg4(pw[i] + 8 * jb); }
     };
-    load_chunk(0, 0);
-    // the operand loads above are in flight while the input layer's per-channel affine is staged (or, with a deferred
-    // BatchNorm, finalised from its statistics) in LDS
+    if (j0 < j1 && staged(j0)) load_blk(j0);
+    // the operand loads above are in flight while the input layer's per-channel affine is staged in LDS
     if (x.affine) stage_affine<64 * SK_NW>(sv, tv, x, zoff, x.c_in);
     __syncthreads();
+    for (int jb = j0; jb < j1; jb += 4) {
+        if (staged(jb)) {                                     // wave-uniform
 #pragma unroll
-    for (int c = 0; c < SK_MAXCH; ++c) {
-        if (j0 + c * SK_CH < j1) {                            // wave-uniform
-            if (c + 1 < SK_MAXCH && j0 + (c + 1) * SK_CH < j1) load_chunk(c + 1, (c + 1) & 1);
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<float4*>(myA + (rsub + 8 * i) * SK_SP + 4 * chunk) = ga[i];
+                *reinterpret_cast<float4*>(myW + (rsub + 8 * i) * SK_SP + 4 * chunk) = gw[i];
+            }
+            if (jb + 4 < j1 && staged(jb + 4)) load_blk(jb + 4);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-            for (int u = 0; u < SK_CH; ++u) {
-                const int j = j0 + c * SK_CH + u;
-                if (j < j1) {                                 // wave-uniform
-                    const float4 a4 = x_finish<0>(x, ra[c & 1][u], true, 8 * j + 4 * half, sv, tv);
-                    const float4 b4 = rb[c & 1][u];
+            for (int u = 0; u < 4; ++u) {
+                XRaw raw;
+                raw.a = *reinterpret_cast<const float4*>(myA + l31 * SK_SP + 8 * u + 4 * half);
+                raw.s = f4zero();
+                const float4 a4 = x_finish<0>(x, raw, true, 8 * (jb + u) + 4 * half, sv, tv);
+                const float4 b4 = *reinterpret_cast<const float4*>(myW + l31 * SK_SP + 8 * u + 4 * half);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            const int je = min(jb + 4, j1);
+            XRaw ra[4];
+            float4 rb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = min(jb + u, nj - 1);
+                const int col = 8 * j + 4 * half;
+                ra[u] = x_raw<0>(x, r, true, zoff, col, col + 4 > x.c_in, 0);
+                rb[u] = ldg4(Wg + 8 * j);
+            }
+            if (jb + 4 < j1 && staged(jb + 4)) load_blk(jb + 4);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (jb + u < je) {                            // wave-uniform
+                    const float4 a4 = x_finish<0>(x, ra[u], true, 8 * (jb + u) + 4 * half, sv, tv);
+                    const float4 b4 = rb[u];
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
