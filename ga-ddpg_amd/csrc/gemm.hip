@@ -2173,6 +2173,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
                                                                     const float* __restrict__ W, int Kp, DxEpi e, unsigned long long* __restrict__ ts) {
     KTimer kt(ts);
     __shared__ float part[SK_NW * 16 * 64];
+    __shared__ __attribute__((aligned(16))) float stZ[SK_NW * 32 * SK_SP], stG[SK_NW * 32 * SK_SP];
     __shared__ __attribute__((aligned(16))) float vec[5 * VMAX];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2199,39 +2200,95 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     f32x16 acc;
 #pragma unroll
     for (int v = 0; v < 16; ++v) acc[v] = 0.f;
-    float4 rz[2][SK_CH], rg[2][SK_CH], rb[2][SK_CH];
-    auto load_chunk = [&](int c, int buf) {
+    // z and dY blocks of four channel groups go through a wavefront-private LDS stage, loaded coalesced (see
+    // gemm_fwd_skinny_kernel); the W fragments are coalesced as they are.  Two blocks per loop trip: static register sets.
+    float* const myZ = stZ + wave * (32 * SK_SP);
+    float* const myG = stG + wave * (32 * SK_SP);
+    const int rsub = lane >> 3, chunk = lane & 7;
+    const float* pz[4];
+    const float* pg[4];
 #pragma unroll
-        for (int u = 0; u < SK_CH; ++u) {
-            const int j = min(j0 + c * SK_CH + u, nj - 1);
-            const int n = 8 * j + 4 * half;
+    for (int i = 0; i < 4; ++i) {
+        const size_t rr = (size_t)min(row0 + rsub + 8 * i, n_rows - 1);
+        pz[i] = d.z ? d.z + rr * d.z_pitch + doff + 4 * chunk : nullptr;
+        pg[i] = d.G + rr * d.g_pitch + doff + 4 * chunk;
+    }
+    auto staged = [&](int jb) { return d.z != nullptr && jb + 4 <= j1 && 8 * (jb + 4) <= n_out; };     // wave-uniform
+    float4 gz[4], gg[4], rb[2][4];
+    auto load_blk = [&](int jb) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { gz[i] = ldg4(pz[i] + 8 * jb); gg[i] = ldg4(pg[i] + 8 * jb); }
+    };
+    auto load_w = [&](int jb, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int n = 8 * min(jb + u, nj - 1) + 4 * half;
             const int nc = n < n_out ? n : 0;                 // clamped; dz_finish zeroes n >= n_out
-            rz[buf][u] = d.z ? ldg4(d.z + (size_t)r * d.z_pitch + doff + nc) : f4zero();
-            rg[buf][u] = ldg4(d.G + (size_t)r * d.g_pitch + doff + nc);
             const float* wp = Wg + (size_t)nc * Kp;
-            rb[buf][u] = make_float4(wp[0], wp[Kp], wp[2 * (size_t)Kp], wp[3 * (size_t)Kp]);
+            rb[B][u] = make_float4(wp[0], wp[Kp], wp[2 * (size_t)Kp], wp[3 * (size_t)Kp]);
         }
     };
-    load_chunk(0, 0);
+    auto block = [&](int jb, auto bufc) {
+        constexpr int B = decltype(bufc)::value;
+        const bool more = jb + 4 < j1;
+        float4 rz[4], rg[4];
+        const bool st = staged(jb);
+        if (st) {
 #pragma unroll
-    for (int c = 0; c < SK_MAXCH; ++c) {
-        if (j0 + c * SK_CH < j1) {
-            if (c + 1 < SK_MAXCH && j0 + (c + 1) * SK_CH < j1) load_chunk(c + 1, (c + 1) & 1);
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<float4*>(myZ + (rsub + 8 * i) * SK_SP + 4 * chunk) = gz[i];
+                *reinterpret_cast<float4*>(myG + (rsub + 8 * i) * SK_SP + 4 * chunk) = gg[i];
+            }
+        } else {
 #pragma unroll
-            for (int u = 0; u < SK_CH; ++u) {
-                const int j = j0 + c * SK_CH + u;
-                if (j < j1) {
-                    DzRaw raw;
-                    raw.z = rz[c & 1][u]; raw.g = rg[c & 1][u]; raw.a = make_int4(0, 0, 0, 0);
-                    const float4 a4 = dz_finish<true>(d, raw, r, true, 8 * j + 4 * half, n_out, wrow, vec);
-                    const float4 b4 = rb[c & 1][u];
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int n = 8 * min(jb + u, nj - 1) + 4 * half;
+                const int nc = n < n_out ? n : 0;
+                rz[u] = d.z ? ldg4(d.z + (size_t)r * d.z_pitch + doff + nc) : f4zero();
+                rg[u] = ldg4(d.G + (size_t)r * d.g_pitch + doff + nc);
             }
         }
+        if (more) {
+            if (staged(jb + 4)) load_blk(jb + 4);
+            load_w(jb + 4, std::integral_constant<int, B ^ 1>{});
+        }
+        if (st) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rz[u] = *reinterpret_cast<const float4*>(myZ + l31 * SK_SP + 8 * u + 4 * half);
+                rg[u] = *reinterpret_cast<const float4*>(myG + l31 * SK_SP + 8 * u + 4 * half);
+            }
+        }
+        const int je = min(jb + 4, j1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (jb + u < je) {                                // wave-uniform
+                DzRaw raw;
+                raw.z = rz[u]; raw.g = rg[u]; raw.a = make_int4(0, 0, 0, 0);
+                const float4 a4 = dz_finish<true>(d, raw, r, true, 8 * (jb + u) + 4 * half, n_out, wrow, vec);
+                const float4 b4 = rb[B][u];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+            }
+        }
+        if (st) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    if (j0 < j1) {
+        if (staged(j0)) load_blk(j0);
+        load_w(j0, std::integral_constant<int, 0>{});
+    }
+    for (int jb = j0; jb < j1; jb += 8) {
+        block(jb, std::integral_constant<int, 0>{});
+        if (jb + 4 < j1) block(jb + 4, std::integral_constant<int, 1>{});
     }
 #pragma unroll
     for (int v = 0; v < 16; ++v) part[(wave * 16 + v) * 64 + lane] = acc[v];
