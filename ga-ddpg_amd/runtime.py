@@ -24,9 +24,6 @@ import os as _os
 # beside the critic backward only: 275; the value pass after t1, beside t2 and the actor pass: 282; both side passes
 # swapped: 278 -- profiles/README.md round 2)
 ROW_HINTS = _os.environ.get("GAD_ROW_HINTS", "1") == "1"     # grids of the SA1 / SA2 tile launches sized for the expected live rows
-# the optimiser step of an encoder's FC + SA3 + SA2 parameters (99 % of them) on the weight-gradient lane as soon as their
-# gradients are complete, under the SA1 backward, instead of in the phase's closing launch on the critical chain
-EARLY_ADAM = _os.environ.get("GAD_EARLY_ADAM", "1") == "1"
 EARLY_ZERO = _os.environ.get("GAD_EARLY_ZERO", "1") == "1"   # backward buffers cleared at the end of the forward plans; t2's running update on the value stream
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
 
@@ -211,36 +208,19 @@ class FusedRuntime(object):
         assert lo == 0
         plan.call("gad_grad_from_arena", enc.flat.gacc, enc.flat.m2p, hi, enc.flat.grad, 0)
 
-    def _early_adam(self):
-        """the encoders' FC + SA3 + SA2 parameters are stepped from the backward plans' hooks (EARLY_ADAM): always without
-        data parallelism; with it only when the early bucket's exchange is a kernel of the same lane (direct RCCL)"""
-        if not (EARLY_ADAM and self.fused_optim and self.has_critic):
-            return False
-        return self.dp is None or (self.bucketed and getattr(self.dp, "_direct", False))
-
     def _early_hook(self, head, enc, tag):
-        early_adam = self._early_adam() and (tag == "c" or bool(self.agent.train_feature))
-        if not self.bucketed and not early_adam:
+        if not self.bucketed:
             return None
         lo, hi = enc.flat.segment("0.0.")
-        assert lo == 0
         n_rest = enc.flat.n - hi
-        if self.bucketed:
-            bucket = self.bucket_a if tag == "a" else self.bucket_c
-            assert bucket.data_ptr() == enc.flat.grad.data_ptr()   # [encoder (SA1 first) | pad | head]: the early bucket is one slice
-        jobs = (hip.OptimJob * 1)(self._optim_job(enc.flat, arena=not self.bucketed, lo=hi)) if early_adam else None
+        bucket = self.bucket_a if tag == "a" else self.bucket_c
+        assert bucket.data_ptr() == enc.flat.grad.data_ptr()       # [encoder (SA1 first) | pad | head]: the early bucket is one slice
 
         def hook(plan, lane):
-            if self.bucketed:
-                plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0, side=lane)
-                plan.call("gad_grad_from_arena", enc.flat.gacc, engine._ptr(enc.flat.m2p, hi), n_rest, engine._ptr(enc.flat.grad, hi),
-                          0, side=lane)
-                plan.fn(lambda: self._reduce_early(tag, [bucket[hi:]]), side=lane)
-            if early_adam:
-                # everything but SA1 of this encoder: gradients complete (this lane's launches so far), nothing reads these
-                # weights again before the next step; this step's Adam scalars were uploaded at its start (hyper_all)
-                plan.keep.append(jobs)
-                plan.call("gad_optim_jobs", jobs, 1, side=lane)
+            plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0, side=lane)
+            plan.call("gad_grad_from_arena", enc.flat.gacc, engine._ptr(enc.flat.m2p, hi), n_rest, engine._ptr(enc.flat.grad, hi),
+                      0, side=lane)
+            plan.fn(lambda: self._reduce_early(tag, [bucket[hi:]]), side=lane)
         return hook
 
     def _reduce_early(self, tag, tensors):
@@ -356,14 +336,11 @@ class FusedRuntime(object):
                 self.dbuf["time_m1"].copy_(h, non_blocking=True)
 
     def _optim_job(self, flat, adam=True, arena=True, clip=None, target=None, sel=None, absmax_p=None, absmax_grad=None,
-                   counter=None, lo=0, hi=None):
-        """one network's (or, lo / hi: a master-order slice of its) share of a gad_optim_jobs launch"""
-        hi = flat.n if hi is None else hi
-        assert target is None or (lo == 0 and hi == flat.n)
+                   counter=None):
         j = hip.OptimJob()
-        j.n = hi - lo
-        j.p, j.grad, j.exp_avg, j.exp_avg_sq = (hip.ptr(t[lo:hi]) for t in (flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq))
-        j.active, j.m2p, j.packed = hip.ptr(flat.active[lo:hi]), hip.ptr(flat.m2p[lo:hi]), hip.ptr(flat.packed)
+        j.n = flat.n
+        j.p, j.grad, j.exp_avg, j.exp_avg_sq = (hip.ptr(t) for t in (flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq))
+        j.active, j.m2p, j.packed = hip.ptr(flat.active), hip.ptr(flat.m2p), hip.ptr(flat.packed)
         if arena:
             j.gacc = hip.ptr(flat.gacc)
         if adam:
@@ -387,23 +364,18 @@ class FusedRuntime(object):
         ag = self.agent
         jobs = getattr(self, "_optim_jobs_cache", None)
         ar = self.dp is None          # data-parallel: the .grad buffers hold the converted, all-reduced gradients already
-        ea = self._early_adam()
-        if jobs is None or jobs["key"] != (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar, ea):
-            # with the early launches (the hooks of the backward plans) only the SA1 slice of an encoder is left for the end
-            hv = self.venc.flat.segment("0.0.")[1] if ea else None
-            he = self.enc.flat.segment("0.0.")[1] if (ea and ag.train_feature) else None
+        if jobs is None or jobs["key"] != (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar):
             sc = self.scal
             arr = lambda js: (hip.OptimJob * len(js))(*js)
             jobs = self._optim_jobs_cache = {
-                "key": (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar, ea),
+                "key": (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar),
                 # value encoder: arena -> grad + Adam; critic: Adam with the clip (its .grad is converted already) + target
                 # update from the updated parameters (nothing reads critic_target before the next step) + max |parameter|
-                "c": arr([self._optim_job(self.venc.flat, arena=ar, hi=hv),
+                "c": arr([self._optim_job(self.venc.flat, arena=ar),
                           self._optim_job(self.cr.flat, arena=False, clip=self.clip_sumsq, target=self.cr_t.flat, sel=self.critic_sel,
                                           absmax_p=engine._ptr(sc, 48))]),
                 "a": arr([self._optim_job(self.pol.flat, arena=ar, target=self.pol_t.flat, absmax_p=engine._ptr(sc, 32)),
-                          self._optim_job(self.enc.flat, arena=ar, adam=bool(ag.train_feature), counter=self.enc.batches_tracked,
-                                          hi=he)]),
+                          self._optim_job(self.enc.flat, arena=ar, adam=bool(ag.train_feature), counter=self.enc.batches_tracked)]),
                 "end": arr([self._optim_job(self.cr.flat, adam=False, arena=False, absmax_grad=engine._ptr(sc, 40),
                                             counter=self.venc.batches_tracked)])}
         js = jobs[which]
