@@ -1273,7 +1273,7 @@ static bool fwd_streamable(const gad_gemm_fwd_args& a) {
     if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || (a.zout && a.zout_pitch != a.n_out[0])) return false;
     if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
     if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && (a.scale && a.shift) && a.relu;
-    return a.Kp == 16 && a.feat_c + 3 + a.act_c <= 16;
+    return (a.Kp == 16 || a.Kp == 8) && a.feat_c + 3 + a.act_c <= a.Kp;      // Kp 8: the policy encoder's [f (4) | dx (3)] rows
 }
 
 static Groups make_groups(int n, const int32_t* a, const int32_t* w, const int32_t* o, const int32_t* no) {
@@ -1350,6 +1350,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
             LAUNCH_STREAM(8, 4, 0, true);                                  // (fwd_streamable: ACT input, 128 outputs)
         } else {
             if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0, false); else LAUNCH_STREAM(8, 4, 0, false); }
+            else if (a->Kp == 8) { if (a->n_out[0] == 64) LAUNCH_STREAM(1, 2, 1, false); else LAUNCH_STREAM(1, 4, 1, false); }
             else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1, false); else LAUNCH_STREAM(2, 4, 1, false); }
         }
 #undef LAUNCH_STREAM
