@@ -182,7 +182,13 @@ def test_teacher_forced_steps():
             if "running" in k:
                 # value encoder on policy steps: its third pass runs after its own Adam step (noise-coordinate moves)
                 loose = policy_step and "value_encoder" in k
-                assert_close(v.cpu().numpy(), osd[k].numpy(), 2e-2 if loose else 1e-4, 2e-3 if loose else 1e-6, tag + k)
+                # norm-wise (1e-4 of the tensor's largest entry): a batch statistic of the FC layers averages B = 32 rows,
+                # and ONE ReLU / max-pool tie upstream resolved differently by the two float32 evaluations moves a channel's
+                # mean by ~1e-5 relative to the activations' scale (running_mean entry: 1.5e-6 off at 1e-3, seen with the
+                # round-3 kernels' summation order; tests/test_gpu_forced_decisions.py counts such ties: 0-4 per pass)
+                want = osd[k].numpy()
+                scale = float(np.abs(want).max())
+                assert_close(v.cpu().numpy(), want, 2e-2 if loose else 0.0, 2e-3 if loose else 1e-4 * scale + 1e-6, tag + k)
             elif "num_batches" in k:
                 assert int(v) == int(osd[k]), (tag, k)
     # the schedules did cross their milestones: policy 3e-4 -> 1.5e-4 -> 7.5e-5, encoder 1e-3 -> 3e-4, critic 3e-4 -> 1.5e-4
