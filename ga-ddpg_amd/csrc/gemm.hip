@@ -723,14 +723,20 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         const float* ap0 = XM == 0 ? x.zin + (size_t)ra0 * x.zin_pitch + c4 : x.feat + (size_t)x.row_pt[ra0] * x.feat_c + c4;
         const float* ap1 = XM == 0 ? x.zin + (size_t)ra1 * x.zin_pitch + c4 : x.feat + (size_t)x.row_pt[ra1] * x.feat_c + c4;
         const float* bp = W + (size_t)(n0 + ur) * Kp + c4;
-        float4 ra[2], rb[4];
-        auto load_regs = [&](int kt) {
+        // two register sets: the global loads of a K-tile are issued TWO tiles before its LDS write (one tile of MFMAs is
+        // ~0.85 us, less than the memory latency under load: with one set every K-tile's barrier waited for its loads)
+        float4 ra2[2][2], rb2[2][4];
+        auto load_regs = [&](int kt, auto setc) {
+            constexpr int S = decltype(setc)::value;
             const int k0 = kt * KT;
-            ra[0] = ldg4(ap0 + k0); ra[1] = ldg4(ap1 + k0);
+            ra2[S][0] = ldg4(ap0 + k0); ra2[S][1] = ldg4(ap1 + k0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rb[u] = ldg4(bp + (size_t)u * 32 * Kp + k0);
+            for (int u = 0; u < 4; ++u) rb2[S][u] = ldg4(bp + (size_t)u * 32 * Kp + k0);
         };
-        auto write_lds = [&](int kt) {
+        auto write_lds = [&](int kt, auto setc) {
+            constexpr int S = decltype(setc)::value;
+            const float4* ra = ra2[S];
+            const float4* rb = rb2[S];
             float* As = smem + (kt & 1) * STAGE;
             float* Bs = As + BM * P;
             float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f), t4 = f4zero();
@@ -750,7 +756,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
 #pragma unroll
             for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(Bs + (ur + 32 * u) * P + c4) = rb[u];
         };
-        load_regs(0);
+        const std::integral_constant<int, 0> S0;
+        const std::integral_constant<int, 1> S1;
+        load_regs(0, S0);
+        if (nk > 1) load_regs(1, S1);
         __syncthreads();                                 // sv / tv visible; the previous row tile's LDS reads (wS, zt) are done
         if (tid < BM) {
             const int r = row0 + tid;
@@ -766,10 +775,10 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
                 *reinterpret_cast<float4*>(dxS + 4 * tid) = make_float4(q0, q1, q2, 0.f);
             }
         }
-        write_lds(0);
-        if (nk > 1) load_regs(1);
+        write_lds(0, S0);
+        if (nk > 2) load_regs(2, S0);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
+        auto ktile = [&](int kt, auto nxtc) {             // MFMAs of tile kt; tile kt + 1 (register set nxtc) -> LDS; loads of kt + 3
             const float* As = smem + (kt & 1) * STAGE + (wm * 32 + l31) * P + 4 * half;
             const float* Bs = smem + (kt & 1) * STAGE + BM * P + (wn * 64 + l31) * P + 4 * half;
             float4 a4 = *reinterpret_cast<const float4*>(As);
@@ -792,9 +801,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b1.w, acc[1], 0, 0, 0);
                 a4 = an; b0 = bn0; b1 = bn1;
             }
-            if (kt + 1 < nk) write_lds(kt + 1);          // the other buffer: its readers passed the previous barrier
-            if (kt + 2 < nk) load_regs(kt + 2);
+            if (kt + 1 < nk) write_lds(kt + 1, nxtc);    // the other LDS buffer: its readers passed the previous barrier
+            if (kt + 3 < nk) load_regs(kt + 3, nxtc);
             __syncthreads();
+        };
+        for (int kt = 0; kt < nk; kt += 2) {             // (nk is even: K is a multiple of 64 here)
+            ktile(kt, S1);
+            if (kt + 1 < nk) ktile(kt + 1, S0);
         }
         if (XM == 1) {                                   // the three coordinate columns: z += dx . W[n][feat_c .. feat_c + 2]
 #pragma unroll
