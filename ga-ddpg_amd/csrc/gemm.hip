@@ -1997,13 +1997,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
 // staged float4: 16 per thread and K-tile against 32 MFMAs) so that both fragments are one ds_read_b128 per four MFMA steps.
 // Epilogue: dY of the previous layer masked by its ReLU (store_masked) + that layer's BatchNorm-backward sums.
 // ------------------------------------------------------------------------------------------------
-template <int GM>
+// SC = 1: scatter epilogue of the gathered first layers (SA2 / SA3: dX columns = the feature channels of the row's point):
+// float atomics into dfeat[row_pt[r]][k], nothing stored per row, no BatchNorm in front
+template <int GM, int SC>
 __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
                                                               const float* __restrict__ W, int Kp, int n_out, DxEpi e,
                                                               unsigned long long* __restrict__ ts) {
     KTimer kt_(ts);
     constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = (BM + BN) * P, VM = 512;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 3 * VM + BM];
+    __shared__ int32_t ptS[BM];                          // SC: the tile rows' points
     float* vP = smem + 2 * STAGE;                        // P | Q | S of this layer's channels
     float* wS = vP + 3 * VM;
     int32_t* grS = reinterpret_cast<int32_t*>(wS);       // (pooled source: the rows' groups share the slot with the weights: see below)
@@ -2024,11 +2027,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
     }
     (void)grS;
     // previous layer's BatchNorm vectors of this lane's two output columns
-    float ps[2], pt[2], pm[2], pi[2];
+    float ps[2] = {0.f, 0.f}, pt[2] = {0.f, 0.f}, pm[2] = {0.f, 0.f}, pi[2] = {0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int k = k0out + wn * 64 + t * 32 + l31;
-        ps[t] = e.ps[k]; pt[t] = e.pt[k]; pm[t] = e.pm[k]; pi[t] = e.pi[k];
+        if (!SC) { ps[t] = e.ps[k]; pt[t] = e.pt[k]; pm[t] = e.pm[k]; pi[t] = e.pi[k]; }
     }
     float cb[2] = {0.f, 0.f}, cg[2] = {0.f, 0.f};
     for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
@@ -2097,6 +2100,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
         };
         load_regs(0);
         __syncthreads();                                 // vP visible; the previous row tile's LDS reads are done
+        if (SC && tid < BM) ptS[tid] = e.row_pt[min(row0 + tid, n_rows - 1)];     // (read after the K loop's barriers)
         write_lds(0);
         if (nk > 1) load_regs(1);
         __syncthreads();
@@ -2128,6 +2132,18 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
             __syncthreads();
         }
         // epilogue: dY of the previous layer (ReLU-masked) + its BatchNorm-backward sums; all z_prev loads first
+        if (SC) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int k = k0out + wn * 64 + t * 32 + l31;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int il = wm * 32 + acc_row(v, half);
+                    if (row0 + il < n_rows) atomic_add_f32(e.dfeat + (size_t)ptS[il] * e.feat_c + k, acc[t][v]);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int k = k0out + wn * 64 + t * 32 + l31;
@@ -2152,6 +2168,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
             cb[t] += sb; cg[t] += sg;
         }
     }
+    if (SC) return;
     const int rep = blockIdx.x % GAD_STAT_REPLICAS;
     block_column_atomics<2, 2, 2>(smem, cb, cg, lane, wm, wn, k0out, e.k_valid, e.dbeta + (size_t)rep * e.stat_stride,
                                   e.dgamma + (size_t)rep * e.stat_stride);
@@ -2159,9 +2176,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
 
 static bool dx_wideable(const gad_gemm_dx_args& a, bool vec) {
     if (!g_opt_dx_wide || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
-    if (a.n_rows < 2048 || a.epilogue != 0 || a.k_valid % 128 != 0 || a.k_valid > a.Kp) return false;
+    if (a.n_rows < 2048 || a.k_valid % 128 != 0 || a.k_valid > a.Kp) return false;
     if (a.n_out[0] % 32 != 0 || a.n_out[0] < 32 || a.n_out[0] > 512) return false;
-    if (!a.prev_dbeta || !a.store_masked || !(a.zprev && a.prev_scale && a.prev_shift && a.prev_mean && a.prev_istd && a.prev_dgamma)) return false;
+    if (a.epilogue == 1) {                               // scatter into the points' feature gradients (SA2 / SA3 first layers)
+        if (g_opt_dx_wide == 2 || !a.dfeat || a.daction || !a.row_pt || a.k_valid != a.feat_c || a.prev_dbeta) return false;
+    } else if (!a.prev_dbeta || !a.store_masked || !(a.zprev && a.prev_scale && a.prev_shift && a.prev_mean && a.prev_istd && a.prev_dgamma)) return false;
     const gad_dz_src& d = a.dz;
     if (!d.z || d.z_pitch % 4 != 0 || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
     return d.gmode == 0 ? (d.g_pitch % 4 == 0 && d.G) : (d.c % 4 == 0);
@@ -2381,10 +2400,12 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     if (dx_wideable(*a, vec)) {
         int gx = gad_cdiv(grid_rows, 64); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;
         const dim3 grid(gx, kv / 128);
-        if (a->dz.gmode == 0)
-            hipLaunchKernelGGL((gemm_dx_wide_kernel<0>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
+        if (a->epilogue == 1 && a->dz.gmode == 0)
+            hipLaunchKernelGGL((gemm_dx_wide_kernel<0, 1>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
+        else if (a->dz.gmode == 0)
+            hipLaunchKernelGGL((gemm_dx_wide_kernel<0, 0>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
         else
-            hipLaunchKernelGGL((gemm_dx_wide_kernel<1>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
+            hipLaunchKernelGGL((gemm_dx_wide_kernel<1, 0>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
         GAD_CHECK_LAUNCH("gemm_dx(wide)");
         return GAD_OK;
     }
