@@ -151,7 +151,24 @@ class BaseMemory(object):
         data["perturb_flag_batch"] = f32(self.perturb_flags[batch_idx])
         data["batch_idx"] = np.uint8(batch_idx)  # truncating cast, as in the reference (:269)
         if self.self_supervision and self.name != "expert":
-            raise NotImplementedError("set_onpolicy_goal (reference :233-249) is outside the path")
+            self.set_onpolicy_goal(data, batch_idx)
+
+    def set_onpolicy_goal(self, data, batch_idx, vis=False):
+        """hindsight relabelling of the on-policy transitions (reference core/replay_memory.py:233-249): the goal of a
+        non-expert row becomes the pose its own episode ended in, seen from the row's pose (and from its successor's for
+        next_goal_batch), packed rotation-first."""
+        from .utils import pack_pose_rot_first, se3_inverse
+        batch_idx = np.asarray(batch_idx)
+        mask = self.expert_flags[batch_idx] == 0.0
+        episode_end = self.episode_map[batch_idx]
+        increment_idx = np.minimum(episode_end, batch_idx + 1).astype(np.int64)
+        n = len(batch_idx)
+        goal = np.array([pack_pose_rot_first(se3_inverse(self.state_pose[batch_idx[i]]).dot(self.state_pose[episode_end[i]]))
+                         for i in range(n)])
+        next_goal = np.array([pack_pose_rot_first(se3_inverse(self.state_pose[increment_idx[i]]).dot(self.state_pose[episode_end[i]]))
+                              for i in range(n)])
+        data["goal_batch"][mask] = goal[mask]
+        data["next_goal_batch"][mask] = next_goal[mask]
 
     # ------------------------------------------------------------------ writer side (SURVEY 8f N4)
     def update_reward(self, reward, test, explore, target_name):

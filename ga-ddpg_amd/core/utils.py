@@ -170,3 +170,53 @@ def migrate_model(in_model, out_model, surfix="latest", grasp_model=None):
             shutil.copyfile(src, dst)
             copied.append((src, dst))
     return copied
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# pose helpers of the replay buffer's hindsight goal relabelling (reference core/utils.py:299-306, 446-452, 672-676)
+# ---------------------------------------------------------------------------------------------------------------------
+def se3_inverse(RT):
+    """inverse of a rigid 4x4 transform (reference core/utils.py:446-452)"""
+    import numpy as np
+    R, T = RT[:3, :3], RT[:3, 3].reshape((3, 1))
+    out = np.eye(4, dtype=np.float32)
+    out[:3, :3] = R.transpose()
+    out[:3, 3] = -1 * np.dot(R.transpose(), T).reshape(3)
+    return out
+
+
+def mat2quat(M):
+    """rotation matrix -> quaternion (w, x, y, z), w >= 0.  The reference imports this from transforms3d (third-party, not
+    vendored under /root/reference and absent from this image: PARITY UNPINNED); restated from the library's published
+    algorithm (Bar-Itzhack 2000: the eigenvector of the symmetric 4x4 K matrix with the largest eigenvalue)."""
+    import numpy as np
+    Qxx, Qyx, Qzx, Qxy, Qyy, Qzy, Qxz, Qyz, Qzz = np.asarray(M, dtype=np.float64).flat
+    K = np.array([[Qxx - Qyy - Qzz, 0, 0, 0],
+                  [Qyx + Qxy, Qyy - Qxx - Qzz, 0, 0],
+                  [Qzx + Qxz, Qzy + Qyz, Qzz - Qxx - Qyy, 0],
+                  [Qyz - Qzy, Qzx - Qxz, Qxy - Qyx, Qxx + Qyy + Qzz]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)                       # (uses the lower triangle)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    return -q if q[0] < 0 else q
+
+
+def safemat2quat(mat):
+    """reference core/utils.py:299-306: identity quaternion when the conversion fails, NaN entries zeroed"""
+    import numpy as np
+    quat = np.array([1.0, 0.0, 0.0, 0.0])
+    try:
+        quat = mat2quat(mat)
+    except Exception:
+        pass
+    quat[np.isnan(quat)] = 0
+    return quat
+
+
+def pack_pose_rot_first(pose):
+    """4x4 pose -> [quaternion (w, x, y, z) | translation] (reference core/utils.py:672-676)"""
+    import numpy as np
+    packed = np.zeros(7)
+    packed[4:] = pose[:3, 3]
+    packed[:4] = safemat2quat(pose[:3, :3])
+    return packed
+
