@@ -149,7 +149,7 @@ SA_DIMS = {"sa1": [(None, 64), (64, 64), (64, 128)], "sa2": [(131, 128), (128, 1
 DENSE_ROWS = {"sa1": 32 * 64, "sa2": 32 * 128, "sa3": 32, "fc": 1}
 ROUTE_SYMBOL = {"gemm_fwd(stream)": "gemm_fwd_stream_kernel", "gemm_fwd(wide)": "gemm_fwd_wide_kernel", "gemm_fwd(skinny)": "gemm_fwd_skinny_kernel",
                 "gemm_fwd": "gemm_fwd_kernel", "gemm_dx(stream)": "gemm_dx_stream_kernel", "gemm_dx(wide)": "gemm_dx_wide_kernel",
-                "gemm_dx(skinny)": "gemm_dx_skinny_kernel", "gemm_dx": "gemm_dx_kernel", "gemm_dw(stream)": "gemm_dw_stream_kernel",
+                "gemm_dx(skinny)": "gemm_dx_skinny_kernel", "gemm_dx": "gemm_dx_kernel", "gemm_dx(action stream)": "dx_action_stream_kernel", "gemm_dw(stream)": "gemm_dw_stream_kernel",
                 "gemm_dw(gather stream)": "gemm_dw_gather_stream_kernel", "gemm_dw(wide)": "gemm_dw_wide_kernel",
                 "gemm_dw(skinny)": "gemm_dw_skinny_kernel", "gemm_dw": "gemm_dw_kernel", "gemm_bwd(stream)": "gemm_bwd_stream_kernel"}
 ROUTES = {}                 # tag -> routed kernel family, filled from engine.timing_routes() after each probe

@@ -2174,6 +2174,93 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
                                   e.dgamma + (size_t)rep * e.stat_stride);
 }
 
+// ------------------------------------------------------------------------------------------------
+// dX of the value encoder's SA1 first layer, of which only the ACTION columns are wanted (the gradient of Q(s, pi(s)) with
+// respect to pi: reference core/ddpg.py:160-177): daction[sample][a] = sum over the sample's rows of dZ[r][:] . W[:][c0 + a].
+// A 64-channel dot product per row and action component: HBM-bound (z and dY: 512 B per row), no MFMA.  16 lanes per row
+// (one coalesced 256-byte row per quarter wavefront), a contiguous row range per wavefront, so the rows of a sample (~830,
+// consecutive) are summed in registers and leave through six f64 atomics per sample and wavefront.  (The 64 x 64 tile
+// kernel spent 63 us here forming all 16 input columns with MFMAs at 4 % of their peak.)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dx_action_stream_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
+                                                               const float* __restrict__ W, int Kp, int c0, DxEpi e,
+                                                               unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    const int n_waves = gridDim.x * 4;
+    const int gw = blockIdx.x * 4 + (tid >> 6);
+    int chunk = (n_rows + n_waves - 1) / n_waves;
+    chunk = (chunk + 3) & ~3;
+    const int r0 = gw * chunk, r1 = min(n_rows, r0 + chunk);
+    if (r0 >= r1) return;
+    const int sub = lane >> 4, c4 = (lane & 15) * 4;
+    float4 P, Q, S;
+    dz_coef(d, c4 + 0, P.x, Q.x, S.x); dz_coef(d, c4 + 1, P.y, Q.y, S.y);
+    dz_coef(d, c4 + 2, P.z, Q.z, S.z); dz_coef(d, c4 + 3, P.w, Q.w, S.w);
+    float4 wa[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+        wa[a] = make_float4(W[(size_t)(c4 + 0) * Kp + c0 + a], W[(size_t)(c4 + 1) * Kp + c0 + a], W[(size_t)(c4 + 2) * Kp + c0 + a],
+                            W[(size_t)(c4 + 3) * Kp + c0 + a]);
+    double run[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int cur = -1;                                                    // the open sample (wave-uniform)
+    auto flush = [&]() {
+        if (cur >= 0 && lane == 0)
+#pragma unroll
+            for (int a = 0; a < 6; ++a) atomic_add_f64(e.daction + (size_t)cur * 6 + a, run[a]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) run[a] = 0.0;
+    };
+    for (int rb = r0; rb < r1; rb += 4) {
+        const int r = rb + sub;
+        const bool live = r < r1;
+        const int rr = live ? r : r1 - 1;
+        const float4 z = ldg4(d.z + (size_t)rr * d.z_pitch + c4);
+        const float4 g = ldg4(d.G + (size_t)rr * d.g_pitch + c4);
+        const float w = d.row_w ? d.row_w[rr] : 1.f;
+        const int smp = e.row_grp[rr] / e.gps;
+        float4 dz;
+        dz.x = P.x * g.x - w * fmaf(S.x, z.x, Q.x); dz.y = P.y * g.y - w * fmaf(S.y, z.y, Q.y);
+        dz.z = P.z * g.z - w * fmaf(S.z, z.z, Q.z); dz.w = P.w * g.w - w * fmaf(S.w, z.w, Q.w);
+        float p[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            p[a] = fmaf(dz.x, wa[a].x, fmaf(dz.y, wa[a].y, fmaf(dz.z, wa[a].z, dz.w * wa[a].w)));
+            p[a] = live ? p[a] : 0.f;
+#pragma unroll
+            for (int m = 8; m >= 1; m >>= 1) p[a] += __shfl_xor(p[a], m, 16);        // the row's 16 lanes
+        }
+        const int s0 = __builtin_amdgcn_readlane(smp, 0), s1 = __builtin_amdgcn_readlane(smp, 16);
+        const int s2 = __builtin_amdgcn_readlane(smp, 32), s3 = __builtin_amdgcn_readlane(smp, 48);
+        if (s0 == s1 && s1 == s2 && s2 == s3) {                      // wave-uniform: the four rows are of one sample
+            if (s0 != cur) { flush(); cur = s0; }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                float t = p[a] + __shfl_xor(p[a], 16, 64);
+                t += __shfl_xor(t, 32, 64);
+                run[a] += (double)t;
+            }
+        } else {                                                     // a sample boundary inside the four rows: row by row
+            flush();
+            cur = -1;
+            if ((lane & 15) == 0 && live)
+#pragma unroll
+                for (int a = 0; a < 6; ++a) atomic_add_f64(e.daction + (size_t)smp * 6 + a, (double)p[a]);
+        }
+    }
+    flush();
+}
+
+// the action-gradient layer: scatter epilogue that wants nothing but daction, G source, 64 channels, 6 action components
+static bool dx_action_streamable(const gad_gemm_dx_args& a, bool vec) {
+    if (!g_opt_dx_stream || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0) return false;
+    if (a.epilogue != 1 || a.dfeat || !a.daction || a.act_c != 6 || !a.row_grp || a.n_rows < 32768 || a.n_out[0] != 64) return false;
+    const gad_dz_src& d = a.dz;
+    return d.gmode == 0 && d.G && d.z && d.z_pitch % 4 == 0 && d.g_pitch % 4 == 0 && d.premasked && d.coefP && d.coefQ && d.coefS &&
+           a.feat_c + 3 + a.act_c <= a.Kp;
+}
+
 static bool dx_wideable(const gad_gemm_dx_args& a, bool vec) {
     if (!g_opt_dx_wide || !vec || a.n_groups != 1 || a.dz_off[0] != 0 || a.w_off[0] != 0 || a.gout_off[0] != 0) return false;
     if (a.n_rows < 2048 || a.k_valid % 128 != 0 || a.k_valid > a.Kp) return false;
@@ -2395,6 +2482,11 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
         else { if (a->dz.gmode == 0) LAUNCH_DXS(8, 0); else LAUNCH_DXS(8, 1); }
 #undef LAUNCH_DXS
         GAD_CHECK_LAUNCH("gemm_dx(stream)");
+        return GAD_OK;
+    }
+    if (dx_action_streamable(*a, vec)) {
+        hipLaunchKernelGGL(dx_action_stream_kernel, dim3(1024), dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->feat_c + 3, e, ts);
+        GAD_CHECK_LAUNCH("gemm_dx(action stream)");
         return GAD_OK;
     }
     if (dx_wideable(*a, vec)) {
