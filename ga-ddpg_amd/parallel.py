@@ -78,6 +78,13 @@ class DataParallelContext(object):
         """rccl.Communicator of this group, created at first use"""
         if self._direct and self._comm is None:
             from . import engine, rccl
+            try:
+                rccl.lib()                      # same image on every rank: a missing library is missing everywhere
+            except OSError as exc:
+                import sys
+                print("ga_ddpg_amd.parallel: librccl not loadable (%s): collectives through torch.distributed" % exc, file=sys.stderr)
+                self._direct = False
+                return None
             # HIP binds a stream to one of the process's four hardware queues at the stream's FIRST LAUNCH, and
             # ncclCommInitRank launches on streams of its own: created before the step's streams have run anything, the
             # communicator takes queues and the step's chains end up sharing one (measured: 318 -> 260 steps/s at one
