@@ -3131,6 +3131,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
     int4 ra[4];
     float rw[4], rd[4][3];
     int pq[4], gq[4];                                    // XM = 1: point / group of the NEXT tile's rows
+    int gd[4];                                           // GM = 1: group of the NEXT tile's rows (pooled gradient source)
     auto load_idx = [&](int rb0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -3138,6 +3139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
             const int rr = r < r_end ? r : r_end - 1;
             pq[u] = XM == 1 ? x.row_pt[rr] : 0;
             gq[u] = (XM == 1 && x.ctr_xyz) ? x.row_grp[rr] : 0;
+            gd[u] = GM == 1 ? d.row_grp[rr] : 0;
         }
     };
     auto load_regs = [&](int rb0) {
@@ -3150,7 +3152,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
             if (GM == 0) {
                 rg[u] = ldg4(d.G + (size_t)rr * gpitch + n0 + c4);
             } else {
-                const int grp = d.row_grp[rr];
+                const int grp = gd[u];                   // (fetched one K-tile ahead: one memory round trip here, not two)
                 ra[u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * gpitch + n0 + c4);
                 rg[u] = ldg4(d.dout + (size_t)grp * gpitch + n0 + c4);
             }
@@ -3169,7 +3171,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
                 }
             }
         }
-        if (XM == 1) load_idx(rb0 + KT);
+        if (XM == 1 || GM == 1) load_idx(rb0 + KT);
     };
     auto write_lds = [&](int it, int rb0) {
         float* As = smem + (it & 1) * STAGE;
@@ -3209,7 +3211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
             *reinterpret_cast<float4*>(Bs + (sr + 8 * u) * P + c4) = b;
         }
     };
-    if (XM == 1) load_idx(r_begin);
+    if (XM == 1 || GM == 1) load_idx(r_begin);
     load_regs(r_begin);
     __syncthreads();                                     // vP / sv / tv visible
     write_lds(0, r_begin);
