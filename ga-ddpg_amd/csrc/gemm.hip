@@ -969,13 +969,44 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     for (int t = 0; t < TN; ++t) { csum[t] = f32x2{0.f, 0.f}; csq[t] = f32x2{0.f, 0.f}; }
 
     XRaw ra[KJ], rn[KJ];
-    int pt_nxt = 0;
+    int pt_nxt = 0, grp_nxt = 0;
     auto load_pt = [&](int sl) {          // point index of the lane's row in slab sl (gather input only)
         const int r = min(sl * 32 + l31, n_rows - 1);
         return (XM == 1 && sl < n_slabs) ? x.row_pt[r] : 0;
     };
-    auto load_slab = [&](int sl, int pt, XRaw (&dst)[KJ]) {
+    auto load_grp = [&](int sl) {         // ... and its group: both are fetched a slab before the values they address
+        const int r = min(sl * 32 + l31, n_rows - 1);
+        return (XM == 1 && sl < n_slabs) ? x.row_grp[r] : 0;
+    };
+    auto load_slab = [&](int sl, int pt, int grp, XRaw (&dst)[KJ]) {
         const int r = min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1);      // clamped: ragged rows repeat the last row
+        if (XM == 1) {
+            // SA1's gathered rows [f (4) | x_j - c_i (3) | action (0 / 6)]: everything a row needs in FIVE loads (features,
+            // point, centre as 12-byte loads, action as two), then each (k group, half) picks its four columns.  x_raw per
+            // k group issued 11 scalar gathers per lane, most of them for columns the lane does not feed: the layer was
+            // bound by the texture path (64 cache lines per gather instruction), not by its 54 MB of output.
+            struct F3 { float x, y, z; } __attribute__((packed, aligned(4)));
+            const float4 f = ldg4(x.feat + (size_t)pt * 4);
+            const F3 p = *reinterpret_cast<const F3*>(x.src_xyz + (size_t)pt * 3);
+            float q0 = p.x, q1 = p.y, q2 = p.z;
+            if (x.ctr_xyz) {
+                const F3 c = *reinterpret_cast<const F3*>(x.ctr_xyz + (size_t)grp * 3);
+                q0 = __fsub_rn(q0, c.x); q1 = __fsub_rn(q1, c.y); q2 = __fsub_rn(q2, c.z);
+            }
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;
+            if (x.action) {                                                  // (fwd_streamable: act_c == 6)
+                const float* ap = x.action + (size_t)(grp / x.gps) * 6;
+                const F3 u = *reinterpret_cast<const F3*>(ap), v = *reinterpret_cast<const F3*>(ap + 3);
+                a0 = u.x; a1 = u.y; a2 = u.z; a3 = v.x; a4 = v.y; a5 = v.z;
+            }
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                dst[j].a = f;
+                if (j == 0) dst[j].s = make_float4(q0, q1, q2, a0);          // columns 4 .. 7 (half 1; half 0 takes the features)
+                else dst[j].s = half ? make_float4(a5, 0.f, 0.f, 0.f) : make_float4(a1, a2, a3, a4);
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < KJ; ++j) dst[j] = x_raw<XM>(x, r, true, 0, 8 * j + 4 * half, XM == 1, pt);
     };
@@ -984,13 +1015,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         for (int t = 0; t < TN; ++t) b4[t] = *reinterpret_cast<const float4*>(Ws + (t * 32 + l31) * PW + 8 * j + 4 * half);
     };
     {
-        const int pt0 = load_pt(slab);
-        load_slab(slab, pt0, ra);
+        const int pt0 = load_pt(slab), grp0 = load_grp(slab);
+        load_slab(slab, pt0, grp0, ra);
         pt_nxt = load_pt(slab + stride);
+        grp_nxt = load_grp(slab + stride);
     }
     for (; slab < slab_end; slab += stride) {
-        load_slab(slab + stride, pt_nxt, rn);
+        load_slab(slab + stride, pt_nxt, grp_nxt, rn);
         pt_nxt = load_pt(slab + 2 * stride);
+        grp_nxt = load_grp(slab + 2 * stride);
         // the 16 rows this lane owns in the accumulator layout: 4 runs of 4 consecutive rows -> 4 aligned loads
         float4 w4[4];
 #pragma unroll
@@ -1286,7 +1319,8 @@ static bool fwd_streamable(const gad_gemm_fwd_args& a) {
     if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || (a.zout && a.zout_pitch != a.n_out[0])) return false;
     if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
     if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && (a.scale && a.shift) && a.relu;
-    return (a.Kp == 16 || a.Kp == 8) && a.feat_c + 3 + a.act_c <= a.Kp;      // Kp 8: the policy encoder's [f (4) | dx (3)] rows
+    // SA1's gathered rows: [f (4) | dx (3)] (policy encoder, Kp 8) or [f (4) | dx (3) | action (6)] (value encoder, Kp 16)
+    return (a.Kp == 16 || a.Kp == 8) && a.feat_c == 4 && (a.action ? a.act_c == 6 : a.act_c == 0) && a.feat_c + 3 + a.act_c <= a.Kp;
 }
 
 static Groups make_groups(int n, const int32_t* a, const int32_t* w, const int32_t* o, const int32_t* no) {
