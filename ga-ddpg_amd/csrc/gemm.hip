@@ -969,16 +969,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     for (int t = 0; t < TN; ++t) { csum[t] = f32x2{0.f, 0.f}; csq[t] = f32x2{0.f, 0.f}; }
 
     XRaw ra[KJ], rn[KJ];
-    int pt_nxt = 0, grp_nxt = 0;
+    int pt_nxt = 0;
     auto load_pt = [&](int sl) {          // point index of the lane's row in slab sl (gather input only)
         const int r = min(sl * 32 + l31, n_rows - 1);
         return (XM == 1 && sl < n_slabs) ? x.row_pt[r] : 0;
     };
-    auto load_grp = [&](int sl) {         // ... and its group: both are fetched a slab before the values they address
-        const int r = min(sl * 32 + l31, n_rows - 1);
-        return (XM == 1 && sl < n_slabs) ? x.row_grp[r] : 0;
-    };
-    auto load_slab = [&](int sl, int pt, int grp, XRaw (&dst)[KJ]) {
+    auto load_slab = [&](int sl, int pt, XRaw (&dst)[KJ]) {
         const int r = min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1);      // clamped: ragged rows repeat the last row
         if (XM == 1) {
             // SA1's gathered rows [f (4) | x_j - c_i (3) | action (0 / 6)]: everything a row needs in FIVE loads (features,
@@ -988,6 +984,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             struct F3 { float x, y, z; } __attribute__((packed, aligned(4)));
             const float4 f = ldg4(x.feat + (size_t)pt * 4);
             const F3 p = *reinterpret_cast<const F3*>(x.src_xyz + (size_t)pt * 3);
+            const int grp = x.row_grp[r];
             float q0 = p.x, q1 = p.y, q2 = p.z;
             if (x.ctr_xyz) {
                 const F3 c = *reinterpret_cast<const F3*>(x.ctr_xyz + (size_t)grp * 3);
@@ -1015,15 +1012,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         for (int t = 0; t < TN; ++t) b4[t] = *reinterpret_cast<const float4*>(Ws + (t * 32 + l31) * PW + 8 * j + 4 * half);
     };
     {
-        const int pt0 = load_pt(slab), grp0 = load_grp(slab);
-        load_slab(slab, pt0, grp0, ra);
+        const int pt0 = load_pt(slab);
+        load_slab(slab, pt0, ra);
         pt_nxt = load_pt(slab + stride);
-        grp_nxt = load_grp(slab + stride);
     }
     for (; slab < slab_end; slab += stride) {
-        load_slab(slab + stride, pt_nxt, grp_nxt, rn);
+        load_slab(slab + stride, pt_nxt, rn);
         pt_nxt = load_pt(slab + 2 * stride);
-        grp_nxt = load_grp(slab + 2 * stride);
         // the 16 rows this lane owns in the accumulator layout: 4 runs of 4 consecutive rows -> 4 aligned loads
         float4 w4[4];
 #pragma unroll
