@@ -345,6 +345,16 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    dp_info = None
+    if dp is not None:
+        # self-proof of the multi-GPU line: the transport that carried the step's collectives, the rank count RCCL ITSELF
+        # reports for it (ncclCommCount), and whether the replicas' parameters are still bit-identical after every step
+        # of this run (all-reduced MAX / MIN of an int64 checksum) -- a collective, so every rank takes part
+        torch.cuda.synchronize()
+        dp_info = dp.transport()
+        dp_info["replicas_bit_identical"] = dp.replicas_agree([rt.pol.flat, rt.pol_t.flat, rt.cr.flat, rt.cr_t.flat, rt.enc.flat, rt.venc.flat])
+        dp_info["bucketed_exchange"] = bool(getattr(rt, "bucketed", False))
+        dp.close()
     def leave_group():
         # every rank leaves the process group BEFORE rank 0 prints: whatever RCCL writes to stdout while it initialises or
         # shuts down comes first and the JSON line is the last line of the job's output
@@ -389,6 +399,8 @@ def main():
                       "value_definition": "B=%d minibatch gradient steps per second summed over ranks (= iterations/s x n_gpus)" % B, "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
            "losses": {k: out[k] for k in ("critic_loss", "bc_loss", "actor_critic_loss")},
            "roofline": roof}
+    if dp_info is not None:
+        res["config"].update(dp_info)
     # step-level view against the dense-FP32 roofline: mean 5.5078 GFLOP per sample and step
     res["step_dense_tflops"] = steps_per_s * world * B * 5.5078e9 / 1e12
     if world == 1 and not args.no_host_rate:
@@ -404,7 +416,7 @@ def main():
         # the same, with the sampling on a background thread into pinned staging sets (core/prefetch.PrefetchSampler) and
         # run-ahead steps: what a training loop over a HOST replay buffer gets
         from ga_ddpg_amd.core.prefetch import PrefetchSampler
-        with PrefetchSampler(mem, B, depth=3, sample=lambda bs: sample_valid_batch(mem, bs, rng2)) as sampler:
+        with PrefetchSampler(mem, B, depth=3, sample=lambda bs, clouds_out=None, pool=None: sample_valid_batch(mem, bs, rng2, clouds_out, pool)) as sampler:
             for i in range(5):
                 agent.update_parameters(sampler.next(), agent.update_step, i, sync=False)
             torch.cuda.synchronize()

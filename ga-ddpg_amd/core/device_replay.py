@@ -13,6 +13,11 @@ test_device_replay_matches_host_sampling).
     agent.update_parameters(batch, agent.update_step, k)
 
 `refresh(lo, hi)` re-uploads a slice after the host buffer was written to (online training).
+
+Hindsight relabelling (`memory.self_supervision` on a non-expert buffer, reference core/replay_memory.py:233-249,271-272): the
+relabelled goals are 4x4 pose algebra on B rows -- host work, done by the SAME BaseMemory.onpolicy_goals the host path
+uses -- and travel with the index vectors as a (B, 8) block [goal (7) | relabel flag]; the gather's goal rows are
+overwritten where the flag is set, so both paths train on the same goals.
 """
 import numpy as np
 import torch
@@ -100,6 +105,8 @@ class DeviceReplay(object):
         if it is None:
             it = items[j] = {"host": torch.empty(3, n, dtype=torch.int64).pin_memory(),
                              "dev": torch.empty(3, n, dtype=torch.int64, device=self.device),
+                             "ghost": torch.zeros(n, 8, dtype=torch.float32).pin_memory(),       # [relabelled goal | flag]
+                             "gdev": torch.zeros(n, 8, dtype=torch.float32, device=self.device),
                              "copied": torch.cuda.Event(), "used": None, "pending": False}
         else:
             it["copied"].synchronize()           # the copy that last read this pinned block
@@ -108,19 +115,38 @@ class DeviceReplay(object):
         it["pending"] = True
         return it
 
+    def _relabels(self):
+        m = self.memory
+        return bool(getattr(m, "self_supervision", False)) and getattr(m, "name", "") != "expert"
+
     def _indices3(self, idx, nxt, end):
         it = self._stage_set(idx.shape[0])
         host, dev, ev = it["host"], it["dev"], it["copied"]
         h = host.numpy()
         h[0], h[1], h[2] = idx, nxt, end
+        relabel = self._relabels()
+        if relabel:                              # hindsight goals of the on-policy rows (BaseMemory.post_process_batch)
+            mask, goal, _ = self.memory.onpolicy_goals(idx)
+            g = it["ghost"].numpy()
+            g[:, :7] = goal
+            g[:, 7] = np.asarray(mask, dtype=np.float32).reshape(-1)
         if self._copy_stream is None:
             self._copy_stream = torch.cuda.Stream(device=self.device)
         if self._ev_refresh is not None:
             self._copy_stream.wait_event(self._ev_refresh)
         with torch.cuda.stream(self._copy_stream):
             dev.copy_(host, non_blocking=True)
+            if relabel:
+                it["gdev"].copy_(it["ghost"], non_blocking=True)
             ev.record(self._copy_stream)
+        it["relabel"] = relabel
         return dev, ev, it
+
+    @staticmethod
+    def _apply_relabel(it, goal):
+        """goal rows <- the staged hindsight goals where their flag is set (same stream as the gather that wrote `goal`)"""
+        g = it["gdev"]
+        goal.copy_(torch.where(g[:, 7:8] > 0, g[:, :7], goal))
 
     # ------------------------------------------------------------------ sampling
     def sample_lazy(self, batch_size, rng=None, batch_idx=None):
@@ -162,10 +188,20 @@ class DeviceReplay(object):
             setattr(a, dst, hip.ptr(dbuf[key]))
         hip.call_struct("gad_replay_gather", a)
         it = lazy.get("_stage_set")
+        if it is not None and it.get("relabel"):
+            self._apply_relabel(it, dbuf["goal_batch"])
         if it is not None:                       # the staging set is not rewritten before this gather has run
             if it["used"] is None:
                 it["used"] = torch.cuda.Event()
             it["used"].record(cur)
+            it["pending"] = False
+
+    def release(self, lazy):
+        """give back the staging set of a sample_lazy() handle that will never be passed to an update step (a prefetcher
+        closing with handles in flight, a batch dropped by a validity check): without this the set stays `pending` and
+        is never handed out again"""
+        it = lazy.get("_stage_set") if isinstance(lazy, dict) else None
+        if it is not None:
             it["pending"] = False
 
     def _mask_counts(self, batch_idx):
@@ -196,6 +232,8 @@ class DeviceReplay(object):
             out[dst] = self.rows[src].index_select(0, d_idx)
         # remaining steps to the end of the episode (post_process_batch)
         out["time_batch"] = self.timestep.index_select(0, d_end) + 1.0 - self.timestep.index_select(0, d_idx)
+        if it.get("relabel"):
+            self._apply_relabel(it, out["goal_batch"])
         if it["used"] is None:
             it["used"] = torch.cuda.Event()
         it["used"].record(cur)                   # the index_selects above read the staging set's device block

@@ -26,14 +26,29 @@ KEYS = ("point_state_batch", "next_point_state_batch", "action_batch", "expert_a
 
 
 class PrefetchSampler(object):
-    def __init__(self, memory, batch_size, depth=2, rng=None, pin=None, sample=None):
+    def __init__(self, memory, batch_size, depth=2, rng=None, pin=None, sample=None, threads=4):
         """memory: BaseMemory (host sampling into pinned staging sets) or DeviceReplay (lazy gather handles).
-        sample: optional callable(batch_size) -> batch dict replacing memory.sample (e.g. a validity-checking sampler)."""
+        sample: optional callable(batch_size) -> batch dict replacing memory.sample (e.g. a validity-checking sampler); if it
+        accepts `clouds_out` / `pool` keywords (BaseMemory.sample's, synth_data.sample_valid_batch's) the two cloud gathers --
+        97 % of the bytes -- are written straight into the pinned staging set by `threads` pool threads (np.take releases the
+        GIL) instead of being fancy-indexed into a temporary on this one thread and copied again."""
         self.memory, self.batch_size, self.depth = memory, int(batch_size), int(depth)
         self.rng = rng
         self.lazy = hasattr(memory, "sample_lazy")
         self.pin = torch.cuda.is_available() if pin is None else bool(pin)
         self._sample = sample
+        self._pool = None
+        self._direct = False
+        if not self.lazy and hasattr(memory, "gather_clouds"):
+            import inspect
+            fn = sample if sample is not None else memory.sample
+            try:
+                self._direct = "clouds_out" in inspect.signature(fn).parameters
+            except (TypeError, ValueError):
+                self._direct = False
+            if self._direct and threads > 1:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=int(threads), thread_name_prefix="gad-gather")
         self._free = queue.Queue()
         self._ready = queue.Queue(maxsize=self.depth)
         self._sets = []
@@ -44,13 +59,16 @@ class PrefetchSampler(object):
         self._thread.start()
 
     # ------------------------------------------------------------------ producer
-    def _draw(self):
+    def _draw(self, st=None):
+        kw = {}
+        if st is not None:                       # direct mode: the clouds land in the staging set's own buffers
+            kw = dict(clouds_out=(st["point_state_batch"].numpy(), st["next_point_state_batch"].numpy()), pool=self._pool)
         if self._sample is not None:
-            return self._sample(self.batch_size)
+            return self._sample(self.batch_size, **kw)
         if self.lazy:
             return self.memory.sample_lazy(self.batch_size, self.rng)
         try:
-            return self.memory.sample(self.batch_size, rng=self.rng)
+            return self.memory.sample(self.batch_size, rng=self.rng, **kw)
         except TypeError:
             return self.memory.sample(batch_size=self.batch_size)
 
@@ -62,6 +80,34 @@ class PrefetchSampler(object):
                 t = torch.empty(tuple(np.asarray(batch[k]).shape), dtype=torch.float32)
                 st[k] = t.pin_memory() if self.pin else t
         return st
+
+    def _cloud_staging(self):
+        """direct mode: the set's two cloud buffers exist BEFORE the draw (their shape is the buffer's); the small arrays
+        are added by the first batch that passes through the set"""
+        shape = (self.batch_size,) + tuple(self.memory.point_state.shape[1:])
+        st = {}
+        for k in ("point_state_batch", "next_point_state_batch"):
+            t = torch.empty(shape, dtype=torch.float32)
+            st[k] = t.pin_memory() if self.pin else t
+        return st
+
+    def _acquire(self, make):
+        """a free staging set: one that came back from the consumer (after its upload event), a new one while fewer than
+        depth + 1 exist, else wait for one; None when the sampler is closing"""
+        try:
+            return self._release(self._free.get_nowait())
+        except queue.Empty:
+            pass
+        if len(self._sets) < self.depth + 1:
+            st = make()
+            self._sets.append(st)
+            return st
+        while not self._stop.is_set():
+            try:
+                return self._release(self._free.get(timeout=0.05))
+            except queue.Empty:
+                pass
+        return None
 
     @staticmethod
     def _release(entry):
@@ -75,27 +121,29 @@ class PrefetchSampler(object):
     def _run(self):
         try:
             while not self._stop.is_set():
-                batch = self._draw()
                 if self.lazy:
-                    item = batch
+                    item = self._draw()
                 else:
-                    try:
-                        st = self._release(self._free.get_nowait())
-                    except queue.Empty:
-                        if len(self._sets) < self.depth + 1:
-                            st = self._staging(batch)
-                            self._sets.append(st)
-                        else:
-                            st = None
-                            while st is None and not self._stop.is_set():
-                                try:
-                                    st = self._release(self._free.get(timeout=0.05))
-                                except queue.Empty:
-                                    pass
-                            if st is None:
-                                return
-                    for k, t in st.items():
-                        np.copyto(t.numpy(), np.asarray(batch[k]).reshape(t.shape), casting="same_kind")
+                    if self._direct:
+                        st = self._acquire(self._cloud_staging)
+                        if st is None:
+                            return
+                        batch = self._draw(st)
+                    else:
+                        batch = self._draw()
+                        st = self._acquire(lambda: self._staging(batch))
+                        if st is None:
+                            return
+                    for k in KEYS:
+                        if k not in batch:
+                            continue
+                        if k not in st:                             # (direct mode: the small arrays, first pass through the set)
+                            t = torch.empty(tuple(np.asarray(batch[k]).shape), dtype=torch.float32)
+                            st[k] = t.pin_memory() if self.pin else t
+                        dst = st[k].numpy()
+                        src = np.asarray(batch[k])
+                        if not np.shares_memory(dst, src):          # (direct mode: the clouds are already in place)
+                            np.copyto(dst, src.reshape(dst.shape), casting="same_kind")
                     item = dict(st)
                     for k, v in batch.items():                      # bookkeeping fields (indices, counts) ride along
                         if k not in item and k not in ("image_state_batch", "next_image_state_batch"):
@@ -105,12 +153,20 @@ class PrefetchSampler(object):
                 while not self._stop.is_set():
                     try:
                         self._ready.put(item, timeout=0.05)
+                        item = None
                         break
                     except queue.Full:
                         pass
+                if item is not None:
+                    self._drop(item)                                # closing with a drawn batch in hand
         except BaseException as e:                                  # surfaced by next()
             self._error = e
             self._ready.put(None)
+
+    def _drop(self, item):
+        """a prefetched batch that will never be consumed: a DeviceReplay handle gives its staging set back"""
+        if self.lazy and isinstance(item, dict) and hasattr(self.memory, "release"):
+            self.memory.release(item)
 
     # ------------------------------------------------------------------ consumer
     def next(self):
@@ -130,12 +186,18 @@ class PrefetchSampler(object):
 
     def close(self):
         self._stop.set()
-        try:
-            while True:
-                self._ready.get_nowait()
-        except queue.Empty:
-            pass
-        self._thread.join(timeout=2.0)
+        for _ in range(2):                       # before and after the producer has let go of what it was holding
+            try:
+                while True:
+                    item = self._ready.get_nowait()
+                    if item is not None:
+                        self._drop(item)
+            except queue.Empty:
+                pass
+            self._thread.join(timeout=2.0)
+        if self._pool is not None:
+            self._pool.shutdown(wait=False)
+            self._pool = None
 
     def __enter__(self):
         return self

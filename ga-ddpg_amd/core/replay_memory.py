@@ -104,12 +104,38 @@ class BaseMemory(object):
         r.shuffle(batch_idx)
         return batch_idx
 
-    def sample(self, batch_size, rng=None, batch_idx=None):
+    def sample(self, batch_size, rng=None, batch_idx=None, clouds_out=None, pool=None):
+        """clouds_out = (point, next_point) float32 arrays of shape (B, 4, pts + 6): the two cloud gathers -- 97 % of a
+        minibatch's bytes -- go straight into the caller's (pinned) buffers, split over `pool`'s threads, and
+        data["point_state_batch"] / ["next_point_state_batch"] are those arrays; everything else as without it"""
         if batch_idx is None:
             batch_idx = self.draw_indices(batch_size, rng)
         data = self[batch_idx]
-        self.post_process_batch(data, batch_idx)
+        self.post_process_batch(data, batch_idx, clouds_out=clouds_out, pool=pool)
         return data
+
+    def gather_clouds(self, batch_idx, nxt, out_point, out_next, pool=None, chunk=32):
+        """out_point[i] = point_state[batch_idx[i]], out_next[i] = point_state[nxt[i]] as float32: np.take per chunk of
+        rows (it releases the GIL: the chunks run on `pool`'s threads side by side and beside the caller's Python), with a
+        per-chunk float64 scratch when the buffer stores float64 clouds (the reference's dtype)"""
+        src = self.point_state
+        same = src.dtype == np.float32
+        jobs = []
+        for idx, out in ((np.asarray(batch_idx, dtype=np.int64), out_point), (np.asarray(nxt, dtype=np.int64), out_next)):
+            for a in range(0, len(idx), chunk):
+                jobs.append((idx[a:a + chunk], out[a:a + chunk]))
+
+        def run(job):
+            ix, dst = job
+            if same:
+                np.take(src, ix, axis=0, out=dst, mode="clip")
+            else:
+                np.copyto(dst, np.take(src, ix, axis=0, mode="clip"), casting="same_kind")
+        if pool is None:
+            for j in jobs:
+                run(j)
+        else:
+            list(pool.map(run, jobs))
 
     def __getitem__(self, idx):
         f32 = np.float32
@@ -134,7 +160,7 @@ class BaseMemory(object):
         """index of the successor transition, clamped to the episode's last step (:255)."""
         return np.minimum(self.episode_map[batch_idx], batch_idx + 1).astype(np.int64)
 
-    def post_process_batch(self, data, batch_idx):
+    def post_process_batch(self, data, batch_idx, clouds_out=None, pool=None):
         f32 = np.float32
         nxt = self.next_indices(batch_idx)
         data["grasp_sample_batch"] = np.zeros([0, 4, 4])
@@ -142,9 +168,13 @@ class BaseMemory(object):
         data["next_goal_batch"] = f32(self.goal[nxt])
         data["next_expert_action_batch"] = f32(self.expert_action[nxt])
         data["next_action_batch"] = f32(self.action[nxt])
-        data["next_point_state_batch"] = self.point_state[nxt]
+        if clouds_out is None:
+            data["next_point_state_batch"] = self.point_state[nxt]
+            data["point_state_batch"] = self.point_state[batch_idx]
+        else:
+            self.gather_clouds(batch_idx, nxt, clouds_out[0], clouds_out[1], pool=pool)
+            data["point_state_batch"], data["next_point_state_batch"] = clouds_out
         data["next_return_batch"] = self.returns[nxt]
-        data["point_state_batch"] = self.point_state[batch_idx]
         # remaining steps to the end of the episode
         data["time_batch"] = f32(self.timestep[self.episode_map[batch_idx]]) + 1 - data["time_batch"]
         data["expert_flag_batch"] = f32(self.expert_flags[batch_idx])
@@ -153,10 +183,9 @@ class BaseMemory(object):
         if self.self_supervision and self.name != "expert":
             self.set_onpolicy_goal(data, batch_idx)
 
-    def set_onpolicy_goal(self, data, batch_idx, vis=False):
-        """hindsight relabelling of the on-policy transitions (reference core/replay_memory.py:233-249): the goal of a
-        non-expert row becomes the pose its own episode ended in, seen from the row's pose (and from its successor's for
-        next_goal_batch), packed rotation-first."""
+    def onpolicy_goals(self, batch_idx):
+        """(mask, goal, next_goal) of the hindsight relabelling: rows whose expert flag is 0 get the pose their own episode
+        ended in, seen from the row's pose (goal) / from its successor's (next_goal), packed rotation-first"""
         from .utils import pack_pose_rot_first, se3_inverse
         batch_idx = np.asarray(batch_idx)
         mask = self.expert_flags[batch_idx] == 0.0
@@ -167,6 +196,13 @@ class BaseMemory(object):
                          for i in range(n)])
         next_goal = np.array([pack_pose_rot_first(se3_inverse(self.state_pose[increment_idx[i]]).dot(self.state_pose[episode_end[i]]))
                               for i in range(n)])
+        return mask, goal, next_goal
+
+    def set_onpolicy_goal(self, data, batch_idx, vis=False):
+        """hindsight relabelling of the on-policy transitions (reference core/replay_memory.py:233-249): the goal of a
+        non-expert row becomes the pose its own episode ended in, seen from the row's pose (and from its successor's for
+        next_goal_batch), packed rotation-first."""
+        mask, goal, next_goal = self.onpolicy_goals(batch_idx)
         data["goal_batch"][mask] = goal[mask]
         data["next_goal_batch"][mask] = next_goal[mask]
 

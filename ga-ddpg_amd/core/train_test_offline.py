@@ -9,8 +9,9 @@ agent.update_parameters(batch, agent.update_step, i) -> agent.step_scheduler(age
 100 epochs (first inner iteration) and at every `save_epoch` step (surfix `epoch_<step>`); stop once
 update_step >= max_epoch; batch size = cfg.OFFLINE_BATCH_SIZE (:351); a loss table per epoch.  Not kept (out of scope,
 SURVEY section 2): the Ray harness, tensorboard writer, the test()/rollout branch and the PyBullet environment.
-The replay buffer can be mirrored in HBM (`device_replay=True`): sampling then costs one gather launch
-instead of a 17 MB host gather + PCIe upload per step."""
+The replay buffer is mirrored in HBM by default when it fits (`device_replay="auto"`): sampling then costs one
+gather launch instead of a 17 MB host gather + PCIe upload per step; `device_replay=False` / `--host_replay` keep the
+reference's host sampling."""
 import argparse
 import itertools
 import os
@@ -46,8 +47,19 @@ def setup(config_file="ddpg_td3_aux.yaml", policy=None, pretrained=None, model_s
     return agent, cfg
 
 
+def device_replay_fits(memory, reserve=0.5):
+    """True when a float32 mirror of `memory` (DeviceReplay) takes less than `reserve` of the GPU's FREE memory -- 4 x 1030 x 4 B
+    per transition: the reference's 2e5-transition offline buffer is 3.3 GB of a 288 GB MI355X"""
+    import torch
+    if not torch.cuda.is_available():
+        return False
+    need = int(np.prod(memory.point_state.shape)) * 4 + 64 * memory.point_state.shape[0] * 4
+    free, _ = torch.cuda.mem_get_info()
+    return need < reserve * free
+
+
 def train_off_policy(agent, memory, config, model_output_dir=None, save_model=False, log=None, max_epochs=None,
-                     sample=None, run_ahead=False):
+                     sample=None, run_ahead=False, device_replay="auto"):
     """The reference's train_off_policy() (:107-161) over an agent and a filled replay memory.
     config = cfg.RL_TRAIN (updates_per_step, batch_size, save_epoch, max_epoch).  `sample(batch_size)` overrides
     memory.sample (device-resident replay, prefetching samplers).  Returns the per-key loss history (deques, as the
@@ -55,6 +67,15 @@ def train_off_policy(agent, memory, config, model_output_dir=None, save_model=Fa
     run_ahead: enqueue the `updates_per_step` updates of an epoch without waiting for each (update_parameters(sync=False));
     their losses are read at the end of the epoch, the host samples / stages the next minibatch while the GPU works."""
     losses = get_loss_info_dict()
+    if sample is None and device_replay and (device_replay is True or device_replay_fits(memory)) and hasattr(agent, "runtime"):
+        # default feeding path (VERDICT r03 item 8): the buffer mirrored in HBM, indices drawn on the host with the
+        # reference's arithmetic and random stream (np.random, as memory.sample uses), ONE gather launch per minibatch --
+        # the only feeding path that keeps up with a 3 ms update step (bench.py: value_device_replay vs value_host_inclusive)
+        from .device_replay import DeviceReplay
+        dmem = DeviceReplay(memory)
+        sample = lambda batch_size: dmem.sample_lazy(batch_size)                 # noqa: E731
+        if log is not None:
+            log("replay buffer mirrored in HBM (%d transitions); device_replay=False keeps the host sampling path" % len(memory))
     sample = sample or memory.sample
     epochs = 0
     for epoch in itertools.count(1):
@@ -113,7 +134,8 @@ def main(argv=None):
     ap.add_argument("--save_model", action="store_true")
     ap.add_argument("--batch_size", type=int, default=None)
     ap.add_argument("--max_epoch", type=int, default=None, help="overrides RL_TRAIN.max_epoch (update steps)")
-    ap.add_argument("--device_replay", action="store_true", help="mirror the buffer in HBM (one gather launch per sample)")
+    ap.add_argument("--host_replay", action="store_true", help="sample on the host and upload every minibatch (the reference's "
+                                                               "loop); default: mirror the buffer in HBM when it fits")
     args = ap.parse_args(argv)
     agent, cfg = setup(args.config_file, args.policy, args.pretrained, args.model_surfix, args.batch_size, args.output_dir)
     config = cfg.RL_TRAIN
@@ -126,13 +148,8 @@ def main(argv=None):
         from ..synth_data import fill_synthetic_buffer
         memory = BaseMemory(args.buffer, config, point_dtype=np.float32)
         fill_synthetic_buffer(memory, args.buffer, seed=20260928)
-    sample = None
-    if args.device_replay:
-        from .device_replay import DeviceReplay
-        dmem = DeviceReplay(memory)
-        rng = np.random.default_rng(0)
-        sample = lambda batch_size: dmem.sample_lazy(batch_size, rng)       # noqa: E731
-    losses, epochs = train_off_policy(agent, memory, config, args.output_dir, args.save_model, log=print, sample=sample)
+    losses, epochs = train_off_policy(agent, memory, config, args.output_dir, args.save_model, log=print,
+                                      device_replay=False if args.host_replay else "auto")
     if args.save_model:
         agent.save_model(agent.update_step, output_dir=args.output_dir)
     return losses, epochs

@@ -860,6 +860,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
 static int g_opt_fwd_wide = 1;
 static int g_opt_dx_wide = 1, g_opt_dw_wide = 1;
 static int g_opt_bwd_fused = 1;
+static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch aims for (its partial slab = this x 128 x 128 floats)
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
 static bool fwd_wideable(const gad_gemm_fwd_args& a) {
@@ -1294,6 +1295,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dx_wide")) { g_opt_dx_wide = value; return GAD_OK; }
     if (!strcmp(name, "dw_wide")) { g_opt_dw_wide = value; return GAD_OK; }
     if (!strcmp(name, "bwd_fused")) { g_opt_bwd_fused = value; return GAD_OK; }
+    if (!strcmp(name, "dw_wide_wgs")) { g_opt_dw_wide_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
@@ -3387,7 +3389,7 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     }
     if (dw_wideable(*a, k_used, vec)) {
         const int tn_ = in.n_out[0] / 128, tk_ = (in.mode == 1 ? in.feat_c : in.Kp) / 128;
-        int splits = gad_cdiv(256, tn_ * tk_);                          // ~one workgroup per CU
+        int splits = gad_cdiv(g_opt_dw_wide_wgs, tn_ * tk_);             // ~one workgroup per CU
         const int by_rows = gad_cdiv(rows, 4 * KT);
         if (splits > by_rows) splits = by_rows;
         if (splits < 1) splits = 1;

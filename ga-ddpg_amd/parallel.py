@@ -75,16 +75,22 @@ class DataParallelContext(object):
 
     @property
     def comm(self):
-        """rccl.Communicator of this group, created at first use"""
+        """rccl.Communicator of this group (None: collectives go through torch.distributed).  Built by attach() /
+        broadcast_parameters() -- outside any stream context -- or at first use."""
         if self._direct and self._comm is None:
-            from . import engine, rccl
-            try:
-                rccl.lib()                      # same image on every rank: a missing library is missing everywhere
-            except OSError as exc:
-                import sys
-                print("ga_ddpg_amd.parallel: librccl not loadable (%s): collectives through torch.distributed" % exc, file=sys.stderr)
-                self._direct = False
-                return None
+            self._make_comm()
+        return self._comm
+
+    def _make_comm(self):
+        """Build the direct-RCCL communicator, PROVE it (a known-answer all-reduce on every stream the step issues
+        collectives from) and agree on the outcome over the bootstrap group: if any rank could not load librccl, failed in
+        ncclCommInitRank or saw a wrong sum, EVERY rank logs once and falls back to torch.distributed for this context
+        (never a mix of transports inside one job).  GAD_DP_DIRECT_RCCL=0 skips the attempt."""
+        import sys
+        from . import engine, rccl
+        ok, why, comm = 1, "", None
+        try:
+            rccl.lib()
             # HIP binds a stream to one of the process's four hardware queues at the stream's FIRST LAUNCH, and
             # ncclCommInitRank launches on streams of its own: created before the step's streams have run anything, the
             # communicator takes queues and the step's chains end up sharing one (measured: 318 -> 260 steps/s at one
@@ -95,8 +101,59 @@ class DataParallelContext(object):
                 with torch.cuda.stream(st):
                     torch.zeros(64, device="cuda").add_(1.0)
             torch.cuda.synchronize(dev)
-            self._comm = rccl.Communicator(self.group)
-        return self._comm
+            comm = rccl.Communicator(self.group)
+            if comm.count() != self.world:
+                raise RuntimeError("ncclCommCount = %d, group has %d ranks" % (comm.count(), self.world))
+            for st in streams:                  # the lanes the step's exchanges ride on (counts, dW lanes, main, actor)
+                with torch.cuda.stream(st):
+                    if not comm.self_test():
+                        raise RuntimeError("known-answer all-reduce returned a wrong sum")
+        except Exception as exc:                # noqa: BLE001 -- whatever went wrong, the job continues on torch.distributed
+            ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            self._comm = comm
+            import atexit
+            atexit.register(self.close)
+            return
+        if comm is not None:
+            try:
+                comm.destroy()
+            except Exception:                   # noqa: BLE001
+                pass
+        self._direct = False
+        self._comm = None
+        print("ga_ddpg_amd.parallel: rank %d: direct RCCL path unavailable (%s): every collective of this context goes "
+              "through torch.distributed" % (self.rank, why or "another rank failed"), file=sys.stderr, flush=True)
+
+    def close(self):
+        """destroy the RCCL communicator (before the process group goes away; registered with atexit)"""
+        c, self._comm = self._comm, None
+        if c is not None:
+            try:
+                c.destroy()
+            except Exception:                   # noqa: BLE001
+                pass
+
+    def transport(self):
+        """what carries this context's CUDA collectives, and how many ranks IT reports (bench.py: config.rccl_nranks)"""
+        if self._comm is not None:
+            return {"transport": "rccl-direct", "rccl_nranks": self._comm.count()}
+        return {"transport": "torch.distributed/%s" % dist.get_backend(self.group), "rccl_nranks": dist.get_world_size(self.group)
+                if dist.get_backend(self.group) == "nccl" else None}
+
+    def replicas_agree(self, flats):
+        """True iff every rank holds bit-identical parameters: the all-reduced MAX and MIN of a per-rank checksum (sum of
+        the parameters' int32 bit patterns, exact in int64) coincide.  bench.py puts the flag on its JSON line."""
+        dev = flats[0].master.device
+        cs = torch.zeros(1, dtype=torch.int64, device=dev)
+        for f in flats:
+            cs += f.master.detach().view(torch.int32).to(torch.int64).sum()
+        hi, lo = cs.clone(), cs.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        return bool((hi == lo).item())
 
     def _sum(self, t):
         """in-place SUM over the ranks, ordered on the CURRENT stream"""
@@ -120,6 +177,8 @@ class DataParallelContext(object):
         self._numer = torch.tensor([1.0, 1.0 / 6.0, 1.0 / 6.0, 1.0 / 6.0, 1.0], dtype=torch.float64, device=rt.dev)
         self._pick = torch.tensor([0, 1, 2, 1, 3], dtype=torch.int64, device=rt.dev)
         self._inflight = {}
+        if self._direct and self._comm is None:
+            self._make_comm()                       # eagerly, outside any stream context; may fall back (self._direct False)
         bucketed = BUCKETED if BUCKETED is not None else (self._direct and self.world > 1)
         if bucketed and hasattr(rt, "enable_bucketed_reduce"):
             rt.enable_bucketed_reduce()

@@ -46,6 +46,7 @@ def lib():
         L.ncclAllReduce.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ncclBroadcast.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
     return _lib
 
 
@@ -87,8 +88,26 @@ class Communicator(object):
         _check(lib().ncclBroadcast(C.c_void_p(t.data_ptr()), C.c_void_p(t.data_ptr()), t.numel(), _DTYPES[t.dtype], root,
                                    self._comm, C.c_void_p(s.cuda_stream)), "ncclBroadcast")
 
+    def count(self):
+        """ranks RCCL itself reports for this communicator (ncclCommCount): what bench.py prints as config.rccl_nranks"""
+        n = C.c_int(-1)
+        _check(lib().ncclCommCount(self._comm, C.byref(n)), "ncclCommCount")
+        return int(n.value)
+
+    def self_test(self):
+        """one 64-float all-reduce on the current stream whose answer is known (sum over ranks of rank + 1); True if this
+        rank saw it.  Run once right after the communicator is built: a transport that initialises but cannot move data is
+        found here, not inside the first update step."""
+        t = torch.full((64,), float(self.rank + 1), dtype=torch.float32, device="cuda:%d" % self.device)
+        self.all_reduce_(t)
+        torch.cuda.synchronize(self.device)
+        want = self.world * (self.world + 1) / 2.0
+        return bool((t == want).all().item())
+
     def destroy(self):
         if self._comm:
-            torch.cuda.synchronize(self.device)
-            lib().ncclCommDestroy(self._comm)
-            self._comm = C.c_void_p()
+            try:
+                torch.cuda.synchronize(self.device)
+                lib().ncclCommDestroy(self._comm)
+            finally:
+                self._comm = C.c_void_p()

@@ -102,12 +102,13 @@ def fill_synthetic_buffer(memory, n_transitions, seed=20260928, gamma=None):
     return memory
 
 
-def sample_valid_batch(memory, batch_size, rng):
+def sample_valid_batch(memory, batch_size, rng, clouds_out=None, pool=None):
     """A sampled batch that has >=1 expert row and >=1 positive-return row (the reference's
-    masked means are NaN otherwise: core/loss.py:23,31)."""
+    masked means are NaN otherwise: core/loss.py:23,31).  The validity test reads the flag arrays of the drawn indices, so
+    a rejected draw costs no cloud gather; the accepted draw is memory.sample on those indices (same random stream as a
+    memory.sample(batch_size, rng) loop with rejection).  clouds_out / pool: BaseMemory.sample's."""
     for _ in range(64):
-        batch = memory.sample(batch_size, rng=rng)
-        if (batch["expert_flag_batch"] >= 1).any() and (batch["return_batch"] > 0).any() and \
-                (batch["perturb_flag_batch"] < 1).any():
-            return batch
+        idx = memory.draw_indices(batch_size, rng)
+        if (memory.expert_flags[idx] >= 1).any() and (memory.returns[idx] > 0).any() and (memory.perturb_flags[idx] < 1).any():
+            return memory.sample(batch_size, batch_idx=idx, clouds_out=clouds_out, pool=pool)
     raise RuntimeError("could not draw a batch with expert and positive-return rows")

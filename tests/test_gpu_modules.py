@@ -191,6 +191,49 @@ def test_device_replay_matches_host_sampling():
     assert float((got["action_batch"] - 0.25).abs().max()) == 0.0
 
 
+def test_device_replay_relabels_onpolicy_goals_like_the_host_path():
+    """with self_supervision on a non-expert buffer BaseMemory.sample relabels the goals of the on-policy rows
+    (reference core/replay_memory.py:233-249,271-272); the GPU-resident path must hand the update the same goals -- eager
+    sample(), the lazy gather, and a prefetched lazy handle alike."""
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core.device_replay import DeviceReplay
+    from ga_ddpg_amd.core.prefetch import PrefetchSampler
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.runtime import BATCH_KEYS
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer
+    agent, cfg = make_agent("ddpg_td3_aux.yaml")
+    mem = BaseMemory(700, cfg, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 700, seed=5)
+    mem.name, mem.self_supervision = "online", True
+    rng = np.random.default_rng(2)
+    for i in range(700):                                           # proper rigid poses, so the relabelled goals are well defined
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        w, x, y, z = q
+        mem.state_pose[i] = np.eye(4)
+        mem.state_pose[i][:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+        mem.state_pose[i][:3, 3] = rng.normal(size=3)
+    dmem = DeviceReplay(mem)
+    idx = mem.draw_indices(24, np.random.default_rng(1))
+    host = mem.sample(24, batch_idx=idx)
+    assert (mem.expert_flags[idx] == 0).any() and (mem.expert_flags[idx] != 0).any()     # both kinds of rows are in the batch
+    assert np.abs(host["goal_batch"] - mem.goal[idx]).max() > 1e-3                       # ... and the relabelling changed some goals
+    dev = dmem.sample(24, batch_idx=idx)
+    for k in BATCH_KEYS:
+        np.testing.assert_array_equal(dev[k].cpu().numpy(), np.asarray(host[k], dtype=np.float32).reshape(dev[k].shape), err_msg=k)
+    rt = agent.runtime(24, host["point_state_batch"].shape[2])
+    rt.upload(dmem.sample_lazy(24, batch_idx=idx))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(rt.dbuf["goal_batch"].cpu().numpy(), np.asarray(host["goal_batch"], dtype=np.float32))
+    # handles drawn ahead by a prefetcher and never consumed give their staging sets back (DeviceReplay.release)
+    for _ in range(40):
+        with PrefetchSampler(dmem, 24, depth=3, rng=np.random.default_rng(0)) as s:
+            dmem.release(s.next())                                 # (a batch the caller drops, e.g. after a validity check)
+    sets = dmem._stage[("sets", 24)]["items"]
+    assert sum(1 for it in sets if it is not None and it["pending"]) <= 2, "leaked staging sets"
+
+
 def _manifest(obj):
     """structure of a checkpoint object, as oracle/make_golden.py records it for the reference's files"""
     if torch.is_tensor(obj):
