@@ -151,7 +151,7 @@ ROUTE_SYMBOL = {"gemm_fwd(stream)": "gemm_fwd_stream_kernel", "gemm_fwd(wide)": 
                 "gemm_fwd": "gemm_fwd_kernel", "gemm_dx(stream)": "gemm_dx_stream_kernel", "gemm_dx(wide)": "gemm_dx_wide_kernel",
                 "gemm_dx(skinny)": "gemm_dx_skinny_kernel", "gemm_dx": "gemm_dx_kernel", "gemm_dx(action stream)": "dx_action_stream_kernel", "gemm_dw(stream)": "gemm_dw_stream_kernel",
                 "gemm_dw(gather stream)": "gemm_dw_gather_stream_kernel", "gemm_dw(wide)": "gemm_dw_wide_kernel",
-                "gemm_dw(skinny)": "gemm_dw_skinny_kernel", "gemm_dw": "gemm_dw_kernel", "gemm_bwd(stream)": "gemm_bwd_stream_kernel"}
+                "gemm_dw(skinny)": "gemm_dw_skinny_kernel", "gemm_dw": "gemm_dw_kernel", "gemm_bwd(stream)": "gemm_bwd_stream_kernel", "gemm_bwd(wide)": "gemm_bwd_wide_kernel"}
 ROUTES = {}                 # tag -> routed kernel family, filled from engine.timing_routes() after each probe
 
 
@@ -368,7 +368,7 @@ def main():
     table_timed = kernel_table(timed_tags, rows, B, n_stamped)
     d0 = table_timed.get(dom, table[dom])                           # measured over the timed region itself
     tj = {}
-    for rnd in ("r03", "r02"):                                      # this round's PMC passes (tests/collect_profiles.sh)
+    for rnd in ("r03", "r02"):                                      # this round's PMC passes (tools/collect_profiles.sh)
         tpath = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))

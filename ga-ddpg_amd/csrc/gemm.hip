@@ -673,7 +673,7 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
 // multiple of 32 wide, already activated): the K loop runs over the feature columns only, the three coordinate columns
 // are a rank-3 update of the accumulators in the epilogue (z += dx . W[n][feat_c .. feat_c + 2]) instead of a fifth,
 // almost empty K-tile.
-// Measured alone (tests/diag_gemm.py, B = 256 shapes): see profiles/README.md round 3.
+// Measured alone (tools/diag_gemm.py, B = 256 shapes): see profiles/README.md round 3.
 // ------------------------------------------------------------------------------------------------
 template <int XM, bool POOL>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
@@ -860,6 +860,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
 static int g_opt_fwd_wide = 1;
 static int g_opt_dx_wide = 1, g_opt_dw_wide = 1;
 static int g_opt_bwd_fused = 1;
+static int g_opt_bwd_wide = 0;                  // fused wide backward: 0 off (default: slower in the step), 1 SA2 and SA3 shapes, 2 only layers with >= 16384 rows (SA2)
+static int g_opt_bwd_wide_slab = 4;             // most partial-dW elements (millions) a fused launch may write: bounds its workgroups per k block
 static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch aims for (its partial slab = this x 128 x 128 floats)
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
@@ -887,7 +889,7 @@ static bool fwd_wideable(const gad_gemm_fwd_args& a) {
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// NOTE (measured, tests/ubench/mfma_valu.hip): on gfx950 the f32 MFMA shares the vector ALU -- every VALU
+// NOTE (measured, tools/ubench/mfma_valu.hip): on gfx950 the f32 MFMA shares the vector ALU -- every VALU
 // instruction issued between MFMAs adds its ~4 clocks to the 64 of the MFMA, also with 2 wavefronts per SIMD.
 // So the loop below is written for a minimal VALU instruction count: packed (2-wide) f32 math for the BatchNorm
 // affine and the statistics, buffer stores whose row offset lives in an SGPR (no per-store address arithmetic),
@@ -1139,7 +1141,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 // Here every workgroup owns one 32x32 output tile and its 8 wavefronts split K: each wavefront issues ALL the
 // 16-byte loads of its K slice (A and B operand straight in MFMA register layout, k visited as 8j+4h+i like the
 // streaming kernel, no LDS staging, no barrier) before its first MFMA, so the load latency is paid about once;
-// the partial tiles are summed through LDS.  256 rows x 1024 -> 512: 37.8 us -> see tests/diag_gemm.py.
+// the partial tiles are summed through LDS.  256 rows x 1024 -> 512: 37.8 us -> see tools/diag_gemm.py.
 // ------------------------------------------------------------------------------------------------
 #define SK_NW 8          // wavefronts per workgroup (K split); 16 -> 128-VGPR budget -> spills, 2x slower
 #define SK_CH 6          // 8-wide k groups per register chunk (17 x 1 = the whole K share in one round of loads: measured 2 % slower)
@@ -1295,6 +1297,8 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dx_wide")) { g_opt_dx_wide = value; return GAD_OK; }
     if (!strcmp(name, "dw_wide")) { g_opt_dw_wide = value; return GAD_OK; }
     if (!strcmp(name, "bwd_fused")) { g_opt_bwd_fused = value; return GAD_OK; }
+    if (!strcmp(name, "bwd_wide")) { g_opt_bwd_wide = value; return GAD_OK; }
+    if (!strcmp(name, "bwd_wide_slab")) { g_opt_bwd_wide_slab = value > 0 ? value : 4; return GAD_OK; }
     if (!strcmp(name, "dw_wide_wgs")) { g_opt_dw_wide_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
@@ -1417,7 +1421,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         return GAD_OK;
     }
     // 64 x 64 tiles throughout: with K <= 1024 these launches are prologue/epilogue-bound, more and smaller
-    // workgroups win over the 128-wide tiles at every shape of the step (tests/diag_gemm.py)
+    // workgroups win over the 128-wide tiles at every shape of the step (tools/diag_gemm.py)
     if (pe.key) LAUNCH_FWD2(2, 2, 1, 1, 0, true);
     else if (nmax <= 32) LAUNCH_FWD(4, 1, 1, 1); else LAUNCH_FWD(2, 2, 1, 1);
 #undef LAUNCH_FWD
@@ -3456,25 +3460,415 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// FUSED wide-tile backward for the MID-SIZE layers (SA2 / SA3; round 4): dX AND dW of one layer from ONE pass over dZ.
+// The separate kernels (gemm_dx_wide / gemm_dw_wide) each form dZ = P*dY - w*(Q + S*z) from their own loads of z and dY
+// (1 + K/128 times per element for dX, once per 128-wide k block for dW), and each launch is only a few K-tiles deep per
+// workgroup: barrier and load latency, not MFMA issue, is what they spend their time on (0.17 - 0.25 of the FP32-MFMA peak
+// inside the step).  Here a workgroup owns 64-row tiles x ONE 64-wide block of input channels (grid.y = K / 64) and walks the
+// layer's N output channels in steps of 64: every staged dZ tile [64 rows x 64 channels] and W tile [64 channels x 64 k]
+// feeds 32 dX MFMAs (32 rows x 32 k per wavefront, reduction over the 64 channels) AND 32 dW MFMAs (32 channels x 32 k per
+// wavefront, reduction over the tile's 64 rows) -- twice the MFMA work per barrier, per staged byte and per dZ formation.
+//   * dZ tile: row-major [row][64 + 4] -- the dX A fragments are ds_read_b128 along the channels (k = 8j+4h+i order), the dW
+//     A fragments (dZ^T) are conflict-free ds_read_b32 across the channels of rows 2s + h;
+//   * W tile as stored ([n][64 + 4]): the dX B fragments are ds_read_b32 across k of row n = 8j+4h+i -- no transposing store;
+//   * the dW B operand -- the layer INPUT X[row][k], k = this lane's column -- never touches LDS: 32 coalesced 4-byte loads
+//     per lane and row tile (relu(scale * z_prev + shift) with the lane's own scale / shift, or the gathered feature), held
+//     in 32 registers and reused by every channel step of the tile;
+//   * the dW accumulators (N / 64 per wavefront: the wavefront pair (w >> 1) splits each 64-channel step by halves) persist
+//     over the workgroup's row tiles and leave as ONE partial block per workgroup; dw_reduce sums the blocks in f64.  (f64
+//     atomics straight into the arena are SLOWER than slab + reduce on this part: 5.6 vs 3.5 us per million partial
+//     elements, tools/ubench/atomic_reduce.hip -> profiles/r04_atomic_reduce.txt.)
+//   * dX epilogue as in gemm_dx_wide: dY of the previous layer masked by its ReLU + that layer's BatchNorm-backward sums, or
+//     (L1: the gathered first layers) float atomics into the points' feature gradients; L1 also forms the three coordinate
+//     columns of dW with vector FMAs while dZ is staged (k block 0 only).
+// One LDS buffer + register prefetch (two barriers per 64 MFMAs): 36 KB of LDS and <= 128 VGPRs of accumulators leave room
+// for 3 - 4 workgroups per CU, which is what hides the barriers here.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned gad_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int vo, int so) {
+    const gad_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int vo, int so) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+}
+
+template <int NIT, int GM, int L1>
+__global__ __launch_bounds__(256, NIT >= 8 ? 1 : 2) void gemm_bwd_wide_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                               int n_rows_static, const float* __restrict__ W, int Kp, DxEpi e,
+                                                               float* __restrict__ partial, unsigned long long* __restrict__ ts) {
+    KTimer kt_(ts);
+    constexpr int N = NIT * 64, P = 68, TILE = 64 * P;
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE + 3 * N + 64 * 4];
+    __shared__ int32_t ptS[64];
+    float* As = smem;
+    float* Ws = smem + TILE;
+    float* vP = smem + 2 * TILE;                          // P | Q | S of the layer's N channels
+    float* relS = vP + 3 * N;                             // L1: [row][4] = src_xyz[pt] - ctr_xyz[grp]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;              // dX: row half / k half;  dW: channel half of the step / k half
+    const int l31 = lane & 31, half = lane >> 5;
+    const int k0 = blockIdx.y * 64;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    const int n_tiles = (n_rows + 63) >> 6;
+    const int c4 = (tid & 15) * 4, sr = tid >> 4;         // staging: 16-byte chunk of the 64-wide tile, rows sr + 16 u
+    for (int i = tid; i < N; i += 256) {
+        float Pc, Qc, Sc;
+        dz_coef(d, i, Pc, Qc, Sc);
+        vP[i] = Pc; vP[N + i] = Qc; vP[2 * N + i] = Sc;
+    }
+    // every global operand goes through a buffer descriptor: 32-bit per-lane byte offsets (one VGPR each, set up once per
+    // tile) + a wave-uniform scalar offset per access, instead of a 64-bit pointer pair per unrolled load
+    const int gpitch = GM == 0 ? d.g_pitch : d.c;
+    // z, dY and the layer input are bounded by the LIVE rows: a read past them returns 0, so a dead row's dZ is exactly 0
+    // (its weight is 0 as well) without a select per element -- on this part every VALU instruction is MFMA issue time
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, n_rows * d.z_pitch * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0,
+                                                                         GM == 0 ? n_rows * gpitch * 4 : 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L1 ? x.feat : x.zin), 0,
+                                                                        L1 ? 0x7ffffffc : n_rows * x.zin_pitch * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr_ = __builtin_amdgcn_make_buffer_rsrc(partial, 0, 0x7ffffffc, 0x00020000);
+    // previous layer's raw output / the gradient this launch writes: bounded by the live rows (reads past them give 0,
+    // stores past them are dropped)
+    const int zp_pitch4 = L1 ? 0 : e.zprev_pitch * 4, go_pitch4 = L1 ? 0 : e.gout_pitch * 4;
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L1 ? W : e.zprev), 0, L1 ? 0 : n_rows * zp_pitch4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(L1 ? const_cast<float*>(W) : e.gout, 0, L1 ? 0 : n_rows * go_pitch4, 0x00020000);
+    const int kx = k0 + wn * 32 + l31;                    // this lane's input channel (dW column, dX column)
+    float xs = 1.f, xt = 0.f, ps = 0.f, pt = 0.f, pm = 0.f, pi = 0.f;
+    if (!L1) { xs = x.scale[kx]; xt = x.shift[kx]; ps = e.ps[kx]; pt = e.pt[kx]; pm = e.pm[kx]; pi = e.pi[kx]; }
+    const bool coords = L1 && k0 == 0;
+    float wx[NIT][3];                                     // coords: channel it * 64 + lane, rows wave * 16 .. + 15 of every tile
+    if (L1) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) { wx[it][0] = 0.f; wx[it][1] = 0.f; wx[it][2] = 0.f; }
+    }
+    f32x16 accw[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accw[it][v] = 0.f;
+    float cb = 0.f, cg = 0.f;
+    int vw[4];                                            // W staging offsets: rows sr + 16 u of the step's 64 channels
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vw[u] = ((sr + 16 * u) * Kp + k0 + c4) * 4;
+    const int xpitch4 = L1 ? x.feat_c * 4 : x.zin_pitch * 4;
+    const int vx = (half * (L1 ? 0 : x.zin_pitch) + kx) * 4;             // X fragment lane offset (row 2 s + half, column kx)
+    const int vzp = (4 * half * (L1 ? 0 : e.zprev_pitch) + kx) * 4, vgo = (4 * half * (L1 ? 0 : e.gout_pitch) + kx) * 4;
+    // this thread's four staged rows of a tile (offsets, weights) and the staging registers; the NEXT tile's first step is
+    // loaded under the current tile's last MFMAs and epilogue (cross-tile prefetch: a workgroup has 1 - 3 tiles, so the
+    // staging latency in front of every tile was a third of its time)
+    int vz[4], vg[4];
+    float wrow[4];
+    float4 rz[4], rg[4], rb[4];
+    gad_u32x4 ra[4];
+    auto meta = [&](int row0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = row0 + sr + 16 * u;
+            const bool live = r < n_rows;
+            const int rr = live ? r : n_rows - 1;
+            const float w = d.row_w ? d.row_w[rr] : 1.f;
+            wrow[u] = live ? w : 0.f;
+            vz[u] = (r * d.z_pitch + c4) * 4;             // (the true row: past the live rows the bounded descriptor reads 0)
+            vg[u] = ((GM == 1 ? d.row_grp[rr] : r) * gpitch + c4) * 4;
+        }
+    };
+    auto load_regs = [&](int it) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rz[u] = buf_ld4(zr, vz[u], it * 256);
+            rg[u] = buf_ld4(gr_, vg[u], it * 256);
+            if (GM == 1) ra[u] = __builtin_amdgcn_raw_buffer_load_b128(ar, vg[u], it * 256, 0);
+            rb[u] = buf_ld4(wr, vw[u], it * 256 * Kp);
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) { meta(blockIdx.x << 6); load_regs(0); }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int row0 = tile << 6;
+        __syncthreads();                                  // vP visible; the previous tile's LDS reads (As, Ws, ptS, relS) are done
+        if (L1 && tid < 64) {
+            const int r = min(row0 + tid, n_rows - 1);
+            const int p = x.row_pt[r];
+            ptS[tid] = p;
+            const float* q = x.src_xyz + (size_t)p * 3;
+            float q0 = q[0], q1 = q[1], q2 = q[2];
+            if (x.ctr_xyz) {
+                const float* cp = x.ctr_xyz + (size_t)x.row_grp[r] * 3;
+                q0 = __fsub_rn(q0, cp[0]); q1 = __fsub_rn(q1, cp[1]); q2 = __fsub_rn(q2, cp[2]);
+            }
+            *reinterpret_cast<float4*>(relS + 4 * tid) = make_float4(q0, q1, q2, 0.f);
+        }
+        if (L1) __syncthreads();
+        // ---- the dW B operand: X[row0 + 2 s + half][kx], s = 0 .. 31, straight into registers (activated below)
+        float xf[32];
+#pragma unroll
+        for (int sidx = 0; sidx < 32; ++sidx) {
+            if (L1) {
+                xf[sidx] = buf_ld(xr, ptS[2 * sidx + half] * xpitch4 + vx, 0);
+            } else {
+                xf[sidx] = buf_ld(xr, vx, (row0 + 2 * sidx) * xpitch4);     // (past the live rows: 0; their dZ is 0 as well)
+            }
+        }
+        f32x16 accx;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) accx[v] = 0.f;
+        float zp[16];
+        const int rb0 = row0 + wm * 32;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (it > 0) __syncthreads();                  // the previous step's fragment reads are done
+            {   // registers -> LDS: dZ formed once per staged element
+                const int nb = it * 64 + c4;
+                const float4 P4 = *reinterpret_cast<const float4*>(vP + nb), Q4 = *reinterpret_cast<const float4*>(vP + N + nb);
+                const float4 S4 = *reinterpret_cast<const float4*>(vP + 2 * N + nb);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float4 g = rg[u];
+                    const float4 z = rz[u];
+                    if (GM == 1) {
+                        const unsigned r = row0 + sr + 16 * u;   // the true row (a clamped row never matches an arg-max)
+                        g.x = ra[u].x == r ? g.x : 0.f; g.y = ra[u].y == r ? g.y : 0.f;
+                        g.z = ra[u].z == r ? g.z : 0.f; g.w = ra[u].w == r ? g.w : 0.f;
+                    }
+                    const float w = wrow[u];
+                    float4 v;
+                    v.x = P4.x * g.x - w * fmaf(S4.x, z.x, Q4.x); v.y = P4.y * g.y - w * fmaf(S4.y, z.y, Q4.y);
+                    v.z = P4.z * g.z - w * fmaf(S4.z, z.z, Q4.z); v.w = P4.w * g.w - w * fmaf(S4.w, z.w, Q4.w);
+                    *reinterpret_cast<float4*>(As + (sr + 16 * u) * P + c4) = v;
+                    *reinterpret_cast<float4*>(Ws + (sr + 16 * u) * P + c4) = rb[u];
+                }
+            }
+            if (it + 1 < NIT) {
+                load_regs(it + 1);
+            } else {
+                const int nxt = tile + gridDim.x;         // next tile's first step (wave-uniform branch)
+                if (nxt < n_tiles) { meta(nxt << 6); load_regs(0); }
+                if (!L1) {                                // this tile's z_prev for the epilogue: in flight under the last MFMAs
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) zp[v] = buf_ld(pr, vzp, (rb0 + (v & 3) + 8 * (v >> 2)) * zp_pitch4);
+                }
+            }
+            if (it == 0) {                                // activate the X fragments once per tile (their loads have had a whole staging pass)
+                if (!L1) {
+#pragma unroll
+                    for (int sidx = 0; sidx < 32; ++sidx) xf[sidx] = fmaxf(fmaf(xf[sidx], xs, xt), 0.f);
+                }
+            }
+            __syncthreads();
+            if (coords) {                                 // dW[n][feat_c .. + 2] += dZ[r][n] * rel[r][0 .. 2]: lane = channel, 16 rows per wavefront
+                const float* ap = As + (wave * 16) * P + lane;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = ap[r * P];
+                    const float4 q = *reinterpret_cast<const float4*>(relS + 4 * (wave * 16 + r));
+                    wx[it][0] = fmaf(a, q.x, wx[it][0]); wx[it][1] = fmaf(a, q.y, wx[it][1]); wx[it][2] = fmaf(a, q.z, wx[it][2]);
+                }
+            }
+            // ---- dX: 32 rows x 32 k of this wavefront, reduction over the step's 64 channels
+            {
+                const float* ap = As + (wm * 32 + l31) * P + 4 * half;
+                const float* bp = Ws + (4 * half) * P + wn * 32 + l31;
+                float4 a4 = *reinterpret_cast<const float4*>(ap);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float4 an = a4;
+                    if (j + 1 < 8) an = *reinterpret_cast<const float4*>(ap + 8 * (j + 1));
+                    const float b0 = bp[(8 * j + 0) * P], b1 = bp[(8 * j + 1) * P], b2 = bp[(8 * j + 2) * P], b3 = bp[(8 * j + 3) * P];
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b1, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b2, accx, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b3, accx, 0, 0, 0);
+                    a4 = an;
+                }
+            }
+            // ---- dW: 32 channels (half wm of the step) x 32 k, reduction over the tile's 64 rows
+            {
+                const float* ap = As + half * P + wm * 32 + l31;
+#pragma unroll
+                for (int s8 = 0; s8 < 4; ++s8) {
+                    float a[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a[q] = ap[(2 * (8 * s8 + q)) * P];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) accw[it] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], xf[8 * s8 + q], accw[it], 0, 0, 0);
+                }
+            }
+        }
+        // ---- dX epilogue
+        if (L1) {
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int il = wm * 32 + acc_row(v, half);
+                if (row0 + il < n_rows) atomic_add_f32(e.dfeat + (size_t)ptS[il] * e.feat_c + kx, accx[v]);
+            }
+        } else {
+            // (a row past the live count: z_prev reads 0, its accumulator row is exactly 0 -- dZ = 0 -- and the store is dropped)
+            const float npm = -pm * pi;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float ga = fmaf(zp[v], ps, pt) > 0.f ? accx[v] : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), or_, vgo, (rb0 + (v & 3) + 8 * (v >> 2)) * go_pitch4, 0);
+                cb += ga;
+                cg = fmaf(ga, fmaf(zp[v], pi, npm), cg);
+            }
+        }
+    }
+    // ---- this workgroup's partial dW block (zeros if it had no tile: dw_reduce sums every block)
+    float* pout = partial + (size_t)blockIdx.x * N * Kp;
+    {
+        const int vs = (4 * half * Kp + kx) * 4, sbase = (blockIdx.x * N + wm * 32) * Kp * 4;       // (< 2^31: the slab is <= 36 MB)
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(accw[it][v]), sr_, vs, sbase + (it * 64 + (v & 3) + 8 * (v >> 2)) * Kp * 4, 0);
+    }
+    __syncthreads();                                      // the tile loop's last LDS reads are done: As / Ws are free
+    if (coords) {
+        float* red = smem;                                // [4 wavefronts = row quarters][N][3]
+#pragma unroll
+        for (int it = 0; it < NIT; ++it)
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) red[(wave * N + it * 64 + lane) * 3 + dd] = wx[it][dd];
+        __syncthreads();
+        for (int i = tid; i < N * 3; i += 256)
+            pout[(size_t)(i / 3) * Kp + x.feat_c + i % 3] = red[i] + red[N * 3 + i] + red[2 * N * 3 + i] + red[3 * N * 3 + i];
+        __syncthreads();
+    }
+    if (!L1) {
+        const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+        const float c0[1] = {cb}, c1[1] = {cg};
+        block_column_atomics<2, 2, 1>(smem, c0, c1, lane, wm, wn, k0, e.k_valid, e.dbeta + (size_t)rep * e.stat_stride,
+                                      e.dgamma + (size_t)rep * e.stat_stride);
+    }
+}
+
+// workgroups per k block of a fused wide launch = partial dW blocks it writes (static: the reduce launch recomputes it)
+static int bwd_wide_splits(const gad_gemm_dx_args& ax) {
+    const long long per = (long long)ax.n_out[0] * ax.Kp;
+    long long g = (long long)g_opt_bwd_wide_slab * 1000000ll / per;
+    const int tiles = gad_cdiv(ax.n_rows, 64);
+    const int kb = ax.k_valid / 64;
+    if (g * kb > 1024) g = 1024 / kb;                    // (no more workgroups than fit the chip at once)
+    if (g > tiles) g = tiles;
+    if (g < 16) g = 16 < tiles ? 16 : tiles;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
 // dX and dW of one layer in one call.  The SA1 layers the two streaming kernels cover take the fused kernel
 // (gemm_bwd_stream_kernel); everything else runs gad_gemm_dw then gad_gemm_dx on the same stream.
 // ------------------------------------------------------------------------------------------------
+// the fused wide backward covers what gemm_dx_wide + gemm_dw_wide cover together: one group, BatchNorm + ReLU on both
+// sides (premasked gradients), N in {128, 256, 512}, K a multiple of 64; the gathered first layers with their scatter epilogue
+static bool bwd_wideable(const gad_gemm_dx_args& ax, const gad_gemm_dw_args& aw, bool vec) {
+    const gad_gemm_fwd_args& in = aw.in;
+    if (!g_opt_bwd_wide || !vec || ax.n_groups != 1 || in.n_groups != 1) return false;
+    if (ax.dz_off[0] != 0 || ax.w_off[0] != 0 || ax.gout_off[0] != 0 || in.zin_off[0] != 0 || aw.dz_off[0] != 0) return false;
+    const int N = ax.n_out[0];
+    if (N != 128 && N != 256 && N != 512) return false;
+    if (ax.n_rows < 2048 || (g_opt_bwd_wide == 2 && ax.n_rows < 16384) || ax.n_rows != in.n_rows || ax.n_rows_dev != in.n_rows_dev) return false;
+    if (in.n_out[0] != N || in.Kp != ax.Kp || in.ones_col >= 0 || !aw.partial || !aw.gacc || !ax.W) return false;
+    if (ax.k_valid % 64 != 0 || ax.k_valid < 64 || (long long)bwd_wide_splits(ax) * N * ax.Kp > aw.partial_elems) return false;   // (workspace of another route)
+    const gad_dz_src& d = ax.dz;
+    if (!d.z || d.z_pitch % 4 != 0 || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
+    if (d.gmode == 0 ? (d.g_pitch % 4 != 0 || !d.G) : (d.c % 4 != 0 || !d.argmax || !d.dout || !d.row_grp)) return false;
+    // both descriptions are of the same layer
+    if (d.z != aw.dz.z || d.gmode != aw.dz.gmode || d.G != aw.dz.G || d.dout != aw.dz.dout || d.argmax != aw.dz.argmax ||
+        d.row_w != aw.dz.row_w || d.coefP != aw.dz.coefP) return false;
+    if (ax.epilogue == 1) {                              // gathered first layer: scatter into the points' feature gradients
+        if (in.mode != 1 || d.gmode != 0 || !ax.dfeat || ax.daction || !ax.row_pt || ax.prev_dbeta || in.act_c != 0) return false;
+        if (in.feat_c % 64 != 0 || in.feat_c > 512 || ax.k_valid != in.feat_c || ax.feat_c != in.feat_c) return false;
+        return in.Kp == ((in.feat_c + 3 + 7) & ~7) && in.row_pt == ax.row_pt;
+    }
+    if (in.mode != 0 || !ax.prev_dbeta || !ax.store_masked || !ax.gout) return false;
+    if (!(ax.zprev && ax.prev_scale && ax.prev_shift && ax.prev_mean && ax.prev_istd && ax.prev_dgamma)) return false;
+    if (in.Kp % 64 != 0 || in.Kp > 512 || in.c_in != in.Kp || ax.k_valid != in.Kp || !in.scale || !in.shift || !in.relu || in.extra) return false;
+    return in.zin == ax.zprev && in.scale == ax.prev_scale && in.shift == ax.prev_shift && in.zin_pitch == ax.zprev_pitch;
+}
+
+static bool bwd_streamable(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* aw) {
+    const gad_gemm_fwd_args& in = aw->in;
+    if (!g_opt_bwd_fused) return false;
+    const bool vec = dz_vectorizable(ax->dz, ax->dz_off, ax->n_out, ax->n_groups);
+    int k_used = in.mode == 0 ? in.c_in + (in.extra ? 1 : 0) : in.feat_c + 3 + in.act_c;
+    bool fused = dx_streamable(*ax, vec) && dw_streamable(*aw, k_used);
+    // the two descriptions must be of the same layer: same dZ source, and dW's input = the layer dX feeds
+    return fused && ax->dz.z == aw->dz.z && ax->dz.gmode == aw->dz.gmode && ax->dz.G == aw->dz.G && ax->dz.dout == aw->dz.dout &&
+           ax->dz.argmax == aw->dz.argmax && ax->dz.row_w == aw->dz.row_w && ax->n_rows == in.n_rows && ax->n_rows_dev == in.n_rows_dev &&
+           ax->n_out[0] == in.n_out[0] && in.zin == ax->zprev && in.scale == ax->prev_scale && in.shift == ax->prev_shift &&
+           in.zin_pitch == 64 && ax->gout && ax->prev_dgamma;
+}
+
+// the reduce launch of a fused backward call whose aw->row_splits was GAD_DW_REDUCE_LATER (include/gaddpg.h): sums the partial
+// dW blocks that call left in aw->partial into the arena.  A layer gad_gemm_bwd does not fuse has reduced already: no-op.
+extern "C" int gad_gemm_dw_reduce(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* aw, void* stream) {
+    GAD_REQUIRE(ax && aw, GAD_ERR_NULL, "gemm_dw_reduce: null pointer");
+    const gad_gemm_fwd_args& in = aw->in;
+    if (ax->n_rows <= 0) return GAD_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = dz_vectorizable(ax->dz, ax->dz_off, ax->n_out, ax->n_groups);
+    const bool streamable = bwd_streamable(ax, aw);
+    if (!streamable && bwd_wideable(*ax, *aw, vec)) {
+        const int splits = bwd_wide_splits(*ax);
+        const int k_used = in.mode == 1 ? in.feat_c + 3 : in.Kp;
+        Groups gr = make_groups(1, aw->dz_off, in.w_off, in.zin_off, in.n_out);
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)in.n_out[0] * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), 1), dim3(256), 0,
+                           st, aw->partial, (long long)splits * in.n_out[0] * in.Kp, gr, in.n_rows_dev, ax->n_rows, splits, in.Kp, k_used,
+                           aw->gacc, 1);
+        GAD_CHECK_LAUNCH("dw_reduce");
+        return GAD_OK;
+    }
+    if (streamable) {
+        const int wgs = DW_STREAM_SPLITS;
+        const int splits = ax->n_out[0] == 64 ? 2 * wgs : wgs;
+        Groups gr = make_groups(1, aw->dz_off, in.w_off, in.zin_off, in.n_out);
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)in.n_out[0] * 64, 256), gad_cdiv(splits, DW_RED_CHUNK), 1), dim3(256), 0, st,
+                           aw->partial, (long long)splits * in.n_out[0] * 64, gr, in.n_rows_dev, ax->n_rows, splits, 64, 64, aw->gacc, 1);
+        GAD_CHECK_LAUNCH("dw_reduce");
+    }
+    return GAD_OK;
+}
+
 extern "C" int gad_gemm_bwd(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* aw, void* stream) {
     GAD_REQUIRE(ax && aw, GAD_ERR_NULL, "gemm_bwd: null pointer");
     const gad_gemm_fwd_args& in = aw->in;
-    bool fused = g_opt_bwd_fused != 0;
-    if (fused) {
-        const bool vec = dz_vectorizable(ax->dz, ax->dz_off, ax->n_out, ax->n_groups);
-        int k_used = in.mode == 0 ? in.c_in + (in.extra ? 1 : 0) : in.feat_c + 3 + in.act_c;
-        fused = dx_streamable(*ax, vec) && dw_streamable(*aw, k_used);
-        // the two descriptions must be of the same layer: same dZ source, and dW's input = the layer dX feeds
-        fused = fused && ax->dz.z == aw->dz.z && ax->dz.gmode == aw->dz.gmode && ax->dz.G == aw->dz.G && ax->dz.dout == aw->dz.dout &&
-                ax->dz.argmax == aw->dz.argmax && ax->dz.row_w == aw->dz.row_w && ax->n_rows == in.n_rows && ax->n_rows_dev == in.n_rows_dev &&
-                ax->n_out[0] == in.n_out[0] && in.zin == ax->zprev && in.scale == ax->prev_scale && in.shift == ax->prev_shift &&
-                in.zin_pitch == 64 && ax->gout && ax->prev_dgamma;
+    const bool later = aw->row_splits == GAD_DW_REDUCE_LATER;          // the caller launches gad_gemm_dw_reduce itself
+    const bool vec0 = dz_vectorizable(ax->dz, ax->dz_off, ax->n_out, ax->n_groups);
+    const bool streamable = bwd_streamable(ax, aw);                    // (the SA1 shapes: the streaming kernel has precedence)
+    if (!streamable && bwd_wideable(*ax, *aw, vec0)) {
+        unsigned long long* ts = gad_take_timing_slot();
+        (void)gad_take_grid_rows();
+        if (ax->n_rows <= 0) return GAD_OK;
+        const int N = ax->n_out[0], splits = bwd_wide_splits(*ax);
+        GAD_REQUIRE((long long)splits * N * in.Kp <= aw->partial_elems, GAD_ERR_SHAPE, "gemm_bwd(wide): partial workspace too small (%lld floats needed)",
+                    (long long)splits * N * in.Kp);
+        DzSrc d = make_dzsrc(ax->dz);
+        XSrc x = make_xsrc(in);
+        DxEpi e;
+        e.mode = ax->epilogue; e.gout = ax->gout; e.gout_pitch = ax->gout_pitch; e.k_valid = ax->k_valid;
+        e.zprev = ax->zprev; e.zprev_pitch = ax->zprev_pitch; e.ps = ax->prev_scale; e.pt = ax->prev_shift;
+        e.pm = ax->prev_mean; e.pi = ax->prev_istd; e.dbeta = ax->prev_dbeta; e.dgamma = ax->prev_dgamma;
+        e.stat_stride = ax->stat_stride; e.store_masked = 1;
+        e.dfeat = ax->dfeat; e.feat_c = ax->feat_c; e.row_pt = ax->row_pt; e.row_grp = ax->row_grp; e.daction = nullptr; e.act_c = 0; e.gps = 1;
+        hipStream_t st = (hipStream_t)stream;
+        const dim3 grid(splits, ax->k_valid / 64);
+#define LAUNCH_BWW(NIT, GM, L1) hipLaunchKernelGGL((gemm_bwd_wide_kernel<NIT, GM, L1>), grid, dim3(256), 0, st, d, x, ax->n_rows_dev, ax->n_rows, ax->W, ax->Kp, e, aw->partial, ts)
+        const bool l1 = ax->epilogue == 1, pooled = ax->dz.gmode != 0;
+        if (N == 128) { if (l1) LAUNCH_BWW(2, 0, 1); else if (pooled) LAUNCH_BWW(2, 1, 0); else LAUNCH_BWW(2, 0, 0); }
+        else if (N == 256) { if (l1) LAUNCH_BWW(4, 0, 1); else if (pooled) LAUNCH_BWW(4, 1, 0); else LAUNCH_BWW(4, 0, 0); }
+        else { if (l1) LAUNCH_BWW(8, 0, 1); else if (pooled) LAUNCH_BWW(8, 1, 0); else LAUNCH_BWW(8, 0, 0); }
+#undef LAUNCH_BWW
+        GAD_CHECK_LAUNCH("gemm_bwd(wide)");
+        return later ? GAD_OK : gad_gemm_dw_reduce(ax, aw, stream);
     }
-    if (!fused) {
-        if (int e = gad_gemm_dw(aw, stream)) return e;
+    if (!streamable) {
+        gad_gemm_dw_args aw2 = *aw;
+        if (later) aw2.row_splits = 0;
+        if (int e = gad_gemm_dw(&aw2, stream)) return e;
         return gad_gemm_dx(ax, stream);
     }
     unsigned long long* ts = gad_take_timing_slot();
@@ -3497,9 +3891,5 @@ extern "C" int gad_gemm_bwd(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* 
     else { if (ax->dz.gmode == 0) LAUNCH_BWS(8, 0); else LAUNCH_BWS(8, 1); }
 #undef LAUNCH_BWS
     GAD_CHECK_LAUNCH("gemm_bwd(stream)");
-    Groups gr = make_groups(1, aw->dz_off, in.w_off, in.zin_off, in.n_out);
-    hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)in.n_out[0] * 64, 256), gad_cdiv(splits, DW_RED_CHUNK), 1), dim3(256), 0, st,
-                       aw->partial, (long long)splits * in.n_out[0] * 64, gr, in.n_rows_dev, rows, splits, 64, 64, aw->gacc, 1);
-    GAD_CHECK_LAUNCH("dw_reduce");
-    return GAD_OK;
+    return later ? GAD_OK : gad_gemm_dw_reduce(ax, aw, stream);
 }

@@ -430,7 +430,7 @@ _SIDE = {}
 SERIAL = False            # bench.py / diagnostics: run the whole step on ONE stream (per-kernel durations without contention)
 
 
-# Logical stream -> physical HIP stream.  MEASURED (MI355X, ROCm 7.2, tests/bisect_bench.sh): ROCm runs the streams of a
+# Logical stream -> physical HIP stream.  MEASURED (MI355X, ROCm 7.2, tools/bisect_bench.sh): ROCm runs the streams of a
 # process on GPU_MAX_HW_QUEUES = 4 hardware queues; a fifth active queue (GPU_MAX_HW_QUEUES >= 5, or one stream created with a
 # priority) drops the step rate from ~265 to ~140 steps/s, and streams beyond the fourth silently SHARE a queue with an earlier
 # one -- which of the step's chains then serialise depends on stream creation order (two extra prefetch streams cost 7 %).
@@ -466,6 +466,11 @@ def side_stream(device=None, which=0):
 
 CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
 FUSED_SA1_BWD = _os.environ.get("GAD_FUSED_SA1_BWD", "1") == "1"     # SA1 l3 / l2 backward: dX + dW in one kernel (gad_gemm_bwd)
+FUSED_WIDE_BWD = _os.environ.get("GAD_FUSED_WIDE_BWD", "0") == "1"   # SA2 / SA3 backward: dX + dW in one kernel (round 4; the reduce of its
+                                                                     # partial dW blocks forked onto the weight-gradient lane).  OFF: measured 4 - 6 % slower at B = 256 and 512 --
+                                                                     # the step follows the length of its dX chain, and dW on its own lane is nearly free
+WIDE_SLAB_ELEMS = 9 * 1024 * 1024        # floats per fused wide layer's partial-dW workspace (library option bwd_wide_slab <= 8)
+DW_REDUCE_LATER = -2                     # include/gaddpg.h GAD_DW_REDUCE_LATER
 DW_LANES = 1              # number of dW side streams (2 measured no faster: the overlapped kernels already saturate the GPU) the layers alternate between (each with its own partial workspace)
 
 
@@ -770,18 +775,27 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         stage = {"sa1": 0, "sa2": 1}.get(rows_kw.get("name"))
         if stage is not None:
             plan.call("gad_grid_rows_hint", hip.Ptr(geo.rows_hint.ctypes.data + 4 * stage))
-        if fused_dw:                       # SA1 l3 / l2: dX and dW in one streaming pass on this stream (gad_gemm_bwd)
+        if fused_dw:                       # dX and dW in one pass on this stream (gad_gemm_bwd): SA1 l3 / l2, SA2, SA3
             aw = fused_dw.pop()
             import ctypes as C
             plan.keep.extend([a, aw])
             plan.call("gad_gemm_bwd", C.byref(a), C.byref(aw))
             plan.tag_last("bwd.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
+            if aw.row_splits == DW_REDUCE_LATER:
+                # the f64 sum of the kernel's partial dW blocks leaves the dX chain: forked onto the weight-gradient lane
+                # (each layer has a workspace of its own, so the next layer's kernel cannot overwrite blocks still to be summed)
+                lane = dw_lane if CONCURRENT_DW else 0
+                dw_lanes.append(lane)
+                if lane:
+                    plan.fork(lane)
+                plan.call("gad_gemm_dw_reduce", C.byref(a), C.byref(aw), side=lane)
             return
         plan.call_struct("gad_gemm_dx", a)
         plan.tag_last("dx.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
 
     dw_lanes = []
     fused_dw = []
+    has_dx_now = [True]                # (set by layer(): a layer without a dX launch cannot take the fused call)
 
     def dw(s, l, dz, m, action):
         if not want_dw:
@@ -798,6 +812,12 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
             a.partial, a.partial_elems = _ptr(ws), ws.numel()
             fused_dw.append(a)
             return
+        if FUSED_WIDE_BWD and s in (1, 2) and has_dx_now[0]:
+            ws = dw_workspace(enc.flat.device, elems=WIDE_SLAB_ELEMS, lane=300 + 10 * dw_lane + 3 * s + l)
+            a.partial, a.partial_elems = _ptr(ws), ws.numel()
+            a.row_splits = DW_REDUCE_LATER
+            fused_dw.append(a)
+            return
         lane = dw_lane + (len(dw_lanes) % DW_LANES) if CONCURRENT_DW else 0
         dw_lanes.append(lane)
         ws = dw_workspace(enc.flat.device, lane=lane)
@@ -811,6 +831,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         """(dz for the dW, dz for the dX) of one layer: the dX carries the arena accumulation of dgamma / dbeta when
         there is one, else the dW does"""
         _bn_coef(plan, enc, slot, m, count, want_dw)
+        has_dx_now[0] = bool(has_dx)
         d_dw = bn_dz(m, z, count, not has_dx, **src)
         dw(s, l, d_dw, m, action)
         return bn_dz(m, z, count, True, **src) if has_dx else None

@@ -28,7 +28,7 @@ import torch.distributed as dist
 # backward pass.  Round 2 measured the bucketed exchange at -9 % at one rank because torch.distributed runs an asynchronous
 # collective on a stream of its own -- a fifth active queue in a process that keeps four busy (engine._PHYS).  With the
 # collectives issued through RCCL's C API on the weight-gradient lane itself (rccl.Communicator, DIRECT below) there is no
-# extra stream.  MEASURED, round 3, one rank, same box (tests/ab_dp2.sh; GAD_BENCH_FORCE_DP=1): no hooks 320.0 steps/s, one
+# extra stream.  MEASURED, round 3, one rank, same box (tools/ab_dp2.sh; GAD_BENCH_FORCE_DP=1): no hooks 320.0 steps/s, one
 # exchange per phase 318.7 (direct) / 316.8 (torch.distributed), bucketed 319.4 (direct) / 288.8 (torch.distributed).  So
 # buckets are the default wherever the direct path is available (backend 'nccl', world > 1); over gloo / torch.distributed
 # the default stays one exchange per phase.

@@ -317,8 +317,18 @@ int gad_gemm_dw(const gad_gemm_dw_args* host_args, void* stream);
  * dx writes the gradient of).  The SA1 layers of the update step (>= 32768 rows, 64 input channels, 64 / 128 outputs,
  * BatchNorm+ReLU on both sides: reference core/networks.py:29-51 through pointnet2's SharedMLP) run as one streaming
  * pass that reads z / dY / z_prev once for both products; any other layer runs gad_gemm_dw then gad_gemm_dx on
- * `stream`.  Results are those of the two separate calls (dW: f32 partial sums per workgroup, f64 across them).      */
+ * `stream`.  Results are those of the two separate calls (dW: f32 partial sums per workgroup, f64 across them).
+ * Round 4: the mid-size layers (SA2 / SA3: >= 2048 rows, 128 / 256 / 512 outputs, K a multiple of 64, incl. the gathered
+ * first layers with their scatter epilogue) are fused as well (gemm_bwd_wide_kernel): one staged dZ tile feeds the dX and
+ * the dW product.  The fused kernels leave one partial dW block per workgroup in dw->partial and a reduce launch sums
+ * them into the arena: on `stream` right behind the kernel, or -- dw->row_splits == GAD_DW_REDUCE_LATER -- by the caller's
+ * own gad_gemm_dw_reduce(dx, dw, other_stream) once `other_stream` waits for the kernel, which takes the reduce off the
+ * dX chain (the workspace must then stay untouched until that launch has run).                                          */
+#define GAD_DW_REDUCE_LATER (-2)
 int gad_gemm_bwd(const gad_gemm_dx_args* dx, const gad_gemm_dw_args* dw, void* stream);
+/* the deferred reduce of a gad_gemm_bwd(dx, dw) call made with GAD_DW_REDUCE_LATER (same argument blocks); a no-op for a
+ * layer gad_gemm_bwd does not fuse (its dW was reduced by that call).                                                     */
+int gad_gemm_dw_reduce(const gad_gemm_dx_args* dx, const gad_gemm_dw_args* dw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * D. heads' losses (forward value + gradient wrt head outputs in one pass)

@@ -28,6 +28,8 @@ def _run(B, value, options, keep_slot=False):
     probe = torch.from_numpy(np.random.default_rng(5).normal(size=(B, 512)).astype(np.float32)).cuda()
     for k, v in options.items():
         hip.set_option(k, v)
+    fused_wide_was = engine.FUSED_WIDE_BWD
+    engine.FUSED_WIDE_BWD = bool(options.get("bwd_wide", 0))         # (the plans take the fused call only when asked to)
     try:
         enc = engine.EncoderNet(net.value_encoder if value else net.encoder, dev)
         slot = engine.EncoderSlot(geo, enc, dev)
@@ -48,8 +50,9 @@ def _run(B, value, options, keep_slot=False):
         if keep_slot:
             out.update(slot=slot, enc=enc, geo=geo)
     finally:
+        engine.FUSED_WIDE_BWD = fused_wide_was
         for k in options:
-            hip.set_option(k, 1)                       # library defaults of the family switches
+            hip.set_option(k, 0 if k == "bwd_wide" else 1)         # library defaults of the family switches
     return out
 
 
@@ -90,6 +93,10 @@ def test_specialised_and_tile_kernels_agree(value):
     unfused = _run(B, value, {"bwd_fused": 0})
     bad += _compare(unfused, default, acts, 1e-6, 1e-7, "same forward kernels (unfused backward):")
     bad += _compare(unfused, default, grads, 2e-4, 1e-5, "separate dX / dW vs fused SA1 backward:")
+    # round 4: the fused SA2 / SA3 dX + dW kernel (gemm_bwd_wide_kernel) against the separate wide-tile kernels
+    fused_w = _run(B, value, {"bwd_wide": 1})
+    bad += _compare(fused_w, default, acts, 1e-6, 1e-7, "same forward kernels (fused wide backward):")
+    bad += _compare(fused_w, default, grads, 2e-4, 1e-5, "separate wide dX / dW vs fused wide backward:")
     assert not bad, "\n".join(bad)
 
 

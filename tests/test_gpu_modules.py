@@ -136,7 +136,7 @@ def test_checkpoint_roundtrip(tmp_path):
     r2 = a2.update_parameters(b1, a2.update_step, 1, noise_u=u)
     # not bit-for-bit: the BatchNorm / weight-gradient sums are built with f64 atomics whose order varies run to run;
     # analytically-zero gradient entries (bias in front of a BatchNorm, weights of dead inputs) are then pure noise
-    # and Adam's sign-like first steps move them by +-lr in either run (tests/diag_determinism.py: ~95 of 254 tensors
+    # and Adam's sign-like first steps move them by +-lr in either run (tools/diag_determinism.py: ~95 of 254 tensors
     # differ between two identical runs, in every kernel configuration).  The losses barely see those weights.
     for k in r1:
         assert_close(r2[k], r1[k], 5e-3, 1e-6, "after reload: " + k)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of library option values on ONE box:  bash tests/ab_opt.sh <option> "<v1> <v2> ..." [repeats]
+# A/B of library option values on ONE box:  bash tools/ab_opt.sh <option> "<v1> <v2> ..." [repeats]
 OPT=$1; VALS=$2; N=${3:-3}
 for i in $(seq $N); do for v in $VALS; do
   env GAD_OPT_$OPT=$v python bench.py --steps 200 --warmup 30 --no-cpu-baseline --no-host-rate --no-sa-kernel 2>/dev/null | tail -1 | \

@@ -1,6 +1,6 @@
 """Diagnostic: per-layer GEMM launch durations of the B=256 update step with the step serialised on one stream
 (engine.SERIAL: every kernel has the GPU to itself), every tagged launch stamped by the kernel itself (engine.timing_start).
-    python tests/diag_alone.py [tag-prefix ...]      e.g.  python tests/diag_alone.py dw. dx."""
+    python tools/diag_alone.py [tag-prefix ...]      e.g.  python tools/diag_alone.py dw. dx."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
 """Diagnostic: configs[3] radius search / query_and_group timings, cell-list vs brute-force tile scan.
-    python tests/diag_bq.py [modes ...] [qg]"""
+    python tools/diag_bq.py [modes ...] [qg]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

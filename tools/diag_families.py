@@ -58,8 +58,8 @@ for _ in range(6):
     step(sync=True)
 base = None
 for opts in configs:
-    for k in ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny", "fwd_wide", "dx_wide", "dw_wide", "bwd_fused"):
-        hip.set_option(k, opts.get(k, 1))
+    for k in ("fwd_stream", "dx_stream", "dw_stream", "fwd_skinny", "dx_skinny", "dw_skinny", "fwd_wide", "dx_wide", "dw_wide", "bwd_fused", "bwd_wide"):
+        hip.set_option(k, opts.get(k, 0 if k == "bwd_wide" else 1))
     for _ in range(4):
         step(sync=True)
     alone, cnt = probe(True)

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): micro-benchmark of gad_gemm_fwd (ACT input mode) on the step's layer shapes.
-    python -m tests.diag_gemm"""
+    python -m tools.diag_gemm"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,7 +1,7 @@
 """Diagnostic (not a test): 3000 DDPG update steps at B=256 fed by the GPU-resident replay mirror -- finite losses,
 learning curves, device memory.  Round-1 run: 265 steps/s including sampling; critic_loss 0.072 -> 0.011, aux losses
 0.36 -> 0.25, bc_loss flat (the synthetic expert actions are noise).
-    python tests/diag_long_run.py"""
+    python tools/diag_long_run.py"""
 import sys, time, numpy as np, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from ga_ddpg_amd.api import make_agent

@@ -1,5 +1,5 @@
 """Diagnostic (not a test): error of the HIP step vs the CPU oracle as a function of batch size.
-    python -m tests.diag_parity 32 128
+    python -m tools.diag_parity 32 128
 Prints max-abs and max-norm-relative errors of one DDPG step that starts from identical parameters."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,7 +1,7 @@
 """Diagnostic: per phase of one update step, WHEN the host enqueues it and WHEN the GPU runs it (untraced: HIP events
 recorded on the phase's own stream + perf_counter).  A phase whose GPU start follows its host enqueue by microseconds is
 waiting for the host, not for data.
-    python tests/diag_phases.py"""
+    python tools/diag_phases.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -1,5 +1,5 @@
-"""Derived per-kernel table from the two SQ counter summaries tests/collect_profiles.sh writes (prof_pmc.py output):
-   python tests/prof_derived.py gpurun_out/r03_rocprofv3_pmc_SQ_mfma.txt gpurun_out/r03_rocprofv3_pmc_SQ_waits.txt
+"""Derived per-kernel table from the two SQ counter summaries tools/collect_profiles.sh writes (prof_pmc.py output):
+   python tools/prof_derived.py gpurun_out/r03_rocprofv3_pmc_SQ_mfma.txt gpurun_out/r03_rocprofv3_pmc_SQ_waits.txt
 Counter rows are per dispatch and XCD (8 per dispatch; 32 CUs each).  Columns:
   mfma_busy   SQ_VALU_MFMA_BUSY_CYCLES / (32 x SQ_BUSY_CYCLES): share of CU-cycles with the matrix pipe busy
   valu/mfma   SQ_INSTS_VALU / SQ_INSTS_MFMA (SQ_INSTS_VALU counts the MFMAs too)

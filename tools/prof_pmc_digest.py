@@ -1,5 +1,5 @@
-"""Digest of a tests/prof_pmc.py summary (SQ MFMA / VALU counters): per kernel the MFMA-busy fraction, executed FP32-MFMA
-TFLOP/s and VALU instructions per MFMA.   python tests/prof_pmc_digest.py <summary.txt>"""
+"""Digest of a tools/prof_pmc.py summary (SQ MFMA / VALU counters): per kernel the MFMA-busy fraction, executed FP32-MFMA
+TFLOP/s and VALU instructions per MFMA.   python tools/prof_pmc_digest.py <summary.txt>"""
 import re
 import sys
 
