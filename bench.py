@@ -99,6 +99,54 @@ def sa_kernel_hbm(iters=50):
                     "Infinity Cache, so part of the write-back to HBM overlaps the next launch"}
 
 
+def sa_kernel_mfma(iters=6):
+    """SURVEY 8d "config 4b" (BASELINE configs[3]): the FUSED set-abstraction stack -- two PointnetSAModules, radii 0.1 / 0.2,
+    B = 128, N = 4096 -- forward AND backward through the pointnet2_ops facade (torch.autograd.Function over the same
+    gemm_fwd / dX / dW kernels as the update step, de-duplicated neighbourhood rows), as the MFMA-bound member of the family:
+    executed FLOPs = live rows x K x N x 2 per layer, x 3 for forward + dX + dW, over the wall time of one
+    forward + backward between two HIP events on the launching stream (geometry -- FPS, ball query, row compaction -- and
+    the facade's tensor copies included: this is the operator as a user calls it, not a kernel in isolation)."""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    B, N = 128, 4096
+    g = torch.Generator(device="cuda").manual_seed(SEED)
+    xyz = torch.rand(B, N, 3, device="cuda", generator=g)
+    feats = torch.randn(B, 4, N, device="cuda", generator=g).requires_grad_(True)
+    sa = [pm.PointnetSAModule(npoint=512, radius=0.1, nsample=64, mlp=[4, 64, 64, 128]).cuda().train(),
+          pm.PointnetSAModule(npoint=128, radius=0.2, nsample=128, mlp=[128, 128, 128, 256]).cuda().train()]
+    probe = torch.randn(B, 256, 128, device="cuda", generator=g)
+
+    def fwd_bwd():
+        x1, f1 = sa[0](xyz, feats)
+        _, f2 = sa[1](x1, f1)
+        (f2 * probe).sum().backward()
+
+    for _ in range(2):
+        fwd_bwd()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        fwd_bwd()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    rows, flops = [], 0.0
+    for mod, dims in ((sa[0], [(7, 64), (64, 64), (64, 128)]), (sa[1], [(131, 128), (128, 128), (128, 256)])):
+        run = mod.__dict__["_gad_rt"]["net"].free[(B, N if mod is sa[0] else 512)][-1]
+        n = int(run.rows["n"].item())
+        rows.append(n)
+        flops += 3.0 * sum(2.0 * n * k * c for k, c in dims)
+    dense = 3.0 * B * (512 * 64 * (7 * 64 + 64 * 64 + 64 * 128) + 128 * 128 * (131 * 128 + 128 * 128 + 128 * 256)) * 2.0
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"kernel": "PointnetSAModule x 2 forward + backward through ga_ddpg_amd.pointnet2_ops (configs[3]: B=128, N=4096, "
+                      "npoint 512 / 128, radii 0.1 / 0.2, nsample 64 / 128)", "bound": "mfma", "ms_fwd_bwd": ms,
+            "live_rows": rows, "padded_rows": [B * 512 * 64, B * 128 * 128], "executed_gflop": flops / 1e9,
+            "achieved": tf, "peak": FP32_MFMA_PEAK / 1e12, "unit": "TFLOP/s", "frac": tf / (FP32_MFMA_PEAK / 1e12),
+            "dense_equiv_tflops": dense / (ms * 1e-3) / 1e12,
+            "note": "whole operator incl. FPS (512 of 4096 points: one CU per cloud, VALU-bound), ball query, row compaction and "
+                    "the autograd facade's copies; HIP events on the launching stream"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -453,6 +501,7 @@ def main():
         sa["query_and_group"] = sa_kernel_hbm()
         sa["query_and_group"]["traffic"] = tj.get("query_and_group", {}).get("bytes_per_launch")
         res["sa_kernel_hbm"] = sa
+        res["sa_kernel_mfma"] = sa_kernel_mfma()          # configs[3] "4b": the fused stack, forward + backward
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, host_batches[0], np.random.default_rng(3).random((B, 6)).astype(np.float32))
     else:

@@ -320,7 +320,10 @@ __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(float* __restrict__
     for (int g = blockIdx.y * gl + threadIdx.x / cpb; g < G; g += gstride) {
         const float v = dout[(size_t)g * C + c];
         float zp;
-        if (zmax) zp = zmax[(size_t)g * C + c];              // the winner's raw value, saved by gad_pool_finalize: no gather
+        // the winner's raw value, saved by gad_pool_finalize: no gather.  A channel with scale == 0 (gamma == 0) is constant
+        // over the rows: every row ties and the arg-max is the group's FIRST row (torch's max_pool2d), not the key's row
+        // whose value zmax holds -- there the routed row's value is gathered, so that dgamma sees the same x_hat as the reference
+        if (zmax && !(sc == 0.f && z && argmax)) zp = zmax[(size_t)g * C + c];
         else zp = z[(size_t)argmax[(size_t)g * C + c] * z_pitch + c];
         if (fmaf(zp, sc, sh) > 0.f) { sb += v; sg = fmaf(v, (zp - mu) * is, sg); }
         else if (mask) dout[(size_t)g * C + c] = 0.f;

@@ -12,8 +12,11 @@ pytestmark = pytest.mark.gpu
 SKIP = (".1.0.bias", ".1.3.bias")          # biases in front of a train-mode BatchNorm: analytically zero gradient
 
 
-@pytest.mark.parametrize("B,seed,policy_step", [(32, 1, False), (64, 2, False), (32, 3, True)])
+@pytest.mark.parametrize("B,seed,policy_step", [(32, 1, False), (64, 2, False), (32, 3, True), (256, 4, False)])
 def test_step_gradients_with_forced_decisions(B, seed, policy_step):
+    """B = 256 is the bench size: there the row counts route the layers to other kernels than at B <= 64
+    (wide tiles instead of 64 x 64 tiles for SA2 / SA3, the fused streaming backward for SA1) -- every gradient tensor is held
+    to the same criterion against the float64 oracle (two ~30 - 60 s CPU steps: float64 and float32 with the HIP decisions)."""
     from ga_ddpg_amd.core.replay_memory import BaseMemory
     from ga_ddpg_amd.experiments.config import load_cfg
     from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch

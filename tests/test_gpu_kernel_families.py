@@ -10,7 +10,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(B, value, options, keep_slot=False):
+def _run(B, value, options, keep_slot=False, mutate=None):
     from ga_ddpg_amd import engine, hip
     from ga_ddpg_amd.core.replay_memory import BaseMemory
     from ga_ddpg_amd.experiments.config import load_cfg
@@ -22,6 +22,8 @@ def _run(B, value, options, keep_slot=False):
     fill_synthetic_buffer(mem, 400, seed=11)
     batch = sample_valid_batch(mem, B, np.random.default_rng(3))
     net = _feature_net()
+    if mutate is not None:
+        mutate(net)
     geo = _geometry(B)
     geo.run(torch.from_numpy(batch["point_state_batch"]).cuda())
     action = torch.from_numpy(batch["action_batch"]).cuda() if value else None
@@ -135,3 +137,53 @@ def test_fused_pool_equals_segment_pool_operator(value):
             zm = out["zmax%d" % (s + 1)]
             live = out["F%d" % (s + 1)] > 0
             assert torch.equal(zm[live], z[Af.long(), cols][live]), "stage %d: zmax is not the raw value at the arg-max row" % (s + 1)
+
+
+def test_pooled_layers_with_zero_and_negative_gamma():
+    """the fused max-pool reduces sgn(gamma) * z per group, so channels with gamma < 0 (the minimum of z wins) and
+    gamma == 0 (the activation is constant over the rows: every row ties, torch keeps the FIRST row) are its special cases.
+    Pooled features and arg-max rows must equal the stand-alone segment max-pool operator on the same raw activations, and
+    dgamma of the pooled layers must equal sum_g dF[g, c] * x_hat[argmax[g, c], c] with that operator's arg-max rows -- for the
+    gamma == 0 channels this is the first row of each group, not the row whose raw value won."""
+    from ga_ddpg_amd import hip
+
+    def mutate(net):
+        with torch.no_grad():
+            for enc in (net.encoder, net.value_encoder):
+                for name, mod in enc.named_modules():
+                    if isinstance(mod, torch.nn.BatchNorm2d) and name.endswith(".7"):      # BatchNorm of each stage's third conv
+                        mod.weight[0:4] = 0.0
+                        mod.bias[0:2] = 0.3                                               # relu(shift) > 0: the gradient flows
+                        mod.bias[2:4] = -0.3
+                        mod.weight[4:12] = -mod.weight[4:12].abs() - 0.1
+    out = _run(48, True, {}, keep_slot=True, mutate=mutate)
+    slot, enc, geo = out["slot"], out["enc"], out["geo"]
+    grad = out["grad"]
+    for s in range(3):
+        m = enc.sa_mats[s][2]
+        assert float(m.bn.weight[0]) == 0.0 and float(m.bn.weight[5]) < 0.0, "the mutation did not reach stage %d" % (s + 1)
+        o = enc.bn_off[m.bn_index]
+        r = geo.rows[s]
+        F = torch.empty_like(slot.F[s])
+        A = torch.empty_like(slot.argmax[s])
+        sc, sh = slot.scale[o:o + m.n_out], slot.shift[o:o + m.n_out]
+        hip.call("gad_segment_pool", slot.Z[s][2], m.n_out, m.n_out, sc, sh, r["off"], r["G"], F, A)
+        torch.cuda.synchronize()
+        assert torch.equal(F, out["F%d" % (s + 1)]), "stage %d: pooled features differ" % (s + 1)
+        Af = out["A%d" % (s + 1)]
+        assert torch.equal(A[:, :12], Af[:, :12]), "stage %d: arg-max rows of the gamma <= 0 channels differ" % (s + 1)
+        first = r["off"][:r["G"]].long()
+        assert torch.equal(Af[:, :4].long(), first[:, None].expand(-1, 4)), "gamma == 0: the first row of every group"
+        # dgamma of the pooled layer from its definition, with the operator's arg-max rows
+        z = slot.Z[s][2]
+        cols = torch.arange(m.n_out, device=z.device).expand_as(A)
+        zs = z[A.long(), cols].double()
+        live = torch.addcmul(sh.double(), zs, sc.double()).float() > 0
+        xhat = (zs - slot.mean[o:o + m.n_out].double()) * slot.istd[o:o + m.n_out].double()
+        want = (out["dF%d" % (s + 1)].double() * live * xhat).sum(0)
+        idx = [i for i, p in enumerate(enc.flat.params) if p is m.bn.weight][0]
+        off = int(enc.flat.offsets[idx])
+        got = grad[off:off + m.n_out].double()
+        scale = float(want.abs().max()) + 1e-30
+        err = (got - want).abs() / scale
+        assert float(err.max()) <= 2e-4, "stage %d: dgamma of the pooled layer, worst channel %d: %.3e" % (s + 1, int(err.argmax()), float(err.max()))
