@@ -24,9 +24,9 @@ def main():
     marks = []
     orig = rt._download
 
-    def dl():
+    def dl(*a, **k):
         marks.append(time.perf_counter())
-        return orig()
+        return orig(*a, **k)
     rt._download = dl
     for i in range(10):
         agent.update_parameters(d, agent.update_step, i)
