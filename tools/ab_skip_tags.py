@@ -68,6 +68,13 @@ def main():
             return
         return plain_optim(self, which, policy_step)
     rtm.FusedRuntime._optim_phase = optim
+    plain_geo = engine.Geometry.run
+
+    def geo_run(self, pts):                                    # token "geometry": FPS / ball query / row compaction of both cloud sets
+        if "geometry" in skip["prefixes"]:
+            return
+        return plain_geo(self, pts)
+    engine.Geometry.run = geo_run
 
     def rate(n=150):
         for i in range(20):
