@@ -24,8 +24,10 @@ Extra objects on the JSON line:
                 symbol serves) / their summed duration, against the 157.3 TFLOP/s FP32-MFMA peak.  HBM-bound kernels
                 (streaming SA1 family): algorithmic bytes / duration against 8 TB/s.  `frac` <= 1 by construction;
                 `dense_equiv` is the same time priced with the padded-neighbourhood FLOPs the reference computes
-                (SURVEY 8d); `traffic` = HBM bytes per launch from this round's rocprofv3 PMC passes
-                (profiles/r02_traffic.json) or null; `kernel_avg_us` is what profiles/r02_*kernel_stats* must agree with.
+                (SURVEY 8d); `traffic` = HBM bytes per launch from this round's rocprofv3 PMC passes of the same command
+                (FETCH_SIZE / WRITE_SIZE in separate passes, tools/collect_profiles.sh -> profiles/rNN_traffic.json: counters
+                cannot be collected inside an untraced run; `traffic_source` names the file read) or null; `kernel_avg_us` is
+                what profiles/rNN_*kernel_stats* must agree with.
   kernels       the per-symbol table behind that choice (per-step time, launches, achieved fraction of its bound).
   cpu_baseline  the CPU oracle (pure-PyTorch port of the reference step) timed on this box's cores, rank 0 / N=1
                 only: ONE full B=256 update step (about 20 - 30 s of CPU work) after a small warm-up step.
@@ -415,17 +417,18 @@ def main():
     n_stamped = sum(1 for i in range(args.steps) if i % 8 in (0, 3))
     table_timed = kernel_table(timed_tags, rows, B, n_stamped)
     d0 = table_timed.get(dom, table[dom])                           # measured over the timed region itself
-    tj = {}
-    for rnd in ("r03", "r02"):                                      # this round's PMC passes (tools/collect_profiles.sh)
+    tj, tsrc = {}, None
+    for rnd in ("r04", "r03", "r02"):                               # this round's PMC passes (tools/collect_profiles.sh)
         tpath = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
+            tsrc = "profiles/%s_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" % rnd
             break
     roof = {"bound": d0["bound"], "kernel": dom, "layers": d0["tags"],
             "achieved": d0["executed_tflops"] if d0["bound"] == "mfma" else d0["algorithmic_gbps"],
             "peak": FP32_MFMA_PEAK / 1e12 if d0["bound"] == "mfma" else 8000.0,
             "unit": "TFLOP/s" if d0["bound"] == "mfma" else "GB/s", "frac": d0["frac"],
-            "traffic": tj.get(dom, {}).get("bytes_per_launch"),
+            "traffic": tj.get(dom, {}).get("bytes_per_launch"), "traffic_source": tsrc,
             "kernel_avg_us": d0["kernel_avg_us"], "launches_per_step": d0["launches_per_step"],
             "ms_per_step": d0["ms_per_step"], "dense_equiv_tflops": d0["dense_equiv_tflops"],
             "frac_alone": table_alone.get(dom, {}).get("frac"), "kernel_avg_us_alone": table_alone.get(dom, {}).get("kernel_avg_us"),
