@@ -47,8 +47,14 @@ def main():
         pre = skip["prefixes"]
         if not pre:
             return plain_run(self)
+        plans = tuple(x.split(":", 1)[1] for x in pre if x.startswith("plan:"))            # whole plans of the runtime ("plan:p_fwd")
+        if plans:
+            rt = agent._rt
+            for st in rt._sets:
+                if any(st["plans"].get(k) is self for k in plans):
+                    return
         calls = self.calls
-        tagp = tuple(x for x in pre if ":" not in x)
+        tagp = tuple(x for x in pre if ":" not in x and x not in ("optim", "geometry"))
         names = tuple(x.split(":", 1)[1] for x in pre if x.startswith("name:"))            # every call of that entry point
         untag = tuple(x.split(":", 1)[1] for x in pre if x.startswith("untagged:"))        # its untagged calls (the heads' GEMMs)
         keep = [c for i, c in enumerate(calls) if not ((tagp and i in self.tags and self.tags[i].startswith(tagp)) or
