@@ -91,16 +91,7 @@ class DataParallelContext(object):
         ok, why, comm = 1, "", None
         try:
             rccl.lib()
-            # HIP binds a stream to one of the process's four hardware queues at the stream's FIRST LAUNCH, and
-            # ncclCommInitRank launches on streams of its own: created before the step's streams have run anything, the
-            # communicator takes queues and the step's chains end up sharing one (measured: 318 -> 260 steps/s at one
-            # rank).  So every stream of the step launches something first.
-            dev = torch.cuda.current_device()
-            streams = [torch.cuda.current_stream(dev)] + [engine.side_stream(dev, w) for w in (1, 2, 3)]
-            for st in streams:
-                with torch.cuda.stream(st):
-                    torch.zeros(64, device="cuda").add_(1.0)
-            torch.cuda.synchronize(dev)
+            streams = self._warm_streams()
             comm = rccl.Communicator(self.group)
             if comm.count() != self.world:
                 raise RuntimeError("ncclCommCount = %d, group has %d ranks" % (comm.count(), self.world))
@@ -111,6 +102,7 @@ class DataParallelContext(object):
         except Exception as exc:                # noqa: BLE001 -- whatever went wrong, the job continues on torch.distributed
             ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
         flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+        self._make_comm_outcome = (ok, why)                 # (this rank's own attempt, before the agreement: tests / logs)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         if int(flag.item()) == 1:
             self._comm = comm
@@ -126,6 +118,21 @@ class DataParallelContext(object):
         self._comm = None
         print("ga_ddpg_amd.parallel: rank %d: direct RCCL path unavailable (%s): every collective of this context goes "
               "through torch.distributed" % (self.rank, why or "another rank failed"), file=sys.stderr, flush=True)
+
+    @staticmethod
+    def _warm_streams():
+        """HIP binds a stream to one of the process's four hardware queues at the stream's FIRST LAUNCH, and ncclCommInitRank
+        launches on streams of its own: created before the step's streams have run anything, the communicator takes queues
+        and the step's chains end up sharing one (measured: 318 -> 260 steps/s at one rank).  So every stream of the step
+        launches something first; returns those streams (the known-answer all-reduce then runs on each of them)."""
+        from . import engine
+        dev = torch.cuda.current_device()
+        streams = [torch.cuda.current_stream(dev)] + [engine.side_stream(dev, w) for w in (1, 2, 3)]
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.zeros(64, device="cuda").add_(1.0)
+        torch.cuda.synchronize(dev)
+        return streams
 
     def close(self):
         """destroy the RCCL communicator (before the process group goes away; registered with atexit)"""

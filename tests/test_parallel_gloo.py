@@ -128,3 +128,46 @@ def test_bucketed_reduce_is_bit_identical_to_one_exchange(tmp_path):
     got = torch.load(out)
     assert torch.equal(got["whole"], got["parts"])
     assert not torch.equal(got["whole"], got["local"])
+
+
+def _worker_agreement(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib
+    from ga_ddpg_amd import parallel, rccl
+
+    class FakeComm(object):                      # what a healthy communicator answers
+        def __init__(self, group=None):
+            if rank == 1:
+                raise RuntimeError("ncclCommInitRank failed: unhandled system error (injected on rank 1)")
+            self.destroyed = False
+
+        def count(self):
+            return world
+
+        def self_test(self):
+            return True
+
+        def destroy(self):
+            self.destroyed = True
+    rccl.Communicator = FakeComm
+    rccl.lib = lambda: object()
+    parallel.DataParallelContext._warm_streams = staticmethod(lambda: [contextlib.nullcontext()])
+    torch.cuda.stream = lambda st: st             # (CPU box: the stream contexts of the self-test are no-ops)
+    ctx = parallel.DataParallelContext()
+    ctx._direct = True                            # as with backend nccl on a GPU box
+    ctx._make_comm()
+    torch.save({"direct": ctx._direct, "comm": ctx._comm is None, "own": ctx._make_comm_outcome[0]}, os.path.join(out, "agree%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_failing_rccl_init_sends_every_rank_to_torch_distributed(tmp_path):
+    """VERDICT r03 item 2a, the asymmetric case no single-GPU box can produce: the direct-RCCL communicator comes up on rank
+    0 and fails on rank 1.  The outcome is agreed over the bootstrap group (all-reduce MIN of the ranks' flags): BOTH ranks
+    drop the direct path (rank 0 destroys the communicator it built) -- never a mix of transports inside one job."""
+    port = 31500 + os.getpid() % 2000
+    mp.spawn(_worker_agreement, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = [torch.load(os.path.join(str(tmp_path), "agree%d.pt" % r), weights_only=False) for r in range(2)]
+    assert r0["own"] == 1 and r1["own"] == 0                       # rank 0's own attempt succeeded, rank 1's failed
+    assert r0["direct"] is False and r1["direct"] is False and r0["comm"] and r1["comm"]
