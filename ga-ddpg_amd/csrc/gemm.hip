@@ -2028,8 +2028,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
 // wide-tile dX for the MID-SIZE layers (the backward twin of gemm_fwd_wide_kernel): a workgroup owns 64 rows x 128 input
 // channels of gout, a wavefront 32 x 64.  A operand: dZ[r][n] = P*dY - w*(Q + S*z) formed once per staged element from
 // 16-byte loads of z and dY (or of the pooled arg-max / gradient pair; the ReLU mask is already in dY: premasked), stored
-// row-major ([row][32 + 4]); B operand: W[n][k] as stored, written TRANSPOSED into LDS ([k][32 + 4], four ds_write_b32 per
-// staged float4: 16 per thread and K-tile against 32 MFMAs) so that both fragments are one ds_read_b128 per four MFMA steps.
+// row-major ([row][32 + 4]: one ds_read_b128 per four MFMA steps); B operand: W[n][k] kept AS STORED in LDS ([n][128 + 4], one
+// ds_write_b128 per staged float4), its fragments are conflict-free ds_read_b32 across k of row n = 8j+4h+i.  (Round 3 wrote
+// the W tile TRANSPOSED -- four ds_write_b32 per float4, 6 - 8 % bank-conflict cycles, 10 - 14 % LDS waits -- to read it back
+// with ds_read_b128: round 4 measured the stored layout 18 % faster, 20 - 37 us -> 16 - 30 us per launch, +2.3 % steps/s.)
 // Epilogue: dY of the previous layer masked by its ReLU (store_masked) + that layer's BatchNorm-backward sums.
 // ------------------------------------------------------------------------------------------------
 // SC = 1: scatter epilogue of the gathered first layers (SA2 / SA3: dX columns = the feature channels of the row's point):
@@ -2039,7 +2041,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
                                                               const float* __restrict__ W, int Kp, int n_out, DxEpi e,
                                                               unsigned long long* __restrict__ ts) {
     KTimer kt_(ts);
-    constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = (BM + BN) * P, VM = 512;
+    constexpr int BM = 64, BN = 128, P = KT + 4, PB = BN + 4, STAGE = BM * P + KT * PB, VM = 512;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 3 * VM + BM];
     __shared__ int32_t ptS[BM];                          // SC: the tile rows' points
     float* vP = smem + 2 * STAGE;                        // P | Q | S of this layer's channels
@@ -2128,10 +2130,8 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
                 *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {                    // W[n][k..k+3] -> Bs[k + i][n]
-                float* bp = Bs + bk4 * P + bn + 8 * u;
-                bp[0] = rb[u].x; bp[P] = rb[u].y; bp[2 * P] = rb[u].z; bp[3 * P] = rb[u].w;
-            }
+            for (int u = 0; u < 4; ++u)                      // W[n][k..k+3] as stored: Bs[n][k], one ds_write_b128 (no transposing stores)
+                *reinterpret_cast<float4*>(Bs + (bn + 8 * u) * PB + bk4) = rb[u];
         };
         load_regs(0);
         __syncthreads();                                 // vP visible; the previous row tile's LDS reads are done
@@ -2141,16 +2141,19 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const float* As = smem + (kt & 1) * STAGE + (wm * 32 + l31) * P + 4 * half;
-            const float* Bs = smem + (kt & 1) * STAGE + BM * P + (wn * 64 + l31) * P + 4 * half;
+            // B fragments: row n = 8 j + 4 h + i of the stored tile, this lane's column -- conflict-free ds_read_b32 across k
+            const float* Bs = smem + (kt & 1) * STAGE + BM * P + (4 * half) * PB + wn * 64 + l31;
             float4 a4 = *reinterpret_cast<const float4*>(As);
-            float4 b0 = *reinterpret_cast<const float4*>(Bs), b1 = *reinterpret_cast<const float4*>(Bs + 32 * P);
+            float4 b0 = make_float4(Bs[0], Bs[PB], Bs[2 * PB], Bs[3 * PB]);
+            float4 b1 = make_float4(Bs[32], Bs[PB + 32], Bs[2 * PB + 32], Bs[3 * PB + 32]);
 #pragma unroll
             for (int j = 0; j < KT / 8; ++j) {
                 float4 an = a4, bn0 = b0, bn1 = b1;
                 if (j + 1 < KT / 8) {
                     an = *reinterpret_cast<const float4*>(As + 8 * (j + 1));
-                    bn0 = *reinterpret_cast<const float4*>(Bs + 8 * (j + 1));
-                    bn1 = *reinterpret_cast<const float4*>(Bs + 32 * P + 8 * (j + 1));
+                    const float* bq = Bs + 8 * (j + 1) * PB;
+                    bn0 = make_float4(bq[0], bq[PB], bq[2 * PB], bq[3 * PB]);
+                    bn1 = make_float4(bq[32], bq[PB + 32], bq[2 * PB + 32], bq[3 * PB + 32]);
                 }
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b0.x, acc[0], 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b1.x, acc[1], 0, 0, 0);
