@@ -267,7 +267,8 @@ extern "C" int gad_pool_finalize(uint64_t* key, int C, int G, const int32_t* grp
     b.stat_sum = stat_sum; b.stat_sq = stat_sq; b.stat_stride = stat_stride; b.count = count; b.gamma = gamma; b.beta = beta;
     b.eps = eps; b.momentum = momentum; b.running_mean = running_mean; b.running_var = running_var; b.scale = scale;
     b.shift = shift; b.mean = mean; b.istd = istd;
-    int gx = gad_cdiv(G, 16 * 4);                 // four group steps per workgroup
+    int gx = gad_cdiv(G, 16);                     // one 16-group step per workgroup (four steps per workgroup: -1.2 % steps/s --
+                                                  // the launch is latency-bound, more workgroups = more loads in flight)
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(pool_finalize_kernel, dim3(gx, gad_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<unsigned long long*>(key), C, G, grp_off, b, out, argmax, zmax);
@@ -355,7 +356,7 @@ extern "C" int gad_pool_bwd_stats(float* dout, const int32_t* argmax, int G, int
     if (G == 0) return GAD_OK;
     const int cpb = C < 256 ? C : 256, gl = 256 / cpb;
     int gy = gad_cdiv(G, gl * 4);
-    if (gy > 512) gy = 512;
+    if (gy > 512) gy = 512;                       // (1024 / 2048 workgroups: -0.5 / -1 % steps/s -- more same-address atomics)
     if (gy < 1) gy = 1;
     hipLaunchKernelGGL(pool_bwd_stats_kernel, dim3(C / cpb, gy), dim3(256), 0, (hipStream_t)stream, dout, argmax, G, C,
                        z, z_pitch, scale, shift, mean, istd, dbeta, dgamma, stat_stride, mask_in_place, zmax);
