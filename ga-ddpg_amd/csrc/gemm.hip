@@ -35,6 +35,16 @@ __device__ __forceinline__ float4 f4sel(bool c, float4 a, float4 b) {
 }
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+typedef unsigned gad_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int vo, int so) {
+    const gad_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int vo, int so) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // operand producers.  Every producer is split in two so that global loads overlap the MFMAs:
 //   *_raw    issues the 16-byte loads of the NEXT tile into registers (no arithmetic on them),
@@ -2055,8 +2065,24 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     if ((int)(blockIdx.x * BM) >= n_rows) return;
     const int nk = n_out / KT;
+    // every global operand through a buffer descriptor: one 32-bit byte offset per lane and tile + a wave-uniform scalar offset
+    // per access instead of a 64-bit pointer multiply-add per load / store (on this part every VALU instruction is MFMA issue
+    // time: the epilogue's 64 address computations per tile were a third of the vector instructions of the N = 128 layers)
+    const int gpitch = GM == 0 ? d.g_pitch : d.c;
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7ffffffc, 0x00020000);
+    // previous layer's raw output / the gradient this launch writes: bounded by the live rows (reads past them give 0,
+    // stores past them are dropped)
+    const int zp_pitch4 = SC ? 0 : e.zprev_pitch * 4, go_pitch4 = SC ? 0 : e.gout_pitch * 4;
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SC ? W : e.zprev), 0, SC ? 0 : n_rows * zp_pitch4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(SC ? const_cast<float*>(W) : e.gout, 0, SC ? 0 : n_rows * go_pitch4, 0x00020000);
     const int c4 = (tid & 7) * 4, ur = tid >> 3;         // A staging: 16-byte chunk of the K-tile, row (ur, ur + 32)
     const int bk4 = (tid & 31) * 4, bn = tid >> 5;       // B staging: W rows bn, +8, +16, +24 of the K-tile, k chunk bk4
+    int vw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vw[u] = ((bn + 8 * u) * Kp + k0out + bk4) * 4;
     for (int i = tid; i < n_out; i += 256) {
         float Pc, Qc, Sc;
         dz_coef(d, i, Pc, Qc, Sc);
@@ -2078,34 +2104,29 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
         // this thread's two staged rows (clamped past the live count: their dZ is zeroed through the weight / validity)
-        int rr[2], grp[2];
+        int vz[2], vg[2];
         float wrow[2];
         bool live[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = row0 + ur + 32 * u;
             live[u] = r < n_rows;
-            rr[u] = live[u] ? r : n_rows - 1;
-            wrow[u] = d.row_w ? d.row_w[rr[u]] : 1.f;
-            grp[u] = GM == 1 ? d.row_grp[rr[u]] : 0;
+            const int rr = live[u] ? r : n_rows - 1;
+            wrow[u] = d.row_w ? d.row_w[rr] : 1.f;
+            vz[u] = (rr * d.z_pitch + c4) * 4;
+            vg[u] = ((GM == 1 ? d.row_grp[rr] : rr) * gpitch + c4) * 4;
         }
-        const int gpitch = GM == 0 ? d.g_pitch : d.c;
         float4 rz[2], rg[2], rb[4];
-        int4 ra[2];
+        gad_u32x4 ra[2];
         auto load_regs = [&](int kt) {
-            const int nb = kt * KT + c4;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                rz[u] = ldg4(d.z + (size_t)rr[u] * d.z_pitch + nb);
-                if (GM == 0) {
-                    rg[u] = ldg4(d.G + (size_t)rr[u] * gpitch + nb);
-                } else {
-                    ra[u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp[u] * gpitch + nb);
-                    rg[u] = ldg4(d.dout + (size_t)grp[u] * gpitch + nb);
-                }
+                rz[u] = buf_ld4(zr, vz[u], kt * (KT * 4));
+                rg[u] = buf_ld4(gr_, vg[u], kt * (KT * 4));
+                if (GM == 1) ra[u] = __builtin_amdgcn_raw_buffer_load_b128(ar, vg[u], kt * (KT * 4), 0);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rb[u] = ldg4(W + (size_t)(kt * KT + bn + 8 * u) * Kp + k0out + bk4);
+            for (int u = 0; u < 4; ++u) rb[u] = buf_ld4(wr, vw[u], kt * (KT * 4) * Kp);
         };
         auto write_lds = [&](int kt) {
             float* As = smem + (kt & 1) * STAGE;
@@ -2118,7 +2139,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
                 float4 g = rg[u];
                 const float4 z = rz[u];
                 if (GM == 1) {
-                    const int r = row0 + ur + 32 * u;        // the true row (a clamped row never matches an arg-max)
+                    const unsigned r = row0 + ur + 32 * u;   // the true row (a clamped row never matches an arg-max)
                     g.x = ra[u].x == r ? g.x : 0.f; g.y = ra[u].y == r ? g.y : 0.f;
                     g.z = ra[u].z == r ? g.z : 0.f; g.w = ra[u].w == r ? g.w : 0.f;
                 }
@@ -2182,26 +2203,24 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
             }
             continue;
         }
+        // (a row past the live count: z_prev reads 0 through the bounded descriptor, its accumulator row is exactly 0 -- its dZ
+        // was zeroed -- and the store is dropped)
+        const int rb0 = row0 + wm * 32;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const int k = k0out + wn * 64 + t * 32 + l31;
+            const int kcol = k0out + wn * 64 + t * 32 + l31;
+            const int vzp = (4 * half * e.zprev_pitch + kcol) * 4, vgo = (4 * half * e.gout_pitch + kcol) * 4;
             float zp[16];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int r = min(row0 + wm * 32 + acc_row(v, half), n_rows - 1);
-                zp[v] = e.zprev[(size_t)r * e.zprev_pitch + k];
-            }
+            for (int v = 0; v < 16; ++v) zp[v] = buf_ld(pr, vzp, (rb0 + (v & 3) + 8 * (v >> 2)) * zp_pitch4);
+            const float npm = -pm[t] * pi[t];
             float sb = 0.f, sg = 0.f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
-                const int r = row0 + wm * 32 + acc_row(v, half);
-                const bool ok = r < n_rows;
-                const float gv = acc[t][v];
-                const bool act = ok && fmaf(zp[v], ps[t], pt[t]) > 0.f;
-                const float ga = act ? gv : 0.f;
-                if (ok) e.gout[(size_t)r * e.gout_pitch + k] = ga;
+                const float ga = fmaf(zp[v], ps[t], pt[t]) > 0.f ? acc[t][v] : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), or_, vgo, (rb0 + (v & 3) + 8 * (v >> 2)) * go_pitch4, 0);
                 sb += ga;
-                sg = fmaf(ga, act ? (zp[v] - pm[t]) * pi[t] : 0.f, sg);
+                sg = fmaf(ga, fmaf(zp[v], pi[t], npm), sg);
             }
             cb[t] += sb; cg[t] += sg;
         }
@@ -3487,15 +3506,6 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
 // One LDS buffer + register prefetch (two barriers per 64 MFMAs): 36 KB of LDS and <= 128 VGPRs of accumulators leave room
 // for 3 - 4 workgroups per CU, which is what hides the barriers here.
 // ------------------------------------------------------------------------------------------------
-typedef unsigned gad_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int vo, int so) {
-    const gad_u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(r, vo, so, 0);
-    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-}
-__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int vo, int so) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
-}
-
 template <int NIT, int GM, int L1>
 __global__ __launch_bounds__(256, NIT >= 8 ? 1 : 2) void gemm_bwd_wide_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
                                                                int n_rows_static, const float* __restrict__ W, int Kp, DxEpi e,
