@@ -709,6 +709,16 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
     const int nk = (XM == 0 ? Kp : x.feat_c) / KT;
     const int c4 = (tid & 7) * 4;                        // this thread's 16-byte column chunk inside a K-tile
     const int ur = tid >> 3;                             // ... and row (A: rows ur, ur + 32; B: ur, +32, +64, +96)
+    // operands and output through buffer descriptors: a 32-bit byte offset per lane (set up once per row tile) + a scalar
+    // offset per access instead of 64-bit pointer arithmetic per load / store; the output descriptor is bounded by the live
+    // rows (a NULL zout: zero records), so stores of rows past them -- or of a pass that keeps no raw output -- are dropped
+    const __amdgpu_buffer_rsrc_t ar_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(XM == 0 ? x.zin : x.feat), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7ffffffc, 0x00020000);
+    const int zo_pitch4 = zout_pitch * 4;
+    const __amdgpu_buffer_rsrc_t zo_ = __builtin_amdgcn_make_buffer_rsrc(zout ? zout : const_cast<float*>(W), 0, zout ? n_rows * zo_pitch4 : 0, 0x00020000);
+    int vb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) vb[u] = ((n0 + ur + 32 * u) * Kp + c4) * 4;
     if (XM == 0) stage_affine<256>(sv, tv, x, 0, Kp);
 
     float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
@@ -730,18 +740,17 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         }
         // rows past the live count are clamped to the last live row (never stored, weight 0 in the statistics)
         const int ra0 = min(row0 + ur, n_rows - 1), ra1 = min(row0 + ur + 32, n_rows - 1);
-        const float* ap0 = XM == 0 ? x.zin + (size_t)ra0 * x.zin_pitch + c4 : x.feat + (size_t)x.row_pt[ra0] * x.feat_c + c4;
-        const float* ap1 = XM == 0 ? x.zin + (size_t)ra1 * x.zin_pitch + c4 : x.feat + (size_t)x.row_pt[ra1] * x.feat_c + c4;
-        const float* bp = W + (size_t)(n0 + ur) * Kp + c4;
+        const int va0 = ((XM == 0 ? ra0 * x.zin_pitch : x.row_pt[ra0] * x.feat_c) + c4) * 4;
+        const int va1 = ((XM == 0 ? ra1 * x.zin_pitch : x.row_pt[ra1] * x.feat_c) + c4) * 4;
         // two register sets: the global loads of a K-tile are issued TWO tiles before its LDS write (one tile of MFMAs is
         // ~0.85 us, less than the memory latency under load: with one set every K-tile's barrier waited for its loads)
         float4 ra2[2][2], rb2[2][4];
         auto load_regs = [&](int kt, auto setc) {
             constexpr int S = decltype(setc)::value;
-            const int k0 = kt * KT;
-            ra2[S][0] = ldg4(ap0 + k0); ra2[S][1] = ldg4(ap1 + k0);
+            const int k0 = kt * (KT * 4);
+            ra2[S][0] = buf_ld4(ar_, va0, k0); ra2[S][1] = buf_ld4(ar_, va1, k0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rb2[S][u] = ldg4(bp + (size_t)u * 32 * Kp + k0);
+            for (int u = 0; u < 4; ++u) rb2[S][u] = buf_ld4(wr_, vb[u], k0);
         };
         auto write_lds = [&](int kt, auto setc) {
             constexpr int S = decltype(setc)::value;
@@ -844,13 +853,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int n = n0 + wn * 64 + t * 32 + l31;
+            const int vzo = (4 * half * zout_pitch + n) * 4;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int il = wm * 32 + acc_row(v, half);
-                const int r = row0 + il;
                 const float zv = acc[t][v];
-                if (zout && r < n_rows) zout[(size_t)r * zout_pitch + n] = zv;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(zv), zo_, vzo, (row0 + wm * 32 + (v & 3) + 8 * (v >> 2)) * zo_pitch4, 0);
                 const float w = wS[il];
                 s1 = fmaf(w, zv, s1);
                 s2 = fmaf(w * zv, zv, s2);
