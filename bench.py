@@ -468,14 +468,16 @@ def main():
         # run-ahead steps: what a training loop over a HOST replay buffer gets
         from ga_ddpg_amd.core.prefetch import PrefetchSampler
         with PrefetchSampler(mem, B, depth=3, sample=lambda bs, clouds_out=None, pool=None: sample_valid_batch(mem, bs, rng2, clouds_out, pool)) as sampler:
-            for i in range(5):
+            for i in range(20):                          # (the producer thread and its pinned sets reach steady state)
                 agent.update_parameters(sampler.next(), agent.update_step, i, sync=False)
             torch.cuda.synchronize()
+            n_pf = max(150, n)
             t0 = time.perf_counter()
-            for i in range(n):
+            for i in range(n_pf):
                 agent.update_parameters(sampler.next(), agent.update_step, i, sync=False)
             agent.flush()
-            res["value_host_prefetch"] = n / (time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            res["value_host_prefetch"] = n_pf / (time.perf_counter() - t0)
         # same loop fed by the GPU-resident replay mirror: indices drawn on the host with the
         # reference's arithmetic, gather in HBM -- the rate a training loop sees without the 17 MB/step host gather
         from ga_ddpg_amd.core.device_replay import DeviceReplay
