@@ -62,6 +62,7 @@ struct XSrc {   // how a layer's INPUT row r, column c is produced (gad_gemm_fwd
     const float* action; int act_c; int gps;
     const int32_t* row_pt; const int32_t* row_grp;
     int affine;          // ACT input: a per-channel affine (scale / shift) is applied
+    gad_bn_fin bn;       // input layer's BatchNorm finalised in this launch's prologue (bn.stat_sum == NULL: scale / shift as given)
 };
 
 static XSrc make_xsrc(const gad_gemm_fwd_args& a) {
@@ -72,6 +73,10 @@ static XSrc make_xsrc(const gad_gemm_fwd_args& a) {
     x.action = a.action; x.act_c = a.act_c; x.gps = a.grp_per_sample > 0 ? a.grp_per_sample : 1;
     x.row_pt = a.row_pt; x.row_grp = a.row_grp;
     x.affine = (x.scale && x.shift) ? 1 : 0;
+    x.bn.stat_sum = a.in_stat_sum; x.bn.stat_sq = a.in_stat_sq; x.bn.stat_stride = a.in_stat_stride; x.bn.count = a.in_count;
+    x.bn.gamma = a.in_gamma; x.bn.beta = a.in_beta; x.bn.eps = a.in_eps; x.bn.momentum = a.in_momentum;
+    x.bn.running_mean = a.in_running_mean; x.bn.running_var = a.in_running_var;
+    x.bn.scale = const_cast<float*>(a.scale); x.bn.shift = const_cast<float*>(a.shift); x.bn.mean = a.in_mean; x.bn.istd = a.in_istd;
     return x;
 }
 
@@ -719,7 +724,21 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
     int vb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) vb[u] = ((n0 + ur + 32 * u) * Kp + c4) * 4;
-    if (XM == 0) stage_affine<256>(sv, tv, x, 0, Kp);
+    if (XM == 0) {
+        if (x.bn.stat_sum) {
+            // the input layer's train-mode BatchNorm finalised here (no gad_bn_finalize launch between the two GEMMs): every
+            // workgroup forms scale / shift of the K input channels from the f64 statistics -- 16 loads per channel, in flight
+            // beside the first K-tile's operand loads below -- and the first workgroup publishes them for the backward pass
+            const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+            for (int i = tid; i < Kp; i += 256) {
+                float sc, sh;
+                gad_bn_fin_channel(x.bn, i, writer, sc, sh);
+                sv[i] = sc; tv[i] = sh;
+            }
+        } else {
+            stage_affine<256>(sv, tv, x, 0, Kp);
+        }
+    }
 
     float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
     for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
@@ -879,6 +898,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
 static int g_opt_fwd_wide = 1;
 static int g_opt_dx_wide = 1, g_opt_dw_wide = 1;
 static int g_opt_bwd_fused = 1;
+static int g_opt_fwd_bn_prologue = 1;           // 0: routes with a BatchNorm-finalising prologue launch gad_bn_finalize instead (A/B)
 static int g_opt_bwd_wide = 0;                  // fused wide backward: 0 off (default: slower in the step), 1 SA2 and SA3 shapes, 2 only layers with >= 16384 rows (SA2)
 static int g_opt_bwd_wide_slab = 4;             // most partial-dW elements (millions) a fused launch may write: bounds its workgroups per k block
 static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch aims for (its partial slab = this x 128 x 128 floats)
@@ -1317,6 +1337,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "dw_wide")) { g_opt_dw_wide = value; return GAD_OK; }
     if (!strcmp(name, "bwd_fused")) { g_opt_bwd_fused = value; return GAD_OK; }
     if (!strcmp(name, "bwd_wide")) { g_opt_bwd_wide = value; return GAD_OK; }
+    if (!strcmp(name, "fwd_bn_prologue")) { g_opt_fwd_bn_prologue = value; return GAD_OK; }
     if (!strcmp(name, "bwd_wide_slab")) { g_opt_bwd_wide_slab = value > 0 ? value : 4; return GAD_OK; }
     if (!strcmp(name, "dw_wide_wgs")) { g_opt_dw_wide_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
@@ -1392,6 +1413,16 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
                     a->n_out[0], rows);
     }
     const int grid_rows = (a->n_rows_dev && rows_hint > 0 && rows_hint < rows) ? rows_hint : rows;   // gad_grid_rows_hint
+    if (a->in_stat_sum) {
+        GAD_REQUIRE(a->mode == 0 && a->n_groups == 1 && a->zin_off[0] == 0 && a->in_stat_sq && a->in_gamma && a->in_beta && a->scale && a->shift,
+                    GAD_ERR_NULL, "gemm_fwd: input-layer BatchNorm block needs an ACT input, one group, in_stat_sq, in_gamma, in_beta, scale, shift");
+        if (!(fwd_wideable(*a) && g_opt_fwd_bn_prologue)) {          // this route reads scale / shift as given: finalise first
+            if (int e = gad_bn_finalize(a->in_stat_sum, a->in_stat_sq, a->in_stat_stride, a->in_gamma, a->in_beta, a->c_in, a->in_count,
+                                        a->in_eps, a->in_momentum, a->in_running_mean, a->in_running_var, const_cast<float*>(a->scale),
+                                        const_cast<float*>(a->shift), a->in_mean, a->in_istd, stream)) return e;
+            x.bn.stat_sum = nullptr;
+        }
+    }
     if (!pe.key && fwd_skinny(*a)) {
         hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
                            gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);

@@ -466,6 +466,7 @@ def side_stream(device=None, which=0):
 
 CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
 FUSED_SA1_BWD = _os.environ.get("GAD_FUSED_SA1_BWD", "1") == "1"     # SA1 l3 / l2 backward: dX + dW in one kernel (gad_gemm_bwd)
+DEFER_BN_WIDE = _os.environ.get("GAD_DEFER_BN_WIDE", "1") == "1"     # SA2 / SA3 layers 1, 2: BatchNorm finalised in the consumer GEMM's prologue
 FUSED_WIDE_BWD = _os.environ.get("GAD_FUSED_WIDE_BWD", "0") == "1"   # SA2 / SA3 backward: dX + dW in one kernel (round 4; the reduce of its
                                                                      # partial dW blocks forked onto the weight-gradient lane).  OFF: measured 4 - 6 % slower at B = 256 and 512 --
                                                                      # the step follows the length of its dX chain, and dW on its own lane is nearly free
@@ -618,8 +619,10 @@ def _gather_src(geo, slot, s, action):
                 action=None, act_c=0, grp_per_sample=1, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]))
 
 
-def _layer_input(enc, slot, geo, s, l, action):
-    """gad_gemm_fwd_args fields describing the INPUT of SA stage s layer l (s==3: FC layer l)."""
+def _layer_input(enc, slot, geo, s, l, action, fin=None):
+    """gad_gemm_fwd_args fields describing the INPUT of SA stage s layer l (s==3: FC layer l).
+    fin = (count, update_running): the input layer's train-mode BatchNorm is finalised by THIS launch (gad_gemm_fwd_args
+    in_*: no gad_bn_finalize launch between the two GEMMs)"""
     if s < 3:
         r = geo.rows[s]
         base = dict(n_rows_dev=_ptr(r["n"]), n_rows=r["cap"], row_w=_ptr(r["w"]))
@@ -629,6 +632,13 @@ def _layer_input(enc, slot, geo, s, l, action):
             pm = enc.sa_mats[s][l - 1]
             base.update(mode=0, zin=_ptr(slot.Z[s][l - 1]), zin_pitch=pm.n_out, c_in=pm.n_out,
                         scale=_bn_vec(slot, enc, pm, "scale"), shift=_bn_vec(slot, enc, pm, "shift"), relu=1)
+            if fin is not None:
+                o, tot = enc.bn_off[pm.bn_index], slot.tot
+                base.update(in_stat_sum=_ptr(slot.stats, o, 8), in_stat_sq=_ptr(slot.stats, tot + o, 8), in_stat_stride=2 * tot,
+                            in_count=float(fin[0]), in_gamma=enc.flat.p_gamma(pm), in_beta=enc.flat.p_beta(pm), in_eps=BN_EPS,
+                            in_momentum=BN_MOMENTUM, in_running_mean=_ptr(enc.running_mean, o) if fin[1] else None,
+                            in_running_var=_ptr(enc.running_var, o) if fin[1] else None,
+                            in_mean=_bn_vec(slot, enc, pm, "mean"), in_istd=_bn_vec(slot, enc, pm, "istd"))
         return base
     B = slot.B
     if l == 0:
@@ -671,9 +681,15 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     plan.zero(slot.stats)
     tot = slot.tot
 
+    def deferred(s, l):
+        """layer (s, l)'s BatchNorm is finalised in the prologue of its consumer (s, l + 1): the SA2 / SA3 layers, whose
+        consumers are the wide-tile forward kernel"""
+        return DEFER_BN_WIDE and train and s in (1, 2) and l < 2
+
     def gemm(m, zout, s, l, tag, pool=None):
         o = enc.bn_off[m.bn_index]
-        kw = _layer_input(enc, slot, geo, s, l, action)
+        fin = (geo.counts[s], update_running) if (s < 3 and l > 0 and deferred(s, l - 1)) else None
+        kw = _layer_input(enc, slot, geo, s, l, action, fin=fin)
         if pool is not None:
             kw.update(pool_key=_ptr(slot.key[s], 0, 8), pool_row_grp=_ptr(geo.rows[s]["grp"]), pool_gamma=enc.flat.p_gamma(m))
         a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(zout), zout_pitch=m.n_out,
@@ -700,7 +716,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     for s in range(3):
         for l, m in enumerate(enc.sa_mats[s]):
             gemm(m, slot.Z[s][l], s, l, "fwd.sa%d.l%d" % (s + 1, l + 1), pool=(s if l == 2 else None))
-            if l < 2:
+            if l < 2 and not deferred(s, l):
                 _finalize(plan, enc, slot, m, geo.counts[s], train, update_running)
         pool_finalize(s, enc.sa_mats[s][2], geo.counts[s])
     for l, m in enumerate(enc.fc_mats):

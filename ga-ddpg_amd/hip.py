@@ -25,7 +25,10 @@ class GemmFwdArgs(C.Structure):
                 ("out_off", _i32 * MAX_GROUPS), ("n_out", _i32 * MAX_GROUPS),
                 ("W", _vp), ("Kp", _i32), ("zout", _vp), ("zout_pitch", _i32),
                 ("stat_sum", _vp), ("stat_sq", _vp), ("stat_stride", _i32),
-                ("pool_key", _vp), ("pool_row_grp", _vp), ("pool_gamma", _vp)]
+                ("pool_key", _vp), ("pool_row_grp", _vp), ("pool_gamma", _vp),
+                ("in_stat_sum", _vp), ("in_stat_sq", _vp), ("in_stat_stride", _i32), ("in_count", _f64),
+                ("in_gamma", _vp), ("in_beta", _vp), ("in_eps", _f32), ("in_momentum", _f32),
+                ("in_running_mean", _vp), ("in_running_var", _vp), ("in_mean", _vp), ("in_istd", _vp)]
 
 
 class DzSrc(C.Structure):

@@ -186,6 +186,23 @@ typedef struct {
     uint64_t* pool_key;        /* (groups, n_out) keys, all 0 before the launch                   */
     const int32_t* pool_row_grp; /* (rows) group index of every row (contiguous runs: CSR order)  */
     const float* pool_gamma;   /* (n_out) BatchNorm weight of THIS layer                          */
+    /* train-mode BatchNorm finalisation of the INPUT layer folded into this launch (round 4; in_stat_sum == NULL: not used --
+     * scale / shift are read as given).  The launch forms scale / shift of its c_in input channels from that layer's f64
+     * statistics (the arithmetic of gad_bn_finalize) in every workgroup's prologue; its FIRST workgroup also publishes them to
+     * `scale` / `shift` (written although declared const above), in_mean / in_istd, and applies the running-statistics update.
+     * A route that has no such prologue runs gad_bn_finalize on `stream` first: results do not depend on the route.         */
+    const double* in_stat_sum; /* (GAD_STAT_REPLICAS, in_stat_stride) sums of the input layer, its first channel */
+    const double* in_stat_sq;
+    int32_t in_stat_stride;
+    double in_count;           /* rows behind the statistics (padded duplicates included)         */
+    const float* in_gamma;
+    const float* in_beta;
+    float in_eps;
+    float in_momentum;
+    float* in_running_mean;    /* nullable                                                        */
+    float* in_running_var;
+    float* in_mean;            /* published for the backward pass; nullable                       */
+    float* in_istd;
 } gad_gemm_fwd_args;
 
 int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);
