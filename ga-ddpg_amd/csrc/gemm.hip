@@ -966,7 +966,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
         }
     }
-    if (XM == 0) stage_affine<512>(sv, tv, x, 0, KP);
+    if (XM == 0) {
+        if (x.bn.stat_sum) {                              // input layer's BatchNorm finalised here (see gemm_fwd_wide_kernel)
+            for (int i = tid; i < KP; i += 512) {
+                float sc, sh;
+                gad_bn_fin_channel(x.bn, i, blockIdx.x == 0, sc, sh);
+                sv[i] = sc; tv[i] = sh;
+            }
+        } else {
+            stage_affine<512>(sv, tv, x, 0, KP);
+        }
+    }
     __syncthreads();
 
     const int n_slabs = (n_rows + 31) >> 5;
@@ -1416,7 +1426,8 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     if (a->in_stat_sum) {
         GAD_REQUIRE(a->mode == 0 && a->n_groups == 1 && a->zin_off[0] == 0 && a->in_stat_sq && a->in_gamma && a->in_beta && a->scale && a->shift,
                     GAD_ERR_NULL, "gemm_fwd: input-layer BatchNorm block needs an ACT input, one group, in_stat_sq, in_gamma, in_beta, scale, shift");
-        if (!(fwd_wideable(*a) && g_opt_fwd_bn_prologue)) {          // this route reads scale / shift as given: finalise first
+        const bool has_prologue = fwd_wideable(*a) || (fwd_streamable(*a) && a->mode == 0);
+        if (!(has_prologue && g_opt_fwd_bn_prologue)) {               // this route reads scale / shift as given: finalise first
             if (int e = gad_bn_finalize(a->in_stat_sum, a->in_stat_sq, a->in_stat_stride, a->in_gamma, a->in_beta, a->c_in, a->in_count,
                                         a->in_eps, a->in_momentum, a->in_running_mean, a->in_running_var, const_cast<float*>(a->scale),
                                         const_cast<float*>(a->shift), a->in_mean, a->in_istd, stream)) return e;

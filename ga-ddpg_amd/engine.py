@@ -466,6 +466,7 @@ def side_stream(device=None, which=0):
 
 CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
 FUSED_SA1_BWD = _os.environ.get("GAD_FUSED_SA1_BWD", "1") == "1"     # SA1 l3 / l2 backward: dX + dW in one kernel (gad_gemm_bwd)
+DEFER_BN_STAGES = tuple(int(c) for c in _os.environ.get("GAD_DEFER_BN_STAGES", "012"))     # SA stages it applies to (A/B)
 DEFER_BN_WIDE = _os.environ.get("GAD_DEFER_BN_WIDE", "1") == "1"     # SA2 / SA3 layers 1, 2: BatchNorm finalised in the consumer GEMM's prologue
 FUSED_WIDE_BWD = _os.environ.get("GAD_FUSED_WIDE_BWD", "0") == "1"   # SA2 / SA3 backward: dX + dW in one kernel (round 4; the reduce of its
                                                                      # partial dW blocks forked onto the weight-gradient lane).  OFF: measured 4 - 6 % slower at B = 256 and 512 --
@@ -684,7 +685,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     def deferred(s, l):
         """layer (s, l)'s BatchNorm is finalised in the prologue of its consumer (s, l + 1): the SA2 / SA3 layers, whose
         consumers are the wide-tile forward kernel"""
-        return DEFER_BN_WIDE and train and s in (1, 2) and l < 2
+        return DEFER_BN_WIDE and train and s in DEFER_BN_STAGES and l < 2
 
     def gemm(m, zout, s, l, tag, pool=None):
         o = enc.bn_off[m.bn_index]
