@@ -173,8 +173,9 @@ struct DzSrc {   // gad_dz_src on the device
     const float* P; const float* Q; const float* S; const float* row_w;
     int gmode; const float* G; int g_pitch; const int32_t* argmax; const float* dout;
     const int32_t* row_grp; int c;
-    int coef;            // BatchNorm backward applies (P/Q/S given)
+    int coef;            // BatchNorm backward applies (P/Q/S given, or formed here from bw)
     int premasked;       // the ReLU mask is already in G / dout
+    gad_bn_bwd bw;       // bw.dbeta != NULL: P, Q, S are formed by this launch from the layer's f64 sums
 };
 
 static DzSrc make_dzsrc(const gad_dz_src& d) {
@@ -184,15 +185,21 @@ static DzSrc make_dzsrc(const gad_dz_src& d) {
     s.gmode = d.gmode; s.G = d.G; s.g_pitch = d.g_pitch; s.argmax = d.argmax; s.dout = d.dout;
     s.row_grp = d.row_grp; s.c = d.c;
     s.premasked = d.premasked;
-    s.coef = d.coefP != nullptr ? 1 : 0;
+    s.bw.dbeta = d.bn_dbeta; s.bw.dgamma = d.bn_dgamma; s.bw.stat_stride = d.bn_stride; s.bw.count = d.bn_count;
+    s.bw.mean = d.bn_mean; s.bw.istd = d.bn_istd; s.bw.gacc_gamma = d.gacc_gamma; s.bw.gacc_beta = d.gacc_beta;
+    s.bw.accumulate = (d.gacc_gamma || d.gacc_beta) ? 1 : 0;
+    s.coef = (d.coefP != nullptr || d.bn_dbeta != nullptr) ? 1 : 0;
     return s;
 }
 
 // P, Q, S of channel ch (identity when the layer has no BatchNorm)
-__device__ __forceinline__ void dz_coef(const DzSrc& d, int ch, float& P, float& Q, float& S) {
-    if (d.P) { P = d.P[ch]; Q = d.Q[ch]; S = d.S[ch]; }
+// `writer`: this thread is the launch's one thread for channel ch that may add dgamma / dbeta to the gradient arena
+__device__ __forceinline__ void dz_coef(const DzSrc& d, int ch, float& P, float& Q, float& S, bool writer = false) {
+    if (d.bw.dbeta) gad_bn_bwd_channel(d.bw, d.scale, ch, writer, P, Q, S);
+    else if (d.P) { P = d.P[ch]; Q = d.Q[ch]; S = d.S[ch]; }
     else { P = 1.f; Q = 0.f; S = 0.f; }
 }
+__device__ __forceinline__ bool first_workgroup() { return blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0; }
 
 struct DzRaw { float4 z; float4 g; int4 a; };
 
@@ -285,7 +292,7 @@ __device__ __forceinline__ void stage_dz_vecs(float* vec, const DzSrc& d, int of
     }
     for (int i = threadIdx.x; i < n; i += 256) {
         float P, Q, S;
-        dz_coef(d, off + i, P, Q, S);
+        dz_coef(d, off + i, P, Q, S, first_workgroup());
         vec[2 * VM + i] = P; vec[3 * VM + i] = Q; vec[4 * VM + i] = S;
     }
 }
@@ -1692,7 +1699,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
     }
     for (int i = tid; i < NO; i += 512) {
         float P, Q, S;
-        dz_coef(d, i, P, Q, S);
+        dz_coef(d, i, P, Q, S, first_workgroup());
         vec[i] = P; vec[NO + i] = Q; vec[2 * NO + i] = S;
     }
     __syncthreads();
@@ -1880,7 +1887,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
     }
     for (int i = tid; i < NO; i += 512) {
         float P, Q, S;
-        dz_coef(d, i, P, Q, S);
+        dz_coef(d, i, P, Q, S, first_workgroup());
         vec[i] = P; vec[NO + i] = Q; vec[2 * NO + i] = S;
     }
     __syncthreads();
@@ -2136,7 +2143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
     for (int u = 0; u < 4; ++u) vw[u] = ((bn + 8 * u) * Kp + k0out + bk4) * 4;
     for (int i = tid; i < n_out; i += 256) {
         float Pc, Qc, Sc;
-        dz_coef(d, i, Pc, Qc, Sc);
+        dz_coef(d, i, Pc, Qc, Sc, first_workgroup());
         vP[i] = Pc; vP[VM + i] = Qc; vP[2 * VM + i] = Sc;
     }
     (void)grS;
@@ -2413,7 +2420,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
         vec[i] = d.scale ? d.scale[doff + i] : 1.f;
         vec[VMAX + i] = d.shift ? d.shift[doff + i] : 0.f;
         float P, Q, S;
-        dz_coef(d, doff + i, P, Q, S);
+        dz_coef(d, doff + i, P, Q, S, first_workgroup());
         vec[2 * VMAX + i] = P; vec[3 * VMAX + i] = Q; vec[4 * VMAX + i] = S;
     }
     __syncthreads();
@@ -2556,6 +2563,19 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     }
 }
 
+// A route whose kernels read P / Q / S per lane (no cooperative prologue) cannot form the BatchNorm-backward coefficients
+// itself: gad_bn_bwd_coef runs first, into the caller's coefP / Q / S scratch, and the block is dropped.
+static int coef_fallback(gad_dz_src& dz, void* stream) {
+    if (!dz.bn_dbeta) return GAD_OK;
+    GAD_REQUIRE(dz.coefP && dz.coefQ && dz.coefS && dz.scale && dz.bn_dgamma && dz.bn_mean && dz.bn_istd, GAD_ERR_NULL,
+                "BatchNorm-backward block on a route without a prologue needs coefP / Q / S scratch");
+    if (int e = gad_bn_bwd_coef(dz.bn_dbeta, dz.bn_dgamma, dz.bn_stride, dz.scale, dz.bn_mean, dz.bn_istd, dz.c, dz.bn_count,
+                                const_cast<float*>(dz.coefP), const_cast<float*>(dz.coefQ), const_cast<float*>(dz.coefS), dz.gacc_gamma,
+                                dz.gacc_beta, stream)) return e;
+    dz.bn_dbeta = nullptr; dz.bn_dgamma = nullptr; dz.gacc_gamma = nullptr; dz.gacc_beta = nullptr;
+    return GAD_OK;
+}
+
 extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     unsigned long long* ts = gad_take_timing_slot();
     const int rows_hint = gad_take_grid_rows();
@@ -2593,6 +2613,11 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
         return GAD_OK;
     }
     if (dx_action_streamable(*a, vec)) {
+        if (a->dz.bn_dbeta) {                            // per-lane coefficients: formed by gad_bn_bwd_coef first
+            gad_dz_src dz2 = a->dz;
+            if (int e2 = coef_fallback(dz2, stream)) return e2;
+            d = make_dzsrc(dz2);
+        }
         hipLaunchKernelGGL(dx_action_stream_kernel, dim3(1024), dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->feat_c + 3, e, ts);
         GAD_CHECK_LAUNCH("gemm_dx(action stream)");
         return GAD_OK;
@@ -3217,7 +3242,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
     if (r_begin >= r_end) return;                        // the reducer skips the same splits
     for (int i = tid; i < BT; i += 256) {
         float Pc, Qc, Sc;
-        dz_coef(d, n0 + i, Pc, Qc, Sc);
+        dz_coef(d, n0 + i, Pc, Qc, Sc, blockIdx.y == 0 && k0 == 0);
         vP[i] = Pc; vP[VM + i] = Qc; vP[2 * VM + i] = Sc;
         if (XM == 0) { sv[i] = x.scale[k0 + i]; tv[i] = x.shift[k0 + i]; }
     }
@@ -3431,7 +3456,13 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     const int rows = in.n_rows;
     const bool vec = dz_vectorizable(a->dz, a->dz_off, in.n_out, in.n_groups);
-    if (g_opt_dw_skinny && in.mode == 0 && a->dz.gmode == 0 && !in.n_rows_dev && rows <= 1024) {
+    const bool skinny_route = g_opt_dw_skinny && in.mode == 0 && a->dz.gmode == 0 && !in.n_rows_dev && rows <= 1024;
+    if (a->dz.bn_dbeta && (skinny_route || dw_gather_streamable(*a, k_used) || dw_streamable(*a, k_used))) {
+        gad_dz_src dz2 = a->dz;                          // these kernels read P / Q / S per lane: gad_bn_bwd_coef first
+        if (int e2 = coef_fallback(dz2, stream)) return e2;
+        d = make_dzsrc(dz2);
+    }
+    if (skinny_route) {
         hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
                            gr, rows, in.Kp, k_used, a->gacc, ts);
         GAD_CHECK_LAUNCH("gemm_dw(skinny)");
@@ -3579,7 +3610,7 @@ __global__ __launch_bounds__(256, NIT >= 8 ? 1 : 2) void gemm_bwd_wide_kernel(Dz
     const int c4 = (tid & 15) * 4, sr = tid >> 4;         // staging: 16-byte chunk of the 64-wide tile, rows sr + 16 u
     for (int i = tid; i < N; i += 256) {
         float Pc, Qc, Sc;
-        dz_coef(d, i, Pc, Qc, Sc);
+        dz_coef(d, i, Pc, Qc, Sc, first_workgroup());
         vP[i] = Pc; vP[N + i] = Qc; vP[2 * N + i] = Sc;
     }
     // every global operand goes through a buffer descriptor: 32-bit per-lane byte offsets (one VGPR each, set up once per

@@ -466,6 +466,7 @@ def side_stream(device=None, which=0):
 
 CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
 FUSED_SA1_BWD = _os.environ.get("GAD_FUSED_SA1_BWD", "1") == "1"     # SA1 l3 / l2 backward: dX + dW in one kernel (gad_gemm_bwd)
+INLINE_BN_BWD = _os.environ.get("GAD_INLINE_BN_BWD", "1") == "1"     # BatchNorm-backward coefficients formed in the dX / dW prologues
 DEFER_BN_STAGES = tuple(int(c) for c in _os.environ.get("GAD_DEFER_BN_STAGES", "012"))     # SA stages it applies to (A/B)
 DEFER_BN_WIDE = _os.environ.get("GAD_DEFER_BN_WIDE", "1") == "1"     # SA2 / SA3 layers 1, 2: BatchNorm finalised in the consumer GEMM's prologue
 FUSED_WIDE_BWD = _os.environ.get("GAD_FUSED_WIDE_BWD", "0") == "1"   # SA2 / SA3 backward: dX + dW in one kernel (round 4; the reduce of its
@@ -766,10 +767,18 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
                     prev_istd=_bn_vec(slot, enc, pm, "istd"), prev_dbeta=_ptr(slot.bstats, o, 8),
                     prev_dgamma=_ptr(slot.bstats, tot + o, 8), stat_stride=2 * tot, store_masked=1)
 
-    def bn_dz(m, z, count, accumulate, G=None, pooled=None, row_w=None):
+    def bn_dz(m, z, count, accumulate, G=None, pooled=None, row_w=None, inline=False):
         d = dict(z=_ptr(z), z_pitch=m.n_out, scale=_bn_vec(slot, enc, m, "scale"),
                  shift=_bn_vec(slot, enc, m, "shift"), relu=1, premasked=1, row_w=row_w, c=m.n_out)
         d["coefP"], d["coefQ"], d["coefS"] = _coef_ptrs(slot, enc, m)
+        if inline:
+            # P, Q, S formed in the consuming launch's prologue (no gad_bn_bwd_coef launch); the launch given `accumulate` adds
+            # dgamma / dbeta to the gradient arena
+            o = enc.bn_off[m.bn_index]
+            d.update(bn_dbeta=_ptr(slot.bstats, o, 8), bn_dgamma=_ptr(slot.bstats, tot + o, 8), bn_stride=2 * tot, bn_count=float(count),
+                     bn_mean=_bn_vec(slot, enc, m, "mean"), bn_istd=_bn_vec(slot, enc, m, "istd"))
+            if accumulate and want_dw:
+                d.update(gacc_gamma=_ptr(enc.flat.gacc, m.g_off, 8), gacc_beta=_ptr(enc.flat.gacc, m.b_off, 8))
         if pooled is None:
             d.update(gmode=0, G=_ptr(G), g_pitch=m.n_out)
         else:
@@ -847,11 +856,15 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     def layer(s, l, m, z, count, has_dx, **src):
         """(dz for the dW, dz for the dX) of one layer: the dX carries the arena accumulation of dgamma / dbeta when
         there is one, else the dW does"""
-        _bn_coef(plan, enc, slot, m, count, want_dw)
+        # SA3, SA2 and SA1 layers 3 / 2: the coefficients are formed in the dX / dW launches' own prologues (round 4); SA1
+        # layer 1 and the FC layers keep the launch (their weight-gradient kernels read P / Q / S per lane)
+        inline = INLINE_BN_BWD and s < 3 and not (s == 0 and l == 0)
+        if not inline:
+            _bn_coef(plan, enc, slot, m, count, want_dw)
         has_dx_now[0] = bool(has_dx)
-        d_dw = bn_dz(m, z, count, not has_dx, **src)
+        d_dw = bn_dz(m, z, count, not has_dx, inline=inline, **src)
         dw(s, l, d_dw, m, action)
-        return bn_dz(m, z, count, True, **src) if has_dx else None
+        return bn_dz(m, z, count, True, inline=inline, **src) if has_dx else None
 
     # ---- FC head ----
     fc1, fc2 = enc.fc_mats

@@ -35,7 +35,9 @@ class DzSrc(C.Structure):
     _fields_ = [("z", _vp), ("z_pitch", _i32), ("scale", _vp), ("shift", _vp), ("relu", _i32),
                 ("coefP", _vp), ("coefQ", _vp), ("coefS", _vp), ("row_w", _vp), ("gmode", _i32),
                 ("G", _vp), ("g_pitch", _i32), ("argmax", _vp), ("dout", _vp), ("row_grp", _vp),
-                ("c", _i32), ("premasked", _i32)]
+                ("c", _i32), ("premasked", _i32),
+                ("bn_dbeta", _vp), ("bn_dgamma", _vp), ("bn_stride", _i32), ("bn_count", _f64), ("bn_mean", _vp), ("bn_istd", _vp),
+                ("gacc_gamma", _vp), ("gacc_beta", _vp)]
 
 
 class GemmDxArgs(C.Structure):

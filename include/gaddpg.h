@@ -267,6 +267,20 @@ typedef struct {
     int32_t c;                 /* channels of this layer (n_out)                                 */
     int32_t premasked;         /* the ReLU mask is already applied to G / dout (dX epilogue with store_masked,
                                 * gad_pool_bwd_stats with mask_in_place): `relu`, scale and shift are not needed   */
+    /* BatchNorm-backward coefficients formed by the consuming launch itself (round 4; bn_dbeta == NULL: coefP / Q / S are
+     * read as given).  Every workgroup of a dX / dW launch forms P, Q, S of the layer's channels from the f64 sums
+     * (the arithmetic of gad_bn_bwd_coef: needs `scale`) in its prologue -- no gad_bn_bwd_coef launch in front of it; the
+     * launch whose block carries gacc_gamma / gacc_beta adds dgamma / dbeta to the gradient arena (first workgroup; give
+     * them to exactly ONE of the launches that consume a layer).  A route without such a prologue runs gad_bn_bwd_coef on
+     * `stream` first (coefP / Q / S must then point at scratch for its output).                                          */
+    const double* bn_dbeta;    /* (GAD_STAT_REPLICAS, bn_stride) sums of this layer, its first channel */
+    const double* bn_dgamma;
+    int32_t bn_stride;
+    double bn_count;
+    const float* bn_mean;
+    const float* bn_istd;
+    double* gacc_gamma;        /* nullable */
+    double* gacc_beta;
 } gad_dz_src;
 
 /* pooled-gradient statistics for the BN that feeds a segment pool: dbeta/dgamma f64 sums        */
