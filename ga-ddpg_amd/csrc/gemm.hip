@@ -1254,7 +1254,15 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     };
     if (j0 < j1 && staged(j0)) load_blk(j0);
     // the operand loads above are in flight while the input layer's per-channel affine is staged in LDS
-    if (x.affine) stage_affine<64 * SK_NW>(sv, tv, x, zoff, x.c_in);
+    if (x.bn.stat_sum) {                                      // the input layer's BatchNorm is finalised here (one group, zoff == 0)
+        const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int i = tid; i < x.c_in; i += 64 * SK_NW) {
+            float sc, sh;
+            gad_bn_fin_channel(x.bn, i, writer, sc, sh);
+            sv[i] = sc;
+            tv[i] = sh;
+        }
+    } else if (x.affine) stage_affine<64 * SK_NW>(sv, tv, x, zoff, x.c_in);
     __syncthreads();
     for (int jb = j0; jb < j1; jb += 4) {
         if (staged(jb)) {                                     // wave-uniform
@@ -1433,7 +1441,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     if (a->in_stat_sum) {
         GAD_REQUIRE(a->mode == 0 && a->n_groups == 1 && a->zin_off[0] == 0 && a->in_stat_sq && a->in_gamma && a->in_beta && a->scale && a->shift,
                     GAD_ERR_NULL, "gemm_fwd: input-layer BatchNorm block needs an ACT input, one group, in_stat_sq, in_gamma, in_beta, scale, shift");
-        const bool has_prologue = fwd_wideable(*a) || (fwd_streamable(*a) && a->mode == 0);
+        const bool has_prologue = fwd_wideable(*a) || (fwd_streamable(*a) && a->mode == 0) || (!pe.key && fwd_skinny(*a));
         if (!(has_prologue && g_opt_fwd_bn_prologue)) {               // this route reads scale / shift as given: finalise first
             if (int e = gad_bn_finalize(a->in_stat_sum, a->in_stat_sq, a->in_stat_stride, a->in_gamma, a->in_beta, a->c_in, a->in_count,
                                         a->in_eps, a->in_momentum, a->in_running_mean, a->in_running_var, const_cast<float*>(a->scale),

@@ -635,21 +635,29 @@ def _layer_input(enc, slot, geo, s, l, action, fin=None):
             base.update(mode=0, zin=_ptr(slot.Z[s][l - 1]), zin_pitch=pm.n_out, c_in=pm.n_out,
                         scale=_bn_vec(slot, enc, pm, "scale"), shift=_bn_vec(slot, enc, pm, "shift"), relu=1)
             if fin is not None:
-                o, tot = enc.bn_off[pm.bn_index], slot.tot
-                base.update(in_stat_sum=_ptr(slot.stats, o, 8), in_stat_sq=_ptr(slot.stats, tot + o, 8), in_stat_stride=2 * tot,
-                            in_count=float(fin[0]), in_gamma=enc.flat.p_gamma(pm), in_beta=enc.flat.p_beta(pm), in_eps=BN_EPS,
-                            in_momentum=BN_MOMENTUM, in_running_mean=_ptr(enc.running_mean, o) if fin[1] else None,
-                            in_running_var=_ptr(enc.running_var, o) if fin[1] else None,
-                            in_mean=_bn_vec(slot, enc, pm, "mean"), in_istd=_bn_vec(slot, enc, pm, "istd"))
+                base.update(_input_bn(enc, slot, pm, fin))
         return base
     B = slot.B
     if l == 0:
         return dict(n_rows=B, mode=0, zin=_ptr(slot.F[2]), zin_pitch=slot.F[2].shape[1], c_in=slot.F[2].shape[1],
                     relu=0, ones_col=enc.fc_mats[0].ones_col)
     pm = enc.fc_mats[0]
-    return dict(n_rows=B, mode=0, zin=_ptr(slot.Zfc[0]), zin_pitch=pm.n_out, c_in=pm.n_out,
+    base = dict(n_rows=B, mode=0, zin=_ptr(slot.Zfc[0]), zin_pitch=pm.n_out, c_in=pm.n_out,
                 scale=_bn_vec(slot, enc, pm, "scale"), shift=_bn_vec(slot, enc, pm, "shift"), relu=1,
                 ones_col=enc.fc_mats[1].ones_col)
+    if fin is not None:
+        base.update(_input_bn(enc, slot, pm, fin))
+    return base
+
+
+def _input_bn(enc, slot, pm, fin):
+    """gad_gemm_fwd_args in_* block: layer pm's train-mode BatchNorm, finalised by the launch that consumes its output"""
+    o, tot = enc.bn_off[pm.bn_index], slot.tot
+    return dict(in_stat_sum=_ptr(slot.stats, o, 8), in_stat_sq=_ptr(slot.stats, tot + o, 8), in_stat_stride=2 * tot,
+                in_count=float(fin[0]), in_gamma=enc.flat.p_gamma(pm), in_beta=enc.flat.p_beta(pm), in_eps=BN_EPS,
+                in_momentum=BN_MOMENTUM, in_running_mean=_ptr(enc.running_mean, o) if fin[1] else None,
+                in_running_var=_ptr(enc.running_var, o) if fin[1] else None,
+                in_mean=_bn_vec(slot, enc, pm, "mean"), in_istd=_bn_vec(slot, enc, pm, "istd"))
 
 
 def plan_running_update(enc, slot):
@@ -686,11 +694,13 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     def deferred(s, l):
         """layer (s, l)'s BatchNorm is finalised in the prologue of its consumer (s, l + 1): the SA2 / SA3 layers, whose
         consumers are the wide-tile forward kernel"""
+        if s == 3:
+            return DEFER_BN_WIDE and train and 3 in DEFER_BN_STAGES and l == 0      # FC 1, finalised by FC 2 (skinny kernel)
         return DEFER_BN_WIDE and train and s in DEFER_BN_STAGES and l < 2
 
     def gemm(m, zout, s, l, tag, pool=None):
         o = enc.bn_off[m.bn_index]
-        fin = (geo.counts[s], update_running) if (s < 3 and l > 0 and deferred(s, l - 1)) else None
+        fin = ((geo.counts[s] if s < 3 else float(slot.B)), update_running) if (l > 0 and deferred(s, l - 1)) else None
         kw = _layer_input(enc, slot, geo, s, l, action, fin=fin)
         if pool is not None:
             kw.update(pool_key=_ptr(slot.key[s], 0, 8), pool_row_grp=_ptr(geo.rows[s]["grp"]), pool_gamma=enc.flat.p_gamma(m))
@@ -723,7 +733,8 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
         pool_finalize(s, enc.sa_mats[s][2], geo.counts[s])
     for l, m in enumerate(enc.fc_mats):
         gemm(m, slot.Zfc[l], 3, l, "fwd.fc%d" % (l + 1))
-        _finalize(plan, enc, slot, m, float(slot.B), train, update_running)
+        if not deferred(3, l):
+            _finalize(plan, enc, slot, m, float(slot.B), train, update_running)
     return plan
 
 
