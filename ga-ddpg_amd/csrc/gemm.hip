@@ -86,6 +86,13 @@ __device__ __forceinline__ void stage_affine(float* sv, float* tv, const XSrc& x
     for (int i = threadIdx.x; i < n; i += NT) { sv[i] = x.scale[off + i]; tv[i] = x.shift[off + i]; }
 }
 
+// diagnostic build (-DGAD_X_PHASES=1, tools/ubench_phases.py): the streaming forward kernel writes each wavefront's cycles per
+// phase (wait + prefetch | MFMA loop | epilogue) into the launch's timing slot instead of the start / end stamps
+#ifdef GAD_X_PHASES
+#define GAD_PH_STAMP(t) t = (long long)__builtin_readcyclecounter()
+#else
+#define GAD_PH_STAMP(t)
+#endif
 struct XRaw { float4 a; float4 s; };     // a: the 16 raw bytes; s: special columns (tail tiles only)
 
 // number of leading "bulk" columns served by aligned 16-byte loads
@@ -947,7 +954,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
                                                                   double* __restrict__ stat_sum,
                                                                   double* __restrict__ stat_sq, int stat_stride, PoolEpi pe,
                                                                   unsigned long long* __restrict__ ts) {
+#ifdef GAD_X_PHASES
+    const long long kt_start = __builtin_readcyclecounter();
+#else
     KTimer kt(ts);
+#endif
     constexpr int KP = 8 * KJ, NO = 32 * TN, PW = KP + 4;
     __shared__ __attribute__((aligned(16))) float Ws[NO * PW];
     __shared__ __attribute__((aligned(16))) float sv[KP], tv[KP];
@@ -958,34 +969,6 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    {   // stage W: all 16-byte loads in flight before the first LDS store
-        constexpr int UNITS = NO * KJ * 2, UW = (UNITS + 511) / 512;
-        float4 wr[UW];
-#pragma unroll
-        for (int it = 0; it < UW; ++it) {
-            const int u = it * 512 + tid;
-            wr[it] = ldg4(W + (size_t)(u < UNITS ? u : 0) * 4);
-        }
-#pragma unroll
-        for (int it = 0; it < UW; ++it) {
-            const int u = it * 512 + tid;
-            const int n = u / (KJ * 2), c = (u % (KJ * 2)) * 4;
-            if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
-        }
-    }
-    if (XM == 0) {
-        if (x.bn.stat_sum) {                              // input layer's BatchNorm finalised here (see gemm_fwd_wide_kernel)
-            for (int i = tid; i < KP; i += 512) {
-                float sc, sh;
-                gad_bn_fin_channel(x.bn, i, blockIdx.x == 0, sc, sh);
-                sv[i] = sc; tv[i] = sh;
-            }
-        } else {
-            stage_affine<512>(sv, tv, x, 0, KP);
-        }
-    }
-    __syncthreads();
-
     const int n_slabs = (n_rows + 31) >> 5;
     // 8 wavefronts per workgroup, one workgroup per CU: wavefronts w and w+4 share a SIMD (cyclic placement).  Slabs
     // are dealt wave-major (w * gridDim + block), so the left-over slabs of the last round go to w = 0..3 first and
@@ -1070,11 +1053,46 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #pragma unroll
         for (int t = 0; t < TN; ++t) b4[t] = *reinterpret_cast<const float4*>(Ws + (t * 32 + l31) * PW + 8 * j + 4 * half);
     };
-    {
+    {   // the first slab's loads are in flight while W and the input layer's affine are staged
         const int pt0 = load_pt(slab);
         load_slab(slab, pt0, ra);
         pt_nxt = load_pt(slab + stride);
     }
+    {   // stage W: all 16-byte loads in flight before the first LDS store
+        constexpr int UNITS = NO * KJ * 2, UW = (UNITS + 511) / 512;
+        float4 wr[UW];
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 512 + tid;
+            wr[it] = ldg4(W + (size_t)(u < UNITS ? u : 0) * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 512 + tid;
+            const int n = u / (KJ * 2), c = (u % (KJ * 2)) * 4;
+            if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
+        }
+    }
+    if (XM == 0) {
+        if (x.bn.stat_sum) {                              // input layer's BatchNorm finalised here (see gemm_fwd_wide_kernel)
+            for (int i = tid; i < KP; i += 512) {
+                float sc, sh;
+                gad_bn_fin_channel(x.bn, i, blockIdx.x == 0, sc, sh);
+                sv[i] = sc; tv[i] = sh;
+            }
+        } else {
+            stage_affine<512>(sv, tv, x, 0, KP);
+        }
+    }
+    __syncthreads();
+
+#ifdef GAD_X_PHASES
+    long long tA = 0, tB = 0, tC = 0, ph_top = 0, ph_mfma = 0, ph_epi = 0;
+    int ph_n = 0;
+    long long tP, tS;
+    GAD_PH_STAMP(tP);
+    tS = (long long)kt_start;
+#endif
     for (; slab < slab_end; slab += stride) {
         load_slab(slab + stride, pt_nxt, rn);
         pt_nxt = load_pt(slab + 2 * stride);
@@ -1103,6 +1121,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
         float4 bn[TN];
         lds_b(0, bn);
+        GAD_PH_STAMP(tA);
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
             float4 b4[TN];
@@ -1129,6 +1148,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #pragma unroll
             for (int t = 0; t < TN; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4[t].w, acc[t], 0, 0, 0);
         }
+        GAD_PH_STAMP(tB);
         // epilogue: raw layer output (SGPR row offset + immediate column offset: no address arithmetic) and the
         // weighted BatchNorm partial sums, two accumulator rows per packed instruction
         const int zrow = slab * 32 * NO * 4;
@@ -1163,7 +1183,18 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         }
 #pragma unroll
         for (int j = 0; j < KJ; ++j) ra[j] = rn[j];
+#ifdef GAD_X_PHASES
+        GAD_PH_STAMP(tC);
+        ph_top += tA - tP; ph_mfma += tB - tA; ph_epi += tC - tB; tP = tC; ++ph_n;
+#endif
     }
+#ifdef GAD_X_PHASES
+    if (ts && lane == 0) {
+        const unsigned w = blockIdx.x * 8 + wave;
+        ts[2 * w] = ((unsigned long long)ph_mfma << 32) | (unsigned long long)(ph_epi & 0xffffffffu);
+        ts[2 * w + 1] = ((unsigned long long)ph_top << 32) | ((unsigned long long)(tP - tS) & 0xffffff00u) | (unsigned long long)ph_n;
+    }
+#endif
     if (POOL && range0 < slab_end * 32) {                // the group still open at the end of the range
 #pragma unroll
         for (int p = 0; p < 2; ++p)
