@@ -28,6 +28,11 @@ def _run(B, value, options, keep_slot=False, mutate=None):
     geo.run(torch.from_numpy(batch["point_state_batch"]).cuda())
     action = torch.from_numpy(batch["action_batch"]).cuda() if value else None
     probe = torch.from_numpy(np.random.default_rng(5).normal(size=(B, 512)).astype(np.float32)).cuda()
+    options = dict(options)
+    sched = {k: options.pop(k) for k in list(options) if k.isupper()}       # engine schedule switches (module constants)
+    sched_was = {k: getattr(engine, k) for k in sched}
+    for k, v in sched.items():
+        setattr(engine, k, v)
     for k, v in options.items():
         hip.set_option(k, v)
     fused_wide_was = engine.FUSED_WIDE_BWD
@@ -53,6 +58,8 @@ def _run(B, value, options, keep_slot=False, mutate=None):
             out.update(slot=slot, enc=enc, geo=geo)
     finally:
         engine.FUSED_WIDE_BWD = fused_wide_was
+        for k, v in sched_was.items():
+            setattr(engine, k, v)
         for k in options:
             hip.set_option(k, 0 if k == "bwd_wide" else 1)         # library defaults of the family switches
     return out
@@ -99,6 +106,42 @@ def test_specialised_and_tile_kernels_agree(value):
     fused_w = _run(B, value, {"bwd_wide": 1})
     bad += _compare(fused_w, default, acts, 1e-6, 1e-7, "same forward kernels (fused wide backward):")
     bad += _compare(fused_w, default, grads, 2e-4, 1e-5, "separate wide dX / dW vs fused wide backward:")
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("value", [False, True])
+def test_batchnorm_prologues_equal_the_standalone_launches(value):
+    """round 4: a layer's train-mode BatchNorm finalised in the prologue of the launch that consumes its output
+    (gad_gemm_fwd_args.in_*) and the BatchNorm-backward coefficients formed in the dX / dW prologues (gad_dz_src.bn_*) against the
+    stand-alone gad_bn_finalize / gad_bn_bwd_coef launches: the same arithmetic on the same sums, so every activation, published
+    statistic, running statistic and gradient agrees to the order of the f64 atomics.  With the specialised families switched
+    off the tile kernels -- which have no prologue -- take the blocks: the entry points then run the stand-alone launch
+    themselves, and the result must not depend on the route."""
+    B = 96
+    launches = dict(DEFER_BN_WIDE=False, INLINE_BN_BWD=False)
+    everywhere = dict(DEFER_BN_WIDE=True, DEFER_BN_STAGES=(0, 1, 2, 3), INLINE_BN_BWD=True)
+    ref = _run(B, value, launches)
+    acts = [k for k in ref if k[0] in "ZFzmir" and k != "rows"]
+    grads = [k for k in ref if k not in acts and k != "rows"]
+    bad = []
+    for name, opts in (("default plans", {}), ("every stage + FC pair", everywhere)):
+        got = _run(B, value, opts)
+        assert got["rows"] == ref["rows"]
+        bad += _compare(got, ref, acts, 1e-6, 1e-7, "%s, forward:" % name)
+        bad += _compare(got, ref, grads, 2e-5, 1e-6, "%s, gradients:" % name)
+    tile = {k: 0 for k in FAMILIES}
+    ref_t = _run(B, value, dict(tile, **launches))
+    got_t = _run(B, value, dict(tile, **everywhere))
+    bad += _compare(got_t, ref_t, acts, 1e-6, 1e-7, "tile kernels (entry points run the launches), forward:")
+    bad += _compare(got_t, ref_t, grads, 2e-5, 1e-6, "tile kernels (entry points run the launches), gradients:")
+    # gad_set_option("fwd_bn_prologue", 0): gad_gemm_fwd finalises with a launch of its own on every route
+    from ga_ddpg_amd import hip
+    hip.set_option("fwd_bn_prologue", 0)
+    try:
+        got_o = _run(B, value, everywhere)
+    finally:
+        hip.set_option("fwd_bn_prologue", 1)
+    bad += _compare(got_o, ref, acts, 1e-6, 1e-7, "fwd_bn_prologue = 0, forward:")
     assert not bad, "\n".join(bad)
 
 
