@@ -9,7 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("GAD_LIB_PATH") or os.path.join(_HERE, "libgaddpg.so")   # env override: kernel experiments
 MAX_GROUPS = 3
-STAT_REPLICAS = 8
+STAT_REPLICAS = 4
 
 _i32, _f32, _f64, _vp = C.c_int32, C.c_float, C.c_double, C.c_void_p
 

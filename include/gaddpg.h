@@ -133,9 +133,12 @@ int gad_rows_group_all(int G, int pts_per_group, int32_t* grp_off, int32_t* row_
  * ------------------------------------------------------------------------------------------- */
 
 #define GAD_MAX_GROUPS 3
-/* BatchNorm statistic accumulators are replicated: a block adds into replica blockIdx.x % 8 (bounds
- * same-address atomic contention); gad_bn_finalize / gad_bn_bwd_coef sum the replicas.               */
-#define GAD_STAT_REPLICAS 8
+/* BatchNorm statistic accumulators are replicated: a block adds into replica blockIdx.x % GAD_STAT_REPLICAS (bounds
+ * same-address atomic contention); gad_bn_finalize / gad_bn_bwd_coef and the consumers' prologues sum the replicas.
+ * 4 since ABI 7 (8 before: every consumer workgroup now reads them; 4 measured +0.5 %, 2 measured -0.2 %).       */
+#ifndef GAD_STAT_REPLICAS
+#define GAD_STAT_REPLICAS 4
+#endif
 
 typedef struct {
     /* rows */
