@@ -41,7 +41,9 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * 4: max-pool fused into the pooled layer's GEMM (pool_key fields, nullable
                                             * zout, gad_pool_finalize, zmax in gad_pool_bwd_stats); the deferred-BatchNorm
                                             * fields and the slab / graph switches of version 3 are gone;
-                                            * 5: gad_gemm_bwd, gad_optim_jobs, gad_last_kernel)                       */
+                                            * 5: gad_gemm_bwd, gad_optim_jobs, gad_last_kernel; 6: gad_gemm_dw_reduce,
+                                            * GAD_DW_REDUCE_LATER; 7: trailing BatchNorm blocks of gad_gemm_fwd_args (in_*)
+                                            * and gad_dz_src (bn_*, gacc_*), GAD_STAT_REPLICAS 8 -> 4)                */
 /* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
  * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
  * with it instead of restating the routing rules.                                                  */
