@@ -970,6 +970,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     const int l31 = lane & 31, half = lane >> 5;
     const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
     const int n_slabs = (n_rows + 31) >> 5;
+#if GAD_X_PHASES == 2
+    long long st1, st2, st3, st4;
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    GAD_PH_STAMP(st1);                                   // the live row count has arrived
+#endif
     // 8 wavefronts per workgroup, one workgroup per CU: wavefronts w and w+4 share a SIMD (cyclic placement).  Slabs
     // are dealt wave-major (w * gridDim + block), so the left-over slabs of the last round go to w = 0..3 first and
     // every SIMD ends up with the same slab count +-1 (dealing block-major left whole CUs a round short: -20 %).
@@ -1058,13 +1063,26 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         load_slab(slab, pt0, ra);
         pt_nxt = load_pt(slab + stride);
     }
-    {   // stage W: all 16-byte loads in flight before the first LDS store
+    {   // stage W: all 16-byte loads in flight before the first LDS store; the input layer's per-channel affine (published vectors,
+        // or its BatchNorm finalised here from the statistic replicas -- see gemm_fwd_wide_kernel) is fetched UNDER the W loads:
+        // one global round trip for the whole prologue instead of two
         constexpr int UNITS = NO * KJ * 2, UW = (UNITS + 511) / 512;
         float4 wr[UW];
 #pragma unroll
         for (int it = 0; it < UW; ++it) {
             const int u = it * 512 + tid;
             wr[it] = ldg4(W + (size_t)(u < UNITS ? u : 0) * 4);
+        }
+#if GAD_X_PHASES == 2
+        GAD_PH_STAMP(st2);                               // first slab + W loads issued
+        __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        GAD_PH_STAMP(st3);                               // ... and arrived
+#endif
+        if (XM == 0 && tid < KP) {                        // (KP <= 64 < 512 threads: one channel per thread)
+            float sc, sh;
+            if (x.bn.stat_sum) gad_bn_fin_channel(x.bn, tid, blockIdx.x == 0, sc, sh);
+            else { sc = x.scale[tid]; sh = x.shift[tid]; }
+            sv[tid] = sc; tv[tid] = sh;
         }
 #pragma unroll
         for (int it = 0; it < UW; ++it) {
@@ -1073,18 +1091,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
         }
     }
-    if (XM == 0) {
-        if (x.bn.stat_sum) {                              // input layer's BatchNorm finalised here (see gemm_fwd_wide_kernel)
-            for (int i = tid; i < KP; i += 512) {
-                float sc, sh;
-                gad_bn_fin_channel(x.bn, i, blockIdx.x == 0, sc, sh);
-                sv[i] = sc; tv[i] = sh;
-            }
-        } else {
-            stage_affine<512>(sv, tv, x, 0, KP);
-        }
-    }
     __syncthreads();
+#if GAD_X_PHASES == 2
+    GAD_PH_STAMP(st4);
+    if (ts && lane == 0) {
+        auto c16 = [&](long long t) { const long long d = (t - kt_start) >> 2; return (unsigned long long)(d > 65535 ? 65535 : d); };
+        ts[2 * (blockIdx.x * 8 + wave)] = c16(st1) | (c16(st2) << 16) | (c16(st3) << 32) | (c16(st4) << 48);
+    }
+#endif
 
 #ifdef GAD_X_PHASES
     long long tA = 0, tB = 0, tC = 0, ph_top = 0, ph_mfma = 0, ph_epi = 0;
@@ -1191,7 +1205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #ifdef GAD_X_PHASES
     if (ts && lane == 0) {
         const unsigned w = blockIdx.x * 8 + wave;
-        ts[2 * w] = ((unsigned long long)ph_mfma << 32) | (unsigned long long)(ph_epi & 0xffffffffu);
+        if (GAD_X_PHASES != 2) ts[2 * w] = ((unsigned long long)ph_mfma << 32) | (unsigned long long)(ph_epi & 0xffffffffu);
         ts[2 * w + 1] = ((unsigned long long)ph_top << 32) | ((unsigned long long)(tP - tS) & 0xffffff00u) | (unsigned long long)ph_n;
     }
 #endif

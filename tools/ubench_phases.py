@@ -13,6 +13,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from ga_ddpg_amd import hip
+from ga_ddpg_amd.engine import _ptr
 from tools.ubench_overlap import layer
 
 
@@ -21,6 +22,17 @@ def main():
     L = hip.lib()
     for name, (rows, K, N) in (("SA1 layer 2 (64 -> 64)", (213034, 64, 64)), ("SA1 layer 3 shape, no pool (64 -> 128)", (213034, 64, 128))):
         a = layer(rows, K, N, dev)
+        if os.environ.get("PHASES_IN_BN") == "1":            # the consumer finalises its input layer's BatchNorm in its prologue
+            R = hip.STAT_REPLICAS
+            st = torch.zeros(R * 2 * K, dtype=torch.float64, device=dev)
+            st.view(R, 2, K)[:, 0] = 0.1 * rows / R
+            st.view(R, 2, K)[:, 1] = 1.0 * rows / R
+            g, b = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+            mean, istd = torch.empty(K, device=dev), torch.empty(K, device=dev)
+            a.in_stat_sum, a.in_stat_sq, a.in_stat_stride = _ptr(st, 0, 8), _ptr(st, K, 8), 2 * K
+            a.in_count, a.in_gamma, a.in_beta, a.in_eps, a.in_momentum = float(rows), _ptr(g), _ptr(b), 1e-5, 0.1
+            a.in_mean, a.in_istd = _ptr(mean), _ptr(istd)
+            a._keep2 = (st, g, b, mean, istd)
         for _ in range(3):
             hip.check(L.gad_gemm_fwd(C.byref(a), C.c_void_p(0)), "fwd")
         slots = torch.zeros(16384, 2, dtype=torch.int64, device=dev)
@@ -31,6 +43,12 @@ def main():
         mfma, epi = (s[:, 0] >> 32) & 0xffffffff, s[:, 0] & 0xffffffff
         top, life, n = (s[:, 1] >> 32) & 0xffffffff, s[:, 1] & 0xffffff00, s[:, 1] & 0xff
         live = n > 0
+        if os.environ.get("PHASES_STARTUP") == "1":          # -DGAD_X_PHASES=2 build: the prologue's stamps (units of 4 cycles)
+            q = s[:, 0]
+            parts = [((q >> sh) & 0xffff)[live].float().mean().item() * 4 for sh in (0, 16, 32, 48)]
+            print("%s: cycles from wavefront start to: live row count arrived %.0f | first slab + W loads issued %.0f | arrived %.0f | "
+                  "barrier passed %.0f" % ((name,) + tuple(parts)))
+            continue
         f = lambda t: "%7.0f" % float(t[live].float().mean())
         per = lambda t: "%6.0f" % float((t[live].float() / n[live].float()).mean())
         print("%s: %d wavefronts, slabs per wavefront %.2f (max %d)" % (name, int(live.sum()), float(n[live].float().mean()), int(n.max())))
