@@ -22,12 +22,25 @@ def build_shared_mlp(mlp_spec, bn=True):
     return nn.Sequential(*layers)
 
 
+class _Scale(nn.Module):
+    """one (radius, nsample, shared MLP) scale of a multi-scale module, shaped like a single-scale module for the fused path; it
+    shares the parent's grouper and MLP objects (the same nn.Parameters) and is NOT registered in the parent's module tree, so
+    the parent's state_dict keeps upstream's keys"""
+
+    def __init__(self, parent, i):
+        super().__init__()
+        self.npoint, self.radius, self.nsample = parent.npoint, parent.radii[i], parent.nsamples[i]
+        self.groupers = nn.ModuleList([parent.groupers[i]])
+        self.mlps = nn.ModuleList([parent.mlps[i]])
+
+
 class PointnetSAModuleMSG(nn.Module):
     def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
         super().__init__()
-        if len(radii) != 1 or not bn or not use_xyz:
-            raise NotImplementedError("GA-DDPG uses single-scale SA modules with bn=True, use_xyz=True")
+        if not bn or not use_xyz:
+            raise NotImplementedError("the fused set-abstraction path covers bn=True, use_xyz=True (every GA-DDPG module)")
         self.npoint = npoint
+        self.radii, self.nsamples = list(radii), list(nsamples)
         self.radius, self.nsample = radii[0], nsamples[0]
         self.groupers = nn.ModuleList()
         self.mlps = nn.ModuleList()
@@ -37,10 +50,23 @@ class PointnetSAModuleMSG(nn.Module):
                                  if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
             spec[0] += 3
             self.mlps.append(build_shared_mlp(spec, bn))
+        if len(self.radii) > 1:           # (plain attribute: kept out of _modules / state_dict)
+            object.__setattr__(self, "_scales", [_Scale(self, i) for i in range(len(self.radii))])
 
     def forward(self, xyz, features):
         from ..sa_function import sa_module_forward
-        return sa_module_forward(self, xyz, features)
+        if len(self.radii) == 1:
+            return sa_module_forward(self, xyz, features)
+        # multi-scale grouping (upstream PointnetSAModuleMSG.forward): every scale groups around the SAME centroids -- furthest
+        # point sampling is deterministic, so each scale's fused pass re-derives them -- and the pooled features are
+        # concatenated along the channels in scale order
+        import torch
+        new_xyz, outs = None, []
+        for sc in self._scales:
+            sc.train(self.training)
+            new_xyz, f = sa_module_forward(sc, xyz, features)
+            outs.append(f)
+        return new_xyz, torch.cat(outs, dim=1)
 
 
 class PointnetSAModule(PointnetSAModuleMSG):

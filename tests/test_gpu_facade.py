@@ -154,3 +154,40 @@ def test_eval_mode_backward_is_refused():
     mine.train()
     new_xyz, out = mine(xyz.clone().requires_grad_(True), feats)      # xyz is geometry: accepted, never differentiated
     assert not new_xyz.requires_grad and out.requires_grad
+
+
+def test_multi_scale_module_matches_oracle():
+    """PointnetSAModuleMSG with two scales (upstream's multi-scale grouping; no GA-DDPG config uses it): forward, input-feature
+    gradient and every parameter gradient against the CPU oracle's module, same state-dict keys."""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    from oracle.pointnet2_ops import pointnet2_modules as opm
+    from oracle.detfill import fill_module_
+    kw = dict(npoint=16, radii=[0.15, 0.3], nsamples=[16, 32], mlps=[[4, 16, 16, 32], [4, 16, 32, 64]])
+    mine = fill_module_(pm.PointnetSAModuleMSG(**kw), "msg", 7).cuda().train()
+    ref = fill_module_(opm.PointnetSAModuleMSG(**kw), "msg", 7).train()
+    assert list(mine.state_dict().keys()) == list(ref.state_dict().keys())
+    rng = np.random.default_rng(2)
+    xyz = torch.tensor(rng.random((3, 256, 3)), dtype=torch.float32)
+    feats = torch.tensor(rng.normal(size=(3, 4, 256)), dtype=torch.float32)
+    probe = torch.tensor(rng.normal(size=(3, 96, 16)), dtype=torch.float32)
+    f_ref = feats.clone().requires_grad_(True)
+    f_gpu = feats.cuda().requires_grad_(True)
+    x_ref, o_ref = ref(xyz, f_ref)
+    (o_ref * probe).sum().backward()
+    x_gpu, o_gpu = mine(xyz.cuda(), f_gpu)
+    (o_gpu * probe.cuda()).sum().backward()
+    assert o_gpu.shape == (3, 96, 16)
+    np.testing.assert_array_equal(x_gpu.cpu().numpy(), x_ref.numpy())
+    scale = float(o_ref.abs().max())
+    assert float((o_gpu.detach().cpu() - o_ref.detach()).abs().max()) <= 1e-4 * scale
+    gs = float(f_ref.grad.abs().max())
+    assert float((f_gpu.grad.cpu() - f_ref.grad).abs().max()) <= 2e-4 * gs
+    for (n, a), (_, b) in zip(mine.named_parameters(), ref.named_parameters()):
+        if float(b.grad.abs().max()) < 1e-6 * scale:
+            continue
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 5e-4 * float(b.grad.abs().max()), n
+    mine.eval(), ref.eval()
+    with torch.no_grad():
+        _, e_ref = ref(xyz, feats)
+        _, e_gpu = mine(xyz.cuda(), feats.cuda())
+    assert float((e_gpu.cpu() - e_ref).abs().max()) <= 1e-4 * float(e_ref.abs().max())
