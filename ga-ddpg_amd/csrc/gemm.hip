@@ -62,6 +62,7 @@ struct XSrc {   // how a layer's INPUT row r, column c is produced (gad_gemm_fwd
     const float* action; int act_c; int gps;
     const int32_t* row_pt; const int32_t* row_grp;
     int affine;          // ACT input: a per-channel affine (scale / shift) is applied
+    const float* pre_W; int pre_Kp;   // mode 2: the ACT input is RECOMPUTED from the gathered first layer (its packed weights)
     gad_bn_fin bn;       // input layer's BatchNorm finalised in this launch's prologue (bn.stat_sum == NULL: scale / shift as given)
 };
 
@@ -73,6 +74,7 @@ static XSrc make_xsrc(const gad_gemm_fwd_args& a) {
     x.action = a.action; x.act_c = a.act_c; x.gps = a.grp_per_sample > 0 ? a.grp_per_sample : 1;
     x.row_pt = a.row_pt; x.row_grp = a.row_grp;
     x.affine = (x.scale && x.shift) ? 1 : 0;
+    x.pre_W = a.pre_W; x.pre_Kp = a.pre_Kp;
     x.bn.stat_sum = a.in_stat_sum; x.bn.stat_sq = a.in_stat_sq; x.bn.stat_stride = a.in_stat_stride; x.bn.count = a.in_count;
     x.bn.gamma = a.in_gamma; x.bn.beta = a.in_beta; x.bn.eps = a.in_eps; x.bn.momentum = a.in_momentum;
     x.bn.running_mean = a.in_running_mean; x.bn.running_var = a.in_running_var;
@@ -921,6 +923,7 @@ static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch a
 static bool fwd_wideable(const gad_gemm_fwd_args& a) {
     if (!g_opt_fwd_wide || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
     if (a.n_rows < 2048 || a.n_out[0] % 128 != 0 || a.ones_col >= 0) return false;
+    if (a.mode == 2) return false;
     if (a.mode == 1)                                     // gathered first layer: features a multiple of 32, + 3 coordinates
         return g_opt_fwd_wide != 2 && !a.pool_key && a.act_c == 0 && a.feat_c % 32 == 0 && a.feat_c >= 32 && a.feat_c <= 512 &&
                a.Kp == ((a.feat_c + 3 + 7) & ~7);
@@ -947,6 +950,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // So the loop below is written for a minimal VALU instruction count: packed (2-wide) f32 math for the BatchNorm
 // affine and the statistics, buffer stores whose row offset lives in an SGPR (no per-store address arithmetic),
 // clamped row indices instead of per-element selects.
+// XM = 2 / 3 (round 4): the 64-channel ACT input is not read but RECOMPUTED per slab from the gathered rows of
+// the stage's first layer (packed K = 8 / 16: XM - 1 k groups) -- z1^T = W1 . X^T with the operands of the first layer's own
+// MFMAs swapped, so the accumulator registers of lane (row, half) ARE this kernel's A fragments (channels 8j + 4 half + i) and
+// every product and sum is the one the first layer's launch made (bit-equal z1): 8 / 16 extra MFMAs per slab instead of
+// 8 KB of z1 from HBM.  The first layer's launch still provides the BatchNorm statistics (and z1 for a pass that is
+// back-propagated).
 template <int KJ, int TN, int XM, bool POOL>
 __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
                                                                   int n_rows_static, const float* __restrict__ row_w,
@@ -960,6 +969,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     KTimer kt(ts);
 #endif
     constexpr int KP = 8 * KJ, NO = 32 * TN, PW = KP + 4;
+    constexpr bool RE = XM >= 2;                         // recomputed ACT input
+    constexpr int PK = RE ? XM - 1 : 0;                  // k groups of the recomputed first layer
+    constexpr bool ACT = XM == 0 || RE, GATHER = XM == 1 || RE;
+    constexpr int NG = RE ? PK : KJ;                     // k groups a slab's loads cover
+    static_assert(!RE || (KJ == 8 && !POOL), "recomputed input: 64 channels");
     __shared__ __attribute__((aligned(16))) float Ws[NO * PW];
     __shared__ __attribute__((aligned(16))) float sv[KP], tv[KP];
     __shared__ float red[2 * 8 * NO];
@@ -1015,15 +1029,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #pragma unroll
     for (int t = 0; t < TN; ++t) { csum[t] = f32x2{0.f, 0.f}; csq[t] = f32x2{0.f, 0.f}; }
 
-    XRaw ra[KJ], rn[KJ];
+    XRaw ra[NG], rn[NG];
+    float4 w1f[RE ? 2 : 1][RE ? PK : 1];                 // recomputed input: W1[32 b + l31][8 j + 4 half .. + 3], loop-invariant
+    if (RE) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < PK; ++j) w1f[b][j] = ldg4(x.pre_W + (size_t)(32 * b + l31) * x.pre_Kp + 8 * j + 4 * half);
+    }
     int pt_nxt = 0;
     auto load_pt = [&](int sl) {          // point index of the lane's row in slab sl (gather input only)
         const int r = min(sl * 32 + l31, n_rows - 1);
-        return (XM == 1 && sl < n_slabs) ? x.row_pt[r] : 0;
+        return (GATHER && sl < n_slabs) ? x.row_pt[r] : 0;
     };
-    auto load_slab = [&](int sl, int pt, XRaw (&dst)[KJ]) {
+    auto load_slab = [&](int sl, int pt, XRaw (&dst)[NG]) {
         const int r = min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1);      // clamped: ragged rows repeat the last row
-        if (XM == 1) {
+        if (GATHER) {
             // SA1's gathered rows [f (4) | x_j - c_i (3) | action (0 / 6)]: everything a row needs in FIVE loads (features,
             // point, centre as 12-byte loads, action as two), then each (k group, half) picks its four columns.  x_raw per
             // k group issued 11 scalar gathers per lane, most of them for columns the lane does not feed: the layer was
@@ -1044,7 +1065,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
                 a0 = u.x; a1 = u.y; a2 = u.z; a3 = v.x; a4 = v.y; a5 = v.z;
             }
 #pragma unroll
-            for (int j = 0; j < KJ; ++j) {
+            for (int j = 0; j < NG; ++j) {
                 dst[j].a = f;
                 if (j == 0) dst[j].s = make_float4(q0, q1, q2, a0);          // columns 4 .. 7 (half 1; half 0 takes the features)
                 else dst[j].s = half ? make_float4(a5, 0.f, 0.f, 0.f) : make_float4(a1, a2, a3, a4);
@@ -1052,7 +1073,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             return;
         }
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) dst[j] = x_raw<XM>(x, r, true, 0, 8 * j + 4 * half, XM == 1, pt);
+        for (int j = 0; j < NG; ++j) dst[j] = x_raw<GATHER ? 1 : 0>(x, r, true, 0, 8 * j + 4 * half, GATHER, pt);
     };
     auto lds_b = [&](int j, float4 (&b4)[TN]) {
 #pragma unroll
@@ -1078,7 +1099,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
         GAD_PH_STAMP(st3);                               // ... and arrived
 #endif
-        if (XM == 0 && tid < KP) {                        // (KP <= 64 < 512 threads: one channel per thread)
+        if (ACT && tid < KP) {                            // (KP <= 64 < 512 threads: one channel per thread)
             float sc, sh;
             if (x.bn.stat_sum) gad_bn_fin_channel(x.bn, tid, blockIdx.x == 0, sc, sh);
             else { sc = x.scale[tid]; sh = x.shift[tid]; }
@@ -1136,21 +1157,44 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         float4 bn[TN];
         lds_b(0, bn);
         GAD_PH_STAMP(tA);
+        f32x16 zacc[RE ? 2 : 1];
+        if (RE) {                   // z1^T tile: channels 32 b + (accumulator row), rows = lanes; the first layer's own products
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) zacc[b][v] = 0.f;
+#pragma unroll
+            for (int j = 0; j < PK; ++j) {
+                const float4 xb = x_finish<1>(x, ra[j], true, 8 * j + 4 * half, sv, tv);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) zacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[b][j].x, xb.x, zacc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) zacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[b][j].y, xb.y, zacc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) zacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[b][j].z, xb.z, zacc[b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) zacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1f[b][j].w, xb.w, zacc[b], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < KJ; ++j) {
             float4 b4[TN];
 #pragma unroll
             for (int t = 0; t < TN; ++t) b4[t] = bn[t];
             float4 a4;
-            if (XM == 0) {          // relu(scale * z + shift): two packed FMAs + four max
+            if (ACT) {              // relu(scale * z + shift): two packed FMAs + four max
                 const float4 s4 = *reinterpret_cast<const float4*>(sv + 8 * j + 4 * half);
                 const float4 t4 = *reinterpret_cast<const float4*>(tv + 8 * j + 4 * half);
-                const f32x2 lo = f32x2{ra[j].a.x, ra[j].a.y} * f32x2{s4.x, s4.y} + f32x2{t4.x, t4.y};
-                const f32x2 hi = f32x2{ra[j].a.z, ra[j].a.w} * f32x2{s4.z, s4.w} + f32x2{t4.z, t4.w};
+                float4 zr;
+                if (RE) zr = make_float4(zacc[j >> 2][4 * (j & 3)], zacc[j >> 2][4 * (j & 3) + 1], zacc[j >> 2][4 * (j & 3) + 2],
+                                         zacc[j >> 2][4 * (j & 3) + 3]);
+                else zr = ra[RE ? 0 : j].a;
+                const f32x2 lo = f32x2{zr.x, zr.y} * f32x2{s4.x, s4.y} + f32x2{t4.x, t4.y};
+                const f32x2 hi = f32x2{zr.z, zr.w} * f32x2{s4.z, s4.w} + f32x2{t4.z, t4.w};
                 a4 = make_float4(__builtin_fmaxf(lo.x, 0.f), __builtin_fmaxf(lo.y, 0.f), __builtin_fmaxf(hi.x, 0.f),
                                  __builtin_fmaxf(hi.y, 0.f));
             } else {
-                a4 = x_finish<XM>(x, ra[j], true, 8 * j + 4 * half, sv, tv);
+                a4 = x_finish<1>(x, ra[RE ? 0 : j], true, 8 * j + 4 * half, sv, tv);
             }
             if (j + 1 < KJ) lds_b(j + 1, bn);      // next group's fragments land under this group's MFMAs
 #pragma unroll
@@ -1186,7 +1230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #pragma unroll
             for (int t = 0; t < TN; ++t) {
                 const f32x2 zv = f32x2{acc[t][v], acc[t][v + 1]};
-                if (!POOL || store_z) {                  // (rows past n_rows / a NULL zout fall outside num_records: dropped)
+                if (store_z) {                           // (NULL zout: statistics / pooled maxima only; rows past n_rows are dropped)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zrsrc, zlane + t * 128, zrow + rb, GAD_STREAM_STORE_AUX);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v + 1]), zrsrc, zlane + t * 128, zrow + rb + NO * 4, GAD_STREAM_STORE_AUX);
                 }
@@ -1196,7 +1240,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             }
         }
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) ra[j] = rn[j];
+        for (int j = 0; j < NG; ++j) ra[j] = rn[j];
 #ifdef GAD_X_PHASES
         GAD_PH_STAMP(tC);
         ph_top += tA - tP; ph_mfma += tB - tA; ph_epi += tC - tB; tP = tC; ++ph_n;
@@ -1430,6 +1474,10 @@ static bool fwd_streamable(const gad_gemm_fwd_args& a) {
     if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || (a.zout && a.zout_pitch != a.n_out[0])) return false;
     if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
     if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && (a.scale && a.shift) && a.relu;
+    const bool sa1_rows = a.feat_c == 4 && (a.action ? a.act_c == 6 : a.act_c == 0);
+    if (a.mode == 2)                                                             // 64-channel input recomputed from SA1's gathered rows
+        return a.Kp == 64 && a.c_in == 64 && a.n_out[0] == 64 && !a.pool_key && a.ones_col < 0 && !a.extra && a.scale && a.shift && a.relu &&
+               a.pre_W && (a.pre_Kp == 8 || a.pre_Kp == 16) && sa1_rows && a.feat_c + 3 + a.act_c <= a.pre_Kp;
     // SA1's gathered rows: [f (4) | dx (3)] (policy encoder, Kp 8) or [f (4) | dx (3) | action (6)] (value encoder, Kp 16)
     return (a.Kp == 16 || a.Kp == 8) && a.feat_c == 4 && (a.action ? a.act_c == 6 : a.act_c == 0) && a.feat_c + 3 + a.act_c <= a.Kp;
 }
@@ -1447,6 +1495,13 @@ static Groups make_groups(int n, const int32_t* a, const int32_t* w, const int32
 static int max_nout(const Groups& g) { int m = 0; for (int i = 0; i < g.n; ++i) m = g.nout[i] > m ? g.nout[i] : m; return m; }
 
 static int check_input(const gad_gemm_fwd_args& a, const char* who) {
+    if (a.mode == 2) {
+        GAD_REQUIRE(a.src_xyz && a.row_pt && a.row_grp && a.feat && a.pre_W, GAD_ERR_NULL, "%s: recomputed input needs the gather inputs and pre_W", who);
+        GAD_REQUIRE(a.act_c == 0 || a.action, GAD_ERR_NULL, "%s: action", who);
+        GAD_REQUIRE(fwd_streamable(a), GAD_ERR_SHAPE, "%s: mode 2 (recomputed 64-channel input) is a streaming-kernel form: SA1 rows, "
+                    "Kp = c_in = n_out = 64, rows >= 32768, pre_Kp 8 / 16, scale / shift, relu", who);
+        return GAD_OK;
+    }
     if (a.mode == 0) {
         GAD_REQUIRE(a.zin && a.c_in % 4 == 0 && a.c_in >= 4 && a.c_in <= VMAX && a.zin_pitch % 4 == 0, GAD_ERR_SHAPE,
                     "%s: ACT input needs 4 <= c_in <= %d, c_in and pitch multiples of 4", who, VMAX);
@@ -1463,7 +1518,7 @@ static int check_input(const gad_gemm_fwd_args& a, const char* who) {
 extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     unsigned long long* ts = gad_take_timing_slot();
     const int rows_hint = gad_take_grid_rows();
-    GAD_REQUIRE(a && a->W && (a->zout || a->pool_key), GAD_ERR_NULL, "gemm_fwd: null pointer");
+    GAD_REQUIRE(a && a->W && (a->zout || a->pool_key || a->stat_sum), GAD_ERR_NULL, "gemm_fwd: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_fwd: n_groups");
     GAD_REQUIRE(a->Kp % 8 == 0 && a->Kp >= 8, GAD_ERR_SHAPE, "gemm_fwd: Kp=%d must be a multiple of 8", a->Kp);
     if (int e = check_input(*a, "gemm_fwd")) return e;
@@ -1484,9 +1539,9 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     }
     const int grid_rows = (a->n_rows_dev && rows_hint > 0 && rows_hint < rows) ? rows_hint : rows;   // gad_grid_rows_hint
     if (a->in_stat_sum) {
-        GAD_REQUIRE(a->mode == 0 && a->n_groups == 1 && a->zin_off[0] == 0 && a->in_stat_sq && a->in_gamma && a->in_beta && a->scale && a->shift,
+        GAD_REQUIRE(a->mode != 1 && a->n_groups == 1 && a->zin_off[0] == 0 && a->in_stat_sq && a->in_gamma && a->in_beta && a->scale && a->shift,
                     GAD_ERR_NULL, "gemm_fwd: input-layer BatchNorm block needs an ACT input, one group, in_stat_sq, in_gamma, in_beta, scale, shift");
-        const bool has_prologue = fwd_wideable(*a) || (fwd_streamable(*a) && a->mode == 0) || (!pe.key && fwd_skinny(*a));
+        const bool has_prologue = fwd_wideable(*a) || (fwd_streamable(*a) && a->mode != 1) || (!pe.key && fwd_skinny(*a));
         if (!(has_prologue && g_opt_fwd_bn_prologue)) {               // this route reads scale / shift as given: finalise first
             if (int e = gad_bn_finalize(a->in_stat_sum, a->in_stat_sq, a->in_stat_stride, a->in_gamma, a->in_beta, a->c_in, a->in_count,
                                         a->in_eps, a->in_momentum, a->in_running_mean, a->in_running_var, const_cast<float*>(a->scale),
@@ -1518,7 +1573,8 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         if (pe.key) {
             LAUNCH_STREAM(8, 4, 0, true);                                  // (fwd_streamable: ACT input, 128 outputs)
         } else {
-            if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0, false); else LAUNCH_STREAM(8, 4, 0, false); }
+            if (a->mode == 2) { if (a->pre_Kp == 8) LAUNCH_STREAM(8, 2, 2, false); else LAUNCH_STREAM(8, 2, 3, false); }
+            else if (a->mode == 0) { if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0, false); else LAUNCH_STREAM(8, 4, 0, false); }
             else if (a->Kp == 8) { if (a->n_out[0] == 64) LAUNCH_STREAM(1, 2, 1, false); else LAUNCH_STREAM(1, 4, 1, false); }
             else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1, false); else LAUNCH_STREAM(2, 4, 1, false); }
         }

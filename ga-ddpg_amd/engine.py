@@ -466,6 +466,8 @@ def side_stream(device=None, which=0):
 
 CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
 FUSED_SA1_BWD = _os.environ.get("GAD_FUSED_SA1_BWD", "1") == "1"     # SA1 l3 / l2 backward: dX + dW in one kernel (gad_gemm_bwd)
+RECOMP_SA1 = _os.environ.get("GAD_RECOMP_SA1", "0") == "1"   # SA1 layer 2 recomputes layer 1's output from the gathered rows (gad_gemm_fwd mode 2); layer 1 stores nothing in a pass that is never
+                                                             # back-propagated.  OFF: bit-equal, measured neutral (layer 2 +1.9 us, layer 1 -2.6 us: the re-gather costs what z1's read cost)
 INLINE_BN_BWD = _os.environ.get("GAD_INLINE_BN_BWD", "1") == "1"     # BatchNorm-backward coefficients formed in the dX / dW prologues
 DEFER_BN_STAGES = tuple(int(c) for c in _os.environ.get("GAD_DEFER_BN_STAGES", "012"))     # SA stages it applies to (A/B)
 DEFER_BN_WIDE = _os.environ.get("GAD_DEFER_BN_WIDE", "1") == "1"     # SA2 / SA3 layers 1, 2: BatchNorm finalised in the consumer GEMM's prologue
@@ -621,7 +623,7 @@ def _gather_src(geo, slot, s, action):
                 action=None, act_c=0, grp_per_sample=1, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]))
 
 
-def _layer_input(enc, slot, geo, s, l, action, fin=None):
+def _layer_input(enc, slot, geo, s, l, action, fin=None, forward=False):
     """gad_gemm_fwd_args fields describing the INPUT of SA stage s layer l (s==3: FC layer l).
     fin = (count, update_running): the input layer's train-mode BatchNorm is finalised by THIS launch (gad_gemm_fwd_args
     in_*: no gad_bn_finalize launch between the two GEMMs)"""
@@ -634,6 +636,9 @@ def _layer_input(enc, slot, geo, s, l, action, fin=None):
             pm = enc.sa_mats[s][l - 1]
             base.update(mode=0, zin=_ptr(slot.Z[s][l - 1]), zin_pitch=pm.n_out, c_in=pm.n_out,
                         scale=_bn_vec(slot, enc, pm, "scale"), shift=_bn_vec(slot, enc, pm, "shift"), relu=1)
+            if forward and recomputed_input(enc, geo, s, l):       # (the backward pass reads the stored z1)
+                # layer 1's output is recomputed from the gathered rows inside this launch (bit-equal to what layer 1 stored)
+                base.update(mode=2, pre_W=enc.flat.p_w(pm), pre_Kp=pm.Kp, **_gather_src(geo, slot, s, action))
             if fin is not None:
                 base.update(_input_bn(enc, slot, pm, fin))
         return base
@@ -648,6 +653,14 @@ def _layer_input(enc, slot, geo, s, l, action, fin=None):
     if fin is not None:
         base.update(_input_bn(enc, slot, pm, fin))
     return base
+
+
+def recomputed_input(enc, geo, s, l):
+    """SA1 layer 2 on the streaming kernel's shapes: gad_gemm_fwd mode 2"""
+    if not (RECOMP_SA1 and s == 0 and l == 1):
+        return False
+    m0, m1 = enc.sa_mats[0][0], enc.sa_mats[0][1]
+    return m0.n_out == 64 and m1.n_out == 64 and m1.Kp == 64 and m0.Kp in (8, 16) and geo.rows[0]["cap"] >= 32768
 
 
 def _input_bn(enc, slot, pm, fin):
@@ -701,9 +714,11 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     def gemm(m, zout, s, l, tag, pool=None):
         o = enc.bn_off[m.bn_index]
         fin = ((geo.counts[s] if s < 3 else float(slot.B)), update_running) if (l > 0 and deferred(s, l - 1)) else None
-        kw = _layer_input(enc, slot, geo, s, l, action, fin=fin)
+        kw = _layer_input(enc, slot, geo, s, l, action, fin=fin, forward=True)
         if pool is not None:
             kw.update(pool_key=_ptr(slot.key[s], 0, 8), pool_row_grp=_ptr(geo.rows[s]["grp"]), pool_gamma=enc.flat.p_gamma(m))
+        if s == 0 and l == 0 and not slot.with_backward and recomputed_input(enc, geo, 0, 1):
+            zout = None         # statistics only: layer 2 recomputes this output and nothing else reads it in a forward-only pass
         a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(zout), zout_pitch=m.n_out,
                       stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot, **kw)
         if s < 2:

@@ -28,7 +28,8 @@ class GemmFwdArgs(C.Structure):
                 ("pool_key", _vp), ("pool_row_grp", _vp), ("pool_gamma", _vp),
                 ("in_stat_sum", _vp), ("in_stat_sq", _vp), ("in_stat_stride", _i32), ("in_count", _f64),
                 ("in_gamma", _vp), ("in_beta", _vp), ("in_eps", _f32), ("in_momentum", _f32),
-                ("in_running_mean", _vp), ("in_running_var", _vp), ("in_mean", _vp), ("in_istd", _vp)]
+                ("in_running_mean", _vp), ("in_running_var", _vp), ("in_mean", _vp), ("in_istd", _vp),
+                ("pre_W", _vp), ("pre_Kp", _i32)]
 
 
 class DzSrc(C.Structure):

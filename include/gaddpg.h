@@ -147,7 +147,8 @@ typedef struct {
     const int32_t* n_rows_dev; /* device scalar with the live row count, or NULL -> n_rows       */
     int32_t n_rows;            /* static row count (upper bound when n_rows_dev is given)        */
     const float* row_w;        /* (rows) multiplicity weights, NULL -> 1                         */
-    /* input mode: 0 = ACT (act(scale*z+shift) of a previous layer's raw output), 1 = GATHER     */
+    /* input mode: 0 = ACT (act(scale*z+shift) of a previous layer's raw output), 1 = GATHER,
+     * 2 = ACT recomputed from the gathered first layer (pre_W below)                              */
     int32_t mode;
     const float* zin;          /* ACT: (rows, zin_pitch)                                         */
     int32_t zin_pitch;
@@ -208,6 +209,13 @@ typedef struct {
     float* in_running_var;
     float* in_mean;            /* published for the backward pass; nullable                       */
     float* in_istd;
+    /* mode 2 (round 4): the 64-channel ACT input is NOT read from zin but recomputed, per 32-row slab, from the gathered rows
+     * of the stage's first layer (src_xyz / ctr_xyz / feat / action / row_pt / row_grp as in mode 1) and that layer's packed
+     * weights -- the same products in the same order as that layer's own launch, so the values are bit-equal to what it
+     * stored -- then activated with scale / shift (or the in_* block) as in mode 0.  A streaming-kernel form only: SA1's
+     * rows (feat_c 4, act_c 0 / 6), Kp = c_in = n_out = 64, n_rows >= 32768; anything else is GAD_ERR_SHAPE.            */
+    const float* pre_W;        /* (64, pre_Kp) packed weights of the recomputed layer                */
+    int32_t pre_Kp;            /* 8 or 16                                                             */
 } gad_gemm_fwd_args;
 
 int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);

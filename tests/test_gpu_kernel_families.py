@@ -30,6 +30,8 @@ def _run(B, value, options, keep_slot=False, mutate=None):
     probe = torch.from_numpy(np.random.default_rng(5).normal(size=(B, 512)).astype(np.float32)).cuda()
     options = dict(options)
     sched = {k: options.pop(k) for k in list(options) if k.isupper()}       # engine schedule switches (module constants)
+    if options.get("fwd_stream", 1) == 0:                                   # mode 2 of gad_gemm_fwd is a streaming-kernel form
+        sched.setdefault("RECOMP_SA1", False)
     sched_was = {k: getattr(engine, k) for k in sched}
     for k, v in sched.items():
         setattr(engine, k, v)
@@ -106,6 +108,23 @@ def test_specialised_and_tile_kernels_agree(value):
     fused_w = _run(B, value, {"bwd_wide": 1})
     bad += _compare(fused_w, default, acts, 1e-6, 1e-7, "same forward kernels (fused wide backward):")
     bad += _compare(fused_w, default, grads, 2e-4, 1e-5, "separate wide dX / dW vs fused wide backward:")
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("value", [False, True])
+def test_recomputed_first_layer_is_bit_equal(value):
+    """round 4: SA1 layer 2 recomputes layer 1's output from the gathered rows (gad_gemm_fwd mode 2) with the
+    operands of layer 1's own MFMAs swapped: the same products in the same order, so layer 2's raw output equals the one computed
+    from the stored z1 BIT FOR BIT, and with it everything downstream up to the order of the statistics' f64 atomics."""
+    B = 96
+    ref = _run(B, value, dict(RECOMP_SA1=False))
+    got = _run(B, value, dict(RECOMP_SA1=True))
+    assert got["rows"] == ref["rows"] and ref["rows"][0] >= 32768
+    assert torch.equal(got["Z11"], ref["Z11"]) and torch.equal(got["Z12"], ref["Z12"]), "recomputed z1 is not the stored z1"
+    acts = [k for k in ref if k[0] in "ZFzmir" and k != "rows"]
+    grads = [k for k in ref if k not in acts and k != "rows"]
+    bad = _compare(got, ref, acts, 1e-6, 1e-7, "recomputed SA1 layer 1, forward:")
+    bad += _compare(got, ref, grads, 2e-5, 1e-6, "recomputed SA1 layer 1, gradients:")
     assert not bad, "\n".join(bad)
 
 
