@@ -917,6 +917,7 @@ static int g_opt_bwd_fused = 1;
 static int g_opt_fwd_bn_prologue = 1;           // 0: routes with a BatchNorm-finalising prologue launch gad_bn_finalize instead (A/B)
 static int g_opt_bwd_wide = 0;                  // fused wide backward: 0 off (default: slower in the step), 1 SA2 and SA3 shapes, 2 only layers with >= 16384 rows (SA2)
 static int g_opt_bwd_wide_slab = 4;             // most partial-dW elements (millions) a fused launch may write: bounds its workgroups per k block
+static int g_opt_mfma_split = 0;           // 1: the streaming forward kernel multiplies as split-bf16 MFMAs (f32-accurate; opt-in)
 static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch aims for (its partial slab = this x 128 x 128 floats)
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
@@ -945,6 +946,25 @@ static bool fwd_wideable(const gad_gemm_fwd_args& a) {
 // ------------------------------------------------------------------------------------------------
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// ---- split-bf16 arithmetic (opt-in: option "mfma_split"; NOT the default -- the default path multiplies in f32)
+// An f32 value = hi + mid + lo, three bf16 terms of 8 significand bits each (the residuals are exact f32 subtractions); a product of
+// two such values to 24 bits = the six term products of weight >= 2^-16, each exact in the f32 accumulator of
+// v_mfma_f32_32x32x16_bf16 (16x the rate of v_mfma_f32_32x32x2_f32).  Measured on the SA1 layer-3 shape: the same error against f64
+// as the f32 MFMA (tools/ubench/split_bf16.hip, profiles/r04_split_bf16_ubench.txt).
+typedef __bf16 gad_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned gad_cvt_pk_bf16(float lo, float hi) {     // {bf16(hi), bf16(lo)}, round to nearest even
+    unsigned r;
+    __asm__("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void gad_split2(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
+    H = gad_cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(H << 16), rb = b - __uint_as_float(H & 0xffff0000u);
+    M = gad_cvt_pk_bf16(ra, rb);
+    L = gad_cvt_pk_bf16(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
+}
+__device__ __forceinline__ gad_bf16x8 gad_as_bf16x8(gad_u32x4 u) { return *reinterpret_cast<gad_bf16x8*>(&u); }
+
 // NOTE (measured, tools/ubench/mfma_valu.hip): on gfx950 the f32 MFMA shares the vector ALU -- every VALU
 // instruction issued between MFMAs adds its ~4 clocks to the 64 of the MFMA, also with 2 wavefronts per SIMD.
 // So the loop below is written for a minimal VALU instruction count: packed (2-wide) f32 math for the BatchNorm
@@ -956,7 +976,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // every product and sum is the one the first layer's launch made (bit-equal z1): 8 / 16 extra MFMAs per slab instead of
 // 8 KB of z1 from HBM.  The first layer's launch still provides the BatchNorm statistics (and z1 for a pass that is
 // back-propagated).
-template <int KJ, int TN, int XM, bool POOL>
+template <int KJ, int TN, int XM, bool POOL, bool SP = false>
 __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev,
                                                                   int n_rows_static, const float* __restrict__ row_w,
                                                                   const float* __restrict__ W, float* __restrict__ zout,
@@ -974,7 +994,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     constexpr bool ACT = XM == 0 || RE, GATHER = XM == 1 || RE;
     constexpr int NG = RE ? PK : KJ;                     // k groups a slab's loads cover
     static_assert(!RE || (KJ == 8 && !POOL), "recomputed input: 64 channels");
-    __shared__ __attribute__((aligned(16))) float Ws[NO * PW];
+    // SP (opt-in split-bf16 arithmetic, ACT input with 64 channels): W lives in LDS as three bf16 planes [plane][n][64 (+ 8 pad)] and a
+    // lane's slab columns are 16 s + 8 half + 0 .. 7 (the A layout of v_mfma_f32_32x32x16_bf16) instead of 8 j + 4 half + 0 .. 3
+    static_assert(!SP || (XM == 0 && KJ == 8), "split-bf16: ACT input, 64 channels");
+    constexpr int PB = 2 * KP + 16;                      // bytes per row of a bf16 plane
+    __shared__ __attribute__((aligned(16))) float Ws[SP ? 3 * NO * PB / 4 : NO * PW];
     __shared__ __attribute__((aligned(16))) float sv[KP], tv[KP];
     __shared__ float red[2 * 8 * NO];
     __shared__ float pz[POOL ? 8 * 32 * 64 : 1];        // fused max-pool: a 32-row x 64-column tile per wavefront
@@ -1073,7 +1097,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             return;
         }
 #pragma unroll
-        for (int j = 0; j < NG; ++j) dst[j] = x_raw<GATHER ? 1 : 0>(x, r, true, 0, 8 * j + 4 * half, GATHER, pt);
+        for (int j = 0; j < NG; ++j)
+            dst[j] = x_raw<GATHER ? 1 : 0>(x, r, true, 0, SP ? 16 * (j >> 1) + 8 * half + 4 * (j & 1) : 8 * j + 4 * half, GATHER, pt);
     };
     auto lds_b = [&](int j, float4 (&b4)[TN]) {
 #pragma unroll
@@ -1109,7 +1134,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         for (int it = 0; it < UW; ++it) {
             const int u = it * 512 + tid;
             const int n = u / (KJ * 2), c = (u % (KJ * 2)) * 4;
-            if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
+            if (SP) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                gad_split2(wr[it].x, wr[it].y, h0, m0, l0);
+                gad_split2(wr[it].z, wr[it].w, h1, m1, l1);
+                unsigned char* wp = reinterpret_cast<unsigned char*>(Ws) + n * PB + c * 2;
+                if (u < UNITS) {
+                    *reinterpret_cast<uint2*>(wp) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2*>(wp + NO * PB) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(wp + 2 * NO * PB) = make_uint2(l0, l1);
+                }
+            } else if (u < UNITS) *reinterpret_cast<float4*>(Ws + n * PW + c) = wr[it];
         }
     }
     __syncthreads();
@@ -1155,8 +1190,41 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
         float4 bn[TN];
-        lds_b(0, bn);
+        if (!SP) lds_b(0, bn);
         GAD_PH_STAMP(tA);
+        if (SP) {
+            const unsigned char* wp = reinterpret_cast<const unsigned char*>(Ws) + l31 * PB + 16 * half;
+#pragma unroll
+            for (int sg = 0; sg < KJ / 2; ++sg) {        // 16 input channels per step
+                unsigned ah[4], am[4], al[4];
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {           // relu(scale * z + shift) of the lane's 8 channels, then hi / mid / lo
+                    const int c = 16 * sg + 8 * half + 4 * e;
+                    const float4 s4 = *reinterpret_cast<const float4*>(sv + c), t4 = *reinterpret_cast<const float4*>(tv + c);
+                    const float4 zr = ra[2 * sg + e].a;
+                    const float a0 = __builtin_fmaxf(fmaf(zr.x, s4.x, t4.x), 0.f), a1 = __builtin_fmaxf(fmaf(zr.y, s4.y, t4.y), 0.f);
+                    const float a2 = __builtin_fmaxf(fmaf(zr.z, s4.z, t4.z), 0.f), a3 = __builtin_fmaxf(fmaf(zr.w, s4.w, t4.w), 0.f);
+                    gad_split2(a0, a1, ah[2 * e], am[2 * e], al[2 * e]);
+                    gad_split2(a2, a3, ah[2 * e + 1], am[2 * e + 1], al[2 * e + 1]);
+                }
+                const gad_u32x4 AH = {ah[0], ah[1], ah[2], ah[3]}, AM = {am[0], am[1], am[2], am[3]}, AL = {al[0], al[1], al[2], al[3]};
+                gad_u32x4 BH[TN], BM[TN], BL[TN];
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    const unsigned char* q = wp + t * 32 * PB + 32 * sg;
+                    BH[t] = *reinterpret_cast<const gad_u32x4*>(q);
+                    BM[t] = *reinterpret_cast<const gad_u32x4*>(q + NO * PB);
+                    BL[t] = *reinterpret_cast<const gad_u32x4*>(q + 2 * NO * PB);
+                }
+                // the six products of weight >= 2^-16, smallest first
+#define GAD_SPLIT_MFMA(A, B)                                                                                                   \
+                _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                                  \
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[t]), acc[t], 0, 0, 0)
+                GAD_SPLIT_MFMA(AL, BH); GAD_SPLIT_MFMA(AH, BL); GAD_SPLIT_MFMA(AM, BM);
+                GAD_SPLIT_MFMA(AM, BH); GAD_SPLIT_MFMA(AH, BM); GAD_SPLIT_MFMA(AH, BH);
+#undef GAD_SPLIT_MFMA
+            }
+        }
         f32x16 zacc[RE ? 2 : 1];
         if (RE) {                   // z1^T tile: channels 32 b + (accumulator row), rows = lanes; the first layer's own products
 #pragma unroll
@@ -1177,7 +1245,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
             }
         }
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
+        for (int j = 0; j < (SP ? 0 : KJ); ++j) {
             float4 b4[TN];
 #pragma unroll
             for (int t = 0; t < TN; ++t) b4[t] = bn[t];
@@ -1453,6 +1521,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "bwd_wide")) { g_opt_bwd_wide = value; return GAD_OK; }
     if (!strcmp(name, "fwd_bn_prologue")) { g_opt_fwd_bn_prologue = value; return GAD_OK; }
     if (!strcmp(name, "bwd_wide_slab")) { g_opt_bwd_wide_slab = value > 0 ? value : 4; return GAD_OK; }
+    if (!strcmp(name, "mfma_split")) { g_opt_mfma_split = value; return GAD_OK; }
     if (!strcmp(name, "dw_wide_wgs")) { g_opt_dw_wide_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
@@ -1567,10 +1636,14 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     if (fwd_streamable(*a)) {
         const int slabs = gad_cdiv(rows, 32);
         int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;              // one 8-wavefront workgroup per CU
-#define LAUNCH_STREAM(KJ, TN, XM, POOL)                                                                    \
-        hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM, POOL>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
+#define LAUNCH_STREAM(KJ, TN, XM, POOL, ...)                                                               \
+        hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM, POOL, ##__VA_ARGS__>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
                            a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts)
-        if (pe.key) {
+        if (g_opt_mfma_split && a->mode == 0) {                            // opt-in split-bf16 arithmetic
+            if (pe.key) LAUNCH_STREAM(8, 4, 0, true, true);
+            else if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0, false, true);
+            else LAUNCH_STREAM(8, 4, 0, false, true);
+        } else if (pe.key) {
             LAUNCH_STREAM(8, 4, 0, true);                                  // (fwd_streamable: ACT input, 128 outputs)
         } else {
             if (a->mode == 2) { if (a->pre_Kp == 8) LAUNCH_STREAM(8, 2, 2, false); else LAUNCH_STREAM(8, 2, 3, false); }

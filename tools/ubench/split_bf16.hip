@@ -188,16 +188,17 @@ int main() {
     }
     auto check = [&](const char* what, float us) {
         hipMemcpy(hZ.data(), Z, hZ.size() * 4, hipMemcpyDeviceToHost);
-        double emax = 0, esum = 0;
+        double emax = 0, esum = 0, ssum = 0;
         for (int i = 0; i < sample; ++i) {
             const int r = (int)((long long)i * rows / sample);
             for (int n = 0; n < N; ++n) {
                 const double e = fabs(hZ[(size_t)r * N + n] - ref[(size_t)i * N + n]);
-                emax = fmax(emax, e); esum += e;
+                emax = fmax(emax, e); esum += e; ssum += hZ[(size_t)r * N + n] - ref[(size_t)i * N + n];
             }
         }
-        printf("%-46s %7.1f us per launch   error vs f64: max %.3e  mean %.3e   (of max |z| = %.3f: %.2e / %.2e)\n", what, us, emax,
-               esum / ((double)sample * N), scale, emax / scale, esum / ((double)sample * N) / scale);
+        printf("%-46s %7.1f us per launch   error vs f64: max %.3e  mean |e| %.3e  mean SIGNED %+.3e   (of max |z| = %.3f: %.2e / %.2e / %+.2e)\n",
+               what, us, emax, esum / ((double)sample * N), ssum / ((double)sample * N), scale, emax / scale,
+               esum / ((double)sample * N) / scale, ssum / ((double)sample * N) / scale);
     };
     hipMemset(Z, 0, hZ.size() * 4);
     float us = time_us([&] { hipLaunchKernelGGL(k_f32, dim3(256), dim3(512), 0, 0, X, W, Z, rows); });
