@@ -1194,35 +1194,59 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
         GAD_PH_STAMP(tA);
         if (SP) {
             const unsigned char* wp = reinterpret_cast<const unsigned char*>(Ws) + l31 * PB + 16 * half;
+            constexpr int NS = SP ? KJ / 2 : 1;           // 16-channel steps
+            gad_u32x4 AH[NS], AM[NS], AL[NS];
 #pragma unroll
-            for (int sg = 0; sg < KJ / 2; ++sg) {        // 16 input channels per step
+            for (int sg = 0; sg < NS; ++sg) {
                 unsigned ah[4], am[4], al[4];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {           // relu(scale * z + shift) of the lane's 8 channels, then hi / mid / lo
                     const int c = 16 * sg + 8 * half + 4 * e;
                     const float4 s4 = *reinterpret_cast<const float4*>(sv + c), t4 = *reinterpret_cast<const float4*>(tv + c);
-                    const float4 zr = ra[2 * sg + e].a;
+                    const float4 zr = ra[SP ? 2 * sg + e : 0].a;
                     const float a0 = __builtin_fmaxf(fmaf(zr.x, s4.x, t4.x), 0.f), a1 = __builtin_fmaxf(fmaf(zr.y, s4.y, t4.y), 0.f);
                     const float a2 = __builtin_fmaxf(fmaf(zr.z, s4.z, t4.z), 0.f), a3 = __builtin_fmaxf(fmaf(zr.w, s4.w, t4.w), 0.f);
                     gad_split2(a0, a1, ah[2 * e], am[2 * e], al[2 * e]);
                     gad_split2(a2, a3, ah[2 * e + 1], am[2 * e + 1], al[2 * e + 1]);
                 }
-                const gad_u32x4 AH = {ah[0], ah[1], ah[2], ah[3]}, AM = {am[0], am[1], am[2], am[3]}, AL = {al[0], al[1], al[2], al[3]};
-                gad_u32x4 BH[TN], BM[TN], BL[TN];
+                // the bf16 MFMA's adder truncates toward -inf (a -1e-8 relative bias, tools/ubench/split_bf16.hip): odd steps
+                // accumulate the NEGATED products into a second accumulator pair, the difference of the two cancels it
+                const unsigned sgn = (sg & 1) ? 0x80008000u : 0u;
+                AH[sg] = gad_u32x4{ah[0] ^ sgn, ah[1] ^ sgn, ah[2] ^ sgn, ah[3] ^ sgn};
+                AM[sg] = gad_u32x4{am[0] ^ sgn, am[1] ^ sgn, am[2] ^ sgn, am[3] ^ sgn};
+                AL[sg] = gad_u32x4{al[0] ^ sgn, al[1] ^ sgn, al[2] ^ sgn, al[3] ^ sgn};
+            }
 #pragma unroll
-                for (int t = 0; t < TN; ++t) {
-                    const unsigned char* q = wp + t * 32 * PB + 32 * sg;
-                    BH[t] = *reinterpret_cast<const gad_u32x4*>(q);
-                    BM[t] = *reinterpret_cast<const gad_u32x4*>(q + NO * PB);
-                    BL[t] = *reinterpret_cast<const gad_u32x4*>(q + 2 * NO * PB);
-                }
-                // the six products of weight >= 2^-16, smallest first
+            for (int pp = 0; pp < TN / 2; ++pp) {        // two 32-column tiles at a time: (plain, negated) accumulator pairs
+                f32x16 an[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) an[i][v] = 0.f;
+#pragma unroll
+                for (int sg = 0; sg < NS; ++sg) {
+                    gad_u32x4 BH[2], BM[2], BL[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const unsigned char* q = wp + (2 * pp + i) * 32 * PB + 32 * sg;
+                        BH[i] = *reinterpret_cast<const gad_u32x4*>(q);
+                        BM[i] = *reinterpret_cast<const gad_u32x4*>(q + NO * PB);
+                        BL[i] = *reinterpret_cast<const gad_u32x4*>(q + 2 * NO * PB);
+                    }
+                    // the six products of weight >= 2^-16, smallest first
 #define GAD_SPLIT_MFMA(A, B)                                                                                                   \
-                _Pragma("unroll") for (int t = 0; t < TN; ++t)                                                                  \
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[t]), acc[t], 0, 0, 0)
-                GAD_SPLIT_MFMA(AL, BH); GAD_SPLIT_MFMA(AH, BL); GAD_SPLIT_MFMA(AM, BM);
-                GAD_SPLIT_MFMA(AM, BH); GAD_SPLIT_MFMA(AH, BM); GAD_SPLIT_MFMA(AH, BH);
+                    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+                        if (sg & 1) an[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A[sg]), gad_as_bf16x8(B[i]), an[i], 0, 0, 0); \
+                        else acc[2 * pp + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A[sg]), gad_as_bf16x8(B[i]), acc[2 * pp + i], 0, 0, 0); \
+                    }
+                    GAD_SPLIT_MFMA(AL, BH) GAD_SPLIT_MFMA(AH, BL) GAD_SPLIT_MFMA(AM, BM)
+                    GAD_SPLIT_MFMA(AM, BH) GAD_SPLIT_MFMA(AH, BM) GAD_SPLIT_MFMA(AH, BH)
 #undef GAD_SPLIT_MFMA
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[2 * pp + i][v] -= an[i][v];
             }
         }
         f32x16 zacc[RE ? 2 : 1];

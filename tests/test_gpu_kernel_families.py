@@ -116,11 +116,12 @@ def test_split_bf16_option_stays_within_f32_summation_noise(value):
     """opt-in library option "mfma_split" (NOT the default): the streaming forward kernel forms its FP32
     products as six bf16 x bf16 term products (hi / mid / lo splits, 24 significand bits) on v_mfma_f32_32x32x16_bf16.  Against
     the default f32-MFMA path: activations, statistics and gradients agree as tightly as two f32 summation orders do (the same
-    bounds as tile vs specialised kernels), i.e. its random error is f32-sized, not bf16-sized (which would show as 4e-3).  (Its
-    error is slightly BIASED -- the bf16 MFMA's adder truncates -- which the forced-decision gradient gate sees on bias gradients:
-    profiles/r04_split_bf16_ubench.txt; one more reason the option is off.)"""
+    bounds as tile vs specialised kernels), i.e. its error is f32-sized, not bf16-sized (which would show as 4e-3).  (The bf16
+    MFMA's adder truncates toward -inf; the kernel cancels that bias with (plain, negated) accumulator pairs -- with them the
+    whole GPU suite, the forced-decision gradient gate included, passes under GAD_OPT_mfma_split=1:
+    profiles/r04_split_bf16_ubench.txt.  The option stays off: the dtype rule.)"""
     B = 96
-    ref = _run(B, value, {})
+    ref = _run(B, value, {"mfma_split": 0})
     got = _run(B, value, {"mfma_split": 1})
     from ga_ddpg_amd import hip
     hip.set_option("mfma_split", 0)                      # (_run's clean-up restores family switches to 1)

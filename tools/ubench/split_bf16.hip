@@ -113,36 +113,47 @@ __global__ __launch_bounds__(512, 2) void k_split(const float* __restrict__ X, c
             *reinterpret_cast<float4*>(v + 4) = *reinterpret_cast<const float4*>(X + (size_t)r * K + 16 * s + 8 * half + 4);
             split8(v, AH[s], AM[s], AL[s]);
         }
-        f32x16 acc[4];
+        f32x16 acc[4], acn[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+            for (int v = 0; v < 16; ++v) { acc[t][v] = 0.f; acn[t][v] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            if (NP == 12 && (s & 1)) {                     // odd steps accumulate the NEGATED products in a second accumulator set
+#pragma unroll
+                for (int p = 0; p < 4; ++p) { AH[s][p] ^= 0x80008000u; AM[s][p] ^= 0x80008000u; AL[s][p] ^= 0x80008000u; }
+            }
+            f32x16 (&ac)[4] = (NP == 12 && (s & 1)) ? acn : acc;
             u32x4 BH[4], BM[4], BL[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const int off = (t * 32 + l31) * PB + (16 * s + 8 * half) * 2;
                 BH[t] = *reinterpret_cast<const u32x4*>(Wp + 0 * N * PB + off);
                 BM[t] = *reinterpret_cast<const u32x4*>(Wp + 1 * N * PB + off);
-                if (NP == 6) BL[t] = *reinterpret_cast<const u32x4*>(Wp + 2 * N * PB + off);
+                if (NP >= 6) BL[t] = *reinterpret_cast<const u32x4*>(Wp + 2 * N * PB + off);
             }
             // smallest terms first
-            if (NP == 6) {
+            if (NP >= 6) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AL[s]), as_bf(BH[t]), acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AL[s]), as_bf(BH[t]), ac[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AH[s]), as_bf(BL[t]), acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AH[s]), as_bf(BL[t]), ac[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AM[s]), as_bf(BM[t]), acc[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AM[s]), as_bf(BM[t]), ac[t], 0, 0, 0);
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AM[s]), as_bf(BH[t]), acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AM[s]), as_bf(BH[t]), ac[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AH[s]), as_bf(BM[t]), acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AH[s]), as_bf(BM[t]), ac[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AH[s]), as_bf(BH[t]), acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) ac[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf(AH[s]), as_bf(BH[t]), ac[t], 0, 0, 0);
+        }
+        if (NP == 12) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] -= acn[t][v];
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -209,5 +220,8 @@ int main() {
     hipMemset(Z, 0, hZ.size() * 4);
     us = time_us([&] { hipLaunchKernelGGL(k_split<3>, dim3(256), dim3(512), 0, 0, X, W, Z, rows); });
     check("split bf16, 3 products (16 significand bits)", us);
+    hipMemset(Z, 0, hZ.size() * 4);
+    us = time_us([&] { hipLaunchKernelGGL(k_split<12>, dim3(256), dim3(512), 0, 0, X, W, Z, rows); });
+    check("split bf16, 6 products, +/- accumulator pair", us);
     return 0;
 }
