@@ -488,6 +488,30 @@ def main():
             agent.update_parameters(dmem.sample_lazy(B, rng2), agent.update_step, i, sync=False)
         agent.flush()
         res["value_device_replay"] = n / (time.perf_counter() - t0)
+        # NOT `value` (which is FP32-MFMA arithmetic throughout): the same run-ahead loop over the HBM ring with the library's opt-in
+        # "mfma_split" option -- the streaming forward kernel (SA1 layers 2 / 3) forms its FP32 products as six bf16 x bf16 term
+        # products with sign-balanced accumulator pairs (f32-sized, unbiased error; the whole GPU suite passes
+        # with it) -- reported so that the option's effect is measured by whoever runs this file, beside the default path
+        from ga_ddpg_amd import hip as _hip
+        n_x = 150                                        # (shorter runs drown a 2 % difference in the run-ahead loop's start-up)
+        rates = {}
+        for flag in (0, 1, 0, 1):
+            _hip.set_option("mfma_split", flag)
+            for i in range(10):
+                step(i)
+            agent.flush()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n_x):
+                step(i)
+            agent.flush()
+            torch.cuda.synchronize()
+            rates.setdefault(flag, []).append(n_x / (time.perf_counter() - t0))
+        _hip.set_option("mfma_split", 0)
+        res["experimental"] = {"mfma_split": {"steps_per_s_option_off": [round(v, 1) for v in rates[0]],
+                                              "steps_per_s_option_on": [round(v, 1) for v in rates[1]],
+                                              "note": "opt-in split-bf16 arithmetic in the streaming forward kernel only; default off; "
+                                                      "alternating runs of %d steps in this process; not `value`" % n_x}}
     res["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "tags"}
                       for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}
     if world == 1 and not args.no_sa_kernel:
