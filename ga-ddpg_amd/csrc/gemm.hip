@@ -689,6 +689,101 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
     }
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// ---- split-bf16 arithmetic (library option "mfma_split": a mask of kernel families, include/gaddpg.h GAD_SPLIT_*) ----
+// An f32 value = hi + mid + lo, three bf16 terms of 8 significand bits each (the residuals are exact f32 subtractions); a product of
+// two such values to 24 bits = the six term products of weight >= 2^-16, each exact in the f32 accumulator of
+// v_mfma_f32_32x32x16_bf16 (16x the rate of v_mfma_f32_32x32x2_f32).  The bf16 MFMA's adder truncates toward -inf (a -1e-8
+// relative bias, tools/ubench/split_bf16.hip): the products of every second block of 16 along the reduction index are
+// NEGATED (one operand's sign) and summed into a second accumulator; result = plain - negated, which cancels the bias and
+// leaves a smaller random error than the f32 MFMA's (profiles/r04_split_bf16_ubench.txt).
+// Range: |x| must stay below 3.39e38 (bf16(x) must not round to infinity); an infinite operand gives NaN where the f32
+// path gives +-inf (both non-finite).
+typedef __bf16 gad_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned gad_cvt_pk_bf16(float lo, float hi) {     // {bf16(hi), bf16(lo)}, round to nearest even
+    unsigned r;
+    __asm__("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ void gad_split2(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
+    H = gad_cvt_pk_bf16(a, b);
+    const f32x2 r = f32x2{a, b} - f32x2{__uint_as_float(H << 16), __uint_as_float(H & 0xffff0000u)};
+    M = gad_cvt_pk_bf16(r.x, r.y);
+    const f32x2 q = r - f32x2{__uint_as_float(M << 16), __uint_as_float(M & 0xffff0000u)};
+    L = gad_cvt_pk_bf16(q.x, q.y);
+}
+__device__ __forceinline__ gad_bf16x8 gad_as_bf16x8(gad_u32x4 u) { return *reinterpret_cast<gad_bf16x8*>(&u); }
+
+static int g_opt_mfma_split = 0;           // family mask (GAD_SPLIT_*; 1 = all): which GEMM families multiply as split-bf16 MFMAs
+static bool split_on(int family) { return g_opt_mfma_split == GAD_SPLIT_ALL || (g_opt_mfma_split & family) != 0; }
+
+// Wide-tile kernels in split form (gemm_fwd_wide / gemm_dx_wide with SP): a 64 x 128 block tile per 4-wavefront workgroup,
+// K-tile 32.  Both operand tiles live in LDS as three bf16 planes of 64-byte rows (32 reduction indices), double-buffered:
+//   stage = A planes 3 x 64 rows | B planes 3 x 128 rows = 36 KB;
+// a row's four 16-byte chunks are XOR-swizzled by (row >> 2) & 3, so the fragment reads -- lane (row l31, half) takes chunk
+// 2 s + half of k16-step s: one ds_read_b128 = the 8 consecutive reduction indices v_mfma_f32_32x32x16_bf16 wants per lane --
+// are conflict-free without padding (every 16-lane group of the instruction covers 16 rows that differ mod 16), and so are
+// the staging stores (ds_write_b64 for the A side, split in registers; ds_write_b128 for the B side, copied from the
+// pre-split weight mirror).  k16-step 0 of a K-tile accumulates into `acc`, step 1 -- whose mirror values are stored negated --
+// into `an`.
+namespace spw {
+constexpr int APL = 64 * 64, BPL = 128 * 64, STAGE = 3 * (APL + BPL);       // bytes
+struct BRegs { gad_u32x4 r[2][3]; };
+// this thread's B chunks of K-tile kt: rows (tid >> 2) + 64 u of the block's 128 mirror rows, chunk tid & 3
+__device__ __forceinline__ void load_b(BRegs& b, __amdgpu_buffer_rsrc_t rs, const int (&vb)[2], int plane_bytes, int kt) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b.r[u][p] = __builtin_amdgcn_raw_buffer_load_b128(rs, vb[u], p * plane_bytes + kt * 64, 0);
+}
+__device__ __forceinline__ void store_b(unsigned char* stage, const BRegs& b, int tid) {
+    const int row = tid >> 2;
+    unsigned char* q = stage + 3 * APL + row * 64 + ((((tid & 3) ^ ((row >> 2) & 3))) << 4);
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<gad_u32x4*>(q + p * BPL + u * (64 * 64)) = b.r[u][p];
+}
+// four consecutive reduction indices (c4 = (tid & 7) * 4 of the K-tile) of A row `row` -> the three planes (8 bytes each)
+__device__ __forceinline__ void store_a4(unsigned char* stage, int row, int tid, float4 v) {
+    unsigned h0, m0, l0, h1, m1, l1;
+    gad_split2(v.x, v.y, h0, m0, l0);
+    gad_split2(v.z, v.w, h1, m1, l1);
+    unsigned char* q = stage + row * 64 + (((((tid & 7) >> 1) ^ ((row >> 2) & 3))) << 4) + ((tid & 1) << 3);
+    *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(q + APL) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(q + 2 * APL) = make_uint2(l0, l1);
+}
+// MFMAs of one staged K-tile for the wavefront's 32 x 64 tile: arow / brow = byte offsets of the lane's A row and first B row
+// inside the stage, fo = ((half ^ swizzle) << 4) -- the lane's chunk of k16-step 0; step 1's is fo ^ 32
+__device__ __forceinline__ void ktile(const unsigned char* stage, int arow, int brow, int fo, f32x16 (&acc)[2], f32x16 (&an)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const int off = fo ^ (s << 5);
+        const unsigned char* ap = stage + arow + off;
+        const unsigned char* bp = stage + 3 * APL + brow + off;
+        const gad_u32x4 AH = *reinterpret_cast<const gad_u32x4*>(ap), AM = *reinterpret_cast<const gad_u32x4*>(ap + APL);
+        const gad_u32x4 AL = *reinterpret_cast<const gad_u32x4*>(ap + 2 * APL);
+        gad_u32x4 BH[2], BM[2], BL[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            BH[t] = *reinterpret_cast<const gad_u32x4*>(bp + t * (32 * 64));
+            BM[t] = *reinterpret_cast<const gad_u32x4*>(bp + BPL + t * (32 * 64));
+            BL[t] = *reinterpret_cast<const gad_u32x4*>(bp + 2 * BPL + t * (32 * 64));
+        }
+        // the six products of weight >= 2^-16, smallest first
+#define GAD_SPW(A, B)                                                                                                          \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                        \
+            if (s) an[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[t]), an[t], 0, 0, 0);     \
+            else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[t]), acc[t], 0, 0, 0);     \
+        }
+        GAD_SPW(AL, BH) GAD_SPW(AH, BL) GAD_SPW(AM, BM) GAD_SPW(AM, BH) GAD_SPW(AH, BM) GAD_SPW(AH, BH)
+#undef GAD_SPW
+    }
+}
+}  // namespace spw
+
 // ------------------------------------------------------------------------------------------------
 // wide-tile forward for the MID-SIZE layers (SA2 / SA3 layers 2 and 3: 8e3 - 3e4 rows, K 128 - 256, 128 - 512 outputs).
 // The 64 x 64 kernel above gives every wavefront ONE 32 x 32 accumulator: 16 MFMAs (0.45 us) per K-tile against ~1 us of
@@ -706,14 +801,17 @@ __global__ __launch_bounds__(256) void gemm_fwd_kernel(XSrc x, Groups gr, const 
 // almost empty K-tile.
 // Measured alone (tools/diag_gemm.py, B = 256 shapes): see profiles/README.md round 3.
 // ------------------------------------------------------------------------------------------------
-template <int XM, bool POOL>
+// SP: the products as split-bf16 MFMAs (namespace spw above): A is split while it is staged, B comes from the layer's forward
+// weight mirror (wsp: three planes of wsp_plane bf16, rows of wsp_pitch), same tiles, prologue and epilogue.
+template <int XM, bool POOL, bool SP = false>
 __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
                                                                const float* __restrict__ row_w, const float* __restrict__ W,
                                                                int Kp, int n_out, float* __restrict__ zout, int zout_pitch,
                                                                double* __restrict__ stat_sum, double* __restrict__ stat_sq,
-                                                               int stat_stride, PoolEpi pe, unsigned long long* __restrict__ ts) {
+                                                               int stat_stride, PoolEpi pe, const uint16_t* __restrict__ wsp,
+                                                               int wsp_pitch, int wsp_plane, unsigned long long* __restrict__ ts) {
     KTimer kt_(ts);
-    constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = (BM + BN) * P, VM = 512;
+    constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = SP ? spw::STAGE / 4 : (BM + BN) * P, VM = 512;
     static_assert(2 * STAGE >= 64 * 129, "the pooled epilogue's tile lives in the operand buffers");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * VM + BM + 4 * BM];
     float* sv = smem + 2 * STAGE;
@@ -740,6 +838,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
     int vb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) vb[u] = ((n0 + ur + 32 * u) * Kp + c4) * 4;
+    // SP: the weight mirror's rows n0 + (tid >> 2) + 64 u, 16-byte chunk tid & 3 of a K-tile's 64 bytes
+    const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? wsp : reinterpret_cast<const uint16_t*>(W)), 0, 0x7ffffffc, 0x00020000);
+    int vbs[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) vbs[u] = ((n0 + (tid >> 2) + 64 * u) * wsp_pitch + (tid & 3) * 8) * 2;
+    unsigned char* const smem_b = reinterpret_cast<unsigned char*>(smem);
+    const int sp_fo = ((half ^ ((l31 >> 2) & 3)) << 4);
     if (XM == 0) {
         if (x.bn.stat_sum) {
             // the input layer's train-mode BatchNorm finalised here (no gad_bn_finalize launch between the two GEMMs): every
@@ -759,10 +864,11 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
     float csum[2] = {0.f, 0.f}, csq[2] = {0.f, 0.f};
     for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
         f32x16 acc[2];
+        f32x16 an[2];                                    // SP: the negated accumulators (odd k16-steps)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+            for (int v = 0; v < 16; ++v) { acc[t][v] = 0.f; if (SP) an[t][v] = 0.f; }
         int pgl = -1, pg_before = -1, pg_after = -1;
         float psgn[2] = {1.f, 1.f};
         if (POOL) {
@@ -779,13 +885,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         const int va1 = ((XM == 0 ? ra1 * x.zin_pitch : x.row_pt[ra1] * x.feat_c) + c4) * 4;
         // two register sets: the global loads of a K-tile are issued TWO tiles before its LDS write (one tile of MFMAs is
         // ~0.85 us, less than the memory latency under load: with one set every K-tile's barrier waited for its loads)
-        float4 ra2[2][2], rb2[2][4];
+        float4 ra2[2][2], rb2[2][SP ? 1 : 4];
+        spw::BRegs rbs[SP ? 2 : 1];
         auto load_regs = [&](int kt, auto setc) {
             constexpr int S = decltype(setc)::value;
             const int k0 = kt * (KT * 4);
             ra2[S][0] = buf_ld4(ar_, va0, k0); ra2[S][1] = buf_ld4(ar_, va1, k0);
+            if (SP) { spw::load_b(rbs[SP ? S : 0], ws_, vbs, wsp_plane * 2, kt); return; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rb2[S][u] = buf_ld4(wr_, vb[u], k0);
+            for (int u = 0; u < (SP ? 1 : 4); ++u) rb2[S][u] = buf_ld4(wr_, vb[u], k0);
         };
         auto write_lds = [&](int kt, auto setc) {
             constexpr int S = decltype(setc)::value;
@@ -805,10 +913,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
                     v.x = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f);
                     v.z = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f);
                 }
-                *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
+                if (SP) spw::store_a4(smem_b + (kt & 1) * spw::STAGE, ur + 32 * u, tid, v);
+                else *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
             }
+            if (SP) { spw::store_b(smem_b + (kt & 1) * spw::STAGE, rbs[SP ? S : 0], tid); return; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) *reinterpret_cast<float4*>(Bs + (ur + 32 * u) * P + c4) = rb[u];
+            for (int u = 0; u < (SP ? 1 : 4); ++u) *reinterpret_cast<float4*>(Bs + (ur + 32 * u) * P + c4) = rb[u];
         };
         const std::integral_constant<int, 0> S0;
         const std::integral_constant<int, 1> S1;
@@ -833,6 +943,13 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         if (nk > 2) load_regs(2, S0);
         __syncthreads();
         auto ktile = [&](int kt, auto nxtc) {             // MFMAs of tile kt; tile kt + 1 (register set nxtc) -> LDS; loads of kt + 3
+            if (SP) {
+                spw::ktile(smem_b + (kt & 1) * spw::STAGE, (wm * 32 + l31) * 64, (wn * 64 + l31) * 64, sp_fo, acc, an);
+                if (kt + 1 < nk) write_lds(kt + 1, nxtc);
+                if (kt + 3 < nk) load_regs(kt + 3, nxtc);
+                __syncthreads();
+                return;
+            }
             const float* As = smem + (kt & 1) * STAGE + (wm * 32 + l31) * P + 4 * half;
             const float* Bs = smem + (kt & 1) * STAGE + BM * P + (wn * 64 + l31) * P + 4 * half;
             float4 a4 = *reinterpret_cast<const float4*>(As);
@@ -862,6 +979,12 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         for (int kt = 0; kt < nk; kt += 2) {             // (nk is even: K is a multiple of 64 here)
             ktile(kt, S1);
             if (kt + 1 < nk) ktile(kt + 1, S0);
+        }
+        if (SP) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] -= an[t][v];
         }
         if (XM == 1) {                                   // the three coordinate columns: z += dx . W[n][feat_c .. feat_c + 2]
 #pragma unroll
@@ -917,7 +1040,6 @@ static int g_opt_bwd_fused = 1;
 static int g_opt_fwd_bn_prologue = 1;           // 0: routes with a BatchNorm-finalising prologue launch gad_bn_finalize instead (A/B)
 static int g_opt_bwd_wide = 0;                  // fused wide backward: 0 off (default: slower in the step), 1 SA2 and SA3 shapes, 2 only layers with >= 16384 rows (SA2)
 static int g_opt_bwd_wide_slab = 4;             // most partial-dW elements (millions) a fused launch may write: bounds its workgroups per k block
-static int g_opt_mfma_split = 0;           // 1: the streaming forward kernel multiplies as split-bf16 MFMAs (f32-accurate; opt-in)
 static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch aims for (its partial slab = this x 128 x 128 floats)
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
@@ -944,27 +1066,6 @@ static bool fwd_wideable(const gad_gemm_fwd_args& a) {
 //     grid is persistent at 2 wavefronts per SIMD, so loads, MFMAs and the epilogue stores of different
 //     wavefronts overlap.
 // ------------------------------------------------------------------------------------------------
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-// ---- split-bf16 arithmetic (opt-in: option "mfma_split"; NOT the default -- the default path multiplies in f32)
-// An f32 value = hi + mid + lo, three bf16 terms of 8 significand bits each (the residuals are exact f32 subtractions); a product of
-// two such values to 24 bits = the six term products of weight >= 2^-16, each exact in the f32 accumulator of
-// v_mfma_f32_32x32x16_bf16 (16x the rate of v_mfma_f32_32x32x2_f32).  Measured on the SA1 layer-3 shape: the same error against f64
-// as the f32 MFMA (tools/ubench/split_bf16.hip, profiles/r04_split_bf16_ubench.txt).
-typedef __bf16 gad_bf16x8 __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ unsigned gad_cvt_pk_bf16(float lo, float hi) {     // {bf16(hi), bf16(lo)}, round to nearest even
-    unsigned r;
-    __asm__("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ void gad_split2(float a, float b, unsigned& H, unsigned& M, unsigned& L) {
-    H = gad_cvt_pk_bf16(a, b);
-    const float ra = a - __uint_as_float(H << 16), rb = b - __uint_as_float(H & 0xffff0000u);
-    M = gad_cvt_pk_bf16(ra, rb);
-    L = gad_cvt_pk_bf16(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
-}
-__device__ __forceinline__ gad_bf16x8 gad_as_bf16x8(gad_u32x4 u) { return *reinterpret_cast<gad_bf16x8*>(&u); }
-
 // NOTE (measured, tools/ubench/mfma_valu.hip): on gfx950 the f32 MFMA shares the vector ALU -- every VALU
 // instruction issued between MFMAs adds its ~4 clocks to the 64 of the MFMA, also with 2 wavefronts per SIMD.
 // So the loop below is written for a minimal VALU instruction count: packed (2-wide) f32 math for the BatchNorm
@@ -1663,7 +1764,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 #define LAUNCH_STREAM(KJ, TN, XM, POOL, ...)                                                               \
         hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM, POOL, ##__VA_ARGS__>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
                            a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts)
-        if (g_opt_mfma_split && a->mode == 0) {                            // opt-in split-bf16 arithmetic
+        if (split_on(GAD_SPLIT_FWD_STREAM) && a->mode == 0) {             // split-bf16 products (the kernel splits W itself)
             if (pe.key) LAUNCH_STREAM(8, 4, 0, true, true);
             else if (a->n_out[0] == 64) LAUNCH_STREAM(8, 2, 0, false, true);
             else LAUNCH_STREAM(8, 4, 0, false, true);
@@ -1682,16 +1783,18 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     if (fwd_wideable(*a)) {
         int gx = gad_cdiv(grid_rows, 64); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;
         const dim3 grid(gx, a->n_out[0] / 128);
-        if (a->mode == 1)
-            hipLaunchKernelGGL((gemm_fwd_wide_kernel<1, false>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
-                               a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
-        else if (pe.key)
-            hipLaunchKernelGGL((gemm_fwd_wide_kernel<0, true>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
-                               a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
-        else
-            hipLaunchKernelGGL((gemm_fwd_wide_kernel<0, false>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp,
-                               a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts);
-        GAD_CHECK_LAUNCH("gemm_fwd(wide)");
+        // split-bf16 form: family bit set and the call carries the forward weight mirror of exactly the columns the K loop covers
+        const bool sp = split_on(GAD_SPLIT_FWD_WIDE) && a->W_split && a->W_split_pitch == (a->mode == 1 ? a->feat_c : a->Kp) &&
+                        a->W_split_plane >= a->n_out[0] * a->W_split_pitch;
+#define LAUNCH_WIDE(XM, POOL, SP)                                                                                              \
+        hipLaunchKernelGGL((gemm_fwd_wide_kernel<XM, POOL, SP>), grid, dim3(256), 0, st, x, a->n_rows_dev, rows, a->row_w, a->W, a->Kp, \
+                           a->n_out[0], a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, pe, a->W_split, a->W_split_pitch, \
+                           a->W_split_plane, ts)
+        if (a->mode == 1) { if (sp) LAUNCH_WIDE(1, false, true); else LAUNCH_WIDE(1, false, false); }
+        else if (pe.key) { if (sp) LAUNCH_WIDE(0, true, true); else LAUNCH_WIDE(0, true, false); }
+        else { if (sp) LAUNCH_WIDE(0, false, true); else LAUNCH_WIDE(0, false, false); }
+#undef LAUNCH_WIDE
+        if (sp) GAD_CHECK_LAUNCH("gemm_fwd(wide split)"); else GAD_CHECK_LAUNCH("gemm_fwd(wide)");
         return GAD_OK;
     }
     // 64 x 64 tiles throughout: with K <= 1024 these launches are prologue/epilogue-bound, more and smaller

@@ -423,3 +423,63 @@ extern "C" int gad_zero_buffers(void* p0, long long n0, void* p1, long long n1, 
     GAD_CHECK_LAUNCH("zero_buffers");
     return GAD_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// split-bf16 mirrors of packed weight matrices (include/gaddpg.h: gad_split_weights).  One thread per (row n, column pair
+// k, k + 1): hi / mid / lo by round-to-nearest-even conversions of the exact residuals, forward mirror as packed pairs
+// (coalesced 4-byte stores), transposed mirror as 2-byte stores (the matrices are a few hundred KB: the launch is ~4 us).
+// A value is negated where its reduction index (k forward, n transposed) lies in an odd block of 16.
+// ------------------------------------------------------------------------------------------------
+struct SplitLayers { gad_split_layer l[GAD_MAX_SPLIT_LAYERS]; };
+
+__device__ __forceinline__ unsigned split_cvt_pk_bf16(float lo, float hi) {      // {bf16(hi) << 16 | bf16(lo)}, RNE
+    unsigned r;
+    __asm__("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ packed, SplitLayers L, uint16_t* __restrict__ out) {
+    const gad_split_layer& y = L.l[blockIdx.y];
+    const int half_k = y.Ks >> 1;
+    const long long pairs = (long long)y.n_out * half_k;
+    const long long plane = (long long)y.n_out * y.Ks;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long long)gridDim.x * 256) {
+        const int n = (int)(i / half_k), k = 2 * (int)(i % half_k);
+        const float2 w = *reinterpret_cast<const float2*>(packed + y.w_off + (size_t)n * y.Kp + k);
+        const unsigned H = split_cvt_pk_bf16(w.x, w.y);
+        const float ra = w.x - __uint_as_float(H << 16), rb = w.y - __uint_as_float(H & 0xffff0000u);
+        const unsigned M = split_cvt_pk_bf16(ra, rb);
+        const unsigned Lo = split_cvt_pk_bf16(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
+        const unsigned sk = ((k >> 4) & 1) ? 0x80008000u : 0u;       // forward: reduction index k
+        const unsigned sn = ((n >> 4) & 1) ? 0x8000u : 0u;           // transposed: reduction index n
+        const unsigned v[3] = {H, M, Lo};
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            *reinterpret_cast<unsigned*>(out + y.fwd_off + p * plane + (size_t)n * y.Ks + k) = v[p] ^ sk;
+            uint16_t* t = out + y.t_off + p * plane + (size_t)k * y.n_out + n;
+            t[0] = (uint16_t)((v[p] & 0xffffu) ^ sn);
+            t[y.n_out] = (uint16_t)((v[p] >> 16) ^ sn);
+        }
+    }
+}
+
+extern "C" int gad_split_weights(const float* packed, const gad_split_layer* host_layers, int n_layers, uint16_t* out, void* stream) {
+    GAD_REQUIRE(packed && host_layers && out, GAD_ERR_NULL, "split_weights: null pointer");
+    GAD_REQUIRE(n_layers >= 1 && n_layers <= GAD_MAX_SPLIT_LAYERS, GAD_ERR_SHAPE, "split_weights: 1..%d layers", GAD_MAX_SPLIT_LAYERS);
+    SplitLayers L;
+    long long most = 0;
+    for (int i = 0; i < n_layers; ++i) {
+        const gad_split_layer& y = host_layers[i];
+        GAD_REQUIRE(y.n_out > 0 && y.Ks > 0 && y.Ks % 32 == 0 && y.Ks <= y.Kp && y.Kp % 2 == 0 && y.w_off % 2 == 0 && y.fwd_off % 2 == 0 &&
+                    y.w_off >= 0 && y.fwd_off >= 0 && y.t_off >= 0, GAD_ERR_SHAPE,
+                    "split_weights: layer %d: Ks must be a multiple of 32 and <= Kp, offsets even", i);
+        L.l[i] = y;
+        const long long pairs = (long long)y.n_out * (y.Ks / 2);
+        most = pairs > most ? pairs : most;
+    }
+    int gx = gad_cdiv(most, 256);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    hipLaunchKernelGGL(split_weights_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, packed, L, out);
+    GAD_CHECK_LAUNCH("split_weights");
+    return GAD_OK;
+}

@@ -142,6 +142,47 @@ class FlatNet(object):
     def sync_packed(self):
         """master -> packed (after load_state_dict / external edits)."""
         hip.call("gad_pack_params", self.master, self.m2p, self.n, self.packed)
+        self.refresh_split()
+
+    # ---- split-bf16 weight mirrors (include/gaddpg.h gad_split_weights; library option "mfma_split") ----
+    split = None
+
+    def enable_split(self, layers):
+        """layers: [(MatSpec, Ks)] -- the matrices whose launches may take the split-bf16 form and the number of leading packed
+        columns they multiply on the MFMA (Kp of an ACT layer, feat_c of a gathered first layer); Ks % 32 == 0.  Allocates the
+        forward + transposed mirrors (3 bf16 planes each) and fills them; refresh_split() must follow every change of `packed`."""
+        layers = [(m, ks) for m, ks in layers if ks % 32 == 0 and 32 <= ks <= m.Kp and m.w_off % 2 == 0]
+        if not layers:
+            return
+        assert len(layers) <= hip.MAX_SPLIT_LAYERS
+        arr = (hip.SplitLayer * len(layers))()
+        off = 0
+        for y, (m, ks) in zip(arr, layers):
+            plane = m.n_out * ks
+            y.w_off, y.n_out, y.Kp, y.Ks, y.fwd_off, y.t_off = m.w_off, m.n_out, m.Kp, ks, off, off + 3 * plane
+            m.split = dict(fwd=off, t=off + 3 * plane, Ks=ks, plane=plane)
+            off += 6 * plane
+        self.split = torch.zeros(off, dtype=torch.int16, device=self.device)
+        self._split_layers = arr
+        self.refresh_split()
+
+    def refresh_split(self):
+        if self.split is not None:
+            hip.call("gad_split_weights", self.packed, self._split_layers, len(self._split_layers), self.split)
+
+    def split_fwd_kw(self, m):
+        """gad_gemm_fwd_args fields of layer m's forward mirror ({} if it has none)"""
+        sp = getattr(m, "split", None)
+        if self.split is None or sp is None:
+            return {}
+        return dict(W_split=hip.Ptr(self.split.data_ptr() + 2 * sp["fwd"]), W_split_pitch=sp["Ks"], W_split_plane=sp["plane"])
+
+    def split_t_kw(self, m):
+        """gad_gemm_dx_args fields of layer m's transposed mirror"""
+        sp = getattr(m, "split", None)
+        if self.split is None or sp is None:
+            return {}
+        return dict(W_split_t=hip.Ptr(self.split.data_ptr() + 2 * sp["t"]), W_split_t_pitch=m.n_out, W_split_t_plane=sp["plane"])
 
     def p_w(self, m):
         return hip.Ptr(self.packed.data_ptr() + 4 * m.w_off)
@@ -245,6 +286,10 @@ class EncoderNet(object):
         for i, m in enumerate(self.mats):
             m.bn_index = i
         self.flat = FlatNet(list(module.named_parameters()), self.mats, device)
+        # split-bf16 mirrors: every SA layer behind a BatchNorm + ReLU (K = the channel count) and the gathered first layers of
+        # SA2 / SA3 (their feature columns; the three coordinate columns stay a rank-3 f32 update)
+        self.flat.enable_split([(m, (m.gather_feat_c if l == 0 else m.Kp)) for st in self.sa_mats for l, m in enumerate(st)
+                                if (l > 0 or m.gather_feat_c >= 32)])
         self.c_feat = self.sa_mats[0][0].k_in - 3              # 4 (policy) or 10 (critic: + 6 action channels)
         self.act_c = self.c_feat - 4
         # BatchNorm running statistics: one flat buffer per kind, module buffers become views
@@ -719,6 +764,7 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
             kw.update(pool_key=_ptr(slot.key[s], 0, 8), pool_row_grp=_ptr(geo.rows[s]["grp"]), pool_gamma=enc.flat.p_gamma(m))
         if s == 0 and l == 0 and not slot.with_backward and recomputed_input(enc, geo, 0, 1):
             zout = None         # statistics only: layer 2 recomputes this output and nothing else reads it in a forward-only pass
+        kw.update(enc.flat.split_fwd_kw(m))
         a = _fwd_args(W=enc.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(zout), zout_pitch=m.n_out,
                       stat_sum=_ptr(slot.stats, o, 8), stat_sq=_ptr(slot.stats, tot + o, 8), stat_stride=2 * tot, **kw)
         if s < 2:
@@ -822,7 +868,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         a.Kp = m.Kp
         a.k_valid = k_valid
         a.grp_per_sample = 1
-        for k, v in epi.items():
+        for k, v in dict(epi, **enc.flat.split_t_kw(m)).items():
             setattr(a, k, v)
         stage = {"sa1": 0, "sa2": 1}.get(rows_kw.get("name"))
         if stage is not None:

@@ -29,7 +29,8 @@ class GemmFwdArgs(C.Structure):
                 ("in_stat_sum", _vp), ("in_stat_sq", _vp), ("in_stat_stride", _i32), ("in_count", _f64),
                 ("in_gamma", _vp), ("in_beta", _vp), ("in_eps", _f32), ("in_momentum", _f32),
                 ("in_running_mean", _vp), ("in_running_var", _vp), ("in_mean", _vp), ("in_istd", _vp),
-                ("pre_W", _vp), ("pre_Kp", _i32)]
+                ("pre_W", _vp), ("pre_Kp", _i32),
+                ("W_split", _vp), ("W_split_pitch", _i32), ("W_split_plane", _i32)]
 
 
 class DzSrc(C.Structure):
@@ -49,7 +50,8 @@ class GemmDxArgs(C.Structure):
                 ("zprev", _vp), ("zprev_pitch", _i32), ("prev_scale", _vp), ("prev_shift", _vp),
                 ("prev_mean", _vp), ("prev_istd", _vp), ("prev_dbeta", _vp), ("prev_dgamma", _vp),
                 ("stat_stride", _i32), ("store_masked", _i32), ("dfeat", _vp), ("feat_c", _i32), ("row_pt", _vp), ("row_grp", _vp),
-                ("daction", _vp), ("act_c", _i32), ("grp_per_sample", _i32)]
+                ("daction", _vp), ("act_c", _i32), ("grp_per_sample", _i32),
+                ("W_split_t", _vp), ("W_split_t_pitch", _i32), ("W_split_t_plane", _i32)]
 
 
 class GemmDwArgs(C.Structure):
@@ -73,6 +75,14 @@ class OptimJob(C.Structure):
                 ("hard_enable", _i32), ("absmax_p", _vp), ("absmax_grad", _vp), ("counter", _vp), ("counter_n", _i32),
                 ("counter_add", _i32)]
 
+
+class SplitLayer(C.Structure):
+    _fields_ = [("w_off", _i32), ("n_out", _i32), ("Kp", _i32), ("Ks", _i32), ("fwd_off", C.c_int64), ("t_off", C.c_int64)]
+
+
+MAX_SPLIT_LAYERS = 16
+# option "mfma_split": family mask (include/gaddpg.h GAD_SPLIT_*); 1 = every family that has the split-bf16 form
+SPLIT_ALL, SPLIT_FWD_STREAM, SPLIT_FWD_WIDE, SPLIT_DX_WIDE, SPLIT_DW_WIDE, SPLIT_BWD_STREAM, SPLIT_DW_STREAM = 1, 2, 4, 8, 16, 32, 64
 
 _lib = None
 
@@ -104,7 +114,7 @@ EXPORTS = (
     "gad_pool_bwd_stats", "gad_bn_bwd_coef", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_bwd", "gad_gemm_dw_reduce", "gad_critic_loss",
     "gad_policy_outputs", "gad_policy_sample", "gad_actor_loss", "gad_actor_critic_loss", "gad_mask_counts", "gad_target_noise",
     "gad_grad_from_arena", "gad_optim_jobs", "gad_sumsq", "gad_absmax_segments", "gad_adam_step", "gad_polyak",
-    "gad_pack_params")
+    "gad_pack_params", "gad_split_weights")
 
 
 class Ptr(int):

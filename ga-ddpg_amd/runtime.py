@@ -388,6 +388,10 @@ class FusedRuntime(object):
         else:
             js[0].counter_add = 3 if policy_step else 2
         hip.check(hip.lib().gad_optim_jobs(js, len(js), hip.stream()), "gad_optim_jobs")
+        if which == "c":                     # the encoders' split-bf16 weight mirrors follow their packed weights
+            self.venc.flat.refresh_split()
+        elif which == "a" and ag.train_feature:
+            self.enc.flat.refresh_split()
 
     def _adam_host(self, flat, optim):
         g = optim.param_groups[0]
@@ -398,6 +402,7 @@ class FusedRuntime(object):
         flat.hyper.copy_(flat.hyper_host, non_blocking=True)
         hip.call("gad_adam_step", flat.master, flat.grad, flat.exp_avg, flat.exp_avg_sq, flat.active, flat.m2p,
                  flat.packed, flat.n, flat.hyper, clip, float(self.agent.clip_grad) if clip is not None else 0.0)
+        flat.refresh_split()
 
     def _reduce(self, flats, tag=None):
         if self.allreduce is None:

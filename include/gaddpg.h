@@ -43,7 +43,9 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * fields and the slab / graph switches of version 3 are gone;
                                             * 5: gad_gemm_bwd, gad_optim_jobs, gad_last_kernel; 6: gad_gemm_dw_reduce,
                                             * GAD_DW_REDUCE_LATER; 7: trailing BatchNorm blocks of gad_gemm_fwd_args (in_*)
-                                            * and gad_dz_src (bn_*, gacc_*), GAD_STAT_REPLICAS 8 -> 4)                */
+                                            * and gad_dz_src (bn_*, gacc_*), GAD_STAT_REPLICAS 8 -> 4;
+                                            * 8: split-bf16 weight mirrors (gad_split_weights; W_split* of gad_gemm_fwd_args,
+                                            * W_split_t* of gad_gemm_dx_args), option "mfma_split" as a family mask)  */
 /* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
  * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
  * with it instead of restating the routing rules.                                                  */
@@ -52,7 +54,19 @@ const char* gad_last_error(void);          /* thread-local description of the la
 /* Kernel-selection switches for A/B diagnostics (defaults in brackets).  "fwd_stream" [1]: route the wide and
  * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route
  * the small-M (<= 1024 rows) forward / dX / dW layers to the split-K kernels.  Returns GAD_ERR_SHAPE for an
- * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.          */
+ * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.
+ * "mfma_split" [0 until round 5's gates were green on hardware, see DESIGN.md]: the arithmetic of the layer GEMMs' products.
+ * 0: v_mfma_f32_32x32x2_f32 throughout.  Non-zero: a mask of kernel families that form every FP32 product from split-bf16
+ * terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation (GAD_SPLIT_* below; 1 = every family that has the form).  A launch
+ * takes the split form only if its family's bit is set AND the call carries the weight mirror it needs (W_split /
+ * W_split_t; the streaming SA1 kernels split W themselves); otherwise it runs the FP32-MFMA kernel.                     */
+#define GAD_SPLIT_ALL 1
+#define GAD_SPLIT_FWD_STREAM 2
+#define GAD_SPLIT_FWD_WIDE 4
+#define GAD_SPLIT_DX_WIDE 8
+#define GAD_SPLIT_DW_WIDE 16
+#define GAD_SPLIT_BWD_STREAM 32
+#define GAD_SPLIT_DW_STREAM 64
 int gad_set_option(const char* name, int value);
 
 /* In-kernel launch timing (diagnostics / bench.py roofline): arm `slot` -- device memory, GAD_TIMING_WAVES x {start, end}
@@ -216,6 +230,12 @@ typedef struct {
      * rows (feat_c 4, act_c 0 / 6), Kp = c_in = n_out = 64, n_rows >= 32768; anything else is GAD_ERR_SHAPE.            */
     const float* pre_W;        /* (64, pre_Kp) packed weights of the recomputed layer                */
     int32_t pre_Kp;            /* 8 or 16                                                             */
+    /* split-bf16 mirror of W (ABI 8; NULL: the launch multiplies on the FP32 MFMA whatever "mfma_split" says): three bf16
+     * planes hi | mid | lo written by gad_split_weights, plane p at W_split + p * W_split_plane, row n at + n * W_split_pitch,
+     * the first W_split_pitch input columns of every row.  One group only.                                              */
+    const uint16_t* W_split;
+    int32_t W_split_pitch;     /* bf16 elements per row (= columns mirrored: Kp, or feat_c for a gathered first layer)    */
+    int32_t W_split_plane;     /* bf16 elements per plane                                                                  */
 } gad_gemm_fwd_args;
 
 int gad_gemm_fwd(const gad_gemm_fwd_args* host_args, void* stream);
@@ -341,6 +361,11 @@ typedef struct {
      * the per-sample action gradient is a sum of many cancelling terms)                            */
     float* dfeat; int32_t feat_c; const int32_t* row_pt; const int32_t* row_grp;
     double* daction; int32_t act_c; int32_t grp_per_sample;
+    /* split-bf16 mirror of W^T (ABI 8; NULL: FP32 MFMA): planes hi | mid | lo of W_split_t_plane bf16 elements, row k (input
+     * channel) at + k * W_split_t_pitch, columns = the layer's n_out output channels (gad_split_weights).  One group only. */
+    const uint16_t* W_split_t;
+    int32_t W_split_t_pitch;
+    int32_t W_split_t_plane;
 } gad_gemm_dx_args;
 
 int gad_gemm_dx(const gad_gemm_dx_args* host_args, void* stream);
@@ -472,6 +497,27 @@ int gad_optim_jobs(const gad_optim_job* host_jobs, int n_jobs, void* stream);
 
 /* packed[m2p[i]] = p[i] (refresh the compute layout after an external parameter change)          */
 int gad_pack_params(const float* p, const int32_t* m2p, int n, float* packed, void* stream);
+
+/* Split-bf16 mirrors of packed weight matrices (ABI 8; the arithmetic behind option "mfma_split": every FP32 product is
+ * formed as the six leading bf16 x bf16 term products of hi + mid + lo splits -- 24 significand bits -- accumulated in f32 by
+ * v_mfma_f32_32x32x16_bf16).  For each layer, from its packed f32 weights W (n_out, Kp) at packed + w_off, the first Ks
+ * columns (Ks a multiple of 32):
+ *   forward mirror   out + fwd_off: planes hi | mid | lo of n_out * Ks bf16, row n, column k  (reduction index k contiguous)
+ *   transposed mirror out + t_off : planes hi | mid | lo of Ks * n_out bf16, row k, column n  (reduction index n contiguous)
+ * hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (round to nearest even; the residuals are exact), and every
+ * value whose REDUCTION index lies in an odd block of 16 is stored NEGATED: the kernels add those blocks' products into a
+ * second accumulator and subtract it, which cancels the bf16 MFMA adder's truncation bias.  Call it whenever
+ * `packed` changes (after gad_pack_params / gad_adam_step / gad_optim_jobs) for networks whose launches carry W_split*. */
+#define GAD_MAX_SPLIT_LAYERS 16
+typedef struct {
+    int32_t w_off;             /* element offset of the layer's weights in `packed`                 */
+    int32_t n_out;
+    int32_t Kp;                /* row pitch of the packed weights                                   */
+    int32_t Ks;                /* leading columns mirrored (multiple of 32, <= Kp)                  */
+    int64_t fwd_off;           /* bf16-element offsets into `out`                                   */
+    int64_t t_off;
+} gad_split_layer;
+int gad_split_weights(const float* packed, const gad_split_layer* host_layers, int n_layers, uint16_t* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * F. replay minibatch gather (the step before the path: reference core/replay_memory.py:109-127,251-272 run as a

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libgaddpg.so does not export " + n
     assert set(names) == set(hip.EXPORTS), set(names) ^ set(hip.EXPORTS)
-    assert L.gad_abi_version() == 7
+    assert L.gad_abi_version() == 8
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -40,9 +40,9 @@ def test_struct_sizes_match_header():
     """ctypes mirrors must have the C layout: compile a tiny probe with the real header."""
     import ctypes, subprocess, tempfile
     from ga_ddpg_amd import hip
-    src = '#include "gaddpg.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(gad_gemm_fwd_args), ' \
+    src = '#include "gaddpg.h"\n#include <stdio.h>\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(gad_gemm_fwd_args), ' \
           'sizeof(gad_dz_src), sizeof(gad_gemm_dx_args), sizeof(gad_gemm_dw_args), sizeof(gad_replay_gather_args), ' \
-          'sizeof(gad_optim_job));return 0;}\n'
+          'sizeof(gad_optim_job), sizeof(gad_split_layer));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "p.c")
         open(c, "w").write(src)
@@ -50,7 +50,8 @@ def test_struct_sizes_match_header():
         subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe])
         sizes = [int(x) for x in subprocess.check_output([exe]).split()]
     assert sizes == [ctypes.sizeof(hip.GemmFwdArgs), ctypes.sizeof(hip.DzSrc), ctypes.sizeof(hip.GemmDxArgs),
-                     ctypes.sizeof(hip.GemmDwArgs), ctypes.sizeof(hip.ReplayGatherArgs), ctypes.sizeof(hip.OptimJob)]
+                     ctypes.sizeof(hip.GemmDwArgs), ctypes.sizeof(hip.ReplayGatherArgs), ctypes.sizeof(hip.OptimJob),
+                     ctypes.sizeof(hip.SplitLayer)]
 
 
 def test_argument_errors_are_status_codes_not_crashes():

@@ -1,0 +1,101 @@
+"""VERDICT r04 item 1, conditions (b) and (c): the split-bf16 form of every GEMM family against a float64 reference, at the
+family's bench shape (B = 256), next to the FP32-MFMA path on the same operands.
+  (b) max and mean |error| <= 1.25 x the FP32-MFMA path's, |signed mean error| <= max(2 x the f32 path's, 1e-9 max|ref|)
+      (the bf16 MFMA's adder truncates toward -inf; the (plain, negated) accumulator pairs must cancel that bias);
+  (c) range and specials: operands scaled by 2^+-100 keep the same accuracy; rows holding Inf / NaN give non-finite outputs
+      exactly where the f32 path does and leave every other row untouched.
+Reference arithmetic: /root/reference/core/networks.py:66-81 under core/ddpg.py:136-139 (float32 conv / BatchNorm / ReLU)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    from tests import split_cases as sc
+    return {
+        "fwd_wide.sa2.l2": lambda: sc.FwdWide(27240, 128, 128, "act"),
+        "fwd_wide.sa2.l3": lambda: sc.FwdWide(27240, 128, 256, "pool"),
+        "fwd_wide.sa3.l2": lambda: sc.FwdWide(8192, 256, 256, "act"),
+        "fwd_wide.sa3.l3": lambda: sc.FwdWide(8192, 256, 512, "pool"),
+        "fwd_wide.sa2.l1": lambda: sc.FwdWide(27240, 128, 128, "gather"),
+        "fwd_wide.sa3.l1": lambda: sc.FwdWide(8192, 256, 256, "gather"),
+    }
+
+
+CASES = ("fwd_wide.sa2.l2", "fwd_wide.sa2.l3", "fwd_wide.sa3.l2", "fwd_wide.sa3.l3", "fwd_wide.sa2.l1", "fwd_wide.sa3.l1")
+
+
+def check_case(case, name, report=None, keys=None):
+    from tests import split_cases as sc
+    ref = case.ref()
+    f32, r32 = case.run_mode(False)
+    spl, rsp = case.run_mode(True)
+    assert "split" in rsp and "split" not in r32, "%s: routed to %s / %s" % (name, r32, rsp)
+    bad = []
+    for k, rv in ref.items():
+        if keys is not None and k not in keys:
+            continue
+        a32, m32, s32, scale = sc.errors(f32[k], rv)
+        asp, msp, ssp, _ = sc.errors(spl[k], rv)
+        if report is not None:
+            report.append("%-18s %-9s f32-MFMA: max %.3e mean %.3e signed %+.3e | split: max %.3e mean %.3e signed %+.3e | of max|ref| %.3e"
+                          % (name, k, a32, m32, s32, asp, msp, ssp, scale))
+        # (statistics / gradient sums: f64 accumulation of f32 partial sums -- the same bounds apply; floors for outputs
+        # whose f32 error happens to be ~0)
+        floor = 1e-9 * scale
+        if asp > 1.25 * a32 + floor or msp > 1.25 * m32 + floor:
+            bad.append("%s %s: split max %.3e mean %.3e vs f32 max %.3e mean %.3e" % (name, k, asp, msp, a32, m32))
+        if abs(ssp) > max(2.0 * abs(s32), floor):
+            bad.append("%s %s: split signed mean %.3e vs f32 %.3e (floor %.1e)" % (name, k, ssp, s32, floor))
+    if "key" in f32:                                  # fused max-pool: keys decode to the launch's own raw output
+        for out in (f32, spl):
+            z = out["z"]
+            key = out["key"][: z.shape[0] // case.gsz]
+            hi = (key >> 32) & 0xffffffff
+            bits = torch.where((hi & 0x80000000) != 0, hi ^ 0x80000000, (~hi) & 0xffffffff).to(torch.int32)
+            val = bits.view(torch.float32)
+            want = z[: key.shape[0] * case.gsz].view(-1, case.gsz, z.shape[1]).max(1).values
+            assert torch.equal(val, want), name + ": pooled keys do not decode to the maxima of the stored output"
+    return bad
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_split_error_vs_float64_at_bench_shape(name):
+    case = _cases()[name]()
+    bad = check_case(case, name)
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", ["fwd_wide.sa2.l2", "fwd_wide.sa2.l1"])
+@pytest.mark.parametrize("exp", [100, -100])
+def test_split_range(name, exp):
+    """operands scaled by 2^+-100 (activations) and 2^-+100 (weights) / both by 2^+-50: same relative accuracy -- no term of the
+    split overflows or is flushed where the f32 product survives"""
+    from tests import split_cases as sc
+    kind = name.split(".")[0]
+    for a_s, w_s in ((2.0 ** exp, 0.05 * 2.0 ** -exp), (2.0 ** (exp // 2), 0.05 * 2.0 ** (exp // 2))):
+        case = sc.FwdWide(4096, 128, 128, "gather" if name.endswith("l1") else "act", a_scale=a_s, w_scale=w_s)
+        bad = check_case(case, "%s x2^%d" % (name, exp), keys=("z",))          # (the f32 statistics sums over- / underflow alike)
+        assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("name", ["fwd_wide.sa2.l2"])
+def test_split_specials(name):
+    """rows holding +Inf / NaN / -Inf: outputs are non-finite exactly where the f32 path's are (Inf may become NaN: hi = Inf
+    leaves mid = Inf - Inf; a NaN or -Inf pre-activation is squashed to 0 by the ReLU's max in both paths), every other row
+    keeps its accuracy"""
+    from tests import split_cases as sc
+    case = sc.FwdWide(4096, 128, 128, "act")
+    case.zin[17, 5] = float("inf")
+    case.zin[99, 64] = float("nan")
+    case.zin[200, 3] = -float("inf")           # relu(-inf * s + t) = 0 for s > 0: stays finite in both
+    f32, _ = case.run_mode(False)
+    spl, _ = case.run_mode(True)
+    assert torch.equal(torch.isfinite(f32["z"]), torch.isfinite(spl["z"]))
+    assert not torch.isfinite(f32["z"][17]).any() and torch.isfinite(f32["z"][200]).all()
+    ok = torch.isfinite(f32["z"]).all(1)
+    ref = case.ref()["z"]
+    e32 = (f32["z"].double() - ref)[ok].abs().max()
+    esp = (spl["z"].double() - ref)[ok].abs().max()
+    assert float(esp) <= 1.25 * float(e32) + 1e-12
