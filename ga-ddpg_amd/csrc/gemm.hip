@@ -1008,6 +1008,34 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
             const int gb = __builtin_amdgcn_readfirstlane(pg_before), ga = __builtin_amdgcn_readfirstlane(pg_after);
             pool_tile64<2>(zt + lane, 129, 64, pgl, row0, min(64, n_rows - row0), psgn, wave, 4, gb, ga, pe.key + n0 + lane, pe.C);
         }
+        if (SP) {
+            // stores first, then the statistics from ONE batch of weight reads.  (Interleaved as in the FP32 path below, hipcc
+            // packs the two column tiles into v_pk_* pairs and refills the weight registers piecemeal -- ds_read_b96 / b32 / b64
+            // into registers whose stores are still in flight; with two workgroups per CU that form produced wrong sums of
+            // squares for the first column tile in 29 of 40 launches on an MI355X, this one in 0 of 40: tools/diag_split_sq.py.)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n = n0 + wn * 64 + t * 32 + l31;
+            const int vzo = (4 * half * zout_pitch + n) * 4;
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[t][v]), zo_, vzo, (row0 + wm * 32 + (v & 3) + 8 * (v >> 2)) * zo_pitch4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float w = wS[wm * 32 + acc_row(v, half)];
+                const float zv = acc[t][v];
+                s1 = fmaf(w, zv, s1);
+                s2 = fmaf(w * zv, zv, s2);
+            }
+            csum[t] += s1;
+            csq[t] += s2;
+        }
+        } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int n = n0 + wn * 64 + t * 32 + l31;
@@ -1024,6 +1052,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
             }
             csum[t] += s1;
             csq[t] += s2;
+        }
         }
         // (the next row tile's first barrier orders these wS / zt reads before its writes)
     }

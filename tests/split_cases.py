@@ -75,7 +75,7 @@ def time_call(fn, iters=30, warm=5):
 class Case(object):
     """one launch: run(split) -> dict of output tensors; ref() -> dict of float64 references for the same keys"""
     family = 0
-    kernel = ""
+    entry = "gad_gemm_fwd"
 
     def run_mode(self, split):
         hip.set_option("mfma_split", self.family if split else 0)
@@ -87,10 +87,15 @@ class Case(object):
             hip.set_option("mfma_split", 0)
         return out, routed
 
-    def time_mode(self, split, iters=30):
+    def time_mode(self, split, iters=50):
+        """microseconds per launch, back-to-back launches of the call alone (outputs accumulate: timing only)"""
         hip.set_option("mfma_split", self.family if split else 0)
         try:
-            return time_call(self.run, iters)
+            a = self.args()
+            name = self.entry
+            f = getattr(hip.lib(), name)
+            st = hip.stream()
+            return time_call(lambda: hip.check(f(C.byref(a), st), name), iters)
         finally:
             hip.set_option("mfma_split", 0)
 
@@ -185,6 +190,7 @@ class DxWide(Case):
     0 stores the ReLU-masked gradient of the previous layer and its BatchNorm-backward sums ("act" / "pool"), epilogue 1
     scatters into the points' feature gradients ("scatter")."""
     family = hip.SPLIT_DX_WIDE
+    entry = "gad_gemm_dx"
 
     def __init__(self, rows, N, K, mode="act", seed=2, g_scale=1.0, w_scale=0.05):
         dev = torch.device("cuda")
@@ -297,6 +303,7 @@ class DxWide(Case):
 class DwWide(Case):
     """gad_gemm_dw on the wide-tile route: dW[n][k] = sum_r dZ[r][n] * relu(bn(z_prev))[r][k] into the f64 arena"""
     family = hip.SPLIT_DW_WIDE
+    entry = "gad_gemm_dw"
 
     def __init__(self, rows, N, K, mode="act", seed=3):
         dev = torch.device("cuda")

@@ -94,8 +94,8 @@ def test_split_specials(name):
     spl, _ = case.run_mode(True)
     assert torch.equal(torch.isfinite(f32["z"]), torch.isfinite(spl["z"]))
     assert not torch.isfinite(f32["z"][17]).any() and torch.isfinite(f32["z"][200]).all()
-    ok = torch.isfinite(f32["z"]).all(1)
     ref = case.ref()["z"]
+    ok = torch.isfinite(f32["z"]).all(1) & torch.isfinite(ref).all(1)       # (the reference keeps the NaN the kernels' max squashes)
     e32 = (f32["z"].double() - ref)[ok].abs().max()
     esp = (spl["z"].double() - ref)[ok].abs().max()
     assert float(esp) <= 1.25 * float(e32) + 1e-12
