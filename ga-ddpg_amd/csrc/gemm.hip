@@ -2442,12 +2442,15 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
 // ------------------------------------------------------------------------------------------------
 // SC = 1: scatter epilogue of the gathered first layers (SA2 / SA3: dX columns = the feature channels of the row's point):
 // float atomics into dfeat[row_pt[r]][k], nothing stored per row, no BatchNorm in front
-template <int GM, int SC>
+// SP: split-bf16 products (namespace spw): dZ is split while it is staged, the B side is the layer's TRANSPOSED weight mirror
+// (rows = input channels k, the reduction index n contiguous: wsp, pitch = n_out).
+template <int GM, int SC, bool SP = false>
 __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
                                                               const float* __restrict__ W, int Kp, int n_out, DxEpi e,
+                                                              const uint16_t* __restrict__ wsp, int wsp_plane,
                                                               unsigned long long* __restrict__ ts) {
     KTimer kt_(ts);
-    constexpr int BM = 64, BN = 128, P = KT + 4, PB = BN + 4, STAGE = BM * P + KT * PB, VM = 512;
+    constexpr int BM = 64, BN = 128, P = KT + 4, PB = BN + 4, STAGE = SP ? spw::STAGE / 4 : BM * P + KT * PB, VM = 512;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 3 * VM + BM];
     __shared__ int32_t ptS[BM];                          // SC: the tile rows' points
     float* vP = smem + 2 * STAGE;                        // P | Q | S of this layer's channels
@@ -2479,6 +2482,13 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
     int vw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) vw[u] = ((bn + 8 * u) * Kp + k0out + bk4) * 4;
+    // SP: rows k0out + (tid >> 2) + 64 u of the transposed mirror, 16-byte chunk tid & 3 of a K-tile's 32 output channels
+    const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? wsp : reinterpret_cast<const uint16_t*>(W)), 0, 0x7ffffffc, 0x00020000);
+    int vbs[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) vbs[u] = ((k0out + (tid >> 2) + 64 * u) * n_out + (tid & 3) * 8) * 2;
+    unsigned char* const smem_b = reinterpret_cast<unsigned char*>(smem);
+    const int sp_fo = ((half ^ ((l31 >> 2) & 3)) << 4);
     for (int i = tid; i < n_out; i += 256) {
         float Pc, Qc, Sc;
         dz_coef(d, i, Pc, Qc, Sc, first_workgroup());
@@ -2495,10 +2505,11 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
     float cb[2] = {0.f, 0.f}, cg[2] = {0.f, 0.f};
     for (int row0 = blockIdx.x * BM; row0 < n_rows; row0 += gridDim.x * BM) {
         f32x16 acc[2];
+        f32x16 an[2];                                    // SP: the negated accumulators (odd k16-steps)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.f;
+            for (int v = 0; v < 16; ++v) { acc[t][v] = 0.f; if (SP) an[t][v] = 0.f; }
         // this thread's two staged rows (clamped past the live count: their dZ is zeroed through the weight / validity)
         int vz[2], vg[2];
         float wrow[2];
@@ -2512,8 +2523,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
             vz[u] = (rr * d.z_pitch + c4) * 4;
             vg[u] = ((GM == 1 ? d.row_grp[rr] : rr) * gpitch + c4) * 4;
         }
-        float4 rz[2], rg[2], rb[4];
+        float4 rz[2], rg[2], rb[SP ? 1 : 4];
         gad_u32x4 ra[2];
+        spw::BRegs rbs;
         auto load_regs = [&](int kt) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -2521,8 +2533,9 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
                 rg[u] = buf_ld4(gr_, vg[u], kt * (KT * 4));
                 if (GM == 1) ra[u] = __builtin_amdgcn_raw_buffer_load_b128(ar, vg[u], kt * (KT * 4), 0);
             }
+            if (SP) { spw::load_b(rbs, ws_, vbs, wsp_plane * 2, kt); return; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rb[u] = buf_ld4(wr, vw[u], kt * (KT * 4) * Kp);
+            for (int u = 0; u < (SP ? 1 : 4); ++u) rb[u] = buf_ld4(wr, vw[u], kt * (KT * 4) * Kp);
         };
         auto write_lds = [&](int kt) {
             float* As = smem + (kt & 1) * STAGE;
@@ -2544,10 +2557,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
                 v.x = P4.x * g.x - w * fmaf(S4.x, z.x, Q4.x); v.y = P4.y * g.y - w * fmaf(S4.y, z.y, Q4.y);
                 v.z = P4.z * g.z - w * fmaf(S4.z, z.z, Q4.z); v.w = P4.w * g.w - w * fmaf(S4.w, z.w, Q4.w);
                 if (!live[u]) v = f4zero();
-                *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
+                if (SP) spw::store_a4(smem_b + (kt & 1) * spw::STAGE, ur + 32 * u, tid, v);
+                else *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
             }
+            if (SP) { spw::store_b(smem_b + (kt & 1) * spw::STAGE, rbs, tid); return; }
 #pragma unroll
-            for (int u = 0; u < 4; ++u)                      // W[n][k..k+3] as stored: Bs[n][k], one ds_write_b128 (no transposing stores)
+            for (int u = 0; u < (SP ? 1 : 4); ++u)           // W[n][k..k+3] as stored: Bs[n][k], one ds_write_b128 (no transposing stores)
                 *reinterpret_cast<float4*>(Bs + (bn + 8 * u) * PB + bk4) = rb[u];
         };
         load_regs(0);
@@ -2557,6 +2572,13 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
         if (nk > 1) load_regs(1);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
+            if (SP) {
+                spw::ktile(smem_b + (kt & 1) * spw::STAGE, (wm * 32 + l31) * 64, (wn * 64 + l31) * 64, sp_fo, acc, an);
+                if (kt + 1 < nk) write_lds(kt + 1);
+                if (kt + 2 < nk) load_regs(kt + 2);
+                __syncthreads();
+                continue;
+            }
             const float* As = smem + (kt & 1) * STAGE + (wm * 32 + l31) * P + 4 * half;
             // B fragments: row n = 8 j + 4 h + i of the stored tile, this lane's column -- conflict-free ds_read_b32 across k
             const float* Bs = smem + (kt & 1) * STAGE + BM * P + (4 * half) * PB + wn * 64 + l31;
@@ -2585,6 +2607,12 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
             if (kt + 1 < nk) write_lds(kt + 1);
             if (kt + 2 < nk) load_regs(kt + 2);
             __syncthreads();
+        }
+        if (SP) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[t][v] -= an[t][v];
         }
         // epilogue: dY of the previous layer (ReLU-masked) + its BatchNorm-backward sums; all z_prev loads first
         if (SC) {
@@ -2963,13 +2991,17 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     if (dx_wideable(*a, vec)) {
         int gx = gad_cdiv(grid_rows, 64); if (gx > GAD_GX_CAP) gx = GAD_GX_CAP;
         const dim3 grid(gx, kv / 128);
-        if (a->epilogue == 1 && a->dz.gmode == 0)
-            hipLaunchKernelGGL((gemm_dx_wide_kernel<0, 1>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
-        else if (a->dz.gmode == 0)
-            hipLaunchKernelGGL((gemm_dx_wide_kernel<0, 0>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
-        else
-            hipLaunchKernelGGL((gemm_dx_wide_kernel<1, 0>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, ts);
-        GAD_CHECK_LAUNCH("gemm_dx(wide)");
+        // split-bf16 form: family bit set, the call carries the transposed weight mirror, the reduction (n_out) is whole K-tiles
+        const bool sp = split_on(GAD_SPLIT_DX_WIDE) && a->W_split_t && a->W_split_t_pitch == a->n_out[0] && a->n_out[0] % 32 == 0 &&
+                        a->W_split_t_plane >= kv * a->n_out[0];
+#define LAUNCH_DXW(GM, SC, SP)                                                                                                 \
+        hipLaunchKernelGGL((gemm_dx_wide_kernel<GM, SC, SP>), grid, dim3(256), 0, st, d, a->n_rows_dev, rows, a->W, a->Kp, a->n_out[0], e, \
+                           a->W_split_t, a->W_split_t_plane, ts)
+        if (a->epilogue == 1 && a->dz.gmode == 0) { if (sp) LAUNCH_DXW(0, 1, true); else LAUNCH_DXW(0, 1, false); }
+        else if (a->dz.gmode == 0) { if (sp) LAUNCH_DXW(0, 0, true); else LAUNCH_DXW(0, 0, false); }
+        else { if (sp) LAUNCH_DXW(1, 0, true); else LAUNCH_DXW(1, 0, false); }
+#undef LAUNCH_DXW
+        if (sp) GAD_CHECK_LAUNCH("gemm_dx(wide split)"); else GAD_CHECK_LAUNCH("gemm_dx(wide)");
         return GAD_OK;
     }
     int nmax_dx = 0;
@@ -3731,6 +3763,221 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wide-tile dW in split-bf16 form (option "mfma_split", GAD_SPLIT_DW_WIDE): the same 128 x 128 block per workgroup, 64 x 64
+// per wavefront, K-tile = 32 rows.  The reduction index (rows) is the SLOW index of both operands in memory, while
+// v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction indices per lane: so a thread stages a 4-row x 4-channel patch
+// (rows 4 rq .. + 3 of the K-tile, channels 4 cq .. + 3; rq = tid & 7: a wavefront's loads cover 8 rows x 128 contiguous
+// bytes), forms dZ / the activated input in registers, splits ROW PAIRS of one channel into hi / mid / lo and stores
+// 8 bytes (four rows) per channel and plane into LDS laid out [plane][channel][32 rows] (64-byte rows, 16-byte chunks
+// XOR-swizzled by (channel >> 2) & 3: fragments are conflict-free ds_read_b128 of 8 consecutive rows).  Rows 16 .. 31 of every
+// K-tile carry NEGATED dZ and accumulate into the second accumulator set (the bf16 MFMA's truncation bias cancels in the
+// difference).  One workgroup per CU (eight accumulators per wavefront), LDS double-buffered, one barrier per K-tile.
+// ------------------------------------------------------------------------------------------------
+template <int XM, int GM>
+__global__ __launch_bounds__(256, 1) void gemm_dw_wide_split_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                                    int n_rows_static, int Kp, int n_out, int tiles_k,
+                                                                    float* __restrict__ partial, unsigned long long* __restrict__ ts) {
+    KTimer kt_(ts);
+    constexpr int BT = 128, OPL = BT * 64, STAGE = 6 * OPL, VM = 512;      // bytes: one operand plane, one stage (A planes | B planes)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_b[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float vP[5 * VM];               // P | Q | S of the dZ channels, scale | shift of the input channels
+    float* sv = vP + 3 * VM;
+    float* tv = sv + VM;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n0 = (blockIdx.x / tiles_k) * BT, k0 = (blockIdx.x % tiles_k) * BT;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    int chunk = gad_cdiv_dev(n_rows, (int)gridDim.y);
+    chunk = (chunk + KT - 1) / KT * KT;                  // == dw_reduce_kernel's split geometry
+    const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, n_rows);
+    if (r_begin >= r_end) return;                        // the reducer skips the same splits
+    for (int i = tid; i < BT; i += 256) {
+        float Pc, Qc, Sc;
+        dz_coef(d, n0 + i, Pc, Qc, Sc, blockIdx.y == 0 && k0 == 0);
+        vP[i] = Pc; vP[VM + i] = Qc; vP[2 * VM + i] = Sc;
+        if (XM == 0) { sv[i] = x.scale[k0 + i]; tv[i] = x.shift[k0 + i]; }
+    }
+    const bool coords = XM == 1 && k0 == 0;              // this workgroup also forms dW[n][feat_c .. feat_c + 2]
+    float wx[4][3];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wx[j][0] = 0.f; wx[j][1] = 0.f; wx[j][2] = 0.f; }
+    f32x16 acc[2][2], an[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { acc[a][b][v] = 0.f; an[a][b][v] = 0.f; }
+    // staging patch of this thread: rows 4 rq + u (u < 4) of the K-tile, channels c4 .. c4 + 3
+    const int rq = tid & 7, c4 = (tid >> 3) * 4;
+    const float sgn = rq >= 4 ? -1.f : 1.f;              // rows 16 .. 31: negated dZ
+    const int gpitch = GM == 0 ? d.g_pitch : d.c;
+    float4 rz[4], rg[4], rx[4];
+    int4 ra[4];
+    float rw[4], rd[4][3];
+    int pq[4], gq[4], gd[4];                             // point / group of the NEXT tile's rows (gathered input, pooled gradient)
+    auto load_idx = [&](int rb0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb0 + 4 * rq + u;
+            const int rr = r < r_end ? r : r_end - 1;
+            pq[u] = XM == 1 ? x.row_pt[rr] : 0;
+            gq[u] = (XM == 1 && x.ctr_xyz) ? x.row_grp[rr] : 0;
+            gd[u] = GM == 1 ? d.row_grp[rr] : 0;
+        }
+    };
+    auto load_regs = [&](int rb0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb0 + 4 * rq + u;
+            const int rr = r < r_end ? r : r_end - 1;
+            rw[u] = d.row_w ? d.row_w[rr] : 1.f;
+            rz[u] = ldg4(d.z + (size_t)rr * d.z_pitch + n0 + c4);
+            if (GM == 0) {
+                rg[u] = ldg4(d.G + (size_t)rr * gpitch + n0 + c4);
+            } else {
+                const int grp = gd[u];
+                ra[u] = *reinterpret_cast<const int4*>(d.argmax + (size_t)grp * gpitch + n0 + c4);
+                rg[u] = ldg4(d.dout + (size_t)grp * gpitch + n0 + c4);
+            }
+            if (XM == 0) {
+                rx[u] = ldg4(x.zin + (size_t)rr * x.zin_pitch + k0 + c4);
+            } else {
+                rx[u] = ldg4(x.feat + (size_t)pq[u] * x.feat_c + k0 + c4);
+                if (coords) {
+                    const float* p = x.src_xyz + (size_t)pq[u] * 3;
+                    float q0 = p[0], q1 = p[1], q2 = p[2];
+                    if (x.ctr_xyz) {
+                        const float* cp = x.ctr_xyz + (size_t)gq[u] * 3;
+                        q0 = __fsub_rn(q0, cp[0]); q1 = __fsub_rn(q1, cp[1]); q2 = __fsub_rn(q2, cp[2]);
+                    }
+                    rd[u][0] = q0; rd[u][1] = q1; rd[u][2] = q2;
+                }
+            }
+        }
+        if (XM == 1 || GM == 1) load_idx(rb0 + KT);
+    };
+    // [plane][channel][rows]: this thread's 8 bytes (rows 4 rq .. + 3) of channel c4 + j
+    const int wr_off = c4 * 64 + (rq & 1) * 8, wr_q = rq >> 1;
+    auto write_lds = [&](int it, int rb0) {
+        unsigned char* As = smem_b + (it & 1) * STAGE;
+        unsigned char* Bs = As + 3 * OPL;
+        const float4 Pv = *reinterpret_cast<const float4*>(vP + c4), Qv = *reinterpret_cast<const float4*>(vP + VM + c4);
+        const float4 Sv = *reinterpret_cast<const float4*>(vP + 2 * VM + c4);
+        float4 s4 = f4zero(), t4 = f4zero();
+        if (XM == 0) { s4 = *reinterpret_cast<const float4*>(sv + c4); t4 = *reinterpret_cast<const float4*>(tv + c4); }
+        float av[4][4], bv[4][4];                        // [row u][channel j]
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = rb0 + 4 * rq + u;
+            float4 g = rg[u];
+            const float4 z = rz[u];
+            if (GM == 1) {
+                g.x = ra[u].x == r ? g.x : 0.f; g.y = ra[u].y == r ? g.y : 0.f;
+                g.z = ra[u].z == r ? g.z : 0.f; g.w = ra[u].w == r ? g.w : 0.f;
+            }
+            const float w = rw[u];
+            float4 a, b;
+            a.x = Pv.x * g.x - w * fmaf(Sv.x, z.x, Qv.x); a.y = Pv.y * g.y - w * fmaf(Sv.y, z.y, Qv.y);
+            a.z = Pv.z * g.z - w * fmaf(Sv.z, z.z, Qv.z); a.w = Pv.w * g.w - w * fmaf(Sv.w, z.w, Qv.w);
+            if (XM == 0) {
+                b.x = fmaxf(fmaf(rx[u].x, s4.x, t4.x), 0.f); b.y = fmaxf(fmaf(rx[u].y, s4.y, t4.y), 0.f);
+                b.z = fmaxf(fmaf(rx[u].z, s4.z, t4.z), 0.f); b.w = fmaxf(fmaf(rx[u].w, s4.w, t4.w), 0.f);
+            } else {
+                b = rx[u];
+            }
+            if (r >= r_end) { a = f4zero(); b = f4zero(); }
+            if (coords) {
+#pragma unroll
+                for (int dd = 0; dd < 3; ++dd) {
+                    wx[0][dd] = fmaf(a.x, rd[u][dd], wx[0][dd]); wx[1][dd] = fmaf(a.y, rd[u][dd], wx[1][dd]);
+                    wx[2][dd] = fmaf(a.z, rd[u][dd], wx[2][dd]); wx[3][dd] = fmaf(a.w, rd[u][dd], wx[3][dd]);
+                }
+            }
+            av[u][0] = a.x * sgn; av[u][1] = a.y * sgn; av[u][2] = a.z * sgn; av[u][3] = a.w * sgn;
+            bv[u][0] = b.x; bv[u][1] = b.y; bv[u][2] = b.z; bv[u][3] = b.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int off = wr_off + j * 64 + (((wr_q ^ (((c4 + j) >> 2) & 3))) << 4);
+            unsigned h0, m0, l0, h1, m1, l1;
+            gad_split2(av[0][j], av[1][j], h0, m0, l0);
+            gad_split2(av[2][j], av[3][j], h1, m1, l1);
+            *reinterpret_cast<uint2*>(As + off) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(As + OPL + off) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(As + 2 * OPL + off) = make_uint2(l0, l1);
+            gad_split2(bv[0][j], bv[1][j], h0, m0, l0);
+            gad_split2(bv[2][j], bv[3][j], h1, m1, l1);
+            *reinterpret_cast<uint2*>(Bs + off) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(Bs + OPL + off) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2*>(Bs + 2 * OPL + off) = make_uint2(l0, l1);
+        }
+    };
+    if (XM == 1 || GM == 1) load_idx(r_begin);
+    load_regs(r_begin);
+    __syncthreads();                                     // vP / sv / tv visible
+    write_lds(0, r_begin);
+    if (r_begin + KT < r_end) load_regs(r_begin + KT);
+    __syncthreads();
+    // fragment addressing: channel rows wm * 64 + a * 32 + l31 (A) / wn * 64 + b * 32 + l31 (B); chunk 2 st + half, swizzled
+    const int fo = ((half ^ ((l31 >> 2) & 3)) << 4);
+    const int arow = (wm * 64 + l31) * 64, brow = 3 * OPL + (wn * 64 + l31) * 64;
+    int it = 0;
+    for (int rb0 = r_begin; rb0 < r_end; rb0 += KT, ++it) {
+        const unsigned char* st = smem_b + (it & 1) * STAGE;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            const int off = fo ^ (s2 << 5);
+            gad_u32x4 A[2][3], B[2][3];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    A[a][pl] = *reinterpret_cast<const gad_u32x4*>(st + arow + a * (32 * 64) + pl * OPL + off);
+                    B[a][pl] = *reinterpret_cast<const gad_u32x4*>(st + brow + a * (32 * 64) + pl * OPL + off);
+                }
+            // the six products of weight >= 2^-16, smallest first: (A plane, B plane) = (lo, hi) (hi, lo) (mid, mid) (mid, hi) (hi, mid) (hi, hi)
+#define GAD_SPD(PA, PB_)                                                                                                       \
+            _Pragma("unroll") for (int a = 0; a < 2; ++a) _Pragma("unroll") for (int b = 0; b < 2; ++b) {                      \
+                if (s2) an[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A[a][PA]), gad_as_bf16x8(B[b][PB_]), an[a][b], 0, 0, 0); \
+                else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A[a][PA]), gad_as_bf16x8(B[b][PB_]), acc[a][b], 0, 0, 0); \
+            }
+            GAD_SPD(2, 0) GAD_SPD(0, 2) GAD_SPD(1, 1) GAD_SPD(1, 0) GAD_SPD(0, 1) GAD_SPD(0, 0)
+#undef GAD_SPD
+        }
+        if (rb0 + KT < r_end) write_lds(it + 1, rb0 + KT);
+        if (rb0 + 2 * KT < r_end) load_regs(rb0 + 2 * KT);
+        __syncthreads();
+    }
+    float* pout = partial + (size_t)blockIdx.y * n_out * Kp;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int n = n0 + wm * 64 + a * 32 + acc_row(v, half), k = k0 + wn * 64 + b * 32 + l31;
+                pout[(size_t)n * Kp + k] = acc[a][b][v] - an[a][b][v];
+            }
+    if (coords) {                                        // 8 row quads per channel quad -> one sum (the tile LDS is free)
+        float* red = reinterpret_cast<float*>(smem_b);   // [8][128][3]
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int dd = 0; dd < 3; ++dd) red[(rq * BT + c4 + j) * 3 + dd] = wx[j][dd];
+        __syncthreads();
+        for (int i = tid; i < BT * 3; i += 256) {
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) sum += red[q * BT * 3 + i];
+            pout[(size_t)(n0 + i / 3) * Kp + x.feat_c + i % 3] = sum;
+        }
+    }
+}
+
 // the wide-tile dW covers: ACT input with BatchNorm + ReLU in front, one group, 128-multiples on both sides, no bias / extra column
 static bool dw_wideable(const gad_gemm_dw_args& a, int k_used, bool vec) {
     const gad_gemm_fwd_args& in = a.in;
@@ -3839,6 +4086,19 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         const int by_rows = gad_cdiv(rows, 4 * KT);
         if (splits > by_rows) splits = by_rows;
         if (splits < 1) splits = 1;
+        if ((long long)splits * in.n_out[0] * in.Kp <= a->partial_elems && split_on(GAD_SPLIT_DW_WIDE)) {
+            // split-bf16 products: both operands are formed and split by the kernel itself (no weight mirror involved)
+#define LAUNCH_DWS(XM, GM)                                                                                                     \
+            hipLaunchKernelGGL((gemm_dw_wide_split_kernel<XM, GM>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, \
+                               in.Kp, in.n_out[0], tk_, a->partial, ts)
+            if (in.mode == 1) LAUNCH_DWS(1, 0); else if (a->dz.gmode == 0) LAUNCH_DWS(0, 0); else LAUNCH_DWS(0, 1);
+#undef LAUNCH_DWS
+            GAD_CHECK_LAUNCH("gemm_dw(wide split)");
+            hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)nmax * in.Kp, 256), gad_cdiv(splits, DW_RED_CHUNK), gr.n), dim3(256),
+                               0, st, a->partial, (long long)splits * nmax * in.Kp, gr, in.n_rows_dev, rows, splits, in.Kp, k_used, a->gacc);
+            GAD_CHECK_LAUNCH("dw_reduce");
+            return GAD_OK;
+        }
         if ((long long)splits * in.n_out[0] * in.Kp <= a->partial_elems) {
             if (in.mode == 1)
                 hipLaunchKernelGGL((gemm_dw_wide_kernel<1, 0>), dim3(tn_ * tk_, splits), dim3(256), 0, st, d, x, in.n_rows_dev, rows, in.Kp,

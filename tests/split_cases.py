@@ -179,7 +179,10 @@ class FwdWide(Case):
         A, W = self.operand()
         z = A @ W.t()
         w = self.row_w[:self.rows].double()[:, None]
-        return {"z": z, "stat_sum": (w * z).sum(0), "stat_sq": (w * z * z).sum(0)}
+        # "#abs": the sum of |terms| behind a reduced output -- a per-element bias b of z shows up as rows * b in a column sum,
+        # so the bias floor of a sum is taken relative to this scale (tests/test_gpu_split_families.py)
+        return {"z": z, "stat_sum": (w * z).sum(0), "stat_sq": (w * z * z).sum(0), "stat_sum#abs": (w * z.abs()).sum(0),
+                "stat_sq#abs": (w * z * z).sum(0)}
 
     def flops(self):
         return 2.0 * self.rows * self.K * self.N
@@ -289,36 +292,53 @@ class DxWide(Case):
         if self.mode == "scatter":
             out = torch.zeros(self.npts, self.K, dtype=torch.float64, device=gx.device)
             out.index_add_(0, self.row_pt[:r].long(), gx)
-            return {"dfeat": out}
+            ab = torch.zeros_like(out)
+            ab.index_add_(0, self.row_pt[:r].long(), gx.abs())
+            return {"dfeat": out, "dfeat#abs": ab}
         ps, pt, pm, pi = self.vecK
         mask = fma32(self.zprev[:r], ps, pt) > 0
         ga = torch.where(mask, gx, torch.zeros((), dtype=torch.float64, device=gx.device))
         xhat = (self.zprev[:r].double() - pm.double()) * pi.double()
-        return {"gout": ga, "dbeta": ga.sum(0), "dgamma": (ga * xhat).sum(0)}
+        return {"gout": ga, "dbeta": ga.sum(0), "dgamma": (ga * xhat).sum(0), "dbeta#abs": ga.abs().sum(0), "dgamma#abs": (ga * xhat).abs().sum(0)}
 
     def flops(self):
         return 2.0 * self.rows * self.K * self.N
 
 
 class DwWide(Case):
-    """gad_gemm_dw on the wide-tile route: dW[n][k] = sum_r dZ[r][n] * relu(bn(z_prev))[r][k] into the f64 arena"""
+    """gad_gemm_dw on the wide-tile route: dW[n][k] = sum_r dZ[r][n] * X[r][k] into the f64 arena; X = relu(bn(z_prev)) ("act",
+    "pool": pooled gradient source) or the gathered rows [feat[pt] | src_xyz[pt] - ctr_xyz[grp]] of an SA2 / SA3 first layer
+    ("gather")"""
     family = hip.SPLIT_DW_WIDE
     entry = "gad_gemm_dw"
 
     def __init__(self, rows, N, K, mode="act", seed=3):
         dev = torch.device("cuda")
-        g = _gen(seed)
         self.dx = DxWide(rows, N, K, mode="pool" if mode == "pool" else "act", seed=seed)
         self.rows, self.N, self.K, self.mode = rows, N, K, mode
-        d = self.dx
-        self.gacc = torch.zeros(N * K, dtype=torch.float64, device=dev)
+        self.Kp = K if mode != "gather" else (K + 3 + 7) // 8 * 8
+        if mode == "gather":
+            g = _gen(seed + 100)
+            cap = self.dx.cap
+            npts, ngrp = max(rows // 3, 64), max(rows // 8, 8)
+            self.feat = torch.randn(npts, K, device=dev, generator=g).abs()
+            self.src = torch.rand(npts, 3, device=dev, generator=g)
+            self.ctr = torch.rand(ngrp, 3, device=dev, generator=g)
+            self.row_pt = torch.randint(0, npts, (cap,), device=dev, generator=g, dtype=torch.int32)
+            self.row_grp = torch.sort(torch.randint(0, ngrp, (cap,), device=dev, generator=g, dtype=torch.int32)).values.contiguous()
+        self.gacc = torch.zeros(N * self.Kp, dtype=torch.float64, device=dev)
         self.ws = torch.empty(48 * 1024 * 1024, device=dev)
 
     def args(self):
         d = self.dx
         a = hip.GemmDwArgs()
-        a.inp = _fwd_args(mode=0, zin=_ptr(d.zprev), zin_pitch=self.K, c_in=self.K, scale=_ptr(d.vecK[0]), shift=_ptr(d.vecK[1]), relu=1,
-                          n_rows_dev=_ptr(d.nrows), n_rows=d.cap, row_w=_ptr(d.row_w), Kp=self.K, n_out=[self.N], w_off=[0])
+        kw = dict(n_rows_dev=_ptr(d.nrows), n_rows=d.cap, row_w=_ptr(d.row_w), Kp=self.Kp, n_out=[self.N], w_off=[0])
+        if self.mode == "gather":
+            kw.update(mode=1, c_in=self.K + 3, src_xyz=_ptr(self.src), ctr_xyz=_ptr(self.ctr), feat=_ptr(self.feat), feat_c=self.K,
+                      act_c=0, grp_per_sample=1, row_pt=_ptr(self.row_pt), row_grp=_ptr(self.row_grp))
+        else:
+            kw.update(mode=0, zin=_ptr(d.zprev), zin_pitch=self.K, c_in=self.K, scale=_ptr(d.vecK[0]), shift=_ptr(d.vecK[1]), relu=1)
+        a.inp = _fwd_args(**kw)
         a.dz = _dz(**d.dz_kw())
         a.gacc, a.partial, a.partial_elems = _ptr(self.gacc), _ptr(self.ws), self.ws.numel()
         return a
@@ -327,13 +347,18 @@ class DwWide(Case):
         self.gacc.zero_()
         a = self.args()
         hip.call_struct("gad_gemm_dw", a)
-        return {"dW": self.gacc.view(self.N, self.K).clone()}
+        return {"dW": self.gacc.view(self.N, self.Kp)[:, :self.K + (3 if self.mode == "gather" else 0)].clone()}
 
     def ref(self):
         d = self.dx
+        r = self.rows
         dz = d.dz32().float().double()
-        x = fma32(d.zprev[:self.rows], d.vecK[0], d.vecK[1]).clamp_min(0).double()
-        return {"dW": dz.t() @ x}
+        if self.mode == "gather":
+            pt, grp = self.row_pt[:r].long(), self.row_grp[:r].long()
+            x = torch.cat([self.feat[pt], self.src[pt] - self.ctr[grp]], 1).double()
+        else:
+            x = fma32(d.zprev[:r], d.vecK[0], d.vecK[1]).clamp_min(0).double()
+        return {"dW": dz.t() @ x, "dW#abs": dz.abs().t() @ x.abs()}
 
     def flops(self):
         return 2.0 * self.rows * self.K * self.N
