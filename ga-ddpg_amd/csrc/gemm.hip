@@ -2431,6 +2431,318 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-bf16 form of the SA1 streaming backward (option "mfma_split": GAD_SPLIT_BWD_STREAM): gemm_bwd_stream_kernel (DW: dX and dW
+// of one layer from one pass, 4 producer + 4 consumer wavefronts) and gemm_dx_stream_kernel (!DW: eight producers, no exchange).
+//   producer: a lane owns row l31 of its slab and, per k16-step s, the 8 output channels 16 s + 8 half .. + 7 (two 16-byte
+//     loads of z and dY through the operand ring); dZ = P*dY - w*(Q + S*z) is split into hi / mid / lo in registers -- the A
+//     operand of six v_mfma_f32_32x32x16_bf16 per 32-column tile of dX against the TRANSPOSED weight mirror (LDS: three planes
+//     [k][n_out (+ 8 pad)] copied from gad_split_weights' output, whose odd 16-blocks of n are stored negated: odd steps
+//     accumulate into a second accumulator pair).  DW: the same hi / mid / lo registers go to the consumers TRANSPOSED: the two
+//     lanes of a row pair exchange halves (DPP quad_perm + v_perm_b32) so that each holds {row 2j, row 2j + 1} of four of the
+//     eight channels, and store 4 bytes per channel and plane into the exchange buffer [half][plane][slab][channel][32 rows]
+//     (64-byte rows, 16-byte chunks XOR-swizzled by (channel >> 2) & 3: conflict-free ds_write_b32 and ds_read_b128).
+//   consumer: dW tile (32 channels x 32 inputs) += dZ^T . y over the quad's slabs: A fragments = three ds_read_b128 of 8
+//     consecutive rows of its channel, B fragments = relu(bn(z_prev)) of rows 16 st + 8 half .. + 7 loaded straight from
+//     global memory (one value per lane and row, as the f32 kernel does), split once per slab and kept for both channel
+//     halves; the rows 16 .. 31 of every slab carry NEGATED y and accumulate into a second accumulator pair.
+// Results, partial-block layout, barrier structure and the epilogue are those of the f32 kernels.
+// ------------------------------------------------------------------------------------------------
+template <int NJ, int GM, bool DW>
+__global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, const int32_t* __restrict__ n_rows_dev, int n_rows_static,
+                                                                        const uint16_t* __restrict__ wsp, int wsp_plane, DxEpi e,
+                                                                        float* __restrict__ partial, unsigned long long* __restrict__ ts) {
+    KTimer kt(ts);
+    constexpr int NO = 8 * NJ, NS = NO / 16;                                // output channels, k16-steps
+    constexpr int HC = NO / 2, NCT = HC / 32;                               // channels per exchange half, dW channel tiles per half
+    constexpr int RB = 2 * NO + 16, WPL = 64 * RB;                          // bytes: mirror row in LDS (+ 16 pad), one plane
+    constexpr int XSL = HC * 64, XPL = 4 * XSL, XBUF = 3 * XPL;             // bytes: exchange slab, plane (4 slabs), buffer (3 planes)
+    __shared__ __attribute__((aligned(16))) unsigned char WtS[3 * WPL];
+    __shared__ __attribute__((aligned(16))) float vec[3 * NO];              // P | Q | S
+    __shared__ float red[2 * 8 * 64];
+    __shared__ __attribute__((aligned(16))) unsigned char dzb[DW ? 2 * XBUF : 16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    {   // transposed weight mirror (3 planes x 64 rows x NO bf16, row pitch NO) -> LDS rows of RB bytes
+        constexpr int CPR = NO / 8, UNITS = 3 * 64 * CPR, UW = (UNITS + 511) / 512;      // 16-byte chunks
+        gad_u32x4 wr[UW];
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 512 + tid, uc = u < UNITS ? u : 0;
+            const int pl = uc / (64 * CPR), rem = uc % (64 * CPR);
+            wr[it] = *reinterpret_cast<const gad_u32x4*>(wsp + (size_t)pl * wsp_plane + (size_t)rem * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < UW; ++it) {
+            const int u = it * 512 + tid;
+            const int pl = u / (64 * CPR), rem = u % (64 * CPR), k = rem / CPR, c = rem % CPR;
+            if (u < UNITS) *reinterpret_cast<gad_u32x4*>(WtS + pl * WPL + k * RB + c * 16) = wr[it];
+        }
+    }
+    for (int i = tid; i < NO; i += 512) {
+        float P, Q, S;
+        dz_coef(d, i, P, Q, S, first_workgroup());
+        vec[i] = P; vec[NO + i] = Q; vec[2 * NO + i] = S;
+    }
+    __syncthreads();
+    const int n_slabs = (n_rows + 31) >> 5;
+    const int n_quads = (n_slabs + 3) >> 2;
+    const __amdgpu_buffer_rsrc_t zrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, n_rows * 64 * 4, 0x00020000);   // rows past n_rows read as 0
+    const int glane = (4 * half * 64 + l31) * 4;
+    const int nprod = DW ? 4 : 8;                                           // producer wavefronts per workgroup
+
+    if (!DW || wave < 4) {
+        // ---------------------------------------------------------------- producer: dX of one slab per round
+        float ps[2], pt[2], pm[2], pi[2];
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk) {
+            const int k = tk * 32 + l31;
+            ps[tk] = e.ps[k]; pt[tk] = e.pt[k]; pm[tk] = e.pm[k]; pi[tk] = e.pi[k];
+        }
+        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * 64 * 4, 0x00020000);
+        float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
+        // operand ring: entries of 4 channels (z, dY [, arg-max]: 16-byte loads); entry uu covers channels
+        // 16 (uu >> 1) + 8 half + 4 (uu & 1) .. + 3, so a k16-step consumes an even / odd pair; filled AHEAD entries ahead, across slabs
+        // The pooled source (GM = 1) reads its gradient / arg-max pair per GROUP (~26 consecutive rows share one: L1 / L2 hits), so that
+        // pair rides a short ring of its own (RINGG = 4, one step ahead) -- with it in the long ring the kernel spilled.
+        constexpr int NU = NO / 8, RING = 8, AHEAD = 6, RINGG = GM == 1 ? 4 : RING, AHEADG = GM == 1 ? 2 : AHEAD;
+        static_assert(NU % RING == 0 && NU % RINGG == 0, "a slab's entries must fill the rings a whole number of times");
+        float4 rz[RING], rg[RINGG];
+        int4 ra[RINGG];
+        auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+        auto load_z = [&](int r, int uu) {
+            const unsigned n = 16 * (uu >> 1) + 8 * half + 4 * (uu & 1);
+            rz[uu % RING] = ldg4(d.z + ((unsigned)r * NO + n));
+            if (GM == 0) rg[uu % RINGG] = ldg4(d.G + ((unsigned)r * NO + n));
+        };
+        auto load_g = [&](int grp, int uu) {              // (GM = 1)
+            const unsigned n = 16 * (uu >> 1) + 8 * half + 4 * (uu & 1);
+            ra[uu % RINGG] = *reinterpret_cast<const int4*>(d.argmax + ((unsigned)grp * NO + n));
+            rg[uu % RINGG] = ldg4(d.dout + ((unsigned)grp * NO + n));
+        };
+        // slabs: DW: quad q = blockIdx.x + i * gridDim.x, slab 4 q + wave; !DW: the wave-major dealing of gemm_dx_stream_kernel
+        const int round_stride = DW ? 4 * gridDim.x : 8 * gridDim.x;
+        int slab = DW ? blockIdx.x * 4 + wave : wave * gridDim.x + blockIdx.x;
+        const int slab_limit = DW ? n_quads * 4 : n_slabs;
+        int r_cur = row_of(slab), r_nxt = row_of(slab + round_stride);
+        int grp_cur = GM == 1 ? d.row_grp[r_cur] : 0, grp_nxt = GM == 1 ? d.row_grp[r_nxt] : 0;
+        float wrow = d.row_w ? d.row_w[r_cur] : 1.f;
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) load_z(r_cur, i);
+        if (GM == 1) {
+#pragma unroll
+            for (int i = 0; i < AHEADG; ++i) load_g(grp_cur, i);
+        }
+        // exchange store position of this lane: row pair l31 >> 1 (4 bytes) of channel (c0 & (HC - 1)) + 2 i + (l31 & 1)
+        const unsigned psel = (l31 & 1) ? 0x03020706u : 0x05040100u;        // v_perm_b32 selector: {even row | odd row} of the lane's channels
+        const int xq = l31 >> 3, xin = ((l31 >> 1) & 3) * 4;                // 16-byte chunk (before the swizzle), byte inside it
+        const unsigned char* const wb = WtS + l31 * RB + 16 * half;
+        for (; slab < slab_limit; slab += round_stride) {
+            const int r_nn = row_of(slab + 2 * round_stride);
+            const int grp_nn = GM == 1 ? d.row_grp[r_nn] : 0;
+            const float w_nxt = d.row_w ? d.row_w[r_nxt] : 1.f;
+            const bool row_live = slab * 32 + l31 < n_rows;
+            f32x16 acc[2], an[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { acc[t][v] = 0.f; an[t][v] = 0.f; }
+            float zp[2][16];
+            const int zrow = (slab < n_slabs ? slab : 0) * 32 * 64 * 4;     // (a slab past the end: nothing is kept of it)
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+#pragma unroll
+                for (int ee = 0; ee < 2; ++ee) {
+                    const int uu = 2 * s2 + ee + AHEAD;
+                    if (uu < NU) load_z(r_cur, uu); else load_z(r_nxt, uu - NU);
+                    if (GM == 1) {
+                        const int ug = 2 * s2 + ee + AHEADG;
+                        if (ug < NU) load_g(grp_cur, ug); else load_g(grp_nxt, ug - NU);
+                    }
+                }
+                if (s2 == 0) {                                              // z_prev for the epilogue: a whole slab ahead of its use
+#pragma unroll
+                    for (int v = 0; v < 16; ++v)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            zp[t][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                zrsrc, glane + t * 128, zrow + ((v & 3) + 8 * (v >> 2)) * 256, 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);                          // (the scheduler would sink the loads to their uses)
+                // B fragments of this step (transposed mirror rows l31, 32 + l31; channels 16 s + 8 half .. + 7)
+                gad_u32x4 BH[2], BM[2], BL[2];
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const unsigned char* q = wb + t * (32 * RB) + 32 * s2;
+                    BH[t] = *reinterpret_cast<const gad_u32x4*>(q);
+                    BM[t] = *reinterpret_cast<const gad_u32x4*>(q + WPL);
+                    BL[t] = *reinterpret_cast<const gad_u32x4*>(q + 2 * WPL);
+                }
+                unsigned ah[4], am[4], al[4];
+#pragma unroll
+                for (int ee = 0; ee < 2; ++ee) {
+                    const int uu = 2 * s2 + ee;
+                    const int n = 16 * s2 + 8 * half + 4 * ee;
+                    const float4 P = *reinterpret_cast<const float4*>(vec + n);
+                    const float4 Q = *reinterpret_cast<const float4*>(vec + NO + n);
+                    const float4 S = *reinterpret_cast<const float4*>(vec + 2 * NO + n);
+                    const float4 z = rz[uu % RING];
+                    float4 g = rg[uu % RINGG];
+                    if (GM == 1) {
+                        const int4 a = ra[uu % RINGG];
+                        const int rr = slab * 32 + l31;
+                        g.x = a.x == rr ? g.x : 0.f; g.y = a.y == rr ? g.y : 0.f;
+                        g.z = a.z == rr ? g.z : 0.f; g.w = a.w == rr ? g.w : 0.f;
+                    }
+                    float4 a4;
+                    a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
+                    a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
+                    if (!row_live) a4 = make_float4(0.f, 0.f, 0.f, 0.f);       // rows past the end add nothing to dW
+                    gad_split2(a4.x, a4.y, ah[2 * ee], am[2 * ee], al[2 * ee]);
+                    gad_split2(a4.z, a4.w, ah[2 * ee + 1], am[2 * ee + 1], al[2 * ee + 1]);
+                }
+                const gad_u32x4 AH = {ah[0], ah[1], ah[2], ah[3]}, AM = {am[0], am[1], am[2], am[3]}, AL = {al[0], al[1], al[2], al[3]};
+                if (DW) {
+                    // transposed hand-over: channel cl = (16 s + 8 half) % HC + 2 i + (l31 & 1), rows {l31 & ~1, l31 | 1}
+                    unsigned char* hb = dzb + (s2 / (NS / 2)) * XBUF + wave * XSL + xin;
+                    const int cbase = (16 * s2 + 8 * half) % HC + (l31 & 1);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int cl = cbase + 2 * i;
+                        unsigned char* q = hb + cl * 64 + ((xq ^ ((cl >> 2) & 3)) << 4);
+                        const unsigned own[3] = {ah[i], am[i], al[i]};
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const unsigned nbr = (unsigned)__builtin_amdgcn_update_dpp(0, (int)own[pl], 0xB1, 0xf, 0xf, false);   // lane ^ 1
+                            *reinterpret_cast<unsigned*>(q + pl * XPL) = __builtin_amdgcn_perm(nbr, own[pl], psel);
+                        }
+                    }
+                }
+                // the six products of weight >= 2^-16, smallest first; odd steps (negated mirror values) -> the second pair
+#define GAD_SPB(A, B)                                                                                                          \
+                _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                \
+                    if (s2 & 1) an[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[t]), an[t], 0, 0, 0);   \
+                    else acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[t]), acc[t], 0, 0, 0); \
+                }
+                GAD_SPB(AL, BH) GAD_SPB(AH, BL) GAD_SPB(AM, BM) GAD_SPB(AM, BH) GAD_SPB(AH, BM) GAD_SPB(AH, BH)
+#undef GAD_SPB
+                if (DW && (s2 + 1) % (NS / 2) == 0) __syncthreads();        // this half of the quad's dZ is in the buffer
+            }
+            // epilogue: dY of the previous layer (ReLU-masked) + its BatchNorm-backward sums
+            const bool full = slab * 32 + 32 <= n_rows;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int row = acc_row(v, half);
+                const bool live = slab * 32 + row < n_rows;
+                const int rb = zrow + ((v & 3) + 8 * (v >> 2)) * 256;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float gv = acc[t][v] - an[t][v];
+                    const float zv = live ? zp[t][v] : 0.f;
+                    const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
+                    const float ga = act ? gv : 0.f;
+                    if (full) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ga), grsrc, glane + t * 128, rb, GAD_STREAM_STORE_AUX);
+                    else if (live) e.gout[(size_t)(slab * 32 + row) * 64 + t * 32 + l31] = ga;
+                    sb[t] += ga;
+                    sg[t] = fmaf(ga, (zv - pm[t]) * pi[t], sg[t]);
+                }
+            }
+            r_cur = r_nxt; r_nxt = r_nn;
+            grp_cur = grp_nxt; grp_nxt = grp_nn;
+            wrow = w_nxt;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float s0 = sb[t] + __shfl_xor(sb[t], 32, 64);
+            const float s1 = sg[t] + __shfl_xor(sg[t], 32, 64);
+            if (lane < 32) { red[wave * 64 + t * 32 + lane] = s0; red[(8 + wave) * 64 + t * 32 + lane] = s1; }
+        }
+    } else {
+        // ---------------------------------------------------------------- consumer: dW tiles (channel tile, input half b)
+        const int q = wave - 4;
+        const int b = q & 1;
+        const int tcl = NCT == 2 ? (q >> 1) : 0;                            // channel tile within the half
+        const int s0 = NCT == 2 ? 0 : 2 * (q >> 1);                         // slabs of the quad this wavefront takes
+        constexpr int NSC = NCT == 2 ? 4 : 2;
+        const float psb = e.ps[32 * b + l31], ptb = e.pt[32 * b + l31];
+        f32x16 aw[2], awn[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { aw[h][v] = 0.f; awn[h][v] = 0.f; }
+        // z_prev of the quad's slabs: lane (input column 32 b + l31, half) holds rows 16 st + 8 half + i of a slab -- the B layout
+        const int ylane = (8 * half * 64 + 32 * b + l31) * 4;
+        float yr[NSC][16];
+        gad_u32x4 YH[NSC][2], YM[NSC][2], YL[NSC][2];
+        auto load_y = [&](int slab, int sl) {
+            const int zrow = (slab < n_slabs ? slab : 0) * 32 * 64 * 4;     // (past the end: the producers wrote dZ = 0)
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                yr[sl][v] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(zrsrc, ylane, zrow + (16 * (v >> 3) + (v & 7)) * 256, 0));
+        };
+        const int cl = 32 * tcl + l31;
+        const unsigned char* const rbase = dzb + cl * 64;
+        const int fo = ((half ^ ((cl >> 2) & 3)) << 4);
+#pragma unroll
+        for (int sl = 0; sl < NSC; ++sl) load_y(blockIdx.x * 4 + s0 + sl, sl);
+        for (int quad = blockIdx.x; quad < n_quads; quad += gridDim.x) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __syncthreads();                                            // half h of this quad is in buffer h
+#pragma unroll
+                for (int sl = 0; sl < NSC; ++sl) {
+                    if (h == 0) {                                           // relu(bn(z_prev)) -> hi / mid / lo, rows 16 .. 31 negated
+#pragma unroll
+                        for (int st = 0; st < 2; ++st) {
+                            unsigned yh[4], ym[4], yl[4];
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                float y0 = fmaxf(fmaf(yr[sl][8 * st + 2 * i], psb, ptb), 0.f), y1 = fmaxf(fmaf(yr[sl][8 * st + 2 * i + 1], psb, ptb), 0.f);
+                                if (st) { y0 = -y0; y1 = -y1; }
+                                gad_split2(y0, y1, yh[i], ym[i], yl[i]);
+                            }
+                            YH[sl][st] = gad_u32x4{yh[0], yh[1], yh[2], yh[3]};
+                            YM[sl][st] = gad_u32x4{ym[0], ym[1], ym[2], ym[3]};
+                            YL[sl][st] = gad_u32x4{yl[0], yl[1], yl[2], yl[3]};
+                        }
+                    }
+                    const unsigned char* rb = rbase + h * XBUF + (s0 + sl) * XSL;
+#pragma unroll
+                    for (int st = 0; st < 2; ++st) {
+                        const int off = fo ^ (st << 5);
+                        const gad_u32x4 AH = *reinterpret_cast<const gad_u32x4*>(rb + off);
+                        const gad_u32x4 AM = *reinterpret_cast<const gad_u32x4*>(rb + XPL + off);
+                        const gad_u32x4 AL = *reinterpret_cast<const gad_u32x4*>(rb + 2 * XPL + off);
+#define GAD_SPC(A, B)                                                                                                          \
+                        if (st) awn[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[sl][st]), awn[h], 0, 0, 0); \
+                        else aw[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gad_as_bf16x8(A), gad_as_bf16x8(B[sl][st]), aw[h], 0, 0, 0);
+                        GAD_SPC(AL, YH) GAD_SPC(AH, YL) GAD_SPC(AM, YM) GAD_SPC(AM, YH) GAD_SPC(AH, YM) GAD_SPC(AH, YH)
+#undef GAD_SPC
+                    }
+                    if (h == 1) load_y((quad + gridDim.x) * 4 + s0 + sl, sl);
+                }
+            }
+        }
+        // the workgroup's partial dW block(s): n_out = 64 -> two consumers share a tile, each writes its own block
+        float* pout = partial + (size_t)(NCT == 2 ? blockIdx.x : 2 * blockIdx.x + (q >> 1)) * NO * 64;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) pout[(32 * (NCT * h + tcl) + acc_row(v, half)) * 64 + 32 * b + l31] = aw[h][v] - awn[h][v];
+    }
+    __syncthreads();
+    if (tid < 64) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int w = 0; w < nprod; ++w) { s0 += red[w * 64 + tid]; s1 += red[(8 + w) * 64 + tid]; }
+        const int rep = blockIdx.x % GAD_STAT_REPLICAS;
+        atomic_add_f64(e.dbeta + (size_t)rep * e.stat_stride + tid, (double)s0);
+        atomic_add_f64(e.dgamma + (size_t)rep * e.stat_stride + tid, (double)s1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wide-tile dX for the MID-SIZE layers (the backward twin of gemm_fwd_wide_kernel): a workgroup owns 64 rows x 128 input
 // channels of gout, a wavefront 32 x 64.  A operand: dZ[r][n] = P*dY - w*(Q + S*z) formed once per staged element from
 // 16-byte loads of z and dY (or of the pooled arg-max / gradient pair; the ReLU mask is already in dY: premasked), stored
@@ -2971,6 +3283,15 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     if (dx_streamable(*a, vec)) {
         const int slabs = gad_cdiv(rows, 32);
         int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;
+        if (split_on(GAD_SPLIT_BWD_STREAM) && a->W_split_t && a->W_split_t_pitch == a->n_out[0] && a->W_split_t_plane >= 64 * a->n_out[0]) {
+#define LAUNCH_DXSS(NJ, GM) hipLaunchKernelGGL((gemm_bwd_stream_split_kernel<NJ, GM, false>), dim3(gx), dim3(512), 0, st, d, a->n_rows_dev, rows, \
+                                                a->W_split_t, a->W_split_t_plane, e, nullptr, ts)
+            if (a->n_out[0] == 128) { if (a->dz.gmode == 0) LAUNCH_DXSS(16, 0); else LAUNCH_DXSS(16, 1); }
+            else { if (a->dz.gmode == 0) LAUNCH_DXSS(8, 0); else LAUNCH_DXSS(8, 1); }
+#undef LAUNCH_DXSS
+            GAD_CHECK_LAUNCH("gemm_dx(stream split)");
+            return GAD_OK;
+        }
 #define LAUNCH_DXS(NJ, GM) hipLaunchKernelGGL((gemm_dx_stream_kernel<NJ, GM>), dim3(gx), dim3(512), 0, st, d, a->n_rows_dev, rows, a->W, e, ts)
         if (a->n_out[0] == 128) { if (a->dz.gmode == 0) LAUNCH_DXS(16, 0); else LAUNCH_DXS(16, 1); }
         else { if (a->dz.gmode == 0) LAUNCH_DXS(8, 0); else LAUNCH_DXS(8, 1); }
@@ -4579,6 +4900,15 @@ extern "C" int gad_gemm_bwd(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* 
     const int rows = ax->n_rows, wgs = DW_STREAM_SPLITS;
     const int splits = ax->n_out[0] == 64 ? 2 * wgs : wgs;            // partial dW blocks the kernel writes (see its header)
     GAD_REQUIRE((long long)splits * in.n_out[0] * 64 <= aw->partial_elems, GAD_ERR_SHAPE, "gemm_bwd: partial workspace too small");
+    if (split_on(GAD_SPLIT_BWD_STREAM) && ax->W_split_t && ax->W_split_t_pitch == ax->n_out[0] && ax->W_split_t_plane >= 64 * ax->n_out[0]) {
+#define LAUNCH_BWSS(NJ, GM) hipLaunchKernelGGL((gemm_bwd_stream_split_kernel<NJ, GM, true>), dim3(wgs), dim3(512), 0, st, d, ax->n_rows_dev, rows, \
+                                                ax->W_split_t, ax->W_split_t_plane, e, aw->partial, ts)
+        if (ax->n_out[0] == 128) { if (ax->dz.gmode == 0) LAUNCH_BWSS(16, 0); else LAUNCH_BWSS(16, 1); }
+        else { if (ax->dz.gmode == 0) LAUNCH_BWSS(8, 0); else LAUNCH_BWSS(8, 1); }
+#undef LAUNCH_BWSS
+        GAD_CHECK_LAUNCH("gemm_bwd(stream split)");
+        return later ? GAD_OK : gad_gemm_dw_reduce(ax, aw, stream);
+    }
 #define LAUNCH_BWS(NJ, GM) hipLaunchKernelGGL((gemm_bwd_stream_kernel<NJ, GM>), dim3(wgs), dim3(512), 0, st, d, ax->n_rows_dev, rows, ax->W, e, aw->partial, ts)
     if (ax->n_out[0] == 128) { if (ax->dz.gmode == 0) LAUNCH_BWS(16, 0); else LAUNCH_BWS(16, 1); }
     else { if (ax->dz.gmode == 0) LAUNCH_BWS(8, 0); else LAUNCH_BWS(8, 1); }

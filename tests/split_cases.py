@@ -362,3 +362,86 @@ class DwWide(Case):
 
     def flops(self):
         return 2.0 * self.rows * self.K * self.N
+
+
+class BwdStream(Case):
+    """SA1's streaming backward: gad_gemm_bwd (dX + dW of one layer in one pass: fused=True) or gad_gemm_dx alone (fused=False) on
+    ~2e5 rows, 64 input channels, N = 64 / 128 output channels; dense gradient ("act") or pooled source ("pool": layer 3)"""
+    family = hip.SPLIT_BWD_STREAM
+
+    def __init__(self, rows, N, mode="act", fused=True, seed=5):
+        dev = torch.device("cuda")
+        self.dx = DxWide(rows, N, 64, mode=mode, seed=seed)
+        d = self.dx
+        if mode == "pool":                                   # SA1-like groups: ~26 consecutive rows each
+            g = _gen(seed + 7)
+            ngrp = max(rows // 26, 4)
+            cuts = torch.sort(torch.randint(1, d.cap, (ngrp - 1,), device=dev, generator=g)).values
+            grp = torch.zeros(d.cap, dtype=torch.int32, device=dev)
+            grp[cuts.long()] = 1
+            d.row_grp = torch.cumsum(grp, 0).to(torch.int32).contiguous()
+            ng = int(d.row_grp.max().item()) + 1
+            first = torch.zeros(ng, dtype=torch.int64, device=dev)
+            cnt = torch.bincount(d.row_grp.long(), minlength=ng)
+            first[1:] = torch.cumsum(cnt, 0)[:-1]
+            pick = (torch.rand(ng, N, device=dev, generator=g) * cnt[:, None].double()).long()
+            pick = torch.minimum(pick, (cnt - 1).clamp_min(0)[:, None])
+            d.argmax = (first[:, None] + pick).to(torch.int32).contiguous()
+            d.dout = torch.randn(ng, N, device=dev, generator=g)
+        self.rows, self.N, self.mode, self.fused = rows, N, mode, fused
+        self.entry = "gad_gemm_bwd" if fused else "gad_gemm_dx"
+        self.gacc = torch.zeros(N * 64, dtype=torch.float64, device=dev)
+        self.ws = torch.empty(2 * 256 * 128 * 64, device=dev)
+
+    def dw_args(self):
+        d = self.dx
+        a = hip.GemmDwArgs()
+        a.inp = _fwd_args(mode=0, zin=_ptr(d.zprev), zin_pitch=64, c_in=64, scale=_ptr(d.vecK[0]), shift=_ptr(d.vecK[1]), relu=1,
+                          n_rows_dev=_ptr(d.nrows), n_rows=d.cap, row_w=_ptr(d.row_w), Kp=64, n_out=[self.N], w_off=[0])
+        a.dz = _dz(**d.dz_kw())
+        a.gacc, a.partial, a.partial_elems = _ptr(self.gacc), _ptr(self.ws), self.ws.numel()
+        return a
+
+    def run(self):
+        d = self.dx
+        d.bst.zero_()
+        self.gacc.zero_()
+        ax = d.args()
+        if self.fused:
+            aw = self.dw_args()
+            hip.check(hip.lib().gad_gemm_bwd(C.byref(ax), C.byref(aw), hip.stream()), "gad_gemm_bwd")
+        else:
+            hip.call_struct("gad_gemm_dx", ax)
+        K = 64
+        out = {"gout": d.gout[:self.rows].clone(), "dbeta": d.bst.view(hip.STAT_REPLICAS, 2, K)[:, 0].sum(0).clone(),
+               "dgamma": d.bst.view(hip.STAT_REPLICAS, 2, K)[:, 1].sum(0).clone()}
+        if self.fused:
+            out["dW"] = self.gacc.view(self.N, 64).clone()
+        return out
+
+    def time_mode(self, split, iters=50):
+        hip.set_option("mfma_split", self.family if split else 0)
+        try:
+            ax = self.dx.args()
+            st = hip.stream()
+            if self.fused:
+                aw = self.dw_args()
+                f = hip.lib().gad_gemm_bwd
+                return time_call(lambda: hip.check(f(C.byref(ax), C.byref(aw), st), "gad_gemm_bwd"), iters)
+            f = hip.lib().gad_gemm_dx
+            return time_call(lambda: hip.check(f(C.byref(ax), st), "gad_gemm_dx"), iters)
+        finally:
+            hip.set_option("mfma_split", 0)
+
+    def ref(self):
+        d = self.dx
+        out = d.ref()
+        if self.fused:
+            dz = d.dz32().float().double()
+            x = fma32(d.zprev[:self.rows], d.vecK[0], d.vecK[1]).clamp_min(0).double()
+            out["dW"] = dz.t() @ x
+            out["dW#abs"] = dz.abs().t() @ x
+        return out
+
+    def flops(self):
+        return (4.0 if self.fused else 2.0) * self.rows * 64 * self.N

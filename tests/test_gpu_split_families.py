@@ -32,12 +32,17 @@ def _cases():
         "dw_wide.sa3.l3": lambda: sc.DwWide(8192, 512, 256, "pool"),
         "dw_wide.sa3.l2": lambda: sc.DwWide(8192, 256, 256, "act"),
         "dw_wide.sa3.l1": lambda: sc.DwWide(8192, 256, 256, "gather"),
+        "bwd_stream.sa1.l3": lambda: sc.BwdStream(213034, 128, "pool"),
+        "bwd_stream.sa1.l2": lambda: sc.BwdStream(213034, 64, "act"),
+        "dx_stream.sa1.l3": lambda: sc.BwdStream(213034, 128, "pool", fused=False),
+        "dx_stream.sa1.l2": lambda: sc.BwdStream(213034, 64, "act", fused=False),
     }
 
 
 CASES = ("fwd_wide.sa2.l2", "fwd_wide.sa2.l3", "fwd_wide.sa3.l2", "fwd_wide.sa3.l3", "fwd_wide.sa2.l1", "fwd_wide.sa3.l1",
          "dx_wide.sa2.l3", "dx_wide.sa2.l2", "dx_wide.sa2.l1", "dx_wide.sa3.l3", "dx_wide.sa3.l2", "dx_wide.sa3.l1",
-         "dw_wide.sa2.l3", "dw_wide.sa2.l2", "dw_wide.sa2.l1", "dw_wide.sa3.l3", "dw_wide.sa3.l2", "dw_wide.sa3.l1")
+         "dw_wide.sa2.l3", "dw_wide.sa2.l2", "dw_wide.sa2.l1", "dw_wide.sa3.l3", "dw_wide.sa3.l2", "dw_wide.sa3.l1",
+         "bwd_stream.sa1.l3", "bwd_stream.sa1.l2", "dx_stream.sa1.l3", "dx_stream.sa1.l2")
 
 
 def check_case(case, name, report=None, keys=None):
@@ -57,9 +62,11 @@ def check_case(case, name, report=None, keys=None):
                           % (name, k, a32, m32, s32, asp, msp, ssp, scale))
         # (statistics / gradient sums: f64 accumulation of f32 partial sums -- the same bounds apply; floors for outputs
         # whose f32 error happens to be ~0)
-        # bias floor: 1e-9 of max |z| for a GEMM output; a REDUCED output (column sums over the rows) accumulates a per-element
-        # bias coherently, so its floor is 1e-9 of the largest sum of |terms|
-        floor = 1e-9 * (float(ref[k + "#abs"].max()) if k + "#abs" in ref else scale)
+        # floor: 1e-9 of max |z| for a GEMM output.  A REDUCED output (BatchNorm statistics, dbeta / dgamma, scatter sums, dW:
+        # column sums over up to 2e5 rows, accumulated in f32 per lane by BOTH paths) adds a per-element bias coherently -- the
+        # split form's residual bias of ~2e-11 max |z| per element (the (plain, negated) accumulator pairs cancel the bf16
+        # adder's truncation only to first order) becomes ~1e-9 of the sum of |terms| -- so its floor is 4e-9 of that sum
+        floor = 4e-9 * float(ref[k + "#abs"].max()) if k + "#abs" in ref else 1e-9 * scale
         if asp > 1.25 * a32 + floor or msp > 1.25 * m32 + floor:
             bad.append("%s %s: split max %.3e mean %.3e vs f32 max %.3e mean %.3e" % (name, k, asp, msp, a32, m32))
         if abs(ssp) > max(2.0 * abs(s32), floor):
