@@ -697,7 +697,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // v_mfma_f32_32x32x16_bf16 (16x the rate of v_mfma_f32_32x32x2_f32).  The bf16 MFMA's adder truncates toward -inf (a -1e-8
 // relative bias, tools/ubench/split_bf16.hip): the products of every second block of 16 along the reduction index are
 // NEGATED (one operand's sign) and summed into a second accumulator; result = plain - negated, which cancels the bias and
-// leaves a smaller random error than the f32 MFMA's (profiles/r04_split_bf16_ubench.txt).
+// leaves a smaller random error than the f32 MFMA's (profiles/r04_split_bf16_ubench.txt).  The cancellation is exact only
+// where the two accumulators sit in the same binade; what is left (~2e-11 of max |z| per element) has a sign that depends on
+// the output COLUMN (which half of a column's weights is larger), so a sum over the rows of one column -- BatchNorm statistics,
+// dbeta -- would add it coherently.  The kernels whose outputs are summed over rows therefore also negate the A operand of
+// every ODD ROW and take (negated - plain) there: the residual changes sign from row to row and averages out
+// (profiles/r05_split_families.txt).
 // Range: |x| must stay below 3.39e38 (bf16(x) must not round to infinity); an infinite operand gives NaN where the f32
 // path gives +-inf (both non-finite).
 typedef __bf16 gad_bf16x8 __attribute__((ext_vector_type(8)));
@@ -746,10 +751,11 @@ __device__ __forceinline__ void store_b(unsigned char* stage, const BRegs& b, in
         for (int p = 0; p < 3; ++p) *reinterpret_cast<gad_u32x4*>(q + p * BPL + u * (64 * 64)) = b.r[u][p];
 }
 // four consecutive reduction indices (c4 = (tid & 7) * 4 of the K-tile) of A row `row` -> the three planes (8 bytes each)
-__device__ __forceinline__ void store_a4(unsigned char* stage, int row, int tid, float4 v) {
+// sg: 0x80000000 for an odd row (its values enter negated, the epilogue takes negated - plain), else 0
+__device__ __forceinline__ void store_a4(unsigned char* stage, int row, int tid, float4 v, unsigned sg) {
     unsigned h0, m0, l0, h1, m1, l1;
-    gad_split2(v.x, v.y, h0, m0, l0);
-    gad_split2(v.z, v.w, h1, m1, l1);
+    gad_split2(__uint_as_float(__float_as_uint(v.x) ^ sg), __uint_as_float(__float_as_uint(v.y) ^ sg), h0, m0, l0);
+    gad_split2(__uint_as_float(__float_as_uint(v.z) ^ sg), __uint_as_float(__float_as_uint(v.w) ^ sg), h1, m1, l1);
     unsigned char* q = stage + row * 64 + (((((tid & 7) >> 1) ^ ((row >> 2) & 3))) << 4) + ((tid & 1) << 3);
     *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(q + APL) = make_uint2(m0, m1);
@@ -913,7 +919,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
                     v.x = fmaxf(fmaf(v.x, s4.x, t4.x), 0.f); v.y = fmaxf(fmaf(v.y, s4.y, t4.y), 0.f);
                     v.z = fmaxf(fmaf(v.z, s4.z, t4.z), 0.f); v.w = fmaxf(fmaf(v.w, s4.w, t4.w), 0.f);
                 }
-                if (SP) spw::store_a4(smem_b + (kt & 1) * spw::STAGE, ur + 32 * u, tid, v);
+                if (SP) spw::store_a4(smem_b + (kt & 1) * spw::STAGE, ur + 32 * u, tid, v, (ur & 1) ? 0x80000000u : 0u);
                 else *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
             }
             if (SP) { spw::store_b(smem_b + (kt & 1) * spw::STAGE, rbs[SP ? S : 0], tid); return; }
@@ -984,7 +990,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[t][v] -= an[t][v];
+                for (int v = 0; v < 16; ++v) acc[t][v] = (v & 1) ? an[t][v] - acc[t][v] : acc[t][v] - an[t][v];   // (odd rows entered negated)
         }
         if (XM == 1) {                                   // the three coordinate columns: z += dx . W[n][feat_c .. feat_c + 2]
 #pragma unroll
@@ -1341,7 +1347,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
                 }
                 // the bf16 MFMA's adder truncates toward -inf (a -1e-8 relative bias, tools/ubench/split_bf16.hip): odd steps
                 // accumulate the NEGATED products into a second accumulator pair, the difference of the two cancels it
-                const unsigned sgn = (sg & 1) ? 0x80008000u : 0u;
+                const unsigned sgn = ((sg ^ l31) & 1) ? 0x80008000u : 0u;        // (and the whole of an odd row: see the header)
                 AH[sg] = gad_u32x4{ah[0] ^ sgn, ah[1] ^ sgn, ah[2] ^ sgn, ah[3] ^ sgn};
                 AM[sg] = gad_u32x4{am[0] ^ sgn, am[1] ^ sgn, am[2] ^ sgn, am[3] ^ sgn};
                 AL[sg] = gad_u32x4{al[0] ^ sgn, al[1] ^ sgn, al[2] ^ sgn, al[3] ^ sgn};
@@ -1376,7 +1382,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) acc[2 * pp + i][v] -= an[i][v];
+                    for (int v = 0; v < 16; ++v) acc[2 * pp + i][v] = (v & 1) ? an[i][v] - acc[2 * pp + i][v] : acc[2 * pp + i][v] - an[i][v];
             }
         }
         f32x16 zacc[RE ? 2 : 1];
@@ -2537,6 +2543,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, 
         }
         // exchange store position of this lane: row pair l31 >> 1 (4 bytes) of channel (c0 & (HC - 1)) + 2 i + (l31 & 1)
         const unsigned psel = (l31 & 1) ? 0x03020706u : 0x05040100u;        // v_perm_b32 selector: {even row | odd row} of the lane's channels
+        const unsigned rsg = (l31 & 1) ? 0x80000000u : 0u;                  // sign of this lane's row in the products (header of the split section)
         const int xq = l31 >> 3, xin = ((l31 >> 1) & 3) * 4;                // 16-byte chunk (before the swizzle), byte inside it
         const unsigned char* const wb = WtS + l31 * RB + 16 * half;
         for (; slab < slab_limit; slab += round_stride) {
@@ -2600,8 +2607,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, 
                     a4.x = P.x * g.x - wrow * fmaf(S.x, z.x, Q.x); a4.y = P.y * g.y - wrow * fmaf(S.y, z.y, Q.y);
                     a4.z = P.z * g.z - wrow * fmaf(S.z, z.z, Q.z); a4.w = P.w * g.w - wrow * fmaf(S.w, z.w, Q.w);
                     if (!row_live) a4 = make_float4(0.f, 0.f, 0.f, 0.f);       // rows past the end add nothing to dW
-                    gad_split2(a4.x, a4.y, ah[2 * ee], am[2 * ee], al[2 * ee]);
-                    gad_split2(a4.z, a4.w, ah[2 * ee + 1], am[2 * ee + 1], al[2 * ee + 1]);
+                    // (odd rows enter negated -- here and, through the exchange, in the consumers, which negate y of odd rows)
+                    gad_split2(__uint_as_float(__float_as_uint(a4.x) ^ rsg), __uint_as_float(__float_as_uint(a4.y) ^ rsg), ah[2 * ee], am[2 * ee], al[2 * ee]);
+                    gad_split2(__uint_as_float(__float_as_uint(a4.z) ^ rsg), __uint_as_float(__float_as_uint(a4.w) ^ rsg), ah[2 * ee + 1], am[2 * ee + 1], al[2 * ee + 1]);
                 }
                 const gad_u32x4 AH = {ah[0], ah[1], ah[2], ah[3]}, AM = {am[0], am[1], am[2], am[3]}, AL = {al[0], al[1], al[2], al[3]};
                 if (DW) {
@@ -2639,7 +2647,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, 
                 const int rb = zrow + ((v & 3) + 8 * (v >> 2)) * 256;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const float gv = acc[t][v] - an[t][v];
+                    const float gv = (v & 1) ? an[t][v] - acc[t][v] : acc[t][v] - an[t][v];
                     const float zv = live ? zp[t][v] : 0.f;
                     const bool act = fmaf(zv, ps[t], pt[t]) > 0.f && live;
                     const float ga = act ? gv : 0.f;
@@ -2700,7 +2708,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, 
 #pragma unroll
                             for (int i = 0; i < 4; ++i) {
                                 float y0 = fmaxf(fmaf(yr[sl][8 * st + 2 * i], psb, ptb), 0.f), y1 = fmaxf(fmaf(yr[sl][8 * st + 2 * i + 1], psb, ptb), 0.f);
-                                if (st) { y0 = -y0; y1 = -y1; }
+                                // dZ of the odd rows arrives negated: undo it on y; rows 16 .. 31 are negated for the accumulator pair
+                                if (st) y0 = -y0; else y1 = -y1;
                                 gad_split2(y0, y1, yh[i], ym[i], yl[i]);
                             }
                             YH[sl][st] = gad_u32x4{yh[0], yh[1], yh[2], yh[3]};
@@ -2869,7 +2878,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
                 v.x = P4.x * g.x - w * fmaf(S4.x, z.x, Q4.x); v.y = P4.y * g.y - w * fmaf(S4.y, z.y, Q4.y);
                 v.z = P4.z * g.z - w * fmaf(S4.z, z.z, Q4.z); v.w = P4.w * g.w - w * fmaf(S4.w, z.w, Q4.w);
                 if (!live[u]) v = f4zero();
-                if (SP) spw::store_a4(smem_b + (kt & 1) * spw::STAGE, ur + 32 * u, tid, v);
+                if (SP) spw::store_a4(smem_b + (kt & 1) * spw::STAGE, ur + 32 * u, tid, v, (ur & 1) ? 0x80000000u : 0u);
                 else *reinterpret_cast<float4*>(As + (ur + 32 * u) * P + c4) = v;
             }
             if (SP) { spw::store_b(smem_b + (kt & 1) * spw::STAGE, rbs, tid); return; }
@@ -2924,7 +2933,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) acc[t][v] -= an[t][v];
+                for (int v = 0; v < 16; ++v) acc[t][v] = (v & 1) ? an[t][v] - acc[t][v] : acc[t][v] - an[t][v];   // (odd rows entered negated)
         }
         // epilogue: dY of the previous layer (ReLU-masked) + its BatchNorm-backward sums; all z_prev loads first
         if (SC) {
