@@ -50,6 +50,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK = 157.3e12     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK = 2500.0e12    # same table: v_mfma_f32_32x32x16_bf16, dense (no sparsity)
+SPLIT_PRODUCTS = 6            # bf16 term products per f32-equivalent product in the split-bf16 form (csrc/gemm.hip)
+DTYPE_F32 = "f32"
+DTYPE_SPLIT = "f32 (3xbf16-split products, f32 accumulate)"
 SEED = 20260928
 
 # dense algorithmic MACs per sample of each shared-MLP layer, as the reference computes them
@@ -201,7 +205,11 @@ ROUTE_SYMBOL = {"gemm_fwd(stream)": "gemm_fwd_stream_kernel", "gemm_fwd(wide)": 
                 "gemm_fwd": "gemm_fwd_kernel", "gemm_dx(stream)": "gemm_dx_stream_kernel", "gemm_dx(wide)": "gemm_dx_wide_kernel",
                 "gemm_dx(skinny)": "gemm_dx_skinny_kernel", "gemm_dx": "gemm_dx_kernel", "gemm_dx(action stream)": "dx_action_stream_kernel", "gemm_dw(stream)": "gemm_dw_stream_kernel",
                 "gemm_dw(gather stream)": "gemm_dw_gather_stream_kernel", "gemm_dw(wide)": "gemm_dw_wide_kernel",
-                "gemm_dw(skinny)": "gemm_dw_skinny_kernel", "gemm_dw": "gemm_dw_kernel", "gemm_bwd(stream)": "gemm_bwd_stream_kernel", "gemm_bwd(wide)": "gemm_bwd_wide_kernel"}
+                "gemm_dw(skinny)": "gemm_dw_skinny_kernel", "gemm_dw": "gemm_dw_kernel", "gemm_bwd(stream)": "gemm_bwd_stream_kernel", "gemm_bwd(wide)": "gemm_bwd_wide_kernel",
+                # split-bf16 forms (library option "mfma_split"): same layers, products on v_mfma_f32_32x32x16_bf16
+                "gemm_fwd(stream split)": "gemm_fwd_stream_kernel<split>", "gemm_fwd(wide split)": "gemm_fwd_wide_kernel<split>",
+                "gemm_dx(wide split)": "gemm_dx_wide_kernel<split>", "gemm_dw(wide split)": "gemm_dw_wide_split_kernel",
+                "gemm_bwd(stream split)": "gemm_bwd_stream_split_kernel", "gemm_dx(stream split)": "gemm_bwd_stream_split_kernel<dX only>"}
 ROUTES = {}                 # tag -> routed kernel family, filled from engine.timing_routes() after each probe
 
 
@@ -260,10 +268,21 @@ def kernel_table(by_tag, rows, B, steps):
     for sym, f in fam.items():
         sec = f["ms"] * 1e-3
         tf, gb = f["flops"] / sec / 1e12, f["bytes"] / sec / 1e9
-        frac = gb / 8000.0 if f["bound"] == "hbm" else tf / (FP32_MFMA_PEAK / 1e12)
+        split = "split" in sym
+        if f["bound"] == "hbm":
+            frac = gb / 8000.0
+        elif split:                                  # six bf16 MFMA products per f32-equivalent product, against the bf16 peak
+            frac = SPLIT_PRODUCTS * tf / (BF16_MFMA_PEAK / 1e12)
+        else:
+            frac = tf / (FP32_MFMA_PEAK / 1e12)
         out[sym] = {"bound": f["bound"], "ms_per_step": f["ms"] / steps, "launches_per_step": f["launches"] / float(steps),
                     "kernel_avg_us": 1e3 * f["ms"] / f["launches"], "executed_tflops": tf, "algorithmic_gbps": gb,
                     "frac": frac, "dense_equiv_tflops": f["dense"] / sec / 1e12, "tags": sorted(f["tags"])}
+        if split:                                    # (executed_tflops stays f32-equivalent: de-duplicated rows x K x N x 2)
+            out[sym]["arithmetic"] = "split-bf16"
+            out[sym]["frac_f32_equiv"] = tf / (FP32_MFMA_PEAK / 1e12)
+            if f["bound"] != "hbm":
+                out[sym]["executed_bf16_tflops"] = SPLIT_PRODUCTS * tf
     return out
 
 
@@ -311,6 +330,11 @@ def main():
     from ga_ddpg_amd.parallel import DataParallelContext, mask_counts
     from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
 
+    from ga_ddpg_amd import hip as _hip
+    # arithmetic of the layer GEMMs' products in THIS run's `value`: the library default (0: FP32 MFMA; non-zero: split-bf16 MFMAs,
+    # include/gaddpg.h "mfma_split"), or the GAD_OPT_mfma_split override
+    split_mode = _hip.get_option_default("mfma_split")
+    _hip.set_option("mfma_split", split_mode)
     torch.manual_seed(1234)                      # identical initial weights on every rank
     agent, cfg = make_agent("ddpg_td3_aux.yaml")
     B = args.batch
@@ -418,16 +442,21 @@ def main():
     table_timed = kernel_table(timed_tags, rows, B, n_stamped)
     d0 = table_timed.get(dom, table[dom])                           # measured over the timed region itself
     tj, tsrc = {}, None
-    for rnd in ("r04", "r03", "r02"):                               # this round's PMC passes (tools/collect_profiles.sh)
+    for rnd in ("r05", "r04", "r03", "r02"):                        # this round's PMC passes (tools/collect_profiles.sh)
         tpath = os.path.join(ROOT, "profiles", "%s_traffic.json" % rnd)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             tsrc = "profiles/%s_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, not measured in this run)" % rnd
             break
+    dom_split = "split" in dom and d0["bound"] == "mfma"
     roof = {"bound": d0["bound"], "kernel": dom, "layers": d0["tags"],
-            "achieved": d0["executed_tflops"] if d0["bound"] == "mfma" else d0["algorithmic_gbps"],
-            "peak": FP32_MFMA_PEAK / 1e12 if d0["bound"] == "mfma" else 8000.0,
+            # split-bf16 kernels: achieved = the bf16 term products the matrix pipe executed (6 per f32-equivalent product)
+            # against the dense bf16 peak; frac_f32_equiv prices the same launches' f32-equivalent FLOPs against the FP32-MFMA peak
+            "achieved": (d0.get("executed_bf16_tflops") if dom_split else d0["executed_tflops"]) if d0["bound"] == "mfma" else d0["algorithmic_gbps"],
+            "peak": (BF16_MFMA_PEAK if dom_split else FP32_MFMA_PEAK) / 1e12 if d0["bound"] == "mfma" else 8000.0,
             "unit": "TFLOP/s" if d0["bound"] == "mfma" else "GB/s", "frac": d0["frac"],
+            "frac_f32_equiv": d0.get("frac_f32_equiv"), "f32_equiv_tflops": d0["executed_tflops"] if d0["bound"] == "mfma" else None,
+            "arithmetic": "split-bf16 (6 bf16 x bf16 term products per f32 product, f32 accumulate)" if "split" in dom else "f32 MFMA",
             "traffic": tj.get(dom, {}).get("bytes_per_launch"), "traffic_source": tsrc,
             "kernel_avg_us": d0["kernel_avg_us"], "launches_per_step": d0["launches_per_step"],
             "ms_per_step": d0["ms_per_step"], "dense_equiv_tflops": d0["dense_equiv_tflops"],
@@ -440,11 +469,11 @@ def main():
     # world x (B=256 minibatch-steps) per iteration; at N=1 this is the plain step rate
     res = {"metric": "DDPG grad-steps/sec (B=%d, N=1024 pts)" % B, "value": steps_per_s * world, "unit": "steps/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE_SPLIT if split_mode else DTYPE_F32, "data": "synthetic",
            "config": {"workload": "BASELINE configs[1]: DDPG/TD3 offline update (td3_critic_aux_policy_aux), "
                                   "batch=%d per GPU, 1024-pt clouds, synthetic replay buffer" % B,
                       "batch_per_gpu": B, "global_batch": B * world, "points": 1024,
-                      "parallelism": "dp%d" % world, "iterations_per_s": steps_per_s,
+                      "parallelism": "dp%d" % world, "iterations_per_s": steps_per_s, "mfma_split": split_mode,
                       "enqueue": "run-ahead (update_parameters(sync=False), all steps complete at the closing fence)",
                       "iterations_per_s_sync_each_step": rate_sync,
                       "value_definition": "B=%d minibatch gradient steps per second summed over ranks (= iterations/s x n_gpus)" % B, "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
@@ -463,7 +492,7 @@ def main():
             b = sample_valid_batch(mem, B, rng2)
             agent.update_parameters(b, agent.update_step, i)
         torch.cuda.synchronize()
-        res["value_host_inclusive"] = n / (time.perf_counter() - t0)
+        res["value_host_inclusive"] = res["config"]["value_host_inclusive"] = n / (time.perf_counter() - t0)
         # the same, with the sampling on a background thread into pinned staging sets (core/prefetch.PrefetchSampler) and
         # run-ahead steps: what a training loop over a HOST replay buffer gets
         from ga_ddpg_amd.core.prefetch import PrefetchSampler
@@ -477,7 +506,7 @@ def main():
                 agent.update_parameters(sampler.next(), agent.update_step, i, sync=False)
             agent.flush()
             torch.cuda.synchronize()
-            res["value_host_prefetch"] = n_pf / (time.perf_counter() - t0)
+            res["value_host_prefetch"] = res["config"]["value_host_prefetch"] = n_pf / (time.perf_counter() - t0)
         # same loop fed by the GPU-resident replay mirror: indices drawn on the host with the
         # reference's arithmetic, gather in HBM -- the rate a training loop sees without the 17 MB/step host gather
         from ga_ddpg_amd.core.device_replay import DeviceReplay
@@ -487,12 +516,10 @@ def main():
         for i in range(n):
             agent.update_parameters(dmem.sample_lazy(B, rng2), agent.update_step, i, sync=False)
         agent.flush()
-        res["value_device_replay"] = n / (time.perf_counter() - t0)
-        # NOT `value` (which is FP32-MFMA arithmetic throughout): the same run-ahead loop over the HBM ring with the library's opt-in
-        # "mfma_split" option -- the streaming forward kernel (SA1 layers 2 / 3) forms its FP32 products as six bf16 x bf16 term
-        # products with sign-balanced accumulator pairs (f32-sized, unbiased error; the whole GPU suite passes
-        # with it) -- reported so that the option's effect is measured by whoever runs this file, beside the default path
-        from ga_ddpg_amd import hip as _hip
+        res["value_device_replay"] = res["config"]["value_device_replay"] = n / (time.perf_counter() - t0)
+        # both arithmetic modes of the layer GEMMs in THIS process, alternating runs of the `value` loop (run-ahead, HBM ring):
+        # config.value_f32_mfma = products on v_mfma_f32_32x32x2_f32, config.value_split = split-bf16 products (every family that has
+        # the form).  `value` above is the one `dtype` names; the other is reported, not claimed.
         n_x = 150                                        # (shorter runs drown a 2 % difference in the run-ahead loop's start-up)
         rates = {}
         for flag in (0, 1, 0, 1):
@@ -507,11 +534,11 @@ def main():
             agent.flush()
             torch.cuda.synchronize()
             rates.setdefault(flag, []).append(n_x / (time.perf_counter() - t0))
-        _hip.set_option("mfma_split", 0)
-        res["experimental"] = {"mfma_split": {"steps_per_s_option_off": [round(v, 1) for v in rates[0]],
-                                              "steps_per_s_option_on": [round(v, 1) for v in rates[1]],
-                                              "note": "opt-in split-bf16 arithmetic in the streaming forward kernel only; default off; "
-                                                      "alternating runs of %d steps in this process; not `value`" % n_x}}
+        _hip.set_option("mfma_split", split_mode)
+        res["config"]["value_f32_mfma"] = float(np.mean(rates[0]))
+        res["config"]["value_split"] = float(np.mean(rates[1]))
+        res["config"]["value_modes_note"] = ("alternating %d-step runs of the value loop in this process: f32-MFMA %s, split-bf16 %s steps/s"
+                                             % (n_x, [round(v, 1) for v in rates[0]], [round(v, 1) for v in rates[1]]))
     res["kernels"] = {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk != "tags"}
                       for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_per_step"])}
     if world == 1 and not args.no_sa_kernel:
@@ -531,6 +558,14 @@ def main():
         sa["query_and_group"]["traffic"] = tj.get("query_and_group", {}).get("bytes_per_launch")
         res["sa_kernel_hbm"] = sa
         res["sa_kernel_mfma"] = sa_kernel_mfma()          # configs[3] "4b": the fused stack, forward + backward
+        # BASELINE.json's second metric where the driver keeps it (it retains `roofline`, `config`, `cpu_baseline` only)
+        qg, sm = sa["query_and_group"], res["sa_kernel_mfma"]
+        res["roofline"]["sa_kernel_hbm"] = {"kernel": "ball_query_cells_kernel (query_and_group, configs[3]: B=128, N=4096)",
+                                            "achieved": qg.get("achieved"), "unit": "GB/s", "peak": 8000.0, "frac": qg.get("frac"),
+                                            "kernel_avg_us": 1e3 * qg["launch_ms"], "traffic": qg.get("traffic"),
+                                            "sa1_streaming_in_step": {k: {"gbps": v["achieved"], "frac": v["frac"], "us": v["kernel_avg_us"]}
+                                                                      for k, v in sa.items() if k != "query_and_group"}}
+        res["roofline"]["sa_kernel_mfma"] = {k: sm.get(k) for k in sm if not isinstance(sm.get(k), (dict, list))}
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(cfg, host_batches[0], np.random.default_rng(3).random((B, 6)).astype(np.float32))
     else:

@@ -1812,7 +1812,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
             else { if (a->n_out[0] == 64) LAUNCH_STREAM(2, 2, 1, false); else LAUNCH_STREAM(2, 4, 1, false); }
         }
 #undef LAUNCH_STREAM
-        GAD_CHECK_LAUNCH("gemm_fwd(stream)");
+        if (split_on(GAD_SPLIT_FWD_STREAM) && a->mode == 0) GAD_CHECK_LAUNCH("gemm_fwd(stream split)"); else GAD_CHECK_LAUNCH("gemm_fwd(stream)");
         return GAD_OK;
     }
     if (fwd_wideable(*a)) {

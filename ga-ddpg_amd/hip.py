@@ -187,6 +187,15 @@ def require_cuda(*tensors):
             raise RuntimeError("libgaddpg operators need contiguous tensors")
 
 
+# library defaults of the options this package changes at run time (csrc/gemm.hip g_opt_*): what a test restores
+OPTION_DEFAULTS = {"mfma_split": 0}
+
+
+def get_option_default(name):
+    """the value an option has when nothing set it: the library default, or the GAD_OPT_<name> environment override"""
+    return int(os.environ.get("GAD_OPT_" + name, OPTION_DEFAULTS.get(name, 1)))
+
+
 def set_option(name, value):
     """kernel-selection switch for A/B diagnostics (include/gaddpg.h: gad_set_option)"""
     check(lib().gad_set_option(name.encode(), int(value)), "gad_set_option")

@@ -33,6 +33,9 @@ class _StageNet(object):
         for i, m in enumerate(self.mats):
             m.bn_index = i
         self.flat = FlatNet(list(mod.named_parameters()), self.mats, device)
+        # split-bf16 weight mirrors (library option "mfma_split"): layers 2 / 3, and layer 1 when its feature block is whole K-tiles
+        self.flat.enable_split([(m, (m.gather_feat_c if l == 0 else m.Kp)) for l, m in enumerate(self.mats)
+                                if (l > 0 or m.gather_feat_c >= 32)])
         tot = sum(m.n_out for m in self.mats)
         self.running_mean = torch.zeros(tot, dtype=torch.float32, device=device)
         self.running_var = torch.ones(tot, dtype=torch.float32, device=device)
@@ -126,6 +129,7 @@ class _StageRun(object):
         for l, m in enumerate(net.mats):
             o = net.bn_off[l]
             kw = self._input(net, mod, l)
+            kw.update(net.flat.split_fwd_kw(m))
             a = _fwd_args(W=net.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(self.Z[l]), zout_pitch=m.n_out,
                           stat_sum=_ptr(self.stats, o, 8) if train else None,
                           stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot, **kw)
@@ -193,7 +197,7 @@ class _StageRun(object):
             a.Kp = m.Kp
             a.k_valid = k_valid
             a.grp_per_sample = 1
-            for k, v in epi.items():
+            for k, v in dict(epi, **fl.split_t_kw(m)).items():
                 setattr(a, k, v)
             plan.call_struct("gad_gemm_dx", a)
 

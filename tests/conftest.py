@@ -15,3 +15,26 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+# the oracle-facing gates run in BOTH arithmetic modes of the layer GEMMs -- products on the FP32 MFMA
+# (library option mfma_split = 0) and as split-bf16 MFMAs with f32 accumulation (mfma_split = 1: every family that has the form)
+BOTH_MODES = {"test_ddpg_steps_vs_reference_golden", "test_bc_steps_vs_reference_golden", "test_step_gradients_with_forced_decisions",
+              "test_bc_step_gradients_with_forced_decisions", "test_ddpg_step_B256_vs_oracle", "test_teacher_forced_steps",
+              "test_two_layer_stack_matches_oracle_small_batch", "test_two_layer_stack_backward_matches_oracle_small_batch",
+              "test_gradients_vs_reference_float64"}
+
+
+def pytest_generate_tests(metafunc):
+    if metafunc.function.__name__ in BOTH_MODES:
+        metafunc.fixturenames.append("mfma_mode")
+        metafunc.parametrize("mfma_mode", ["f32_mfma", "split_bf16"], indirect=True)
+
+
+@pytest.fixture
+def mfma_mode(request):
+    from ga_ddpg_amd import hip
+    was = hip.get_option_default("mfma_split")
+    hip.set_option("mfma_split", 1 if request.param == "split_bf16" else 0)
+    yield request.param
+    hip.set_option("mfma_split", was)

@@ -84,7 +84,7 @@ class Case(object):
             routed = hip.lib().gad_last_kernel().decode()
             torch.cuda.synchronize()
         finally:
-            hip.set_option("mfma_split", 0)
+            hip.set_option("mfma_split", hip.get_option_default("mfma_split"))
         return out, routed
 
     def time_mode(self, split, iters=50):
@@ -97,7 +97,7 @@ class Case(object):
             st = hip.stream()
             return time_call(lambda: hip.check(f(C.byref(a), st), name), iters)
         finally:
-            hip.set_option("mfma_split", 0)
+            hip.set_option("mfma_split", hip.get_option_default("mfma_split"))
 
 
 class FwdWide(Case):
@@ -431,7 +431,7 @@ class BwdStream(Case):
             f = hip.lib().gad_gemm_dx
             return time_call(lambda: hip.check(f(C.byref(ax), st), "gad_gemm_dx"), iters)
         finally:
-            hip.set_option("mfma_split", 0)
+            hip.set_option("mfma_split", hip.get_option_default("mfma_split"))
 
     def ref(self):
         d = self.dx

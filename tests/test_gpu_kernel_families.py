@@ -63,7 +63,7 @@ def _run(B, value, options, keep_slot=False, mutate=None):
         for k, v in sched_was.items():
             setattr(engine, k, v)
         for k in options:
-            hip.set_option(k, 0 if k in ("bwd_wide", "mfma_split") else 1)         # library defaults of the family switches
+            hip.set_option(k, hip.get_option_default(k) if k == "mfma_split" else (0 if k == "bwd_wide" else 1))   # library defaults of the family switches
     return out
 
 
@@ -124,7 +124,7 @@ def test_split_bf16_option_stays_within_f32_summation_noise(value):
     ref = _run(B, value, {"mfma_split": 0})
     got = _run(B, value, {"mfma_split": 1})
     from ga_ddpg_amd import hip
-    hip.set_option("mfma_split", 0)                      # (_run's clean-up restores family switches to 1)
+    hip.set_option("mfma_split", hip.get_option_default("mfma_split"))
     assert got["rows"] == ref["rows"] and ref["rows"][0] >= 32768
     assert not torch.equal(got["Z12"], ref["Z12"]), "the option did not change the arithmetic"
     acts = [k for k in ref if k[0] in "ZFzmir" and k != "rows"]
