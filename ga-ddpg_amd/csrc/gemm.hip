@@ -720,7 +720,10 @@ __device__ __forceinline__ void gad_split2(float a, float b, unsigned& H, unsign
 }
 __device__ __forceinline__ gad_bf16x8 gad_as_bf16x8(gad_u32x4 u) { return *reinterpret_cast<gad_bf16x8*>(&u); }
 
-static int g_opt_mfma_split = 0;           // family mask (GAD_SPLIT_*; 1 = all): which GEMM families multiply as split-bf16 MFMAs
+// family mask (GAD_SPLIT_*; 1 = all): which GEMM families multiply as split-bf16 MFMAs.  Default since round 5: all -- the per-family
+// float64 gates (tests/test_gpu_split_families.py), the range / specials tests and the oracle-facing gates in both modes are green
+// on MI355X; 0 restores v_mfma_f32_32x32x2_f32 throughout (GAD_OPT_mfma_split=0).
+static int g_opt_mfma_split = GAD_SPLIT_ALL;
 static bool split_on(int family) { return g_opt_mfma_split == GAD_SPLIT_ALL || (g_opt_mfma_split & family) != 0; }
 
 // Wide-tile kernels in split form (gemm_fwd_wide / gemm_dx_wide with SP): a 64 x 128 block tile per 4-wavefront workgroup,

@@ -188,7 +188,7 @@ def require_cuda(*tensors):
 
 
 # library defaults of the options this package changes at run time (csrc/gemm.hip g_opt_*): what a test restores
-OPTION_DEFAULTS = {"mfma_split": 0}
+OPTION_DEFAULTS = {"mfma_split": 1}
 
 
 def get_option_default(name):

@@ -55,7 +55,8 @@ const char* gad_last_error(void);          /* thread-local description of the la
  * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route
  * the small-M (<= 1024 rows) forward / dX / dW layers to the split-K kernels.  Returns GAD_ERR_SHAPE for an
  * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.
- * "mfma_split" [0 until round 5's gates were green on hardware, see DESIGN.md]: the arithmetic of the layer GEMMs' products.
+ * "mfma_split" [1 = GAD_SPLIT_ALL since round 5, when its accuracy gates were green on hardware: DESIGN.md]: the arithmetic of the
+ * layer GEMMs' products.
  * 0: v_mfma_f32_32x32x2_f32 throughout.  Non-zero: a mask of kernel families that form every FP32 product from split-bf16
  * terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation (GAD_SPLIT_* below; 1 = every family that has the form).  A launch
  * takes the split form only if its family's bit is set AND the call carries the weight mirror it needs (W_split /

@@ -113,13 +113,11 @@ def test_specialised_and_tile_kernels_agree(value):
 
 @pytest.mark.parametrize("value", [False, True])
 def test_split_bf16_option_stays_within_f32_summation_noise(value):
-    """opt-in library option "mfma_split" (NOT the default): the streaming forward kernel forms its FP32
-    products as six bf16 x bf16 term products (hi / mid / lo splits, 24 significand bits) on v_mfma_f32_32x32x16_bf16.  Against
-    the default f32-MFMA path: activations, statistics and gradients agree as tightly as two f32 summation orders do (the same
-    bounds as tile vs specialised kernels), i.e. its error is f32-sized, not bf16-sized (which would show as 4e-3).  (The bf16
-    MFMA's adder truncates toward -inf; the kernel cancels that bias with (plain, negated) accumulator pairs -- with them the
-    whole GPU suite, the forced-decision gradient gate included, passes under GAD_OPT_mfma_split=1:
-    profiles/r04_split_bf16_ubench.txt.  The option stays off: the dtype rule.)"""
+    """library option "mfma_split" (the default since round 5; 0 = FP32 MFMA throughout): every GEMM family of the encoder forms its
+    FP32 products as six bf16 x bf16 term products (hi / mid / lo splits, 24 significand bits) on v_mfma_f32_32x32x16_bf16.  The
+    two modes agree as tightly as two f32 summation orders do (the bounds of tile vs specialised kernels), i.e. the split form's
+    error is f32-sized, not bf16-sized (which would show as 4e-3).  The per-family float64 gates are
+    tests/test_gpu_split_families.py; the oracle-facing gates run in both modes (tests/conftest.py BOTH_MODES)."""
     B = 96
     ref = _run(B, value, {"mfma_split": 0})
     got = _run(B, value, {"mfma_split": 1})

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence on the GPU box: bench line, rocprofv3 kernel stats, PMC traffic (FETCH / WRITE in separate passes) and the
 # MFMA / VALU instruction counters.  Writes gpurun_out/rNN_*; copy what is to be judged into profiles/.
-R=${1:-r04}
+R=${1:-r05}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
