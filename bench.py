@@ -457,7 +457,7 @@ def main():
             "unit": "TFLOP/s" if d0["bound"] == "mfma" else "GB/s", "frac": d0["frac"],
             "frac_f32_equiv": d0.get("frac_f32_equiv"), "f32_equiv_tflops": d0["executed_tflops"] if d0["bound"] == "mfma" else None,
             "arithmetic": "split-bf16 (6 bf16 x bf16 term products per f32 product, f32 accumulate)" if "split" in dom else "f32 MFMA",
-            "traffic": tj.get(dom, {}).get("bytes_per_launch"), "traffic_source": tsrc,
+            "traffic": (tj.get(dom) or tj.get(dom.split("<")[0]) or tj.get(dom.split("<")[0].replace("_kernel", "_split_kernel")) or {}).get("bytes_per_launch"), "traffic_source": tsrc,
             "kernel_avg_us": d0["kernel_avg_us"], "launches_per_step": d0["launches_per_step"],
             "ms_per_step": d0["ms_per_step"], "dense_equiv_tflops": d0["dense_equiv_tflops"],
             "frac_alone": table_alone.get(dom, {}).get("frac"), "kernel_avg_us_alone": table_alone.get(dom, {}).get("kernel_avg_us"),
@@ -546,12 +546,13 @@ def main():
         # 0.5-1 KB moved per row) from the table above -- inside the overlapped step and alone -- plus the materialising
         # configs[3] kernel behind pointnet2_utils.query_and_group
         sa = {}
-        for sym in ("gemm_fwd_stream_kernel", "gemm_bwd_stream_kernel", "gemm_dx_stream_kernel", "gemm_dw_gather_stream_kernel", "gemm_dw_stream_kernel"):
+        for sym in ("gemm_fwd_stream_kernel", "gemm_fwd_stream_kernel<split>", "gemm_bwd_stream_kernel", "gemm_bwd_stream_split_kernel", "gemm_dx_stream_kernel",
+                    "gemm_bwd_stream_split_kernel<dX only>", "gemm_dw_gather_stream_kernel", "gemm_dw_stream_kernel"):
             if sym in table:
                 t, a1 = table[sym], table_alone.get(sym, {})
                 sa[sym] = {"bound": "hbm", "kernel_avg_us": t["kernel_avg_us"], "achieved": t["algorithmic_gbps"], "peak": 8000.0,
                            "unit": "GB/s", "frac": t["frac"], "frac_alone": a1.get("frac"),
-                           "traffic": tj.get(sym, {}).get("bytes_per_launch"),
+                           "traffic": (tj.get(sym) or tj.get(sym.split("<")[0]) or {}).get("bytes_per_launch"),
                            "note": "frac: inside the overlapped step (other encoder passes run beside it); frac_alone: the "
                                    "same launches with the step serialised on one stream"}
         sa["query_and_group"] = sa_kernel_hbm()
