@@ -1081,8 +1081,11 @@ static int g_opt_bwd_wide_slab = 4;             // most partial-dW elements (mil
 static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch aims for (its partial slab = this x 128 x 128 floats)
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
+static bool fits_i32_bytes(long long rows, int pitch_a, int pitch_b, int pitch_c, int pitch_d);
 static bool fwd_wideable(const gad_gemm_fwd_args& a) {
     if (!g_opt_fwd_wide || a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
+    // (gathered input: the point-major feature tensor has at most as many rows as there are (group, point) rows upstream)
+    if (!fits_i32_bytes(a.n_rows, a.mode == 1 ? a.feat_c : a.zin_pitch, a.zout ? a.zout_pitch : 0, 0, 0)) return false;
     if (a.n_rows < 2048 || a.n_out[0] % 128 != 0 || a.ones_col >= 0) return false;
     if (a.mode == 2) return false;
     if (a.mode == 1)                                     // gathered first layer: features a multiple of 32, + 3 coordinates
@@ -1090,6 +1093,14 @@ static bool fwd_wideable(const gad_gemm_fwd_args& a) {
                a.Kp == ((a.feat_c + 3 + 7) & ~7);
     if (a.Kp % 32 != 0 || a.Kp > 512 || a.Kp != a.c_in) return false;
     return !a.extra && a.scale && a.shift && a.relu;
+}
+// the wide-tile kernels address their row tensors through buffer descriptors with 32-bit byte offsets: a launch whose largest
+// row tensor reaches 2 GiB takes the 64 x 64 tile kernels (64-bit pointer arithmetic) instead
+static bool fits_i32_bytes(long long rows, int pitch_a, int pitch_b, int pitch_c, int pitch_d) {
+    int p = pitch_a > pitch_b ? pitch_a : pitch_b;
+    p = p > pitch_c ? p : pitch_c;
+    p = p > pitch_d ? p : pitch_d;
+    return rows * (long long)p * 4 < (1ll << 31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1782,6 +1793,8 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         }
     }
     if (!pe.key && fwd_skinny(*a)) {
+        // (a NULL zout -- statistics / pooled maxima only -- is honoured by the streaming, wide-tile and 64 x 64 kernels; this one stores unguarded)
+        GAD_REQUIRE(a->zout, GAD_ERR_NULL, "gemm_fwd: zout == NULL is not supported for small-M (skinny) shapes");
         hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
                            gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
         GAD_CHECK_LAUNCH("gemm_fwd(skinny)");
@@ -3075,6 +3088,7 @@ static bool dx_wideable(const gad_gemm_dx_args& a, bool vec) {
     } else if (!a.prev_dbeta || !a.store_masked || !(a.zprev && a.prev_scale && a.prev_shift && a.prev_mean && a.prev_istd && a.prev_dgamma)) return false;
     const gad_dz_src& d = a.dz;
     if (!d.z || d.z_pitch % 4 != 0 || !d.relu || !d.premasked || !(d.coefP && d.coefQ && d.coefS)) return false;
+    if (!fits_i32_bytes(a.n_rows, d.z_pitch, d.gmode == 0 ? d.g_pitch : d.c, a.epilogue == 0 ? a.gout_pitch : 0, a.epilogue == 0 ? a.zprev_pitch : 0)) return false;
     return d.gmode == 0 ? (d.g_pitch % 4 == 0 && d.G) : (d.c % 4 == 0);
 }
 

@@ -113,7 +113,9 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             py[s] = sp[k * 3 + 1];
             pz[s] = sp[k * 3 + 2];
             const float mag = gad_sqnorm(px[s], py[s], pz[s]);
-            if (mag > 1e-3f) valid |= 1u << s;
+            // upstream: `if (mag <= 1e-3) continue;` compares the FLOAT mag with the DOUBLE literal: the float nearest to 0.001
+            // (0x3A83126F = 0.00100000005) is > 0.001 and therefore NOT skipped -- in float terms "skip iff mag < 1e-3f"
+            if (!(mag < 1e-3f)) valid |= 1u << s;
             const unsigned t = (unsigned)k & ((1u << tie_bits) - 1u);          // k mod tie_bs
             const unsigned rev = tie_bits ? (__brev(t) >> (32 - tie_bits)) : 0u;
             key[s] = (rev << 16) | (unsigned)k;

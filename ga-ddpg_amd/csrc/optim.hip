@@ -306,6 +306,10 @@ extern "C" int gad_optim_jobs(const gad_optim_job* host_jobs, int n_jobs, void* 
         GAD_REQUIRE(!J.packed || J.m2p, GAD_ERR_NULL, "optim_jobs: job %d: packed mirror needs m2p", k);
         GAD_REQUIRE(!J.target || (J.p && (!J.target_packed || J.target_m2p)), GAD_ERR_NULL, "optim_jobs: job %d: target update", k);
         GAD_REQUIRE(!J.counter || (J.counter_n >= 0 && J.counter_n <= 256), GAD_ERR_SHAPE, "optim_jobs: job %d: counters", k);
+        // the main loop moves four elements per access: float / int32 streams 16-byte aligned, the uint8 masks 4-byte aligned
+        const void* p16[] = {J.p, J.grad, J.exp_avg, J.exp_avg_sq, J.m2p, J.target, J.target_m2p};
+        for (const void* q : p16) GAD_REQUIRE(((uintptr_t)q & 15) == 0, GAD_ERR_SHAPE, "optim_jobs: job %d: float / int32 buffers must be 16-byte aligned", k);
+        GAD_REQUIRE((((uintptr_t)J.active | (uintptr_t)J.target_sel) & 3) == 0, GAD_ERR_SHAPE, "optim_jobs: job %d: mask buffers must be 4-byte aligned", k);
         jobs.j[k] = J;
         nmax = J.n > nmax ? J.n : nmax;
     }

@@ -36,6 +36,7 @@ BUCKETED = {None: None, "0": False, "1": True}[os.environ.get("GAD_DP_BUCKETS")]
 # gradient / count exchanges of CUDA tensors through rccl.Communicator on the caller's stream (backend 'nccl' only: gloo
 # groups -- the CPU tests, two test ranks sharing one GPU -- keep torch.distributed)
 DIRECT = os.environ.get("GAD_DP_DIRECT_RCCL", "1") != "0"
+PER_LANE_COMMS = os.environ.get("GAD_DP_COMMS", "lanes") != "one"       # one RCCL communicator per issuing stream (see _make_comm)
 
 
 def mask_counts(batch):
@@ -71,6 +72,7 @@ class DataParallelContext(object):
         self.rank = dist.get_rank(group)
         self.rt = None
         self._comm = None
+        self._comms, self._lane_comm = [], {}
         self._direct = DIRECT and dist.get_backend(group) == "nccl" and torch.cuda.is_available()
 
     @property
@@ -81,43 +83,99 @@ class DataParallelContext(object):
             self._make_comm()
         return self._comm
 
+    def _agree(self, ok):
+        """MIN over the ranks of a 0 / 1 flag, over the bootstrap group (every rank calls this at the same point)"""
+        flag = torch.tensor([int(ok)], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        return int(flag.item()) == 1
+
     def _make_comm(self):
-        """Build the direct-RCCL communicator, PROVE it (a known-answer all-reduce on every stream the step issues
-        collectives from) and agree on the outcome over the bootstrap group: if any rank could not load librccl, failed in
-        ncclCommInitRank or saw a wrong sum, EVERY rank logs once and falls back to torch.distributed for this context
-        (never a mix of transports inside one job).  GAD_DP_DIRECT_RCCL=0 skips the attempt."""
+        """Build the direct-RCCL communicators -- ONE PER ISSUING LANE (main stream, value / weight-gradient lane A, actor lane
+        B, small-launch / weight-gradient lane C: engine._PHYS), so that exchanges issued from different streams are independent
+        RCCL operations and can overlap (one communicator serialises its operations in host-issue order, whatever streams
+        they ride on: VERDICT r04 item 5; GAD_DP_COMMS=one keeps a single communicator) -- PROVE each (a known-answer
+        all-reduce on its stream) and agree on the outcome over the bootstrap group IN PHASES, so that no rank can skip a
+        collective another rank is waiting in: (1) library + streams, (2) the unique ids are broadcast by every
+        rank unconditionally, then ncclCommInitRank, (3) every self-test runs on every rank before the verdict is reduced.
+        If any rank fails anywhere, EVERY rank logs once and falls back to torch.distributed for this context (never a mix of
+        transports inside one job).  GAD_DP_DIRECT_RCCL=0 skips the attempt."""
         import sys
-        from . import engine, rccl
-        ok, why, comm = 1, "", None
+        from . import rccl
+        why, comms, streams = "", [], []
+
+        def fail(exc):
+            return "%s: %s" % (type(exc).__name__, exc)
+        # ---- phase 1: librccl loads and every stream of the step has launched something
+        ok = 1
         try:
             rccl.lib()
             streams = self._warm_streams()
-            comm = rccl.Communicator(self.group)
-            if comm.count() != self.world:
-                raise RuntimeError("ncclCommCount = %d, group has %d ranks" % (comm.count(), self.world))
-            for st in streams:                  # the lanes the step's exchanges ride on (counts, dW lanes, main, actor)
-                with torch.cuda.stream(st):
-                    if not comm.self_test():
-                        raise RuntimeError("known-answer all-reduce returned a wrong sum")
         except Exception as exc:                # noqa: BLE001 -- whatever went wrong, the job continues on torch.distributed
-            ok, why = 0, "%s: %s" % (type(exc).__name__, exc)
-        flag = torch.tensor([ok], dtype=torch.int32, device="cuda" if dist.get_backend(self.group) == "nccl" else "cpu")
-        self._make_comm_outcome = (ok, why)                 # (this rank's own attempt, before the agreement: tests / logs)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-        if int(flag.item()) == 1:
-            self._comm = comm
+            ok, why = 0, fail(exc)
+        own = ok
+        agreed = self._agree(ok)
+        # ---- phase 2: unique ids (rank 0) -> every rank; one ncclCommInitRank per lane
+        if agreed:
+            n = len(streams) if PER_LANE_COMMS else 1
+            box = [None]
+            if self.rank == 0:
+                try:
+                    box = [[rccl.unique_id() for _ in range(n)] if hasattr(rccl, "unique_id") else None]
+                except Exception as exc:        # noqa: BLE001
+                    ok, why = 0, fail(exc)
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=self.group)          # unconditionally: nobody waits alone
+            try:
+                if box[0] is None:
+                    raise RuntimeError("rank 0 could not draw the ncclUniqueIds")
+                for uid in box[0]:
+                    comms.append(rccl.Communicator(self.group, uid=uid))
+                    if comms[-1].count() != self.world:
+                        raise RuntimeError("ncclCommCount = %d, group has %d ranks" % (comms[-1].count(), self.world))
+            except Exception as exc:            # noqa: BLE001
+                ok, why = 0, fail(exc)
+            own = ok
+            agreed = self._agree(ok)
+        # ---- phase 3: a known-answer all-reduce of every communicator on its lane's stream, ALL of them on every rank
+        if agreed:
+            for i, st in enumerate(streams):
+                comm = comms[i if len(comms) > 1 else 0]
+                try:
+                    with torch.cuda.stream(st):
+                        if not comm.self_test():
+                            ok, why = 0, "known-answer all-reduce returned a wrong sum (lane %d)" % i
+                except Exception as exc:        # noqa: BLE001
+                    ok, why = 0, fail(exc)
+            own = ok
+            agreed = self._agree(ok)
+        self._make_comm_outcome = (own, why)                # (this rank's own attempt, before the agreement: tests / logs)
+        if agreed:
+            self._comm = comms[0]                           # the main stream's (and, with GAD_DP_COMMS=one, everybody's)
+            self._comms = comms
+            self._lane_comm = {}
+            for i, st in enumerate(streams):
+                h = getattr(st, "cuda_stream", None)
+                if h is not None:
+                    self._lane_comm[int(h)] = comms[i if len(comms) > 1 else 0]
             import atexit
             atexit.register(self.close)
             return
-        if comm is not None:
+        for c in comms:
             try:
-                comm.destroy()
+                c.destroy()
             except Exception:                   # noqa: BLE001
                 pass
         self._direct = False
         self._comm = None
+        self._comms, self._lane_comm = [], {}
         print("ga_ddpg_amd.parallel: rank %d: direct RCCL path unavailable (%s): every collective of this context goes "
               "through torch.distributed" % (self.rank, why or "another rank failed"), file=sys.stderr, flush=True)
+
+    def _lane(self):
+        """the communicator of the CURRENT stream's lane (the main stream's for a stream the step does not know)"""
+        if self.comm is None:
+            return None
+        return self._lane_comm.get(int(torch.cuda.current_stream().cuda_stream), self._comm)
 
     @staticmethod
     def _warm_streams():
@@ -135,9 +193,9 @@ class DataParallelContext(object):
         return streams
 
     def close(self):
-        """destroy the RCCL communicator (before the process group goes away; registered with atexit)"""
-        c, self._comm = self._comm, None
-        if c is not None:
+        """destroy the RCCL communicators (before the process group goes away; registered with atexit)"""
+        cs, self._comm, self._comms, self._lane_comm = list(self._comms), None, [], {}
+        for c in cs:
             try:
                 c.destroy()
             except Exception:                   # noqa: BLE001
@@ -146,7 +204,7 @@ class DataParallelContext(object):
     def transport(self):
         """what carries this context's CUDA collectives, and how many ranks IT reports (bench.py: config.rccl_nranks)"""
         if self._comm is not None:
-            return {"transport": "rccl-direct", "rccl_nranks": self._comm.count()}
+            return {"transport": "rccl-direct", "rccl_nranks": self._comm.count(), "rccl_comms": len(self._comms)}
         return {"transport": "torch.distributed/%s" % dist.get_backend(self.group), "rccl_nranks": dist.get_world_size(self.group)
                 if dist.get_backend(self.group) == "nccl" else None}
 
@@ -164,8 +222,9 @@ class DataParallelContext(object):
 
     def _sum(self, t):
         """in-place SUM over the ranks, ordered on the CURRENT stream"""
-        if self.comm is not None and t.is_cuda:
-            self.comm.all_reduce_(t)
+        c = self._lane() if t.is_cuda else None
+        if c is not None:
+            c.all_reduce_(t)
         else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -198,8 +257,9 @@ class DataParallelContext(object):
         that very stream and an event marks its end; torch.distributed: asynchronous on the backend's own stream."""
         self._inflight.setdefault(tag, [])
         for t in tensors:
-            if self.comm is not None and t.is_cuda:
-                self.comm.all_reduce_(t)
+            c = self._lane() if t.is_cuda else None
+            if c is not None:
+                c.all_reduce_(t)
                 ev = torch.cuda.Event()
                 ev.record()
                 self._inflight[tag].append(ev)
@@ -210,8 +270,9 @@ class DataParallelContext(object):
         """exchange the rest of the phase's gradients and make the current stream wait for every bucket of the phase"""
         works = self._inflight.pop(tag, [])
         for t in tensors:
-            if self.comm is not None and t.is_cuda:
-                self.comm.all_reduce_(t)
+            c = self._lane() if t.is_cuda else None
+            if c is not None:
+                c.all_reduce_(t)
             else:
                 works.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         for w in works:
@@ -250,8 +311,9 @@ class DataParallelContext(object):
 
     def broadcast_parameters(self, flats):
         for f in flats:
-            if self.comm is not None and f.master.is_cuda:
-                self.comm.broadcast_(f.master, root=0)
+            c = self._lane() if f.master.is_cuda else None
+            if c is not None:
+                c.broadcast_(f.master, root=0)
             else:
                 dist.broadcast(f.master, src=0, group=self.group)
             f.sync_packed()

@@ -55,21 +55,30 @@ def _check(rc, what):
         raise RuntimeError("%s failed: %s" % (what, lib().ncclGetErrorString(rc).decode()))
 
 
-class Communicator(object):
-    """one RCCL communicator over the ranks of `group` (default: the world group)"""
+def unique_id():
+    """a fresh ncclUniqueId as 128 bytes (drawn by ONE rank and handed to the others over the bootstrap group)"""
+    uid = _UniqueId()
+    _check(lib().ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+    return bytes(bytearray(uid.internal))
 
-    def __init__(self, group=None):
+
+class Communicator(object):
+    """one RCCL communicator over the ranks of `group` (default: the world group).  uid: the 128 bytes of an ncclUniqueId every
+    rank already holds (parallel.DataParallelContext exchanges them itself, so that no rank can skip the exchange); None: rank 0
+    draws one and broadcasts it here."""
+
+    def __init__(self, group=None, uid=None):
         import torch.distributed as dist
         L = lib()
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
-        uid = _UniqueId()
-        if self.rank == 0:
-            _check(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        box = [bytes(bytearray(uid.internal)) if self.rank == 0 else None]
-        src = dist.get_global_rank(group, 0) if group is not None else 0
-        dist.broadcast_object_list(box, src=src, group=group)
-        C.memmove(C.byref(uid), box[0], 128)
+        if uid is None:
+            box = [unique_id() if self.rank == 0 else None]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=group)
+            uid = box[0]
+        raw, uid = uid, _UniqueId()
+        C.memmove(C.byref(uid), raw, 128)
         self.device = torch.cuda.current_device()
         self._comm = C.c_void_p()
         _check(L.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")

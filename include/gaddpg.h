@@ -482,7 +482,8 @@ int gad_polyak(float* target, const float* source, const uint8_t* sel, const int
  * NULL: none), target-network update FROM THE UPDATED parameter (gad_polyak; target == NULL: none), max |p| / max |grad|
  * atomically maximised into absmax_p / absmax_grad (GAD_ABSMAX_SLOTS floats each, float bits, zeroed by the caller,
  * who takes the maximum of the slots), and counter[0..counter_n) += counter_add (BatchNorm num_batches_tracked).
- * Same arithmetic as the single-purpose entry points.                                                               */
+ * Same arithmetic as the single-purpose entry points.  Alignment: p, grad, exp_avg, exp_avg_sq, m2p, target, target_m2p 16 bytes;
+ * active, target_sel 4 bytes (four elements per access; GAD_ERR_SHAPE otherwise).                                       */
 #define GAD_MAX_OPTIM_JOBS 4
 #define GAD_ABSMAX_SLOTS 8
 typedef struct {

@@ -43,7 +43,8 @@ static int fps_block_size(int n) {
  * Furthest point sampling  (upstream furthest_point_sampling_kernel<block_size>):
  *   idx[0] = 0; temp[k] = 1e10
  *   each round: for every point k with |p_k|^2 > 1e-3:  temp[k] = min(temp[k], d2(p_k, p_old));
- *   pick arg-max of temp.  Points with |p|^2 <= 1e-3 are never updated NOR considered.
+ *   pick arg-max of temp.  Points with |p|^2 <= 1e-3 are never updated NOR considered.  The compare is upstream's: the
+ *   float |p|^2 against the DOUBLE literal 1e-3, so the float nearest to 0.001 (0x3A83126F, slightly above it) is kept.
  * Tie rule (block-size dependent upstream): "thread" t = k mod bs scans k = t, t+bs, ... with a
  * strict '>' (lowest k of a thread wins), threads are then merged by a pairwise tree with
  * `v2 > v1 ? i2 : i1` (the lower thread id wins a tie).  A thread that saw no candidate holds
@@ -72,7 +73,7 @@ void pn2ref_fps(const float* xyz, int B, int N, int M, int32_t* idx) {
                     float m1 = y2 * y2;
                     float m2 = z2 * z2;
                     float mag = (m0 + m1) + m2;
-                    if (mag <= 1e-3f) continue;
+                    if ((double)mag <= 1e-3) continue;      /* upstream's float-vs-double-literal compare (== mag < 1e-3f) */
                     float d = sqdist(x2, y2, z2, x1, y1, z1);
                     float d2 = d < temp[k] ? d : temp[k];
                     temp[k] = d2;

@@ -135,6 +135,8 @@ def _worker_nccl1(rank, port, out_dir):
             assert dp.comm is not None                 # backend nccl: the exchanges go through rccl.Communicator on the caller's stream
             agent._dp = dp
             dp.attach(rt)
+            # one communicator per issuing lane (main, A, B, C): exchanges of different streams are independent RCCL operations
+            assert dp.transport()["rccl_comms"] == 4 and len({id(c) for c in dp._lane_comm.values()}) == 4
             assert rt.bucketed == (use_dp == "bucketed")
         rets = [agent.update_parameters(batches[0], agent.update_step, s, noise_u=u) for s in range(2)]
         torch.cuda.synchronize()
@@ -290,7 +292,7 @@ def test_two_gpus_direct_rccl_keeps_replicas_bit_equal(tmp_path):
     mp.spawn(_worker_two_gpus, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     r0, r1 = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % r), weights_only=False) for r in range(2)]
     for r in (r0, r1):
-        assert r["agree"] and r["transport"]["rccl_nranks"] == 2
+        assert r["agree"] and r["transport"]["rccl_nranks"] == 2 and r["transport"]["rccl_comms"] == 4
     for k, v in r0["state"].items():
         assert torch.equal(v, r1["state"][k]), "replicas diverged at " + k
     for k in r0["ret"]:

@@ -25,6 +25,21 @@ def test_fps_matches_oracle(B, N, M):
     np.testing.assert_array_equal(got, want)
 
 
+def test_fps_skip_rule_edge_point():
+    """|p|^2 == 0x3A83126F (== 1e-3f, > the double 1e-3) is kept, the float below it is skipped: kernel == oracle == upstream"""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
+    from oracle import cref
+    from tests.test_oracle_ops import edge_points
+    edge, below = edge_points()
+    xyz = np.zeros((2, 64, 3), np.float32)
+    xyz[:, :, 0] = np.linspace(0.5, 0.9, 64, dtype=np.float32)
+    xyz[:, 1, :2], xyz[:, 2, :2] = edge, below
+    xyz[1, 7, :2] = edge
+    got = pu.furthest_point_sample(torch.from_numpy(xyz).cuda(), 8).cpu().numpy()
+    np.testing.assert_array_equal(got, cref.fps(xyz, 8))
+    assert got[0, 1] == 1 and 2 not in got[0]                  # the edge point is the farthest from point 0 (x = 0.5 .. 0.9 otherwise)
+
+
 def test_fps_all_points_skipped():
     from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
     xyz = torch.full((2, 64, 3), 0.001).cuda()

@@ -30,10 +30,37 @@ def test_fps_skips_points_near_origin():
     assert 1 not in idx and 4 not in idx
 
 
+def edge_points():
+    """points (x, y, 0) whose |p|^2 = (x*x + y*y) + 0, rounded as the kernels round it, is exactly 0x3A83126F (the float nearest
+    to 0.001, slightly ABOVE it) resp. 0x3A83126E (the float below)"""
+    want = {0x3A83126F: None, 0x3A83126E: None}
+    x = np.float32(0.02)
+    xx = np.float32(x * x)
+    y = np.float32(np.sqrt(1e-3 - float(xx)))
+    for _ in range(4000):
+        y = np.nextafter(y, np.float32(0), dtype=np.float32)
+    for _ in range(8000):
+        bits = int(np.float32(xx + np.float32(y * y)).view(np.uint32))
+        if bits in want and want[bits] is None:
+            want[bits] = (x, y)
+        y = np.nextafter(y, np.float32(1), dtype=np.float32)
+    assert all(v is not None for v in want.values())
+    return want[0x3A83126F], want[0x3A83126E]
+
+
+def test_fps_skip_rule_is_the_float_vs_double_literal_compare():
+    """upstream: `if (mag <= 1e-3) continue;` with a float mag and a DOUBLE literal: |p|^2 = 0x3A83126F (0.00100000005) is NOT
+    skipped although it equals 1e-3f; the next float below is"""
+    (xe, ye), (xb, yb) = edge_points()
+    xyz = np.array([[[0.5, 0, 0], [xe, ye, 0], [xb, yb, 0], [0.6, 0, 0]]], dtype=np.float32)
+    idx = cref.fps(xyz, 3)[0]
+    np.testing.assert_array_equal(idx, [0, 1, 3])              # the edge point is a candidate (the farthest from 0.5); x_below never is
+
+
 def _brute_fps(xyz, m):
     n = xyz.shape[0]
     temp = np.full(n, 1e10, np.float32)
-    valid = (xyz.astype(np.float32) ** 2).sum(1) > 1e-3
+    valid = (xyz.astype(np.float32) ** 2).sum(1).astype(np.float64) > 1e-3
     out = [0]
     old = 0
     for _ in range(1, m):

@@ -137,7 +137,7 @@ def _worker_agreement(rank, world, port, out):
     from ga_ddpg_amd import parallel, rccl
 
     class FakeComm(object):                      # what a healthy communicator answers
-        def __init__(self, group=None):
+        def __init__(self, group=None, uid=None):
             if rank == 1:
                 raise RuntimeError("ncclCommInitRank failed: unhandled system error (injected on rank 1)")
             self.destroyed = False
@@ -152,6 +152,7 @@ def _worker_agreement(rank, world, port, out):
             self.destroyed = True
     rccl.Communicator = FakeComm
     rccl.lib = lambda: object()
+    rccl.unique_id = lambda: b"\0" * 128
     parallel.DataParallelContext._warm_streams = staticmethod(lambda: [contextlib.nullcontext()])
     torch.cuda.stream = lambda st: st             # (CPU box: the stream contexts of the self-test are no-ops)
     ctx = parallel.DataParallelContext()
