@@ -7,6 +7,7 @@
 // shuffle arg-max for FPS (one workgroup per cloud, no global scratch), 16-byte coalesced
 // streams for the materialising group kernels.
 #include "common.hpp"
+#include <type_traits>
 
 #include <stdarg.h>
 #include <string.h>
@@ -81,6 +82,30 @@ __device__ __forceinline__ unsigned long long fps_wave_max(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// wavefront maximum of a float / minimum of an unsigned (uniform results), same DPP ladder
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float fps_dpp_fmax(float v) {
+    const float o = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    return o > v ? o : v;
+}
+__device__ __forceinline__ float fps_wave_fmax(float v) {
+    v = fps_dpp_fmax<0x111, 0xf>(v); v = fps_dpp_fmax<0x112, 0xf>(v); v = fps_dpp_fmax<0x114, 0xf>(v); v = fps_dpp_fmax<0x118, 0xf>(v);
+    v = fps_dpp_fmax<0x142, 0xa>(v);
+    v = fps_dpp_fmax<0x143, 0xc>(v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned fps_dpp_umin(unsigned v) {
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
+    return o < v ? o : v;
+}
+__device__ __forceinline__ unsigned fps_wave_umin(unsigned v) {
+    v = fps_dpp_umin<0x111, 0xf>(v); v = fps_dpp_umin<0x112, 0xf>(v); v = fps_dpp_umin<0x114, 0xf>(v); v = fps_dpp_umin<0x118, 0xf>(v);
+    v = fps_dpp_umin<0x142, 0xa>(v);
+    v = fps_dpp_umin<0x143, 0xc>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // One workgroup (WAVES wavefronts) per cloud; thread t keeps points k = s*T + t (s < NPL) in
 // registers.  The cloud is also staged in LDS so the coordinates of the last pick are a broadcast
 // LDS read.  Tie rule == the upstream block reduction: "thread" t = k mod tie_bs keeps its lowest k
@@ -98,29 +123,6 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
     const float* p = xyz + (size_t)b * N * 3;
     for (int i = tid; i < N * 3; i += T) sp[i] = p[i];
     __syncthreads();
-
-    float px[NPL], py[NPL], pz[NPL], tmp[NPL];
-    unsigned key[NPL];
-    unsigned valid = 0;
-#pragma unroll
-    for (int s = 0; s < NPL; ++s) {
-        const int k = s * T + tid;
-        px[s] = py[s] = pz[s] = 0.f;
-        tmp[s] = 1e10f;
-        key[s] = 0;
-        if (k < N) {
-            px[s] = sp[k * 3 + 0];
-            py[s] = sp[k * 3 + 1];
-            pz[s] = sp[k * 3 + 2];
-            const float mag = gad_sqnorm(px[s], py[s], pz[s]);
-            // upstream: `if (mag <= 1e-3) continue;` compares the FLOAT mag with the DOUBLE literal: the float nearest to 0.001
-            // (0x3A83126F = 0.00100000005) is > 0.001 and therefore NOT skipped -- in float terms "skip iff mag < 1e-3f"
-            if (!(mag < 1e-3f)) valid |= 1u << s;
-            const unsigned t = (unsigned)k & ((1u << tie_bits) - 1u);          // k mod tie_bs
-            const unsigned rev = tie_bits ? (__brev(t) >> (32 - tie_bits)) : 0u;
-            key[s] = (rev << 16) | (unsigned)k;
-        }
-    }
     int old = 0;
     if (tid == 0 && M > 0) {
         idx[(size_t)b * M] = 0;
@@ -129,44 +131,12 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
         }
     }
-    for (int j = 1; j < M; ++j) {
-        const float x1 = sp[old * 3 + 0], y1 = sp[old * 3 + 1], z1 = sp[old * 3 + 2];
-        unsigned long long best = 0ull;
-        if (NPL % 2 == 0) {
-            // two points per instruction: packed FP32 subtract / multiply / add (v_pk_*_f32), each individually rounded like
-            // the scalar gad_sqdist (contraction off: the indices must stay bit-identical to upstream's)
-#pragma clang fp contract(off)
-            typedef float f32x2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-            for (int s = 0; s + 1 < NPL; s += 2) {
-                const f32x2_t ax = {px[s], px[s + 1]}, ay = {py[s], py[s + 1]}, az = {pz[s], pz[s + 1]};
-                const f32x2_t dx = ax - x1, dy = ay - y1, dz = az - z1;
-                const f32x2_t xx = dx * dx, yy = dy * dy, zz = dz * dz;
-                const f32x2_t dd = (xx + yy) + zz;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (valid & (1u << (s + u))) {
-                        const float d = dd[u];
-                        const float d2 = d < tmp[s + u] ? d : tmp[s + u];
-                        tmp[s + u] = d2;
-                        const unsigned long long c = fps_pack(d2, key[s + u]);
-                        best = c > best ? c : best;
-                    }
-                }
-            }
-        } else {
-#pragma unroll
-        for (int s = 0; s < NPL; ++s) {
-            if (valid & (1u << s)) {
-                const float d = gad_sqdist(px[s], py[s], pz[s], x1, y1, z1);
-                const float d2 = d < tmp[s] ? d : tmp[s];
-                tmp[s] = d2;
-                const unsigned long long c = fps_pack(d2, key[s]);
-                best = c > best ? c : best;
-            }
-        }
-        }
-        best = fps_wave_max(best);
+    auto key_of = [&](int k) {
+        const unsigned t = (unsigned)k & ((1u << tie_bits) - 1u);              // k mod tie_bs
+        const unsigned rev = tie_bits ? (__brev(t) >> (32 - tie_bits)) : 0u;
+        return (rev << 16) | (unsigned)k;
+    };
+    auto publish = [&](int j, unsigned long long best) {           // cross-wavefront maximum, the pick, its output
         if (WAVES > 1) {                                           // one barrier per pick: the exchange buffer alternates
             unsigned long long* r = red + (j & 1) * WAVES;
             if ((tid & 63) == 0) r[tid >> 6] = best;
@@ -176,13 +146,120 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             for (int w = 1; w < WAVES; ++w) best = r[w] > best ? r[w] : best;
         }
         const unsigned bkey = best ? ~(unsigned)best : 0u;         // no candidate at all (every point skipped): index 0
-        old = (int)(bkey & 0xFFFFu);
+        const int pick = (int)(bkey & 0xFFFFu);
         if (tid == 0) {
-            idx[(size_t)b * M + j] = old;
+            idx[(size_t)b * M + j] = pick;
             if (new_xyz) {
                 float* o = new_xyz + ((size_t)b * M + j) * 3;
-                o[0] = sp[old * 3 + 0]; o[1] = sp[old * 3 + 1]; o[2] = sp[old * 3 + 2];
+                o[0] = sp[pick * 3 + 0]; o[1] = sp[pick * 3 + 1]; o[2] = sp[pick * 3 + 2];
             }
+        }
+        return pick;
+    };
+    if constexpr (NPL % 2 == 0) {
+        // ---- fast path (round 5).  The thread's points live as packed PAIRS (v_pk_*_f32 operands as they are: the first version
+        // re-packed scalar arrays every round and the 16-point instantiation ran with 248 + 256 registers and 772 bytes of
+        // scratch per lane), a skipped / absent point is a point whose temp is -1 (never updated -- min(d, -1) = -1 -- and never
+        // a candidate), and the arg-max needs no 64-bit compare: the thread visits its points in ASCENDING KEY ORDER with a strict
+        // '>' on the float distance (the first maximum = the smallest key stays), the wavefront takes the float maximum with a
+        // DPP ladder and then asks which lanes hold it: one lane -> its key by v_readlane, several (exact ties) -> the smallest
+        // key among them.  Key order inside a thread: key = (bit-reversed (k mod tie_bs) << 16) | k, k = s * T + tid: for
+        // tie_bs <= T the keys ascend with s; for tie_bs = 2 T (T = 256, N >= 512) the even s come first.
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        constexpr int H = NPL / 2;
+        f32x2_t qx[H], qy[H], qz[H], tm[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int k = (2 * h + u) * T + tid;
+                const int kk = k < N ? k : N - 1;
+                const float x = sp[kk * 3 + 0], y = sp[kk * 3 + 1], z = sp[kk * 3 + 2];
+                // upstream: `if (mag <= 1e-3) continue;` compares the FLOAT mag with the DOUBLE literal: the float nearest to 0.001
+                // (0x3A83126F = 0.00100000005) is > 0.001 and therefore NOT skipped -- in float terms "skip iff mag < 1e-3f"
+                const bool skip = k >= N || gad_sqnorm(x, y, z) < 1e-3f;
+                qx[h][u] = x; qy[h][u] = y; qz[h][u] = z;
+                tm[h][u] = skip ? -1.f : 1e10f;
+            }
+        const int ratio = (1 << tie_bits) / T;              // (tie_bs <= 512: at most 8 for one wavefront per cloud)
+        for (int j = 1; j < M; ++j) {
+            const float x1 = sp[old * 3 + 0], y1 = sp[old * 3 + 1], z1 = sp[old * 3 + 2];
+            {
+                // two points per instruction, each operation individually rounded like the scalar gad_sqdist (contraction off: the
+                // indices must stay bit-identical to upstream's)
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const f32x2_t dx = qx[h] - x1, dy = qy[h] - y1, dz = qz[h] - z1;
+                    const f32x2_t xx = dx * dx, yy = dy * dy, zz = dz * dz;
+                    const f32x2_t dd = (xx + yy) + zz;
+                    tm[h][0] = dd[0] < tm[h][0] ? dd[0] : tm[h][0];
+                    tm[h][1] = dd[1] < tm[h][1] ? dd[1] : tm[h][1];
+                }
+            }
+            float bd = -1.f;
+            int bs = 0;
+            // visit in ascending key order: R = tie_bs / T (upstream's block vs this workgroup); key's leading part is the
+            // bit-reversed (s mod R), then k: so s = m, m + R, m + 2 R, ... for m in bit-reversed counting order
+            auto visit = [&](auto rc) {
+                constexpr int R = decltype(rc)::value;
+                constexpr int LR = R == 1 ? 0 : (R == 2 ? 1 : (R == 4 ? 2 : 3));
+#pragma unroll
+                for (int c = 0; c < R; ++c) {
+                    const int m = LR == 0 ? 0 : (int)(__builtin_bitreverse32((unsigned)c) >> (32 - (LR ? LR : 1)));
+#pragma unroll
+                    for (int s = m; s < NPL; s += R) { const float v = tm[s >> 1][s & 1]; const bool t = v > bd; bd = t ? v : bd; bs = t ? s : bs; }
+                }
+            };
+            if (ratio <= 1) visit(std::integral_constant<int, 1>());
+            else if (ratio == 2) visit(std::integral_constant<int, 2>());
+            else if (ratio == 4) visit(std::integral_constant<int, 4>());
+            else visit(std::integral_constant<int, 8>());
+            unsigned long long best = 0ull;
+            const float dmax = fps_wave_fmax(bd);
+            if (dmax >= 0.f) {
+                const unsigned bk = key_of(bs * T + tid);
+                const unsigned long long tied = __ballot(bd == dmax);
+                unsigned kb;
+                if (__builtin_popcountll(tied) == 1) kb = (unsigned)__builtin_amdgcn_readlane((int)bk, __builtin_ctzll(tied));
+                else kb = fps_wave_umin(bd == dmax ? bk : 0xffffffffu);
+                best = fps_pack(dmax, kb);
+            }
+            old = publish(j, best);
+        }
+    } else {
+        float px[NPL], py[NPL], pz[NPL], tmp[NPL];
+        unsigned key[NPL];
+        unsigned valid = 0;
+#pragma unroll
+        for (int s = 0; s < NPL; ++s) {
+            const int k = s * T + tid;
+            px[s] = py[s] = pz[s] = 0.f;
+            tmp[s] = 1e10f;
+            key[s] = 0;
+            if (k < N) {
+                px[s] = sp[k * 3 + 0];
+                py[s] = sp[k * 3 + 1];
+                pz[s] = sp[k * 3 + 2];
+                const float mag = gad_sqnorm(px[s], py[s], pz[s]);
+                if (!(mag < 1e-3f)) valid |= 1u << s;              // (the float-vs-double-literal compare: see the fast path)
+                key[s] = key_of(k);
+            }
+        }
+        for (int j = 1; j < M; ++j) {
+            const float x1 = sp[old * 3 + 0], y1 = sp[old * 3 + 1], z1 = sp[old * 3 + 2];
+            unsigned long long best = 0ull;
+#pragma unroll
+            for (int s = 0; s < NPL; ++s) {
+                if (valid & (1u << s)) {
+                    const float d = gad_sqdist(px[s], py[s], pz[s], x1, y1, z1);
+                    const float d2 = d < tmp[s] ? d : tmp[s];
+                    tmp[s] = d2;
+                    const unsigned long long c = fps_pack(d2, key[s]);
+                    best = c > best ? c : best;
+                }
+            }
+            old = publish(j, fps_wave_max(best));
         }
     }
 }
@@ -205,9 +282,13 @@ extern "C" int gad_furthest_point_sampling(const float* xyz, int B, int N, int M
     if (N <= 64) {
         hipLaunchKernelGGL((fps_kernel<1, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
     } else if (N <= 1024) {
-        hipLaunchKernelGGL((fps_kernel<4, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
+        if (g_opt_fps_cfg == 3) hipLaunchKernelGGL((fps_kernel<16, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
+        else if (g_opt_fps_cfg == 4) hipLaunchKernelGGL((fps_kernel<8, 2>), dim3(B), dim3(128), lds, st, xyz, N, M, tie, idx, new_xyz);
+        else hipLaunchKernelGGL((fps_kernel<4, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
     } else if (N <= 4096) {
-        if (g_opt_fps_cfg == 1) hipLaunchKernelGGL((fps_kernel<8, 8>), dim3(B), dim3(512), lds, st, xyz, N, M, tie, idx, new_xyz);
+        if (g_opt_fps_cfg == 3) hipLaunchKernelGGL((fps_kernel<64, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
+        else if (g_opt_fps_cfg == 4) hipLaunchKernelGGL((fps_kernel<32, 2>), dim3(B), dim3(128), lds, st, xyz, N, M, tie, idx, new_xyz);
+        else if (g_opt_fps_cfg == 1) hipLaunchKernelGGL((fps_kernel<8, 8>), dim3(B), dim3(512), lds, st, xyz, N, M, tie, idx, new_xyz);
         else if (g_opt_fps_cfg == 2) hipLaunchKernelGGL((fps_kernel<4, 16>), dim3(B), dim3(1024), lds, st, xyz, N, M, tie, idx, new_xyz);
         else hipLaunchKernelGGL((fps_kernel<16, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
     } else {

@@ -196,6 +196,15 @@ def get_option_default(name):
     return int(os.environ.get("GAD_OPT_" + name, OPTION_DEFAULTS.get(name, 1)))
 
 
+_options = {}
+
+
 def set_option(name, value):
     """kernel-selection switch for A/B diagnostics (include/gaddpg.h: gad_set_option)"""
     check(lib().gad_set_option(name.encode(), int(value)), "gad_set_option")
+    _options[name] = int(value)
+
+
+def get_option(name):
+    """the value last set through set_option (else the default / environment override)"""
+    return _options.get(name, get_option_default(name))

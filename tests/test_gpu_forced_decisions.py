@@ -95,7 +95,9 @@ def test_step_gradients_with_forced_decisions(B, seed, policy_step):
     lines.append("violations of  hip med <= max(3 f32 med, 2e-6)  and  hip max <= max(3 f32 max, 1e-4): %d of %d" % (len(bad), len(lines) - 1))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
-        open(os.path.join(out_dir, "grad_accuracy_forced_B%d%s.txt" % (B, "_policy_step" if policy_step else "")), "w").write("\n".join(lines) + "\n")
+        from ga_ddpg_amd import hip as _hip
+        mode = "_split" if _hip.get_option("mfma_split") else "_f32mfma"          # (both arithmetic modes: tests/conftest.py BOTH_MODES)
+        open(os.path.join(out_dir, "grad_accuracy_forced_B%d%s%s.txt" % (B, "_policy_step" if policy_step else "", mode)), "w").write("\n".join(lines) + "\n")
     assert len(lines) > (35 if policy_step else 90)
     assert not bad, "\n".join([lines[0]] + bad)
 
@@ -156,7 +158,9 @@ def test_bc_step_gradients_with_forced_decisions():
     lines.append("violations of  hip med <= max(3 f32 med, 2e-6)  and  hip max <= max(3 f32 max, 1e-4): %d of %d" % (len(bad), len(lines) - 1))
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     if os.path.isdir(out_dir):
-        open(os.path.join(out_dir, "grad_accuracy_forced_BC_B64.txt"), "w").write("\n".join(lines) + "\n")
+        from ga_ddpg_amd import hip as _hip
+        mode = "_split" if _hip.get_option("mfma_split") else "_f32mfma"
+        open(os.path.join(out_dir, "grad_accuracy_forced_BC_B64%s.txt" % mode), "w").write("\n".join(lines) + "\n")
     assert len(lines) > 30
     assert not bad, "\n".join([lines[0]] + bad)
 

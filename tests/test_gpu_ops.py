@@ -25,6 +25,21 @@ def test_fps_matches_oracle(B, N, M):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("N,M", [(4096, 512), (1024, 32), (512, 64), (300, 50)])
+def test_fps_exact_ties_on_a_lattice(N, M):
+    """points on a coarse lattice (and whole duplicated blocks): almost every round has exact ties, resolved by upstream's
+    block-reduction rule (smallest bit-reversed thread id, then smallest index) -- the kernel's float arg-max in key order,
+    its tied-lane fallback and the cross-wavefront exchange must all reproduce the oracle's indices"""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
+    from oracle import cref
+    rng = np.random.default_rng(N)
+    xyz = (rng.integers(0, 6, size=(3, N, 3)).astype(np.float32) * 0.125 + 0.25)
+    xyz[1, N // 2:] = xyz[1, : N - N // 2]                      # every point twice
+    xyz[2, ::7] = 0.0                                           # a seventh of the cloud inside the skip ball
+    got = pu.furthest_point_sample(torch.from_numpy(xyz).cuda(), M).cpu().numpy()
+    np.testing.assert_array_equal(got, cref.fps(xyz, M))
+
+
 def test_fps_skip_rule_edge_point():
     """|p|^2 == 0x3A83126F (== 1e-3f, > the double 1e-3) is kept, the float below it is skipped: kernel == oracle == upstream"""
     from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
