@@ -16,6 +16,36 @@ __global__ __launch_bounds__(256) void grad_from_arena_kernel(const double* __re
     grad[i] = accumulate ? grad[i] + g : g;
 }
 
+// the same conversion + the sum of squares of the resulting gradient (clip_grad_norm_'s total norm): one launch fewer on the
+// critic phase's chain than gad_grad_from_arena followed by gad_sumsq
+__global__ __launch_bounds__(256) void grad_from_arena_sumsq_kernel(const double* __restrict__ gacc, const int32_t* __restrict__ m2p, int n,
+                                                                    float* __restrict__ grad, int accumulate, double* __restrict__ out) {
+    __shared__ double red[4];
+    double s = 0.0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const int j = m2p[i];
+        const float g0 = j >= 0 ? (float)gacc[j] : 0.f;
+        const float g = accumulate ? grad[i] + g0 : g0;
+        grad[i] = g;
+        s += (double)g * (double)g;
+    }
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomic_add_f64(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+extern "C" int gad_grad_from_arena_sumsq(const double* gacc, const int32_t* m2p, int n, float* grad, int accumulate, double* sumsq,
+                                         void* stream) {
+    GAD_REQUIRE(gacc && m2p && grad && sumsq, GAD_ERR_NULL, "grad_from_arena_sumsq: null pointer");
+    if (n <= 0) return GAD_OK;
+    int gx = gad_cdiv(n, 1024);
+    gx = gx < 1 ? 1 : gx;
+    hipLaunchKernelGGL(grad_from_arena_sumsq_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, gacc, m2p, n, grad, accumulate, sumsq);
+    GAD_CHECK_LAUNCH("grad_from_arena_sumsq");
+    return GAD_OK;
+}
+
 extern "C" int gad_grad_from_arena(const double* gacc, const int32_t* m2p, int n, float* grad, int accumulate,
                                    void* stream) {
     GAD_REQUIRE(gacc && m2p && grad, GAD_ERR_NULL, "grad_from_arena: null pointer");
@@ -434,7 +464,7 @@ extern "C" int gad_zero_buffers(void* p0, long long n0, void* p1, long long n1, 
 // (coalesced 4-byte stores), transposed mirror as 2-byte stores (the matrices are a few hundred KB: the launch is ~4 us).
 // A value is negated where its reduction index (k forward, n transposed) lies in an odd block of 16.
 // ------------------------------------------------------------------------------------------------
-struct SplitLayers { gad_split_layer l[GAD_MAX_SPLIT_LAYERS]; };
+struct SplitLayers { gad_split_layer l[GAD_MAX_SPLIT_LAYERS]; int tile0[GAD_MAX_SPLIT_LAYERS + 1]; int n_layers; };
 
 __device__ __forceinline__ unsigned split_cvt_pk_bf16(float lo, float hi) {      // {bf16(hi) << 16 | bf16(lo)}, RNE
     unsigned r;
@@ -442,27 +472,59 @@ __device__ __forceinline__ unsigned split_cvt_pk_bf16(float lo, float hi) {     
     return r;
 }
 
+// One workgroup per 32 (rows n) x 32 (columns k) tile of one layer (tiles of all layers in one flat grid).  Thread (n = t >> 3,
+// k4 = (t & 7) * 4) loads four consecutive k of row n (16 bytes, coalesced), splits them, stores 8 bytes per plane of the forward
+// mirror, and parks the twelve bf16 values in LDS as [plane][k][n]; after the barrier thread (k = t >> 3, n4 = (t & 7) * 4) writes
+// 8 bytes per plane of the transposed mirror (coalesced along n).  (First version: 2-byte scattered stores, 13 us per launch on
+// the step's critical chain behind each optimiser phase.)
 __global__ __launch_bounds__(256) void split_weights_kernel(const float* __restrict__ packed, SplitLayers L, uint16_t* __restrict__ out) {
-    const gad_split_layer& y = L.l[blockIdx.y];
-    const int half_k = y.Ks >> 1;
-    const long long pairs = (long long)y.n_out * half_k;
+    __shared__ uint16_t tile[3][32][36];
+    int li = 0;
+    while (li + 1 < L.n_layers && (int)blockIdx.x >= L.tile0[li + 1]) ++li;
+    const gad_split_layer& y = L.l[li];
+    const int tk = y.Ks >> 5;
+    const int tile_id = blockIdx.x - L.tile0[li];
+    const int n0 = (tile_id / tk) * 32, k0 = (tile_id % tk) * 32;
     const long long plane = (long long)y.n_out * y.Ks;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (long long)gridDim.x * 256) {
-        const int n = (int)(i / half_k), k = 2 * (int)(i % half_k);
-        const float2 w = *reinterpret_cast<const float2*>(packed + y.w_off + (size_t)n * y.Kp + k);
-        const unsigned H = split_cvt_pk_bf16(w.x, w.y);
-        const float ra = w.x - __uint_as_float(H << 16), rb = w.y - __uint_as_float(H & 0xffff0000u);
-        const unsigned M = split_cvt_pk_bf16(ra, rb);
-        const unsigned Lo = split_cvt_pk_bf16(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
+    const int t = threadIdx.x;
+    {
+        const int n = n0 + (t >> 3), k = k0 + (t & 7) * 4;
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < y.n_out) w = *reinterpret_cast<const float4*>(packed + y.w_off + (size_t)n * y.Kp + k);
+        unsigned v[3][2];
+        {
+            const unsigned H = split_cvt_pk_bf16(w.x, w.y);
+            const float ra = w.x - __uint_as_float(H << 16), rb = w.y - __uint_as_float(H & 0xffff0000u);
+            const unsigned M = split_cvt_pk_bf16(ra, rb);
+            v[0][0] = H; v[1][0] = M; v[2][0] = split_cvt_pk_bf16(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
+        }
+        {
+            const unsigned H = split_cvt_pk_bf16(w.z, w.w);
+            const float ra = w.z - __uint_as_float(H << 16), rb = w.w - __uint_as_float(H & 0xffff0000u);
+            const unsigned M = split_cvt_pk_bf16(ra, rb);
+            v[0][1] = H; v[1][1] = M; v[2][1] = split_cvt_pk_bf16(ra - __uint_as_float(M << 16), rb - __uint_as_float(M & 0xffff0000u));
+        }
         const unsigned sk = ((k >> 4) & 1) ? 0x80008000u : 0u;       // forward: reduction index k
         const unsigned sn = ((n >> 4) & 1) ? 0x8000u : 0u;           // transposed: reduction index n
-        const unsigned v[3] = {H, M, Lo};
+        const int nl = t >> 3, kl = (t & 7) * 4;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            *reinterpret_cast<unsigned*>(out + y.fwd_off + p * plane + (size_t)n * y.Ks + k) = v[p] ^ sk;
-            uint16_t* t = out + y.t_off + p * plane + (size_t)k * y.n_out + n;
-            t[0] = (uint16_t)((v[p] & 0xffffu) ^ sn);
-            t[y.n_out] = (uint16_t)((v[p] >> 16) ^ sn);
+            if (n < y.n_out)
+                *reinterpret_cast<uint2*>(out + y.fwd_off + p * plane + (size_t)n * y.Ks + k) = make_uint2(v[p][0] ^ sk, v[p][1] ^ sk);
+            tile[p][kl + 0][nl] = (uint16_t)((v[p][0] & 0xffffu) ^ sn);
+            tile[p][kl + 1][nl] = (uint16_t)((v[p][0] >> 16) ^ sn);
+            tile[p][kl + 2][nl] = (uint16_t)((v[p][1] & 0xffffu) ^ sn);
+            tile[p][kl + 3][nl] = (uint16_t)((v[p][1] >> 16) ^ sn);
+        }
+    }
+    __syncthreads();
+    {
+        const int kl = t >> 3, nl = (t & 7) * 4;
+        const int k = k0 + kl, n = n0 + nl;
+        if (n < y.n_out) {                                           // (n_out is a multiple of 4 for every mirrored layer: checked by the host)
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                *reinterpret_cast<uint2*>(out + y.t_off + p * plane + (size_t)k * y.n_out + n) = *reinterpret_cast<const uint2*>(&tile[p][kl][nl]);
         }
     }
 }
@@ -471,19 +533,19 @@ extern "C" int gad_split_weights(const float* packed, const gad_split_layer* hos
     GAD_REQUIRE(packed && host_layers && out, GAD_ERR_NULL, "split_weights: null pointer");
     GAD_REQUIRE(n_layers >= 1 && n_layers <= GAD_MAX_SPLIT_LAYERS, GAD_ERR_SHAPE, "split_weights: 1..%d layers", GAD_MAX_SPLIT_LAYERS);
     SplitLayers L;
-    long long most = 0;
+    int tiles = 0;
     for (int i = 0; i < n_layers; ++i) {
         const gad_split_layer& y = host_layers[i];
-        GAD_REQUIRE(y.n_out > 0 && y.Ks > 0 && y.Ks % 32 == 0 && y.Ks <= y.Kp && y.Kp % 2 == 0 && y.w_off % 2 == 0 && y.fwd_off % 2 == 0 &&
-                    y.w_off >= 0 && y.fwd_off >= 0 && y.t_off >= 0, GAD_ERR_SHAPE,
-                    "split_weights: layer %d: Ks must be a multiple of 32 and <= Kp, offsets even", i);
+        GAD_REQUIRE(y.n_out > 0 && y.n_out % 4 == 0 && y.Ks > 0 && y.Ks % 32 == 0 && y.Ks <= y.Kp && y.Kp % 4 == 0 && y.w_off % 4 == 0 &&
+                    y.fwd_off % 4 == 0 && y.t_off % 4 == 0 && y.w_off >= 0 && y.fwd_off >= 0 && y.t_off >= 0, GAD_ERR_SHAPE,
+                    "split_weights: layer %d: Ks must be a multiple of 32 and <= Kp; n_out, Kp and the offsets multiples of 4", i);
         L.l[i] = y;
-        const long long pairs = (long long)y.n_out * (y.Ks / 2);
-        most = pairs > most ? pairs : most;
+        L.tile0[i] = tiles;
+        tiles += gad_cdiv(y.n_out, 32) * (y.Ks / 32);
     }
-    int gx = gad_cdiv(most, 256);
-    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-    hipLaunchKernelGGL(split_weights_kernel, dim3(gx, n_layers), dim3(256), 0, (hipStream_t)stream, packed, L, out);
+    L.tile0[n_layers] = tiles;
+    L.n_layers = n_layers;
+    hipLaunchKernelGGL(split_weights_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, packed, L, out);
     GAD_CHECK_LAUNCH("split_weights");
     return GAD_OK;
 }

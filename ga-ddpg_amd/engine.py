@@ -151,7 +151,7 @@ class FlatNet(object):
         """layers: [(MatSpec, Ks)] -- the matrices whose launches may take the split-bf16 form and the number of leading packed
         columns they multiply on the MFMA (Kp of an ACT layer, feat_c of a gathered first layer); Ks % 32 == 0.  Allocates the
         forward + transposed mirrors (3 bf16 planes each) and fills them; refresh_split() must follow every change of `packed`."""
-        layers = [(m, ks) for m, ks in layers if ks % 32 == 0 and 32 <= ks <= m.Kp and m.w_off % 2 == 0]
+        layers = [(m, ks) for m, ks in layers if ks % 32 == 0 and 32 <= ks <= m.Kp and m.w_off % 4 == 0 and m.n_out % 4 == 0]
         if not layers:
             return
         assert len(layers) <= hip.MAX_SPLIT_LAYERS

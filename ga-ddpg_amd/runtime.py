@@ -197,8 +197,8 @@ class FusedRuntime(object):
         if self.fused_optim and self.has_critic and self.dp is None:
             # the optimiser launch converts (gad_optim_jobs); only the critic's gradient is needed before it: clip_grad_norm_
             # (data-parallel runs convert here instead: the exchange sits between the conversion and the optimiser launch)
-            if tag == "c":
-                plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
+            if tag == "c":             # ... with the sum of squares of the result in the same launch (self.clip_sumsq is cleared with
+                plan.call("gad_grad_from_arena_sumsq", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0, self.clip_sumsq)   # the backward buffers)
             return
         if not (self.bucketed and early):
             plan.call("gad_grad_from_arena", head.flat.gacc, head.flat.m2p, head.flat.n, head.flat.grad, 0)
@@ -378,15 +378,32 @@ class FusedRuntime(object):
                           self._optim_job(self.enc.flat, arena=ar, adam=bool(ag.train_feature), counter=self.enc.batches_tracked)]),
                 "end": arr([self._optim_job(self.cr.flat, adam=False, arena=False, absmax_grad=engine._ptr(sc, 40),
                                             counter=self.venc.batches_tracked)])}
-        js = jobs[which]
-        if which == "c":
+            # the end-of-step bookkeeping (max |critic.grad| as the reference logs it after the actor backward, the value encoder's
+            # BatchNorm counters) folded into a launch that runs anyway -- one dependent launch fewer at the step boundary:
+            #   policy steps: a third job of the actor phase's launch (critic.grad is final once the actor-critic backward added to it);
+            #   other steps : inside the critic job of the critic phase's launch (nothing touches critic.grad after it; the Adam
+            #                 kernel's max |grad| is taken after its in-place clip scaling, as torch's clip_grad_norm_ leaves it)
+            jobs["a+end"] = arr([jobs["a"][0], jobs["a"][1], jobs["end"][0]])
+            ce = self._optim_job(self.cr.flat, arena=False, clip=self.clip_sumsq, target=self.cr_t.flat, sel=self.critic_sel,
+                                 absmax_p=engine._ptr(sc, 48), absmax_grad=engine._ptr(sc, 40), counter=self.venc.batches_tracked)
+            jobs["c+end"] = arr([jobs["c"][0], ce])
+        fold = self.dp is None                # (data-parallel runs keep the separate launch: their phases end with exchanges)
+        if which == "end":
+            if fold:
+                return                        # (folded: see above)
+            js = jobs["end"]
+            js[0].counter_add = 3 if policy_step else 2
+        elif which == "c":
+            js = jobs["c+end"] if (fold and not policy_step) else jobs["c"]
             js[1].hard_enable = int(ag.update_step % ag.target_update_interval == 0)
             js[1].tau = float(ag.tau)
-        elif which == "a":
-            js[0].tau = float(ag.tau)
             js[1].counter_add = 2
         else:
-            js[0].counter_add = 3 if policy_step else 2
+            js = jobs["a+end"] if (fold and policy_step) else jobs["a"]
+            js[0].tau = float(ag.tau)
+            js[1].counter_add = 2
+            if len(js) == 3:
+                js[2].counter_add = 3
         hip.check(hip.lib().gad_optim_jobs(js, len(js), hip.stream()), "gad_optim_jobs")
         if which == "c":                     # the encoders' split-bf16 weight mirrors follow their packed weights
             self.venc.flat.refresh_split()
@@ -653,7 +670,8 @@ class FusedRuntime(object):
             main.wait_event(self._ev_run)           # (long done; orders the running statistics before the next value pass)
         if self.fused_optim:
             self._reduce([self.cr.flat, self.venc.flat], "c")
-            hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
+            if self.dp is not None:       # (single process: the backward plan's conversion launch already formed the sum of squares)
+                hip.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq)
             self._optim_phase("c", policy_step)
         else:
             self._reduce([self.cr.flat, self.venc.flat], "c")

@@ -459,6 +459,10 @@ int gad_target_noise(const float* pi, const float* u, int B, float level, int no
  * adds to the existing grad instead (a second backward into the same .grad, as autograd does).   */
 int gad_grad_from_arena(const double* gacc, const int32_t* m2p, int n, float* grad, int accumulate,
                         void* stream);
+/* the same conversion + the sum of squares of the resulting gradient atomically added to *sumsq (f64; zero it first):
+ * gad_grad_from_arena followed by gad_sumsq in one launch (the critic phase: clip_grad_norm_'s total norm)                 */
+int gad_grad_from_arena_sumsq(const double* gacc, const int32_t* m2p, int n, float* grad, int accumulate, double* sumsq,
+                              void* stream);
 /* sum of squares of grad[0..n) into *out (f64, atomically accumulated; zero it first)           */
 int gad_sumsq(const float* grad, int n, double* out, void* stream);
 /* max |x| over segments: out[s] = max |x[seg_off[s] .. seg_off[s+1])|                           */
@@ -506,6 +510,7 @@ int gad_pack_params(const float* p, const int32_t* m2p, int n, float* packed, vo
  * columns (Ks a multiple of 32):
  *   forward mirror   out + fwd_off: planes hi | mid | lo of n_out * Ks bf16, row n, column k  (reduction index k contiguous)
  *   transposed mirror out + t_off : planes hi | mid | lo of Ks * n_out bf16, row k, column n  (reduction index n contiguous)
+ * (n_out, Kp and the three offsets multiples of 4: the kernel moves 8-byte groups of four bf16)
  * hi = bf16(w), mid = bf16(w - hi), lo = bf16(w - hi - mid) (round to nearest even; the residuals are exact), and every
  * value whose REDUCTION index lies in an odd block of 16 is stored NEGATED: the kernels add those blocks' products into a
  * second accumulator and subtract it, which cancels the bf16 MFMA adder's truncation bias.  Call it whenever
