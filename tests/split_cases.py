@@ -188,6 +188,12 @@ class FwdWide(Case):
         return 2.0 * self.rows * self.K * self.N
 
 
+class FwdStream(FwdWide):
+    """gad_gemm_fwd on the streaming route (SA1 layers 2 / 3: ~2e5 rows, 64 input channels, 64 / 128 outputs; "pool": the fused
+    max-pool epilogue of layer 3).  The kernel splits W itself (no mirror involved)."""
+    family = hip.SPLIT_FWD_STREAM
+
+
 class DxWide(Case):
     """gad_gemm_dx on the wide-tile route: dZ = P*g - w*(Q + S*z) from z and a dense (or pooled) gradient, times W; epilogue
     0 stores the ReLU-masked gradient of the previous layer and its BatchNorm-backward sums ("act" / "pool"), epilogue 1

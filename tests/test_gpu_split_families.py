@@ -20,6 +20,8 @@ def _cases():
         "fwd_wide.sa3.l3": lambda: sc.FwdWide(8192, 256, 512, "pool"),
         "fwd_wide.sa2.l1": lambda: sc.FwdWide(27240, 128, 128, "gather"),
         "fwd_wide.sa3.l1": lambda: sc.FwdWide(8192, 256, 256, "gather"),
+        "fwd_stream.sa1.l2": lambda: sc.FwdStream(213034, 64, 64, "act"),
+        "fwd_stream.sa1.l3": lambda: sc.FwdStream(213032, 64, 128, "pool"),
         "dx_wide.sa2.l3": lambda: sc.DxWide(27240, 256, 128, "pool"),
         "dx_wide.sa2.l2": lambda: sc.DxWide(27240, 128, 128, "act"),
         "dx_wide.sa2.l1": lambda: sc.DxWide(27240, 128, 128, "scatter"),
@@ -39,7 +41,7 @@ def _cases():
     }
 
 
-CASES = ("fwd_wide.sa2.l2", "fwd_wide.sa2.l3", "fwd_wide.sa3.l2", "fwd_wide.sa3.l3", "fwd_wide.sa2.l1", "fwd_wide.sa3.l1",
+CASES = ("fwd_stream.sa1.l2", "fwd_stream.sa1.l3", "fwd_wide.sa2.l2", "fwd_wide.sa2.l3", "fwd_wide.sa3.l2", "fwd_wide.sa3.l3", "fwd_wide.sa2.l1", "fwd_wide.sa3.l1",
          "dx_wide.sa2.l3", "dx_wide.sa2.l2", "dx_wide.sa2.l1", "dx_wide.sa3.l3", "dx_wide.sa3.l2", "dx_wide.sa3.l1",
          "dw_wide.sa2.l3", "dw_wide.sa2.l2", "dw_wide.sa2.l1", "dw_wide.sa3.l3", "dw_wide.sa3.l2", "dw_wide.sa3.l1",
          "bwd_stream.sa1.l3", "bwd_stream.sa1.l2", "dx_stream.sa1.l3", "dx_stream.sa1.l2")
