@@ -33,8 +33,21 @@ def pytest_generate_tests(metafunc):
 
 @pytest.fixture
 def mfma_mode(request):
+    return getattr(request, "param", None)
+
+
+@pytest.fixture(autouse=True)
+def _mfma_mode_switch(request):
+    """applies the parametrised arithmetic mode (read from the call spec: a fixture name appended in pytest_generate_tests is
+    not in the test's fixture closure, so `mfma_mode` itself would never be set up) and restores the default afterwards"""
+    mode = getattr(getattr(request.node, "callspec", None), "params", {}).get("mfma_mode")
+    if mode is None:
+        yield
+        return
     from ga_ddpg_amd import hip
     was = hip.get_option_default("mfma_split")
-    hip.set_option("mfma_split", 1 if request.param == "split_bf16" else 0)
-    yield request.param
-    hip.set_option("mfma_split", was)
+    hip.set_option("mfma_split", 1 if mode == "split_bf16" else 0)
+    try:
+        yield
+    finally:
+        hip.set_option("mfma_split", was)
