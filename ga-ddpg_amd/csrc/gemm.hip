@@ -1,4 +1,6 @@
-// FP32-MFMA GEMM family for the per-point shared MLPs, the FC head and the actor/critic heads.
+// Layer-GEMM family for the per-point shared MLPs, the FC head and the actor/critic heads: FP32 results throughout, products either
+// on v_mfma_f32_32x32x2_f32 or -- the default for the set-abstraction layers since round 5 -- as split-bf16 term products with f32
+// accumulation on v_mfma_f32_32x32x16_bf16 (section "split-bf16 arithmetic" below; library option "mfma_split").
 //
 // Reference arithmetic replaced: the 1x1 Conv2d / Linear + BatchNorm(train) + ReLU chains that
 // upstream build_shared_mlp and reference core/networks.py:84-91,280-300,339-351 run through
