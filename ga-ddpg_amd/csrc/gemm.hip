@@ -1686,10 +1686,12 @@ static bool fwd_skinny(const gad_gemm_fwd_args& a) {
 
 
 static int g_opt_fwd_stream = 1;
+static int g_opt_fwd_stream_l1_wgs = 256;      // persistent workgroups of the streaming forward's gathered first layer (A/B: 512 = two per CU)
 
 extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
+    if (!strcmp(name, "fwd_stream_l1_wgs")) { g_opt_fwd_stream_l1_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_wide")) { g_opt_fwd_wide = value; return GAD_OK; }
     if (!strcmp(name, "dx_wide")) { g_opt_dx_wide = value; return GAD_OK; }
     if (!strcmp(name, "dw_wide")) { g_opt_dw_wide = value; return GAD_OK; }
@@ -1813,7 +1815,10 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
 #define LAUNCH_FWD(WM, WN, TM, TN) do { if (a->mode == 0) LAUNCH_FWD2(WM, WN, TM, TN, 0, false); else LAUNCH_FWD2(WM, WN, TM, TN, 1, false); } while (0)
     if (fwd_streamable(*a)) {
         const int slabs = gad_cdiv(rows, 32);
-        int gx = gad_cdiv(slabs, 8); if (gx > 256) gx = 256;              // one 8-wavefront workgroup per CU
+        // one 8-wavefront workgroup per CU; the gathered first layer (K <= 16: ~100 registers, latency-bound on its five dependent
+        // loads per row) may run more (option "fwd_stream_l1_wgs")
+        const int gcap = a->mode == 1 ? g_opt_fwd_stream_l1_wgs : 256;
+        int gx = gad_cdiv(slabs, 8); if (gx > gcap) gx = gcap;
 #define LAUNCH_STREAM(KJ, TN, XM, POOL, ...)                                                               \
         hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM, POOL, ##__VA_ARGS__>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
                            a->row_w, a->W, a->zout, a->stat_sum, a->stat_sq, a->stat_stride, pe, ts)
