@@ -45,6 +45,10 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, int vo, int 
 __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int vo, int so) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, vo, so, 0));
 }
+// buffer descriptors address 32-bit UNSIGNED byte offsets: a row tensor may reach 2 GiB (the host-side route predicates bound
+// rows x pitch x 4 by 2^31 inclusive, fits_i32_bytes) -- record counts are formed in unsigned arithmetic
+#define GAD_BUF_MAX ((int)0x80000000u)
+__device__ __forceinline__ int gad_nbytes(int rows, int row_bytes) { return (int)((unsigned)rows * (unsigned)row_bytes); }
 
 
 // ------------------------------------------------------------------------------------------------
@@ -842,15 +846,15 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
     // operands and output through buffer descriptors: a 32-bit byte offset per lane (set up once per row tile) + a scalar
     // offset per access instead of 64-bit pointer arithmetic per load / store; the output descriptor is bounded by the live
     // rows (a NULL zout: zero records), so stores of rows past them -- or of a pass that keeps no raw output -- are dropped
-    const __amdgpu_buffer_rsrc_t ar_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(XM == 0 ? x.zin : x.feat), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(XM == 0 ? x.zin : x.feat), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, GAD_BUF_MAX, 0x00020000);
     const int zo_pitch4 = zout_pitch * 4;
-    const __amdgpu_buffer_rsrc_t zo_ = __builtin_amdgcn_make_buffer_rsrc(zout ? zout : const_cast<float*>(W), 0, zout ? n_rows * zo_pitch4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zo_ = __builtin_amdgcn_make_buffer_rsrc(zout ? zout : const_cast<float*>(W), 0, zout ? gad_nbytes(n_rows, zo_pitch4) : 0, 0x00020000);
     int vb[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) vb[u] = ((n0 + ur + 32 * u) * Kp + c4) * 4;
     // SP: the weight mirror's rows n0 + (tid >> 2) + 64 u, 16-byte chunk tid & 3 of a K-tile's 64 bytes
-    const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? wsp : reinterpret_cast<const uint16_t*>(W)), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? wsp : reinterpret_cast<const uint16_t*>(W)), 0, GAD_BUF_MAX, 0x00020000);
     int vbs[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) vbs[u] = ((n0 + (tid >> 2) + 64 * u) * wsp_pitch + (tid & 3) * 8) * 2;
@@ -1102,7 +1106,7 @@ static bool fits_i32_bytes(long long rows, int pitch_a, int pitch_b, int pitch_c
     int p = pitch_a > pitch_b ? pitch_a : pitch_b;
     p = p > pitch_c ? p : pitch_c;
     p = p > pitch_d ? p : pitch_d;
-    return rows * (long long)p * 4 < (1ll << 31);
+    return rows * (long long)p * 4 <= (1ll << 31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1183,7 +1187,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     // output through a buffer descriptor: rows >= n_rows fall outside num_records and are dropped by the hardware
     const bool store_z = zout != nullptr;                // (a pass that is never back-propagated keeps only the pooled maxima)
     const __amdgpu_buffer_rsrc_t zrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(store_z ? zout : const_cast<float*>(W), 0, store_z ? n_rows * NO * 4 : 0, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(store_z ? zout : const_cast<float*>(W), 0, store_z ? gad_nbytes(n_rows, NO * 4) : 0, 0x00020000);
     const int zlane = (4 * half * NO + l31) * 4;         // byte offset of (row 4*half, column l31)
     // fused max-pool: in the scan a lane owns columns lane and 64 + lane; +-1 = the sign of their BatchNorm weight
     float psgn[2];
@@ -1719,7 +1723,7 @@ static bool fwd_streamable(const gad_gemm_fwd_args& a) {
     if (a.pool_key && !(a.mode == 0 && a.n_out[0] == 128)) return false;          // pooled instantiation: 64 -> 128 only
     if (a.n_groups != 1 || a.zin_off[0] != 0 || a.w_off[0] != 0 || a.out_off[0] != 0) return false;
     if (a.n_rows < 32768 || (a.n_out[0] != 64 && a.n_out[0] != 128) || (a.zout && a.zout_pitch != a.n_out[0])) return false;
-    if ((long long)a.n_rows * a.n_out[0] * 4 >= (1ll << 31)) return false;             // buffer-descriptor byte offsets
+    if ((long long)a.n_rows * a.n_out[0] * 4 > (1ll << 31)) return false;              // buffer-descriptor byte offsets
     if (a.mode == 0) return a.Kp == 64 && a.c_in == 64 && a.ones_col < 0 && !a.extra && (a.scale && a.shift) && a.relu;
     const bool sa1_rows = a.feat_c == 4 && (a.action ? a.act_c == 6 : a.act_c == 0);
     if (a.mode == 2)                                                             // 64-channel input recomputed from SA1's gathered rows
@@ -2080,9 +2084,9 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
     const int n_slabs = (n_rows + 31) >> 5;
     const int stride = gridDim.x * 8;
     int slab = wave * gridDim.x + blockIdx.x;                 // wave-uniform; same dealing as the forward kernel
-    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * 64 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, gad_nbytes(n_rows, 64 * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t zrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, n_rows_static * 64 * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, gad_nbytes(n_rows_static, 64 * 4), 0x00020000);
     const int glane = (4 * half * 64 + l31) * 4;
 
     float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
@@ -2261,7 +2265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
     const int n_slabs = (n_rows + 31) >> 5;
     const int n_quads = (n_slabs + 3) >> 2;
     const __amdgpu_buffer_rsrc_t zrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, n_rows * 64 * 4, 0x00020000);   // rows past n_rows read as 0
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, gad_nbytes(n_rows, 64 * 4), 0x00020000);   // rows past n_rows read as 0
     const int glane = (4 * half * 64 + l31) * 4;
 
     if (wave < 4) {
@@ -2272,7 +2276,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
             const int k = tk * 32 + l31;
             ps[tk] = e.ps[k]; pt[tk] = e.pt[k]; pm[tk] = e.pm[k]; pi[tk] = e.pi[k];
         }
-        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * 64 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, gad_nbytes(n_rows, 64 * 4), 0x00020000);
         float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
         // operand ring: 8 steps of 8 output channels each (z, dY [, arg-max] of this lane's row: 16-byte loads), filled 7
         // steps ahead of their use and across slab boundaries -- with one producer per SIMD nothing else hides the HBM
@@ -2518,7 +2522,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, 
     const int n_slabs = (n_rows + 31) >> 5;
     const int n_quads = (n_slabs + 3) >> 2;
     const __amdgpu_buffer_rsrc_t zrsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, n_rows * 64 * 4, 0x00020000);   // rows past n_rows read as 0
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(e.zprev), 0, gad_nbytes(n_rows, 64 * 4), 0x00020000);   // rows past n_rows read as 0
     const int glane = (4 * half * 64 + l31) * 4;
     const int nprod = DW ? 4 : 8;                                           // producer wavefronts per workgroup
 
@@ -2530,7 +2534,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, 
             const int k = tk * 32 + l31;
             ps[tk] = e.ps[k]; pt[tk] = e.pt[k]; pm[tk] = e.pm[k]; pi[tk] = e.pi[k];
         }
-        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, n_rows * 64 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t grsrc = __builtin_amdgcn_make_buffer_rsrc(e.gout, 0, gad_nbytes(n_rows, 64 * 4), 0x00020000);
         float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
         // operand ring: entries of 4 channels (z, dY [, arg-max]: 16-byte loads); entry uu covers channels
         // 16 (uu >> 1) + 8 half + 4 (uu & 1) .. + 3, so a k16-step consumes an even / odd pair; filled AHEAD entries ahead, across slabs
@@ -2812,22 +2816,22 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
     // per access instead of a 64-bit pointer multiply-add per load / store (on this part every VALU instruction is MFMA issue
     // time: the epilogue's 64 address computations per tile were a third of the vector instructions of the N = 128 layers)
     const int gpitch = GM == 0 ? d.g_pitch : d.c;
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, GAD_BUF_MAX, 0x00020000);
     // previous layer's raw output / the gradient this launch writes: bounded by the live rows (reads past them give 0,
     // stores past them are dropped)
     const int zp_pitch4 = SC ? 0 : e.zprev_pitch * 4, go_pitch4 = SC ? 0 : e.gout_pitch * 4;
-    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SC ? W : e.zprev), 0, SC ? 0 : n_rows * zp_pitch4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(SC ? const_cast<float*>(W) : e.gout, 0, SC ? 0 : n_rows * go_pitch4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(SC ? W : e.zprev), 0, SC ? 0 : gad_nbytes(n_rows, zp_pitch4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(SC ? const_cast<float*>(W) : e.gout, 0, SC ? 0 : gad_nbytes(n_rows, go_pitch4), 0x00020000);
     const int c4 = (tid & 7) * 4, ur = tid >> 3;         // A staging: 16-byte chunk of the K-tile, row (ur, ur + 32)
     const int bk4 = (tid & 31) * 4, bn = tid >> 5;       // B staging: W rows bn, +8, +16, +24 of the K-tile, k chunk bk4
     int vw[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) vw[u] = ((bn + 8 * u) * Kp + k0out + bk4) * 4;
     // SP: rows k0out + (tid >> 2) + 64 u of the transposed mirror, 16-byte chunk tid & 3 of a K-tile's 32 output channels
-    const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? wsp : reinterpret_cast<const uint16_t*>(W)), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ws_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(SP ? wsp : reinterpret_cast<const uint16_t*>(W)), 0, GAD_BUF_MAX, 0x00020000);
     int vbs[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) vbs[u] = ((k0out + (tid >> 2) + 64 * u) * n_out + (tid & 3) * 8) * 2;
@@ -3108,7 +3112,7 @@ static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
     const bool coef = (d.coefP && d.coefQ && d.coefS);
     if (!d.z || d.z_pitch != a.n_out[0] || !d.scale || !d.relu || !d.premasked || !coef) return false;
     if (d.gmode == 0 ? d.g_pitch != a.n_out[0] : d.c != a.n_out[0]) return false;
-    return (long long)a.n_rows * 128 * 4 < (1ll << 31);
+    return (long long)a.n_rows * 128 * 4 <= (1ll << 31);
 }
 
 // skinny dX for the small-M layers (same idea as gemm_fwd_skinny_kernel): one 32x32 tile of gout per workgroup, the 8
@@ -3679,12 +3683,12 @@ __global__ __launch_bounds__(512) void gemm_dw_stream_kernel(DzSrc d, XSrc x, co
     // half-wave's 4-row stagger) and whose row position lives in the scalar offset -- no vector ALU work per load.
     const unsigned lane_n = 64u * cset + l31;
     const int zpitch4 = d.z_pitch * 4, xpitch4 = x.zin_pitch * 4, gpitch4 = (GM == 0 ? d.g_pitch : d.c) * 4;
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x.zin), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.row_w ? d.row_w : d.z), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.argmax : d.row_grp), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x.zin), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.row_w ? d.row_w : d.z), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.argmax : d.row_grp), 0, GAD_BUF_MAX, 0x00020000);
     const int vl_z = 4 * half * zpitch4 + (int)lane_n * 4, vl_x = 4 * half * xpitch4 + l31 * 4;
     const int vl_g = (GM == 0 ? 4 * half * gpitch4 : 0) + (int)lane_n * 4, vl_r = 4 * half * 4;
 
@@ -3824,11 +3828,11 @@ __global__ __launch_bounds__(512) void gemm_dw_gather_stream_kernel(DzSrc d, XSr
     const float* base2 = sub_ctr ? x.ctr_xyz + off1 : x.src_xyz;   // lanes without a centre read a valid address, unused
 
     const int zpitch4 = d.z_pitch * 4, gpitch4 = d.g_pitch * 4;
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.G), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.row_w ? d.row_w : d.z), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ptr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(x.row_pt), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t grpr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(x.row_grp), 0, 0x7ffffffc, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.G), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.row_w ? d.row_w : d.z), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ptr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(x.row_pt), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t grpr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(x.row_grp), 0, GAD_BUF_MAX, 0x00020000);
     const int vl_z = 4 * half * zpitch4 + (int)lane_n * 4, vl_g = 4 * half * gpitch4 + (int)lane_n * 4, vl_r = 4 * half * 4;
 
     struct Unit { float z[4][2], g[4][2], w[4], x1[4], x2[4]; };
@@ -4570,19 +4574,19 @@ __global__ __launch_bounds__(256, NIT >= 8 ? 1 : 2) void gemm_bwd_wide_kernel(Dz
     const int gpitch = GM == 0 ? d.g_pitch : d.c;
     // z, dY and the layer input are bounded by the LIVE rows: a read past them returns 0, so a dead row's dZ is exactly 0
     // (its weight is 0 as well) without a select per element -- on this part every VALU instruction is MFMA issue time
-    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, n_rows * d.z_pitch * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.z), 0, gad_nbytes(n_rows, d.z_pitch * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t gr_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(GM == 0 ? d.G : d.dout), 0,
-                                                                         GM == 0 ? n_rows * gpitch * 4 : 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, 0x7ffffffc, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, 0x7ffffffc, 0x00020000);
+                                                                         GM == 0 ? gad_nbytes(n_rows, gpitch * 4) : GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ar = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(GM == 0 ? d.row_grp : d.argmax), 0, GAD_BUF_MAX, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(W), 0, GAD_BUF_MAX, 0x00020000);
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L1 ? x.feat : x.zin), 0,
-                                                                        L1 ? 0x7ffffffc : n_rows * x.zin_pitch * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t sr_ = __builtin_amdgcn_make_buffer_rsrc(partial, 0, 0x7ffffffc, 0x00020000);
+                                                                        L1 ? GAD_BUF_MAX : gad_nbytes(n_rows, x.zin_pitch * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t sr_ = __builtin_amdgcn_make_buffer_rsrc(partial, 0, GAD_BUF_MAX, 0x00020000);
     // previous layer's raw output / the gradient this launch writes: bounded by the live rows (reads past them give 0,
     // stores past them are dropped)
     const int zp_pitch4 = L1 ? 0 : e.zprev_pitch * 4, go_pitch4 = L1 ? 0 : e.gout_pitch * 4;
-    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L1 ? W : e.zprev), 0, L1 ? 0 : n_rows * zp_pitch4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(L1 ? const_cast<float*>(W) : e.gout, 0, L1 ? 0 : n_rows * go_pitch4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L1 ? W : e.zprev), 0, L1 ? 0 : gad_nbytes(n_rows, zp_pitch4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t or_ = __builtin_amdgcn_make_buffer_rsrc(L1 ? const_cast<float*>(W) : e.gout, 0, L1 ? 0 : gad_nbytes(n_rows, go_pitch4), 0x00020000);
     const int kx = k0 + wn * 32 + l31;                    // this lane's input channel (dW column, dX column)
     float xs = 1.f, xt = 0.f, ps = 0.f, pt = 0.f, pm = 0.f, pi = 0.f;
     if (!L1) { xs = x.scale[kx]; xt = x.shift[kx]; ps = e.ps[kx]; pt = e.pt[kx]; pm = e.pm[kx]; pi = e.pi[kx]; }

@@ -178,16 +178,30 @@ class _StageRun(object):
                 d.update(gmode=0, G=_ptr(G), g_pitch=m.n_out)
             return _dz(**d)
 
-        def dw(l, dz, m):
+        def dw_args(l, dz, m):
             a = hip.GemmDwArgs()
             a.inp = _fwd_args(Kp=m.Kp, n_out=[m.n_out], w_off=[m.w_off], **self._input(net, None, l))
             a.dz = dz
             a.gacc = _ptr(fl.gacc)
             ws = engine.dw_workspace(fl.device, lane=0)
             a.partial, a.partial_elems = _ptr(ws), ws.numel()
-            plan.call_struct("gad_gemm_dw", a)
+            return a
+
+        def dw(l, dz, m):
+            plan.call_struct("gad_gemm_dw", dw_args(l, dz, m))
+
+        def bwd(l, dz, m, k_valid, **epi):
+            """dW and dX of layer l in one call (gad_gemm_bwd): SA1-like shapes (64 input channels, >= 32768 rows) stream dZ once
+            for both products, every other shape runs the same two launches as dw() + dx()"""
+            import ctypes as C
+            aw, a = dw_args(l, dz, m), dx_args(dz, m, k_valid, **epi)
+            plan.keep.extend([a, aw])
+            plan.call("gad_gemm_bwd", C.byref(a), C.byref(aw))
 
         def dx(dz, m, k_valid, **epi):
+            plan.call_struct("gad_gemm_dx", dx_args(dz, m, k_valid, **epi))
+
+        def dx_args(dz, m, k_valid, **epi):
             a = hip.GemmDxArgs()
             a.n_rows_dev, a.n_rows = _ptr(r["n"]), r["cap"]
             a.dz = dz
@@ -199,7 +213,7 @@ class _StageRun(object):
             a.grp_per_sample = 1
             for k, v in dict(epi, **fl.split_t_kw(m)).items():
                 setattr(a, k, v)
-            plan.call_struct("gad_gemm_dx", a)
+            return a
 
         def prev_stats(pm, po, zprev):
             return dict(zprev=_ptr(zprev), zprev_pitch=pm.n_out, prev_scale=vec("scale", po), prev_shift=vec("shift", po),
@@ -210,12 +224,10 @@ class _StageRun(object):
         plan.call("gad_pool_bwd_stats", self.dF, self.argmax, r["G"], m3.n_out, self.Z[2], m3.n_out, vec("scale", o3),
                   vec("shift", o3), vec("mean", o3), vec("istd", o3), _ptr(self.bstats, o3, 8),
                   _ptr(self.bstats, tot + o3, 8), 2 * tot, 1, None)
-        dw(2, bn_dz(m3, o3, self.Z[2], False, pooled=True), m3)
-        dx(bn_dz(m3, o3, self.Z[2], True, pooled=True), m3, m2.n_out, epilogue=0, gout=_ptr(self.G[0]), gout_pitch=m2.n_out,
-           **prev_stats(m2, o2, self.Z[1]))
-        dw(1, bn_dz(m2, o2, self.Z[1], False, G=self.G[0]), m2)
-        dx(bn_dz(m2, o2, self.Z[1], True, G=self.G[0]), m2, m1.n_out, epilogue=0, gout=_ptr(self.G[1]), gout_pitch=m1.n_out,
-           **prev_stats(m1, o1, self.Z[0]))
+        bwd(2, bn_dz(m3, o3, self.Z[2], False, pooled=True), m3, m2.n_out, epilogue=0, gout=_ptr(self.G[0]), gout_pitch=m2.n_out,
+            **prev_stats(m2, o2, self.Z[1]))
+        bwd(1, bn_dz(m2, o2, self.Z[1], False, G=self.G[0]), m2, m1.n_out, epilogue=0, gout=_ptr(self.G[1]), gout_pitch=m1.n_out,
+            **prev_stats(m1, o1, self.Z[0]))
         dw(0, bn_dz(m1, o1, self.Z[0], False, G=self.G[1]), m1)
         dx(bn_dz(m1, o1, self.Z[0], True, G=self.G[1]), m1, net.c_pad, epilogue=1, dfeat=_ptr(self.dfeat), feat_c=net.c_pad,
            row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]), act_c=0, grp_per_sample=1)

@@ -201,11 +201,11 @@ class DxWide(Case):
     family = hip.SPLIT_DX_WIDE
     entry = "gad_gemm_dx"
 
-    def __init__(self, rows, N, K, mode="act", seed=2, g_scale=1.0, w_scale=0.05):
+    def __init__(self, rows, N, K, mode="act", seed=2, g_scale=1.0, w_scale=0.05, slack=1000):
         dev = torch.device("cuda")
         g = _gen(seed)
         self.rows, self.N, self.K, self.mode = rows, N, K, mode
-        cap = rows + 1000
+        cap = rows + slack                                       # rows past the live count: never read into results
         self.cap = cap
         self.nrows = torch.tensor([rows], dtype=torch.int32, device=dev)
         self.z = torch.randn(cap, N, device=dev, generator=g)
@@ -375,9 +375,9 @@ class BwdStream(Case):
     ~2e5 rows, 64 input channels, N = 64 / 128 output channels; dense gradient ("act") or pooled source ("pool": layer 3)"""
     family = hip.SPLIT_BWD_STREAM
 
-    def __init__(self, rows, N, mode="act", fused=True, seed=5):
+    def __init__(self, rows, N, mode="act", fused=True, seed=5, slack=1000):
         dev = torch.device("cuda")
-        self.dx = DxWide(rows, N, 64, mode=mode, seed=seed)
+        self.dx = DxWide(rows, N, 64, mode=mode, seed=seed, slack=slack)
         d = self.dx
         if mode == "pool":                                   # SA1-like groups: ~26 consecutive rows each
             g = _gen(seed + 7)

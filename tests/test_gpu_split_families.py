@@ -174,3 +174,24 @@ def test_split_zero_live_rows(kind):
     for k in ("z", "gout"):
         if k in out:
             assert bool(torch.isnan(out[k]).all()), k + " was written for dead rows"
+
+
+TWO_GIB = {
+    "fwd_stream": lambda sc: sc.FwdStream(4194304, 64, 128, "act", ragged=False),
+    "fwd_wide": lambda sc: sc.FwdWide(2097152, 128, 256, "act", ragged=False),
+    "dx_wide": lambda sc: sc.DxWide(2097152, 256, 128, "act", slack=0),
+    "bwd_stream": lambda sc: sc.BwdStream(4194304, 128, "act", slack=0),
+    "dx_stream": lambda sc: sc.BwdStream(4194304, 128, "act", fused=False, slack=0),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(TWO_GIB))
+def test_row_tensor_of_exactly_two_gib(kind):
+    """the specialised routes address their row tensors through buffer descriptors with 32-bit unsigned byte offsets; the route
+    predicates admit rows x pitch x 4 <= 2^31 (configs[3] through the facade: capacity 128 x 512 x 64 rows x 128 channels and
+    128 x 128 x 128 rows x 256 channels are exactly 2 GiB).  Here EVERY row of such a tensor is live: the last row's last chunk is
+    read / stored, and both arithmetic modes keep the bench-shape gates."""
+    from tests import split_cases as sc
+    case = TWO_GIB[kind](sc)
+    bad = check_case(case, "two_gib." + kind)
+    assert not bad, "\n".join(bad)
