@@ -94,6 +94,31 @@ __device__ __forceinline__ float fps_wave_fmax(float v) {
     v = fps_dpp_fmax<0x143, 0xc>(v);
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
+// the same ladder as ONE instruction per step (v_max_f32 with a DPP source; a lane without a source is not written and keeps
+// its own value).  hipcc turns the select form above into v_mov / v_mov_dpp / v_cmp / v_cndmask + hazard s_nops: 4x the issue
+// slots on the one dependent chain every arg-max round waits for.  (s_nop 1: VALU write -> DPP read of the same register.)
+__device__ __forceinline__ float fps_wave_fmax_asm(float v) {
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// v_min_f32 / v_max3_f32 as they are (no canonicalising v_max x, x in front: the operands are never NaN here -- distances of
+// finite coordinates, the -1 sentinel, 1e10)
+__device__ __forceinline__ float fps_vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float fps_vmax3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned fps_dpp_umin(unsigned v) {
     const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
@@ -106,6 +131,19 @@ __device__ __forceinline__ unsigned fps_wave_umin(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+#ifdef GAD_FPS_PHASES
+// diagnostic build (tools/ubench_fps.py --phases): cycles wavefront 0 of workgroup 0 spends in each part of an arg-max round
+__device__ unsigned long long gad_fps_phase[8];
+#define FPS_T(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); if (blockIdx.x == 0 && threadIdx.x == 0) gad_fps_phase[i] += t1_ - t0_; t0_ = __builtin_readcyclecounter(); } while (0)
+extern "C" int gad_fps_phase_read(unsigned long long* out8, int reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (out8) hipMemcpyFromSymbol(out8, HIP_SYMBOL(gad_fps_phase), sizeof(z));
+    if (reset) hipMemcpyToSymbol(HIP_SYMBOL(gad_fps_phase), z, sizeof(z));
+    return 0;
+}
+#else
+#define FPS_T(i) do { } while (0)
+#endif
 // One workgroup (WAVES wavefronts) per cloud; thread t keeps points k = s*T + t (s < NPL) in
 // registers.  The cloud is also staged in LDS so the coordinates of the last pick are a broadcast
 // LDS read.  Tie rule == the upstream block reduction: "thread" t = k mod tie_bs keeps its lowest k
@@ -119,41 +157,37 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* sp = lds;                                   // N*3 coordinates
     unsigned long long* red = reinterpret_cast<unsigned long long*>(lds + ((N * 3 + 3) & ~3));   // 2 x WAVES packed maxima
+    int* pk = reinterpret_cast<int*>(lds + ((N * 3 + 3) & ~3) + 64);                             // the M picks (written out at the end)
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* p = xyz + (size_t)b * N * 3;
     for (int i = tid; i < N * 3; i += T) sp[i] = p[i];
     __syncthreads();
     int old = 0;
-    if (tid == 0 && M > 0) {
-        idx[(size_t)b * M] = 0;
-        if (new_xyz) {
-            float* o = new_xyz + (size_t)b * M * 3;
-            o[0] = sp[0]; o[1] = sp[1]; o[2] = sp[2];
-        }
-    }
+    if (tid == 0 && M > 0) pk[0] = 0;
     auto key_of = [&](int k) {
         const unsigned t = (unsigned)k & ((1u << tie_bits) - 1u);              // k mod tie_bs
         const unsigned rev = tie_bits ? (__brev(t) >> (32 - tie_bits)) : 0u;
         return (rev << 16) | (unsigned)k;
     };
+#ifdef GAD_FPS_PHASES
+    unsigned long long t0_ = __builtin_readcyclecounter();
+#endif
     auto publish = [&](int j, unsigned long long best) {           // cross-wavefront maximum, the pick, its output
         if (WAVES > 1) {                                           // one barrier per pick: the exchange buffer alternates
             unsigned long long* r = red + (j & 1) * WAVES;
             if ((tid & 63) == 0) r[tid >> 6] = best;
             __syncthreads();
+            FPS_T(4);
             best = r[0];
 #pragma unroll
             for (int w = 1; w < WAVES; ++w) best = r[w] > best ? r[w] : best;
         }
         const unsigned bkey = best ? ~(unsigned)best : 0u;         // no candidate at all (every point skipped): index 0
         const int pick = (int)(bkey & 0xFFFFu);
-        if (tid == 0) {
-            idx[(size_t)b * M + j] = pick;
-            if (new_xyz) {
-                float* o = new_xyz + ((size_t)b * M + j) * 3;
-                o[0] = sp[pick * 3 + 0]; o[1] = sp[pick * 3 + 1]; o[2] = sp[pick * 3 + 2];
-            }
-        }
+        // the pick goes to LDS, the outputs are written once all M are known: a global store (and the LDS read of the pick's
+        // coordinates for it) in here sat on wavefront 0's path to the next barrier -- 150 of a round's ~1300 cycles
+        if (tid == 0) pk[j] = pick;
+        FPS_T(5);
         return pick;
     };
     if constexpr (NPL % 2 == 0) {
@@ -183,7 +217,11 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             }
         const int ratio = (1 << tie_bits) / T;              // (tie_bs <= 512: at most 8 for one wavefront per cloud)
         for (int j = 1; j < M; ++j) {
-            const float x1 = sp[old * 3 + 0], y1 = sp[old * 3 + 1], z1 = sp[old * 3 + 2];
+            const float* po = sp + ((old << 1) + old);
+            // the pick's coordinates as wave-uniform SCALARS (v_readfirstlane of the broadcast LDS read)
+            const float x1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(po[0])));
+            const float y1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(po[1])));
+            const float z1 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(po[2])));
             {
                 // two points per instruction, each operation individually rounded like the scalar gad_sqdist (contraction off: the
                 // indices must stay bit-identical to upstream's)
@@ -193,30 +231,46 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
                     const f32x2_t dx = qx[h] - x1, dy = qy[h] - y1, dz = qz[h] - z1;
                     const f32x2_t xx = dx * dx, yy = dy * dy, zz = dz * dz;
                     const f32x2_t dd = (xx + yy) + zz;
-                    tm[h][0] = dd[0] < tm[h][0] ? dd[0] : tm[h][0];
-                    tm[h][1] = dd[1] < tm[h][1] ? dd[1] : tm[h][1];
+                    tm[h][0] = fps_vmin(dd[0], tm[h][0]);
+                    tm[h][1] = fps_vmin(dd[1], tm[h][1]);
                 }
             }
-            float bd = -1.f;
+            FPS_T(0);
+            // the thread's maximum by a v_max3 tree -- the wavefront maximum below starts from it at once -- and, in its shadow,
+            // WHICH of the thread's points holds it: the first in ascending key order (upstream's strict '>' keeps the smallest key
+            // among equal distances), found by walking the points in DESCENDING key order with independent compares
+            float bd;
+            if constexpr (NPL == 2) {
+                bd = fps_vmax3(tm[0][0], tm[0][1], -1.f);
+            } else {
+                float lv[NPL / 2];
+#pragma unroll
+                for (int h = 0; h < H; h += 1) lv[h] = h == 0 ? fps_vmax3(tm[0][0], tm[0][1], -1.f) : fps_vmax3(tm[h][0], tm[h][1], lv[h - 1]);
+                bd = lv[H - 1];
+            }
+            const float dmax = fps_wave_fmax_asm(bd);
+            FPS_T(2);
             int bs = 0;
-            // visit in ascending key order: R = tie_bs / T (upstream's block vs this workgroup); key's leading part is the
-            // bit-reversed (s mod R), then k: so s = m, m + R, m + 2 R, ... for m in bit-reversed counting order
+            // key order: R = tie_bs / T (upstream's block vs this workgroup); key's leading part is the bit-reversed (s mod R),
+            // then k: so s = m, m + R, m + 2 R, ... for m in bit-reversed counting order -- walked backwards here
             auto visit = [&](auto rc) {
                 constexpr int R = decltype(rc)::value;
                 constexpr int LR = R == 1 ? 0 : (R == 2 ? 1 : (R == 4 ? 2 : 3));
 #pragma unroll
-                for (int c = 0; c < R; ++c) {
+                for (int c = R - 1; c >= 0; --c) {
                     const int m = LR == 0 ? 0 : (int)(__builtin_bitreverse32((unsigned)c) >> (32 - (LR ? LR : 1)));
+                    if (m < NPL) {
 #pragma unroll
-                    for (int s = m; s < NPL; s += R) { const float v = tm[s >> 1][s & 1]; const bool t = v > bd; bd = t ? v : bd; bs = t ? s : bs; }
+                        for (int q = (NPL - 1 - m) / R; q >= 0; --q) { const int s = m + q * R; bs = tm[s >> 1][s & 1] == bd ? s : bs; }
+                    }
                 }
             };
             if (ratio <= 1) visit(std::integral_constant<int, 1>());
             else if (ratio == 2) visit(std::integral_constant<int, 2>());
             else if (ratio == 4) visit(std::integral_constant<int, 4>());
             else visit(std::integral_constant<int, 8>());
+            FPS_T(1);
             unsigned long long best = 0ull;
-            const float dmax = fps_wave_fmax(bd);
             if (dmax >= 0.f) {
                 const unsigned bk = key_of(bs * T + tid);
                 const unsigned long long tied = __ballot(bd == dmax);
@@ -225,6 +279,7 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
                 else kb = fps_wave_umin(bd == dmax ? bk : 0xffffffffu);
                 best = fps_pack(dmax, kb);
             }
+            FPS_T(3);
             old = publish(j, best);
         }
     } else {
@@ -262,6 +317,15 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             old = publish(j, fps_wave_max(best));
         }
     }
+    __syncthreads();
+    for (int j = tid; j < M; j += T) {
+        const int pick = pk[j];
+        idx[(size_t)b * M + j] = pick;
+        if (new_xyz) {
+            float* o = new_xyz + ((size_t)b * M + j) * 3;
+            o[0] = sp[pick * 3 + 0]; o[1] = sp[pick * 3 + 1]; o[2] = sp[pick * 3 + 2];
+        }
+    }
 }
 
 static int g_opt_fps_cfg = 0;     // points per thread x wavefronts for 1024 < N <= 4096: 0 = 16 x 4, 1 = 8 x 8, 2 = 4 x 16 (A/B)
@@ -278,7 +342,7 @@ extern "C" int gad_furthest_point_sampling(const float* xyz, int B, int N, int M
     if (B == 0 || M == 0) return GAD_OK;
     hipStream_t st = (hipStream_t)stream;
     const int tie = fps_tie_bits(N);
-    const size_t lds = (size_t)(((N * 3 + 3) & ~3) + 64) * sizeof(float);
+    const size_t lds = (size_t)(((N * 3 + 3) & ~3) + 64 + M) * sizeof(float);      // coordinates, exchange slots, picks
     if (N <= 64) {
         hipLaunchKernelGGL((fps_kernel<1, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
     } else if (N <= 1024) {
