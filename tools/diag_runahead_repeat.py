@@ -62,3 +62,15 @@ for k in keys:
             k, par, med, float(np.max(np.abs(w - med))), len(out), len(w),
             ("  steps " + " ".join("%d(%.6f)" % (2 * i + par, w[i]) for i in out[:8])) if len(out) else ""))
 print("mode %s B=%d mfma_split=%s: %d outlier values in %d steps" % (mode, B, os.environ.get("GAD_OPT_mfma_split", "default"), bad, steps))
+# every logged key over the last quarter of the run (the target networks have converged onto the online ones by then: with
+# learning rate 0 all of them -- gradient statistics included -- repeat up to the atomics' rounding)
+tail = logs[3 * steps // 4:]
+for k in sorted(tail[0]):
+    v = np.array([l[k] for l in tail], dtype=np.float64)
+    for par in (0, 1):
+        w = v[par::2]
+        med = np.median(w)
+        dev = np.abs(w - med) / (abs(med) + 1e-12)
+        print("   %-28s parity %d median %+.6e  max rel dev %.2e  #(> 1e-4) %d" % (k, par, med, float(dev.max()), int((dev > 1e-4).sum())))
+if os.environ.get("OUT"):
+    np.savez(os.environ["OUT"], **{k: np.array([l[k] for l in logs], dtype=np.float64) for k in logs[0]})
