@@ -51,7 +51,7 @@ void gad_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gad_last_error(void) { return g_err; }
-extern "C" int gad_abi_version(void) { return 8; }
+extern "C" int gad_abi_version(void) { return 9; }
 
 const char* g_gad_last_kernel = "";
 extern "C" const char* gad_last_kernel(void) { return g_gad_last_kernel; }

@@ -300,6 +300,40 @@ extern "C" int gad_affine_act(const float* z, int z_pitch, int rows, int C, cons
     return GAD_OK;
 }
 
+// batched transpose through a 32 x 33 LDS tile: coalesced 128-byte row segments on both sides
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int C,
+                                                                int src_pitch, long long src_batch, int dst_pitch, long long dst_batch) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const float* s = src + (size_t)blockIdx.z * src_batch;
+    float* d = dst + (size_t)blockIdx.z * dst_batch;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + ty + 8 * u, j = j0 + tx;
+        if (i < R && j < C) tile[ty + 8 * u][tx] = s[(size_t)i * src_pitch + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = j0 + ty + 8 * u, i = i0 + tx;
+        if (i < R && j < C) d[(size_t)j * dst_pitch + i] = tile[tx][ty + 8 * u];
+    }
+}
+
+extern "C" int gad_transpose_batched(const float* src, float* dst, int B, int R, int C, int src_pitch, long long src_batch,
+                                     int dst_pitch, long long dst_batch, void* stream) {
+    GAD_REQUIRE(src && dst, GAD_ERR_NULL, "transpose_batched: null pointer");
+    GAD_REQUIRE(B >= 0 && R >= 0 && C >= 0 && src_pitch >= C && dst_pitch >= R && B <= 65535, GAD_ERR_SHAPE,
+                "transpose_batched: B=%d R=%d C=%d pitches %d / %d", B, R, C, src_pitch, dst_pitch);
+    if (B == 0 || R == 0 || C == 0) return GAD_OK;
+    GAD_REQUIRE(gad_cdiv(R, 32) <= 65535, GAD_ERR_SHAPE, "transpose_batched: R=%d too large", R);
+    hipLaunchKernelGGL(transpose_batched_kernel, dim3(gad_cdiv(C, 32), gad_cdiv(R, 32), B), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       R, C, src_pitch, src_batch, dst_pitch, dst_batch);
+    GAD_CHECK_LAUNCH("transpose_batched");
+    return GAD_OK;
+}
+
 // dbeta[c] += sum_g dout[g][c]*[y*>0],  dgamma[c] += sum_g dout[g][c]*[y*>0]*xhat*  (* = arg-max row)
 __global__ __launch_bounds__(256) void pool_bwd_stats_kernel(float* __restrict__ dout,
                                                              const int32_t* __restrict__ argmax, int G, int C,

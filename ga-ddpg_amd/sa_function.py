@@ -91,6 +91,10 @@ class _StageRun(object):
         self.mean = torch.empty(tot, **f32)
         self.istd = torch.empty(tot, **f32)
         self.count = float(G * S)
+        # max-pool folded into the third GEMM's epilogue (packed arg-max keys, finished by gad_pool_finalize) where the entry point
+        # takes it: rows a multiple of 4, channels a multiple of 64; else the separate segment max-pool operator
+        self.fused_pool = cap % 4 == 0 and c_out % 64 == 0
+        self.key = torch.zeros(G, c_out, dtype=torch.int64, device=device) if self.fused_pool else None
         self.plans = {t: self._plan(net, mod, t) for t in (True, False)}
         self.bwd = None
         if with_backward:
@@ -130,24 +134,36 @@ class _StageRun(object):
             o = net.bn_off[l]
             kw = self._input(net, mod, l)
             kw.update(net.flat.split_fwd_kw(m))
+            pooled = l == 2 and self.fused_pool
+            if pooled:
+                kw.update(pool_key=_ptr(self.key, 0, 8), pool_row_grp=_ptr(r["grp"]), pool_gamma=net.flat.p_gamma(m))
             a = _fwd_args(W=net.flat.p_w(m), Kp=m.Kp, n_out=[m.n_out], zout=_ptr(self.Z[l]), zout_pitch=m.n_out,
                           stat_sum=_ptr(self.stats, o, 8) if train else None,
                           stat_sq=_ptr(self.stats, tot + o, 8) if train else None, stat_stride=2 * tot, **kw)
             plan.call_struct("gad_gemm_fwd", a)
-            if train:
+            if not train:
+                plan.call("gad_bn_eval_affine", net.flat.p_gamma(m), net.flat.p_beta(m), _ptr(net.running_mean, o),
+                          _ptr(net.running_var, o), m.n_out, BN_EPS, _ptr(self.scale, o), _ptr(self.shift, o))
+            if pooled:
+                # finalises the layer's train-mode BatchNorm (same arithmetic and outputs as gad_bn_finalize) or takes the eval-mode
+                # scale / shift as given, then turns the keys into pooled features and arg-max rows
+                stats = (_ptr(self.stats, o, 8), _ptr(self.stats, tot + o, 8), 2 * tot, hip.Dbl(self.count)) if train else (None, None, 0, hip.Dbl(1.0))
+                run = (_ptr(net.running_mean, o), _ptr(net.running_var, o)) if train else (None, None)
+                plan.call("gad_pool_finalize", _ptr(self.key, 0, 8), m.n_out, r["G"], r["off"], *stats, net.flat.p_gamma(m),
+                          net.flat.p_beta(m), BN_EPS, BN_MOMENTUM, *run, _ptr(self.scale, o), _ptr(self.shift, o),
+                          _ptr(self.mean, o), _ptr(self.istd, o), self.F, self.argmax, None)
+            elif train:
                 plan.call("gad_bn_finalize", _ptr(self.stats, o, 8), _ptr(self.stats, tot + o, 8), 2 * tot,
                           net.flat.p_gamma(m), net.flat.p_beta(m), m.n_out, hip.Dbl(self.count), BN_EPS, BN_MOMENTUM,
                           _ptr(net.running_mean, o), _ptr(net.running_var, o), _ptr(self.scale, o), _ptr(self.shift, o),
                           _ptr(self.mean, o), _ptr(self.istd, o))
-            if not train:
-                plan.call("gad_bn_eval_affine", net.flat.p_gamma(m), net.flat.p_beta(m), _ptr(net.running_mean, o),
-                          _ptr(net.running_var, o), m.n_out, BN_EPS, _ptr(self.scale, o), _ptr(self.shift, o))
-        m = net.mats[2]
-        o = net.bn_off[2]
-        # the stand-alone module keeps the separate segment max-pool operator (gad_segment_pool: exactly torch's "first
-        # maximal activation" arg-max); the fused update step folds the pool into the GEMM epilogue (engine.plan_encoder_forward)
-        plan.call("gad_segment_pool", self.Z[2], m.n_out, m.n_out, _ptr(self.scale, o), _ptr(self.shift, o),
-                  r["off"], r["G"], self.F, self.argmax)
+        if not self.fused_pool:
+            m = net.mats[2]
+            o = net.bn_off[2]
+            # (gad_segment_pool: torch's "first maximal activation" arg-max; the fused form takes the largest raw value, which is the
+            # same row unless two different raw values round to one activation)
+            plan.call("gad_segment_pool", self.Z[2], m.n_out, m.n_out, _ptr(self.scale, o), _ptr(self.shift, o),
+                      r["off"], r["G"], self.F, self.argmax)
         return plan
 
     def _plan_backward(self, net):
@@ -243,16 +259,24 @@ def _stage_net(mod, dev):
     return rt
 
 
+def _transpose(src, dst, B, R, C_, src_pitch, src_batch, dst_pitch, dst_batch):
+    """dst[b][j][i] = src[b][i][j] (gad_transpose_batched): the (B, C, N) <-> point-major hand-over at the module boundary"""
+    import ctypes as C
+    src = src if (src.is_contiguous() and src.dtype == torch.float32) else src.contiguous().float()
+    hip.call("gad_transpose_batched", src, dst, B, R, C_, src_pitch, C.c_longlong(src_batch), dst_pitch, C.c_longlong(dst_batch))
+
+
 def _run_forward(mod, net, run, xyz, features):
     B, N = run.B, run.N
     net.flat.sync_packed()            # the parameters may have been stepped by an ordinary torch optimizer
     run.xyz.copy_(xyz)
-    run.feat.view(B, N, net.c_pad)[:, :, :net.c_feat].copy_(features.transpose(1, 2))     # (B,C,N) -> point-major
+    _transpose(features, run.feat, B, net.c_feat, N, N, net.c_feat * N, net.c_pad, N * net.c_pad)     # (B,C,N) -> point-major rows
     run.plans[bool(mod.training)].run()
     if mod.training:
         net.batches_tracked += 1
     c_out = net.mats[2].n_out
-    out = run.F.view(B, run.M, c_out).transpose(1, 2).contiguous()
+    out = torch.empty(B, c_out, run.M, dtype=torch.float32, device=xyz.device)
+    _transpose(run.F, out, B, run.M, c_out, c_out, run.M * c_out, run.M, c_out * run.M)
     return (None if run.group_all else run.new_xyz.clone()), out
 
 
@@ -279,15 +303,17 @@ class _SAFunction(torch.autograd.Function):
         run, net = ctx.run, ctx.net
         B, N = ctx.key
         c_out = net.mats[2].n_out
-        run.dF.view(B, run.M, c_out).copy_(g_out.transpose(1, 2))
+        _transpose(g_out, run.dF, B, c_out, run.M, run.M, c_out * run.M, c_out, run.M * c_out)
         run.bwd.run()
         g_feat = None
         if ctx.feat_grad:
-            g_feat = run.dfeat.view(B, N, net.c_pad)[:, :, :net.c_feat].transpose(1, 2).contiguous()
+            g_feat = torch.empty(B, net.c_feat, N, dtype=torch.float32, device=g_out.device)
+            _transpose(run.dfeat, g_feat, B, N, net.c_feat, net.c_pad, N * net.c_pad, N, net.c_feat * N)
         grads = []
+        gcopy = run.grad.clone()                              # ONE copy of the call's parameter gradients; views of it go out
         for p, o in zip(net.flat.params, net.flat.offsets[:-1]):
             o = int(o)
-            grads.append(run.grad[o:o + p.numel()].view(p.shape).clone() if p.requires_grad else None)
+            grads.append(gcopy[o:o + p.numel()].view(p.shape) if p.requires_grad else None)
         net.free[ctx.key].append(run)                          # recycled: everything handed out above is a copy
         ctx.run = None
         return (None, None, g_feat) + tuple(grads)

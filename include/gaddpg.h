@@ -45,7 +45,8 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * GAD_DW_REDUCE_LATER; 7: trailing BatchNorm blocks of gad_gemm_fwd_args (in_*)
                                             * and gad_dz_src (bn_*, gacc_*), GAD_STAT_REPLICAS 8 -> 4;
                                             * 8: split-bf16 weight mirrors (gad_split_weights; W_split* of gad_gemm_fwd_args,
-                                            * W_split_t* of gad_gemm_dx_args), option "mfma_split" as a family mask)  */
+                                            * W_split_t* of gad_gemm_dx_args), option "mfma_split" as a family mask;
+                                            * 9: gad_transpose_batched)                                               */
 /* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
  * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
  * with it instead of restating the routing rules.                                                  */
@@ -280,6 +281,13 @@ int gad_pool_finalize(uint64_t* key, int C, int G, const int32_t* grp_off, const
 /* apply act(scale*z+shift) elementwise -> out (rows,C) (used at API boundaries only)            */
 int gad_affine_act(const float* z, int z_pitch, int rows, int C, const float* scale,
                    const float* shift, int relu, float* out, int out_pitch, void* stream);
+
+/* batched 2-D transpose at the operator boundary: dst[b][j][i] = src[b][i][j] for i < R, j < C; rows of src / dst are
+ * src_pitch / dst_pitch floats apart, batches src_batch / dst_batch floats (upstream's (B, C, N) channel-major tensors
+ * <-> the point-major rows the kernels read: replaces tensor.transpose(1, 2).contiguous() at the pointnet2_ops facade,
+ * reference call sites pointnet2_modules.py forward: features (B, C, N) in, new_features (B, C', npoint) out).          */
+int gad_transpose_batched(const float* src, float* dst, int B, int R, int C, int src_pitch, long long src_batch,
+                          int dst_pitch, long long dst_batch, void* stream);
 
 /* backward source of dY for a layer: dense G (rows,C) or routed from the pooled gradient        */
 typedef struct {

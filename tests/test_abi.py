@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libgaddpg.so does not export " + n
     assert set(names) == set(hip.EXPORTS), set(names) ^ set(hip.EXPORTS)
-    assert L.gad_abi_version() == 8
+    assert L.gad_abi_version() == 9
 
 
 def test_missing_library_fails_loudly(monkeypatch):

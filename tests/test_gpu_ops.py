@@ -275,3 +275,16 @@ def test_ball_query_distance_is_not_fma_contracted(N, cells):
             np.testing.assert_array_equal(cnt.cpu().numpy(), wcnt)
     finally:
         hip.set_option("bq_cells", 1)
+
+
+@pytest.mark.parametrize("B,R,C_,sp,dp", [(3, 4, 1024, 1024, 4), (2, 128, 512, 512, 128), (5, 37, 45, 48, 40), (1, 1, 1, 1, 1), (2, 1000, 7, 8, 1000)])
+def test_transpose_batched(B, R, C_, sp, dp):
+    """gad_transpose_batched == tensor.transpose(1, 2) on the leading R x C block of every batch, pitches honoured, padding untouched"""
+    import ctypes as C
+    from ga_ddpg_amd import hip
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + R)
+    src = torch.randn(B, R, sp, device="cuda", generator=g)
+    dst = torch.full((B, C_, dp), -7.0, device="cuda")
+    hip.call("gad_transpose_batched", src, dst, B, R, C_, sp, C.c_longlong(R * sp), dp, C.c_longlong(C_ * dp))
+    assert torch.equal(dst[:, :, :R], src[:, :, :C_].transpose(1, 2))
+    assert bool((dst[:, :, R:] == -7.0).all())
