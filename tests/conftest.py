@@ -51,3 +51,26 @@ def _mfma_mode_switch(request):
         yield
     finally:
         hip.set_option("mfma_split", was)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Leave the GPU in a defined state before the interpreter tears its modules down in arbitrary order: drain every stream,
+    drop the package's cached streams / workspaces, collect.  (One full-suite run in three of round 5 ended with the pytest
+    process dumping core at the suite's full duration -- 540 s, where the other two runs printed "180 passed" -- with the log
+    tail lost; a fault in library teardown at exit is the likely reading, and this makes the order explicit.)"""
+    import gc
+    import sys
+    try:
+        import torch
+        if "ga_ddpg_amd.engine" in sys.modules and torch.cuda.is_available():
+            torch.cuda.synchronize()
+            eng = sys.modules["ga_ddpg_amd.engine"]
+            for name in ("_SIDE", "_DW_WS"):
+                d = getattr(eng, name, None)
+                if isinstance(d, dict):
+                    d.clear()
+            gc.collect()
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:                                        # never turn a green run red from here
+        pass
