@@ -28,7 +28,7 @@ for red, nm in ((0, "DPP ladder with row_bcast"), (1, "no DPP"), (2, "DPP row_sh
             for _ in range(200):
                 V.victim_mix_launch(32, 400, flags.data_ptr(), detail.data_ptr(), hip.stream(), red)
         torch.cuda.synchronize()
-    print("victim_mix (%s) beside %s %s: flags %s (1 wave max, 2 bystander registers, 4 packed math, 8 ballot/readlane, 16 LDS), threads in error by 16-lane row %s"
+    print("victim_mix (%s) beside %s %s: flags %s (1 wave max, 2 bystander registers, 4 packed != scalar, 8 ballot/readlane, 16 LDS word, 32 packed path != closed form, 64 scalar path != closed form), threads in error by 16-lane row %s"
           % (nm, other, fam, bin(int(flags.item())), detail.tolist()))
 sys.exit(0)
 V.victim_pk_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -67,14 +67,14 @@ __global__ __launch_bounds__(256) void victim_mix(int iters, unsigned* flags, un
     typedef float f2 __attribute__((ext_vector_type(2)));
     __shared__ float lds[3072];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 3072; i += 256) lds[i] = 0.25f + 0.001f * i;
+    for (int i = tid; i < 3072; i += 256) lds[i] = __fmaf_rn(0.001f, (float)i, 0.25f);
     __syncthreads();
     float keep[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) keep[i] = 100.f + tid + 1000.f * i;
     f2 q[2] = {{0.1f + 0.001f * tid, 0.2f}, {0.3f, 0.4f + 0.002f * tid}};
     f2 tmin[2] = {{1e10f, 1e10f}, {1e10f, 1e10f}};
-    float smin[4] = {1e10f, 1e10f, 1e10f, 1e10f};
+    float smin[4] = {1e10f, 1e10f, 1e10f, 1e10f}, rmin[4] = {1e10f, 1e10f, 1e10f, 1e10f};
     unsigned err = 0;
     for (int it = 0; it < iters; ++it) {
         // (0) DPP wave maximum of v = hash(lane, it): expected by a butterfly over ds_bpermute
@@ -129,6 +129,18 @@ __global__ __launch_bounds__(256) void victim_mix(int iters, unsigned* flags, un
             }
         }
         if (tmin[0][0] != smin[0] || tmin[0][1] != smin[1] || tmin[1][0] != smin[2] || tmin[1][1] != smin[3]) err |= 4u;
+        {   // the same distances from the values the LDS words are KNOWN to hold (no LDS read involved): which side is wrong?
+#pragma clang fp contract(off)
+            const float ex = __fmaf_rn(0.001f, (float)((it * 3) % 3000), 0.25f), ey = __fmaf_rn(0.001f, (float)((it * 3) % 3000 + 1), 0.25f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sx = q[k >> 1][k & 1] - ex, sy = q[k >> 1][k & 1] - ey;
+                const float sd = sx * sx + sy * sy;
+                rmin[k] = sd < rmin[k] ? sd : rmin[k];
+            }
+            if (tmin[0][0] != rmin[0] || tmin[0][1] != rmin[1] || tmin[1][0] != rmin[2] || tmin[1][1] != rmin[3]) err |= 32u;   // packed path wrong
+            if (smin[0] != rmin[0] || smin[1] != rmin[1] || smin[2] != rmin[2] || smin[3] != rmin[3]) err |= 64u;               // scalar path wrong
+        }
         // (3) ballot / readlane
         const unsigned long long b = __ballot(((lane + it) & 3) == 0);
         unsigned long long eb = 0x1111111111111111ull;
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(256) void victim_mix(int iters, unsigned* flags, un
         if (b != eb) err |= 8u;
         if (__builtin_amdgcn_readlane(lane * 7 + it, (it * 5) & 63) != ((it * 5) & 63) * 7 + it) err |= 8u;
         // (4) LDS broadcast
-        if (cx != 0.25f + 0.001f * ((it * 3) % 3000)) err |= 16u;
+        if (cx != __fmaf_rn(0.001f, (float)((it * 3) % 3000), 0.25f)) err |= 16u;
     }
     if (err) { atomicOr(flags, err); atomicAdd(detail + (lane >> 4), 1u); }
 }
