@@ -119,6 +119,11 @@ __device__ __forceinline__ float fps_vmax3(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ float fps_settle(float v) {
+    float r;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ unsigned fps_dpp_umin(unsigned v) {
     const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xf, false);
@@ -149,8 +154,11 @@ extern "C" int gad_fps_phase_read(unsigned long long* out8, int reset) {
 // LDS read.  Tie rule == the upstream block reduction: "thread" t = k mod tie_bs keeps its lowest k
 // (strict >), and the pairwise tree `v2 > v1 ? i2 : i1` over strides bs/2..1 lets the candidate with
 // the smallest BIT-REVERSED thread id win among equal values (slot t beats slot t+s at every level).
+// (the library is built without packed-f32 instructions -- csrc/Makefile; this kernel opts back in: its packed
+// operands are the points' long-lived register pairs and SCALAR pick coordinates, never a pair fresh from an LDS read, and the
+// distance update is half of its round)
 template <int NPL, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict__ xyz, int N, int M,
+__global__ __launch_bounds__(64 * WAVES) __attribute__((target("packed-fp32-ops"))) void fps_kernel(const float* __restrict__ xyz, int N, int M,
                                                           int tie_bits, int32_t* __restrict__ idx,
                                                           float* __restrict__ new_xyz) {
     constexpr int T = 64 * WAVES;
@@ -208,7 +216,9 @@ __global__ __launch_bounds__(64 * WAVES) void fps_kernel(const float* __restrict
             for (int u = 0; u < 2; ++u) {
                 const int k = (2 * h + u) * T + tid;
                 const int kk = k < N ? k : N - 1;
-                const float x = sp[kk * 3 + 0], y = sp[kk * 3 + 1], z = sp[kk * 3 + 2];
+                // (through a v_mov each: the packed instructions below must not be the first readers of registers an LDS read has just
+                // filled -- DESIGN.md section 5; a scalar instruction in that position is safe)
+                const float x = fps_settle(sp[kk * 3 + 0]), y = fps_settle(sp[kk * 3 + 1]), z = fps_settle(sp[kk * 3 + 2]);
                 // upstream: `if (mag <= 1e-3) continue;` compares the FLOAT mag with the DOUBLE literal: the float nearest to 0.001
                 // (0x3A83126F = 0.00100000005) is > 0.001 and therefore NOT skipped -- in float terms "skip iff mag < 1e-3f"
                 const bool skip = k >= N || gad_sqnorm(x, y, z) < 1e-3f;

@@ -9,7 +9,7 @@ from tests import split_cases as sc
 
 other = sys.argv[1] if len(sys.argv) > 1 else "split"
 fam = sys.argv[2] if len(sys.argv) > 2 else "fwd_stream"
-V = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "libvictims.so"))
+V = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", os.environ.get("VICTIMS_LIB", "libvictims.so")))
 V.victim_mix_launch.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 case = {"fwd_stream": lambda: sc.FwdStream(213034, 64, 64, "act"), "fwd": lambda: sc.FwdWide(27240, 128, 128, "act"),
         "dx": lambda: sc.DxWide(27240, 128, 128, "act"), "dw": lambda: sc.DwWide(27240, 128, 128, "act")}[fam]()
