@@ -288,3 +288,27 @@ def test_transpose_batched(B, R, C_, sp, dp):
     hip.call("gad_transpose_batched", src, dst, B, R, C_, sp, C.c_longlong(R * sp), dp, C.c_longlong(C_ * dp))
     assert torch.equal(dst[:, :, :R], src[:, :, :C_].transpose(1, 2))
     assert bool((dst[:, :, R:] == -7.0).all())
+
+
+@pytest.mark.parametrize("G,unaligned", [(65536, False), (4099, False), (8192, True), (5, False), (4096, False), (12288, False)])
+def test_rows_scan_offsets(G, unaligned):
+    """the group-offset scan of gad_rows_from_ball_query (one workgroup, 4096 groups per pass, 16-byte loads when the pointers
+    allow): exclusive sums of max(cnt, 1), counts of 0 included, several passes, a ragged last pass, unaligned buffers"""
+    from ga_ddpg_amd import hip
+    S, M, N = 4, 1, 64
+    rng = np.random.default_rng(G)
+    cnt_h = rng.integers(0, S + 1, size=G).astype(np.int32)
+    pad = 1 if unaligned else 0
+    cnt = torch.zeros(G + pad, dtype=torch.int32, device="cuda")
+    cnt[pad:] = torch.from_numpy(cnt_h).cuda()
+    idx = torch.zeros(G, S, dtype=torch.int32, device="cuda")
+    off = torch.zeros(G + 1 + pad, dtype=torch.int32, device="cuda")
+    cap = G * S
+    pt = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    grp = torch.zeros(cap, dtype=torch.int32, device="cuda")
+    w = torch.zeros(cap, dtype=torch.float32, device="cuda")
+    n = torch.zeros(1, dtype=torch.int32, device="cuda")
+    hip.call("gad_rows_from_ball_query", idx, cnt[pad:], G, M, N, S, off[pad:], pt, grp, w, n)
+    want = np.concatenate([[0], np.cumsum(np.maximum(cnt_h, 1))])
+    np.testing.assert_array_equal(off[pad:].cpu().numpy(), want)
+    assert int(n.item()) == want[-1]
