@@ -95,6 +95,8 @@ class _StageRun(object):
         # takes it: rows a multiple of 4, channels a multiple of 64; else the separate segment max-pool operator
         self.fused_pool = cap % 4 == 0 and c_out % 64 == 0
         self.key = torch.zeros(G, c_out, dtype=torch.int64, device=device) if self.fused_pool else None
+        # raw value of every arg-max row (the backward's BatchNorm sums read it instead of gathering z[argmax])
+        self.zmax = torch.empty(G, c_out, **f32) if (self.fused_pool and with_backward) else None
         self.plans = {t: self._plan(net, mod, t) for t in (True, False)}
         self.bwd = None
         if with_backward:
@@ -151,7 +153,7 @@ class _StageRun(object):
                 run = (_ptr(net.running_mean, o), _ptr(net.running_var, o)) if train else (None, None)
                 plan.call("gad_pool_finalize", _ptr(self.key, 0, 8), m.n_out, r["G"], r["off"], *stats, net.flat.p_gamma(m),
                           net.flat.p_beta(m), BN_EPS, BN_MOMENTUM, *run, _ptr(self.scale, o), _ptr(self.shift, o),
-                          _ptr(self.mean, o), _ptr(self.istd, o), self.F, self.argmax, None)
+                          _ptr(self.mean, o), _ptr(self.istd, o), self.F, self.argmax, self.zmax)
             elif train:
                 plan.call("gad_bn_finalize", _ptr(self.stats, o, 8), _ptr(self.stats, tot + o, 8), 2 * tot,
                           net.flat.p_gamma(m), net.flat.p_beta(m), m.n_out, hip.Dbl(self.count), BN_EPS, BN_MOMENTUM,
@@ -239,7 +241,7 @@ class _StageRun(object):
         # gradients travel ReLU-masked between the layers (store_masked / premasked)
         plan.call("gad_pool_bwd_stats", self.dF, self.argmax, r["G"], m3.n_out, self.Z[2], m3.n_out, vec("scale", o3),
                   vec("shift", o3), vec("mean", o3), vec("istd", o3), _ptr(self.bstats, o3, 8),
-                  _ptr(self.bstats, tot + o3, 8), 2 * tot, 1, None)
+                  _ptr(self.bstats, tot + o3, 8), 2 * tot, 1, self.zmax)
         bwd(2, bn_dz(m3, o3, self.Z[2], False, pooled=True), m3, m2.n_out, epilogue=0, gout=_ptr(self.G[0]), gout_pitch=m2.n_out,
             **prev_stats(m2, o2, self.Z[1]))
         bwd(1, bn_dz(m2, o2, self.Z[1], False, G=self.G[0]), m2, m1.n_out, epilogue=0, gout=_ptr(self.G[1]), gout_pitch=m1.n_out,
