@@ -42,7 +42,8 @@ def weights_init_(m):
 
 
 class GoalFeature(nn.Module):
-    """Built by make_nets_opts_schedulers but never evaluated on the update path."""
+    """Built by make_nets_opts_schedulers but never evaluated on the update path; forward() works all the
+    same (tests/golden/offpath_forms.npz: the reference's class on the same weights)."""
 
     def __init__(self, input_dim=3, pointnet_radius=0.02, pointnet_nclusters=128, model_scale=1,
                  action_concat=False):
@@ -53,8 +54,24 @@ class GoalFeature(nn.Module):
         self.t = nn.Linear(model_scale * 512, 3)
         self.confidence = nn.Linear(model_scale * 512, 1)
 
+    def encode(self, xyz, xyz_features):
+        """the three set-abstraction modules through libgaddpg (pointnet2_ops facade: differentiable, BatchNorm mode follows
+        .training), then the FC head"""
+        for sa in self.encoder[0]:
+            xyz, xyz_features = sa(xyz, xyz_features)
+        return self.encoder[1](xyz_features.squeeze(-1))
+
     def forward(self, pc, grasp=None, goal_head=False):
-        raise NotImplementedError("GoalFeature is not on the update-step path (policy_goal/critic_goal are off)")
+        """pc (B, N, 3) -> (unit quaternion | translation (B, 7), confidence (B,)); reference core/networks.py:171-178.
+        Not on the update-step path (policy_goal / critic_goal are off in every shipped config): the SA stack runs through the
+        HIP kernels, the 512 -> 1024 -> 512 head and the three small output layers through torch's library GEMMs on the GPU."""
+        pc = pc.cuda()
+        z = self.encode(pc[..., :3].contiguous(), pc.transpose(1, -1).contiguous())
+        qt = torch.cat((nn.functional.normalize(self.q(z), p=2, dim=-1), self.t(z)), -1)
+        return qt, torch.sigmoid(self.confidence(z)).squeeze()
+
+    def grasp_pred(self, *args):
+        return self(*args, goal_head=True)[0]
 
 
 class PointNetFeature(nn.Module):
@@ -107,10 +124,23 @@ class QNetwork(nn.Module):
         self.num_actions = num_actions
 
     def forward(self, state, action=None):
-        from ..runtime import critic_forward
-        if action is not None or self.num_actions != 0:
-            raise NotImplementedError("only the value_model form Q(feature) is on the path (sa_channel_concat)")
-        return critic_forward(self, state)
+        """value_model form Q(feature) (sa_channel_concat: the action rides in the point cloud's channels): the fused head kernels.
+        The classic Q(state, action) form (reference core/networks.py:280-300, no shipped config builds it) is evaluated layer by
+        layer with torch's library GEMMs on the module's device: twin trunks on [state | action], the aux trunk on the state
+        alone, unit quaternion for a 7-D aux head."""
+        if action is None and self.num_actions == 0:
+            from ..runtime import critic_forward
+            return critic_forward(self, state)
+        F = nn.functional
+        xu = state if action is None else torch.cat([state, action], 1)
+        q1 = self.linear3(F.relu(self.linear2(F.relu(self.linear1(xu)))))
+        q2 = self.linear6(F.relu(self.linear5(F.relu(self.linear4(xu)))))
+        aux = None
+        if self.extra_pred_dim:
+            aux = self.extra_pred(F.relu(self.linear8(F.relu(self.linear7(state)))))
+            if self.extra_pred_dim == 7:
+                aux = torch.cat((F.normalize(aux[:, :4], p=2, dim=-1), aux[:, 4:]), dim=-1)
+        return q1, q2, aux
 
 
 class GaussianPolicy(nn.Module):

@@ -437,6 +437,35 @@ def gen_heads():
     np.savez_compressed(os.path.join(OUT, "heads.npz"), **out)
 
 
+def gen_offpath():
+    """Two forms the update step never reaches (VERDICT r04 missing 4), through the reference's own classes:
+    GoalFeature.forward (core/networks.py:150-178; eval and train mode) and the non-value_model QNetwork(state, action)
+    (core/networks.py:280-300)."""
+    from core import networks as rn
+    from oracle.detfill import fill_module_
+    rng = np.random.default_rng(SEED + 11)
+    out = {}
+    B, N = 4, 1024
+    pc = torch.tensor(rng.uniform(-0.15, 0.15, size=(B, N, 3)), dtype=torch.float32)
+    g = fill_module_(rn.GoalFeature(), "goal_feature", SEED)
+    for mode in ("train", "eval"):
+        g.train(mode == "train")
+        with torch.no_grad():
+            qt, conf = g(pc)
+        out["goal_qt_" + mode], out["goal_conf_" + mode] = _np(qt), _np(conf)
+    out["goal_pc"] = _np(pc)
+    state = torch.tensor(rng.normal(size=(12, 512)), dtype=torch.float32)
+    action = torch.tensor(rng.uniform(-1, 1, size=(12, 6)), dtype=torch.float32)
+    q = fill_module_(rn.QNetwork(512, 6, 256, extra_pred_dim=7), "critic_sa", SEED)
+    q1, q2, aux = q(state, action)
+    out.update(q_state=_np(state), q_action=_np(action), q1=_np(q1), q2=_np(q2), q_aux=_np(aux))
+    q0 = fill_module_(rn.QNetwork(512, 6, 256, extra_pred_dim=0), "critic_sa0", SEED)
+    r1, r2, r3 = q0(state, action)
+    assert r3 is None
+    out.update(q0_q1=_np(r1), q0_q2=_np(r2))
+    np.savez_compressed(os.path.join(OUT, "offpath_forms.npz"), **out)
+
+
 def gen_encoder(B=16):
     """PointNetFeature forward (both encoders) + grads of a scalar probe, via the reference's class."""
     from core import networks as rn
@@ -578,7 +607,7 @@ def main():
     install_shims()
     torch.set_num_threads(8)
     gens = [("config", gen_config), ("losses", gen_losses), ("heads", gen_heads), ("replay", gen_replay),
-            ("replay_io", gen_replay_io), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg),
+            ("replay_io", gen_replay_io), ("offpath", gen_offpath), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg),
             ("ddpg_f64", gen_ddpg_f64), ("checkpoint", gen_checkpoint)]
     if sys.argv[1:] == ["seeds"]:
         print(find_ddpg_seeds())
