@@ -85,3 +85,43 @@ def test_run_ahead_steps_on_one_minibatch_repeat_exactly():
             med = np.median(w)
             out = np.nonzero(np.abs(w - med) > 2e-5 * abs(med) + 1e-7)[0]
             assert len(out) == 0, "%s: steps %s deviate from the repeated value %.8f: %s" % (k, (2 * out + par).tolist()[:8], med, w[out][:8])
+
+
+def test_sa_stack_beside_split_gemms_equals_the_stack_alone():
+    """the configs[3] two-module stack (eval-mode BatchNorm: no atomics' order in the result) on one stream while split GEMM launches
+    run on another: sampled centroids and pooled features bit-equal to the run alone -- FPS, the cell-list ball query, the row
+    scan / fill, the gathered first layers, the streaming and wide-tile GEMMs, the fused max-pool and its finalisation as victims"""
+    from ga_ddpg_amd import hip
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    from oracle.detfill import fill_module_
+    sa = [fill_module_(pm.PointnetSAModule(npoint=512, radius=0.1, nsample=64, mlp=[4, 64, 64, 128]), "sa0", 41).cuda().eval(),
+          fill_module_(pm.PointnetSAModule(npoint=128, radius=0.2, nsample=128, mlp=[128, 128, 128, 256]), "sa1", 41).cuda().eval()]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xyz = torch.rand(8, 4096, 3, device="cuda", generator=g)
+    feats = torch.randn(8, 4, 4096, device="cuda", generator=g)
+
+    def stack():
+        with torch.no_grad():
+            x1, f1 = sa[0](xyz, feats)
+            x2, f2 = sa[1](x1, f1)
+        return [t.clone() for t in (x1, f1, x2, f2)]
+    ref = stack()
+    torch.cuda.synchronize()
+    cases = _aggressors()
+    args = [(getattr(hip.lib(), c.entry), c.args()) for c in cases]
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    s1.wait_stream(torch.cuda.current_stream())
+    bad = []
+    for rnd in range(3):
+        with torch.cuda.stream(s2):
+            for _ in range(150):
+                for f, a in args:
+                    hip.check(f(C.byref(a), hip.stream()), "gemm")
+        with torch.cuda.stream(s1):
+            outs = [stack() for _ in range(12)]
+        torch.cuda.synchronize()
+        for i, o in enumerate(outs):
+            for name, a, b in zip(("new_xyz 1", "features 1", "new_xyz 2", "features 2"), o, ref):
+                if not torch.equal(a, b):
+                    bad.append("round %d pass %d: %s differs in %d entries (max %.3e)" % (rnd, i, name, int((a != b).sum()), float((a - b).abs().max())))
+    assert not bad, "\n".join(bad[:10])
