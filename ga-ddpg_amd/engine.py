@@ -492,6 +492,31 @@ if _os.environ.get("GAD_STREAM_MAP"):                     # e.g. "1:A,11:A,2:B,1
     _PHYS = dict((int(kv.split(":")[0]), kv.split(":")[1]) for kv in _os.environ["GAD_STREAM_MAP"].split(","))
 
 
+def _masked_stream(dev, letter):
+    """A/B switch GAD_CU_MASK_<letter> = "<n>" (the n lowest CU bits) or "even" / "odd" (every second CU) / hex words "w0,w1,...":
+    the physical side stream `letter` is created with hipExtStreamCreateWithCUMask -- its kernels (e.g. the weight-gradient lanes)
+    may then only occupy those CUs and leave the others to the chains (profiles/README.md round 5: measured, not kept)."""
+    spec = _os.environ.get("GAD_CU_MASK_" + letter)
+    if not spec:
+        return None
+    import ctypes as C
+    if spec in ("even", "odd"):
+        words = [0x55555555 if spec == "even" else 0xAAAAAAAA] * 8
+    elif "," in spec or spec.startswith("0x"):
+        words = [int(w, 16) for w in spec.split(",")]
+    else:
+        n = int(spec)
+        words = [(0xFFFFFFFF if n >= 32 * (i + 1) else ((1 << max(0, n - 32 * i)) - 1)) & 0xFFFFFFFF for i in range(8)]
+    rt = C.CDLL("libamdhip64.so")
+    st = C.c_void_p()
+    arr = (C.c_uint32 * len(words))(*words)
+    with torch.cuda.device(dev):
+        rc = rt.hipExtStreamCreateWithCUMask(C.byref(st), C.c_uint32(len(words)), arr)
+    if rc != 0:
+        raise RuntimeError("hipExtStreamCreateWithCUMask failed (%d)" % rc)
+    return torch.cuda.ExternalStream(st.value, device=dev)
+
+
 def side_stream(device=None, which=0):
     """auxiliary HIP streams (per device, created lazily): 1 / 2 = whole encoder passes overlapped by runtime.FusedRuntime,
     3 = small initialisations, 10 + lane = weight-gradient GEMMs forked off a dX chain, 20 / 21 = input / geometry prefetch;
@@ -503,7 +528,7 @@ def side_stream(device=None, which=0):
     if key not in _SIDE:
         for k in ("A", "B", "C"):                # fixed creation order: the first three side streams get queues of their own
             if (dev, k) not in _SIDE:
-                _SIDE[(dev, k)] = torch.cuda.Stream(device=dev)
+                _SIDE[(dev, k)] = _masked_stream(dev, k) or torch.cuda.Stream(device=dev)
         if key not in _SIDE:
             _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
