@@ -111,7 +111,8 @@ def sa_kernel_mfma(iters=6):
     gemm_fwd / dX / dW kernels as the update step, de-duplicated neighbourhood rows), as the MFMA-bound member of the family:
     executed FLOPs = live rows x K x N x 2 per layer, x 3 for forward + dX + dW, over the wall time of one
     forward + backward between two HIP events on the launching stream (geometry -- FPS, ball query, row compaction -- and
-    the facade's tensor copies included: this is the operator as a user calls it, not a kernel in isolation)."""
+    the facade's hand-over transposes included: this is the operator as a user calls it inside a training iteration, gradients
+    reset before every pass as optimizer.zero_grad() leaves them, not a kernel in isolation)."""
     from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
     B, N = 128, 4096
     g = torch.Generator(device="cuda").manual_seed(SEED)
@@ -121,7 +122,12 @@ def sa_kernel_mfma(iters=6):
           pm.PointnetSAModule(npoint=128, radius=0.2, nsample=128, mlp=[128, 128, 128, 256]).cuda().train()]
     probe = torch.randn(B, 256, 128, device="cuda", generator=g)
 
-    def fwd_bwd():
+    params = [p for m in sa for p in m.parameters()]
+
+    def fwd_bwd():                                         # one training iteration's worth: gradients reset as optimizer.zero_grad()
+        for p in params:                                   # does (set_to_none: the backward then assigns instead of accumulating)
+            p.grad = None
+        feats.grad = None
         x1, f1 = sa[0](xyz, feats)
         _, f2 = sa[1](x1, f1)
         (f2 * probe).sum().backward()
