@@ -125,3 +125,33 @@ def test_sa_stack_beside_split_gemms_equals_the_stack_alone():
                 if not torch.equal(a, b):
                     bad.append("round %d pass %d: %s differs in %d entries (max %.3e)" % (rnd, i, name, int((a != b).sum()), float((a - b).abs().max())))
     assert not bad, "\n".join(bad[:10])
+
+
+def test_run_ahead_loop_equals_synchronous_loop_over_many_steps():
+    """300 steps on one minibatch with learning rate 0 (only the target networks move): every logged value of the run-ahead loop --
+    the TD target path and max |critic.grad| included, which see the backward pass too -- equals the synchronous loop's at the same
+    step (measured: bit for bit over 2000 steps; 1e-5 here leaves room for the order of the f64 atomics)"""
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.experiments.config import load_cfg
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer, sample_valid_batch
+    from tests.test_gpu_step import _filled_agent
+    c = load_cfg("ddpg_td3_aux.yaml")
+    mem = BaseMemory(1500, c, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 1500, seed=5)
+    rng = np.random.default_rng(3)
+    batch = sample_valid_batch(mem, 32, rng)
+    noise = rng.random((32, 6)).astype(np.float32)
+    runs = {}
+    for mode in ("sync", "ahead"):
+        agent, _ = _filled_agent("ddpg_td3_aux.yaml", 11)
+        for opt in (agent.policy_optim, agent.critic_optim, agent.state_feat_encoder_optim, agent.state_feat_val_encoder_optim):
+            for grp in opt.param_groups:
+                grp["lr"] = 0.0
+        logs = [agent.update_parameters(batch, agent.update_step, 0, noise_u=noise, sync=(mode == "sync")) for _ in range(300)]
+        agent.flush()
+        runs[mode] = [dict(l) for l in logs]
+    for k in runs["sync"][0]:
+        a = np.array([l[k] for l in runs["sync"]], dtype=np.float64)
+        b = np.array([l[k] for l in runs["ahead"]], dtype=np.float64)
+        d = np.abs(a - b) / (np.abs(a) + 1e-9)
+        assert float(d.max()) <= 1e-5, "%s: run-ahead differs from the synchronous loop at step %d (%.9g vs %.9g)" % (k, int(d.argmax()), b[d.argmax()], a[d.argmax()])
