@@ -541,6 +541,7 @@ RECOMP_SA1 = _os.environ.get("GAD_RECOMP_SA1", "0") == "1"   # SA1 layer 2 recom
 INLINE_BN_BWD = _os.environ.get("GAD_INLINE_BN_BWD", "1") == "1"     # BatchNorm-backward coefficients formed in the dX / dW prologues
 DEFER_BN_STAGES = tuple(int(c) for c in _os.environ.get("GAD_DEFER_BN_STAGES", "012"))     # SA stages it applies to (A/B)
 DEFER_BN_WIDE = _os.environ.get("GAD_DEFER_BN_WIDE", "1") == "1"     # SA2 / SA3 layers 1, 2: BatchNorm finalised in the consumer GEMM's prologue
+DEFER_DW = _os.environ.get("GAD_DEFER_DW", "0") == "1"              # A/B: weight-gradient GEMMs of a pass launched after its dX chain
 FUSED_WIDE_BWD = _os.environ.get("GAD_FUSED_WIDE_BWD", "0") == "1"   # SA2 / SA3 backward: dX + dW in one kernel (round 4; the reduce of its
                                                                      # partial dW blocks forked onto the weight-gradient lane).  OFF: measured 4 - 6 % slower at B = 256 and 512 --
                                                                      # the step follows the length of its dX chain, and dW on its own lane is nearly free
@@ -918,6 +919,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
 
     dw_lanes = []
     fused_dw = []
+    deferred_dw = []
     has_dx_now = [True]                # (set by layer(): a layer without a dX launch cannot take the fused call)
 
     def dw(s, l, dz, m, action):
@@ -945,10 +947,14 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         dw_lanes.append(lane)
         ws = dw_workspace(enc.flat.device, lane=lane)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
+        tag = "dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1)
+        if DEFER_DW and lane:                 # A/B: every weight-gradient GEMM of the pass behind its dX chain (one fork at the end)
+            deferred_dw.append((a, lane, tag))
+            return
         if lane:
             plan.fork(lane)
         plan.call_struct("gad_gemm_dw", a, side=lane)
-        plan.tag_last("dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1))
+        plan.tag_last(tag)
 
     def layer(s, l, m, z, count, has_dx, **src):
         """(dz for the dW, dz for the dX) of one layer: the dX carries the arena accumulation of dgamma / dbeta when
@@ -1007,6 +1013,11 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
                 plan.zero(slot.daction)
             dx(dict(rows_kw, layer=1), d, m1, m1.k_in, epilogue=1, dfeat=None, feat_c=4, row_pt=_ptr(r["pt"]), row_grp=_ptr(r["grp"]),
                daction=_ptr(slot.daction), act_c=6, grp_per_sample=geo.M1)
+    for lane in sorted(set(l for _, l, _ in deferred_dw)):
+        plan.fork(lane)
+    for a, lane, tag in deferred_dw:
+        plan.call_struct("gad_gemm_dw", a, side=lane)
+        plan.tag_last(tag)
     for lane in sorted(set(dw_lanes) - {0}):
         plan.join(lane)
     return plan
