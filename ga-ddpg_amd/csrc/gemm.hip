@@ -1539,17 +1539,20 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
 #define SK_NW 8          // wavefronts per workgroup (K split); 16 -> 128-VGPR budget -> spills, 2x slower
 #define SK_CH 6          // 8-wide k groups per register chunk (17 x 1 = the whole K share in one round of loads: measured 2 % slower)
 #define SK_SP 36         // pitch (floats) of the wavefront-private operand stage of the skinny forward kernel
+#define SK_KCAP (8 * SK_NW * SK_CH * SK_MAXCH)   // most input channels of a skinny launch (per-channel affine staged in LDS)
 #define SK_MAXCH 3       // chunks per wavefront: K <= 8 * SK_NW * SK_CH * SK_MAXCH = 1152
-__global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Groups gr, int n_rows,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_fwd_skinny_kernel(XSrc x, Groups gr, int n_rows,
                                                                      const float* __restrict__ row_w,
                                                                      const float* __restrict__ W, int Kp,
                                                                      float* __restrict__ zout, int zout_pitch,
                                                                      double* __restrict__ stat_sum,
                                                                      double* __restrict__ stat_sq, int stat_stride, unsigned long long* __restrict__ ts) {
     KTimer kt(ts);
-    __shared__ float part[SK_NW * 16 * 64];
-    __shared__ __attribute__((aligned(16))) float stA[SK_NW * 32 * SK_SP], stW[SK_NW * 32 * SK_SP];
-    __shared__ __attribute__((aligned(16))) float sv[8 * SK_NW * SK_CH * SK_MAXCH], tv[8 * SK_NW * SK_CH * SK_MAXCH];
+    __shared__ __attribute__((aligned(16))) float stA[NW * 32 * SK_SP], stW[NW * 32 * SK_SP];
+    __shared__ __attribute__((aligned(16))) float sv[SK_KCAP], tv[SK_KCAP];
+    float* const part = stA;                                  // partial tiles reuse the operand stage: wavefront w's 4 KB inside its own 4.5 KB
+    static_assert(32 * SK_SP >= 16 * 64, "partial tile must fit the wavefront's stage");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -1562,7 +1565,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     const float* Wg = W + gr.woff[g] + (size_t)min(n0 + l31, n_out - 1) * Kp + 4 * half;   // clamped: extra columns unused
     const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are neither stored nor counted
     const int nj = Kp >> 3;
-    const int per = (nj + SK_NW - 1) / SK_NW;
+    const int per = (nj + NW - 1) / NW;
     const int j0 = wave * per, j1 = min(nj, j0 + per);        // this wavefront's k groups (wave-uniform)
 
     f32x16 acc;
@@ -1593,13 +1596,13 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
     // the operand loads above are in flight while the input layer's per-channel affine is staged in LDS
     if (x.bn.stat_sum) {                                      // the input layer's BatchNorm is finalised here (one group, zoff == 0)
         const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
-        for (int i = tid; i < x.c_in; i += 64 * SK_NW) {
+        for (int i = tid; i < x.c_in; i += 64 * NW) {
             float sc, sh;
             gad_bn_fin_channel(x.bn, i, writer, sc, sh);
             sv[i] = sc;
             tv[i] = sh;
         }
-    } else if (x.affine) stage_affine<64 * SK_NW>(sv, tv, x, zoff, x.c_in);
+    } else if (x.affine) stage_affine<64 * NW>(sv, tv, x, zoff, x.c_in);
     __syncthreads();
     for (int jb = j0; jb < j1; jb += 4) {
         if (staged(jb)) {                                     // wave-uniform
@@ -1652,13 +1655,13 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
         }
     }
 #pragma unroll
-    for (int v = 0; v < 16; ++v) part[(wave * 16 + v) * 64 + lane] = acc[v];
+    for (int v = 0; v < 16; ++v) part[wave * (32 * SK_SP) + v * 64 + lane] = acc[v];
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int w = 1; w < SK_NW; ++w)
+    for (int w = 1; w < NW; ++w)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] += part[(w * 16 + v) * 64 + lane];
+        for (int v = 0; v < 16; ++v) acc[v] += part[w * (32 * SK_SP) + v * 64 + lane];
     const int n = n0 + l31;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -1683,9 +1686,10 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_fwd_skinny_kernel(XSrc x, Gro
 }
 
 #define GAD_GX_CAP 2048           // most row tiles a tile launch spreads over workgroups (the rest by its grid-stride loop)
+static int g_opt_skinny_nw = SK_NW;    // wavefronts per skinny workgroup: 8, or 4 (A/B: a quarter of a CU's registers and < 60 KB of LDS, so a workgroup fits beside the side lanes' wide kernels)
 static int g_opt_fwd_skinny = 1, g_opt_dx_skinny = 1, g_opt_dx_stream = 1, g_opt_dw_skinny = 1, g_opt_dw_stream = 1;
 static bool fwd_skinny(const gad_gemm_fwd_args& a) {
-    return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= 8 * SK_NW * SK_CH * SK_MAXCH;
+    return g_opt_fwd_skinny && a.mode == 0 && !a.n_rows_dev && a.n_rows <= 1024 && a.Kp <= SK_KCAP;
 }
 
 
@@ -1705,6 +1709,7 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "bwd_wide_slab")) { g_opt_bwd_wide_slab = value > 0 ? value : 4; return GAD_OK; }
     if (!strcmp(name, "mfma_split")) { g_opt_mfma_split = value; return GAD_OK; }
     if (!strcmp(name, "dw_wide_wgs")) { g_opt_dw_wide_wgs = value > 0 ? value : 256; return GAD_OK; }
+    if (!strcmp(name, "skinny_nw")) { g_opt_skinny_nw = value == 4 ? 4 : SK_NW; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_stream")) { g_opt_dx_stream = value; return GAD_OK; }
@@ -1803,8 +1808,12 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
     if (!pe.key && fwd_skinny(*a)) {
         // (a NULL zout -- statistics / pooled maxima only -- is honoured by the streaming, wide-tile and 64 x 64 kernels; this one stores unguarded)
         GAD_REQUIRE(a->zout, GAD_ERR_NULL, "gemm_fwd: zout == NULL is not supported for small-M (skinny) shapes");
-        hipLaunchKernelGGL(gemm_fwd_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
-                           gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
+        if (g_opt_skinny_nw == 4)
+            hipLaunchKernelGGL(gemm_fwd_skinny_kernel<4>, dim3(gad_cdiv(nmax, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * 4), 0, st, x,
+                               gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
+        else
+            hipLaunchKernelGGL(gemm_fwd_skinny_kernel<SK_NW>, dim3(gad_cdiv(nmax, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, x,
+                               gr, rows, a->row_w, a->W, a->Kp, a->zout, a->zout_pitch, a->stat_sum, a->stat_sq, a->stat_stride, ts);
         GAD_CHECK_LAUNCH("gemm_fwd(skinny)");
         return GAD_OK;
     }
@@ -3119,11 +3128,12 @@ static bool dx_streamable(const gad_gemm_dx_args& a, bool vec) {
 // wavefronts split the reduction over the layer's output channels n.  A operand = dZ[r][8j+4h..+3] (16-byte loads of
 // z and G, BatchNorm-backward applied in registers), B operand = W[8j+4h+i][k0+lane%32]: four 4-byte loads per group
 // of 8 channels, each a fully coalesced 128-byte row segment -- no transposed weight copy needed.
-__global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Groups gr, int n_rows,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_dx_skinny_kernel(DzSrc d, Groups gr, int n_rows,
                                                                     const float* __restrict__ W, int Kp, DxEpi e, unsigned long long* __restrict__ ts) {
     KTimer kt(ts);
-    __shared__ float part[SK_NW * 16 * 64];
-    __shared__ __attribute__((aligned(16))) float stZ[SK_NW * 32 * SK_SP], stG[SK_NW * 32 * SK_SP];
+    __shared__ __attribute__((aligned(16))) float stZ[NW * 32 * SK_SP], stG[NW * 32 * SK_SP];
+    float* const part = stZ;                                  // partial tiles reuse the wavefront's own operand stage
     __shared__ __attribute__((aligned(16))) float vec[5 * VMAX];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3131,7 +3141,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     const int g = blockIdx.z;
     const int doff = gr.aoff[g], n_out = gr.nout[g], goff = gr.ooff[g];
     const int k0 = blockIdx.x * 32, row0 = blockIdx.y * 32;      // (x = column tile: see gemm_fwd_skinny_kernel)
-    for (int i = tid; i < n_out; i += 64 * SK_NW) {
+    for (int i = tid; i < n_out; i += 64 * NW) {
         vec[i] = d.scale ? d.scale[doff + i] : 1.f;
         vec[VMAX + i] = d.shift ? d.shift[doff + i] : 0.f;
         float P, Q, S;
@@ -3144,7 +3154,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
     const float* Wg = W + gr.woff[g] + k;
     const float wrow = d.row_w ? d.row_w[r] : 1.f;
     const int nj = (n_out + 7) >> 3;
-    const int per = (nj + SK_NW - 1) / SK_NW;
+    const int per = (nj + NW - 1) / NW;
     const int j0 = wave * per, j1 = min(nj, j0 + per);
 
     f32x16 acc;
@@ -3241,13 +3251,13 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dx_skinny_kernel(DzSrc d, Gro
         if (jb + 4 < j1) block(jb + 4, std::integral_constant<int, 1>{});
     }
 #pragma unroll
-    for (int v = 0; v < 16; ++v) part[(wave * 16 + v) * 64 + lane] = acc[v];
+    for (int v = 0; v < 16; ++v) part[wave * (32 * SK_SP) + v * 64 + lane] = acc[v];
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int w = 1; w < SK_NW; ++w)
+    for (int w = 1; w < NW; ++w)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] += part[(w * 16 + v) * 64 + lane];
+        for (int v = 0; v < 16; ++v) acc[v] += part[w * (32 * SK_SP) + v * 64 + lane];
     const int kk = k0 + l31;
     const bool kok = kk < e.k_valid;
     const bool stats = e.dbeta != nullptr && kok;
@@ -3365,9 +3375,13 @@ extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
     int nmax_dx = 0;
     for (int i = 0; i < a->n_groups; ++i) nmax_dx = a->n_out[i] > nmax_dx ? a->n_out[i] : nmax_dx;
     if (g_opt_dx_skinny && vec && e.mode == 0 && a->dz.gmode == 0 && !a->n_rows_dev && rows <= 1024 &&
-        nmax_dx <= 8 * SK_NW * SK_CH * SK_MAXCH && nmax_dx <= VMAX) {
-        hipLaunchKernelGGL(gemm_dx_skinny_kernel, dim3(gad_cdiv(kv, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, d, gr,
-                           rows, a->W, a->Kp, e, ts);
+        nmax_dx <= VMAX) {
+        if (g_opt_skinny_nw == 4)
+            hipLaunchKernelGGL(gemm_dx_skinny_kernel<4>, dim3(gad_cdiv(kv, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * 4), 0, st, d, gr,
+                               rows, a->W, a->Kp, e, ts);
+        else
+            hipLaunchKernelGGL(gemm_dx_skinny_kernel<SK_NW>, dim3(gad_cdiv(kv, 32), gad_cdiv(rows, 32), gr.n), dim3(64 * SK_NW), 0, st, d, gr,
+                               rows, a->W, a->Kp, e, ts);
         GAD_CHECK_LAUNCH("gemm_dx(skinny)");
         return GAD_OK;
     }
@@ -3561,10 +3575,11 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(const float* __restrict_
 // BatchNorm constants) and for the layer input (-> act(scale*z+shift), or the bias / extra column).  No LDS staging,
 // all loads of a wavefront's rows in flight before its first MFMA; partial tiles summed through LDS, then f64 atomics
 // straight into the gradient arena (no split-K workspace, no reduce launch).
-__global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSrc x, Groups gr, int n_rows, int Kp,
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_dw_skinny_kernel(DzSrc d, XSrc x, Groups gr, int n_rows, int Kp,
                                                                     int k_used, double* __restrict__ gacc, unsigned long long* __restrict__ ts) {
     KTimer kt(ts);
-    __shared__ float part[SK_NW * 16 * 64];
+    __shared__ float part[NW * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -3586,7 +3601,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSr
     const float xs = (kind == 0 && x.scale) ? x.scale[kc] : 1.f, xt = (kind == 0 && x.shift) ? x.shift[kc] : 0.f;
 
     const int units = (n_rows + 7) >> 3;
-    const int per = (units + SK_NW - 1) / SK_NW;
+    const int per = (units + NW - 1) / NW;
     const int u0 = wave * per, u1 = min(units, u0 + per);
     f32x16 acc;
 #pragma unroll
@@ -3631,7 +3646,7 @@ __global__ __launch_bounds__(64 * SK_NW) void gemm_dw_skinny_kernel(DzSrc d, XSr
     __syncthreads();
     if (wave != 0) return;
 #pragma unroll
-    for (int w = 1; w < SK_NW; ++w)
+    for (int w = 1; w < NW; ++w)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[v] += part[(w * 16 + v) * 64 + lane];
     if (k >= k_used) return;
@@ -4406,8 +4421,12 @@ extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
         d = make_dzsrc(dz2);
     }
     if (skinny_route) {
-        hipLaunchKernelGGL(gemm_dw_skinny_kernel, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
-                           gr, rows, in.Kp, k_used, a->gacc, ts);
+        if (g_opt_skinny_nw == 4)
+            hipLaunchKernelGGL(gemm_dw_skinny_kernel<4>, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * 4), 0, st, d, x,
+                               gr, rows, in.Kp, k_used, a->gacc, ts);
+        else
+            hipLaunchKernelGGL(gemm_dw_skinny_kernel<SK_NW>, dim3(gad_cdiv(nmax, 32), gad_cdiv(k_used, 32), gr.n), dim3(64 * SK_NW), 0, st, d, x,
+                               gr, rows, in.Kp, k_used, a->gacc, ts);
         GAD_CHECK_LAUNCH("gemm_dw(skinny)");
         return GAD_OK;
     }
