@@ -37,6 +37,9 @@ __device__ __forceinline__ int gad_cdiv_dev(int a, int b) { return (a + b - 1) /
 void gad_geometry_set_option(const char* name, int value, int* found);
 // the timing slot armed by gad_timing_slot() for the NEXT launch of the calling thread (NULL if none); consumed once
 unsigned long long* gad_take_timing_slot();
+// the same, carrying the wavefront issue priority gad_stream_priority() gave `stream` in bits 0..1 of the pointer (KTimer
+// strips them; the slot itself is 8-byte aligned): kernels that construct a KTimer raise their wavefronts with s_setprio
+unsigned long long* gad_take_timing_slot(void* stream);
 int gad_take_grid_rows();       // rows the caller expects to be live (0: unknown) -- sizes the grid of the next tile launch
 
 // Train-mode BatchNorm finalisation of a layer (internal argument blocks of bn_finalize_kernel / bn_bwd_coef_kernel /
@@ -114,7 +117,12 @@ __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomic
 // quantity a profiler reports as the dispatch duration, measurable inside an untraced, multi-stream run.
 struct KTimer {
     unsigned long long* p;
-    __device__ __forceinline__ explicit KTimer(unsigned long long* q) : p(nullptr) {
+    __device__ __forceinline__ explicit KTimer(unsigned long long* q0) : p(nullptr) {
+        const unsigned pr = (unsigned)(reinterpret_cast<size_t>(q0) & 3);          // workgroup-uniform (kernel argument)
+        if (pr == 1) __builtin_amdgcn_s_setprio(1);
+        else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+        else if (pr == 3) __builtin_amdgcn_s_setprio(3);
+        unsigned long long* q = reinterpret_cast<unsigned long long*>(reinterpret_cast<size_t>(q0) & ~(size_t)7);
         if (q && (threadIdx.x & 63) == 0) {
             const unsigned blk = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
             const unsigned w = blk * (blockDim.x >> 6) + (threadIdx.x >> 6);

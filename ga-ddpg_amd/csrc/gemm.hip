@@ -1772,7 +1772,7 @@ static int check_input(const gad_gemm_fwd_args& a, const char* who) {
 }
 
 extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
-    unsigned long long* ts = gad_take_timing_slot();
+    unsigned long long* ts = gad_take_timing_slot(stream);
     const int rows_hint = gad_take_grid_rows();
     GAD_REQUIRE(a && a->W && (a->zout || a->pool_key || a->stat_sum), GAD_ERR_NULL, "gemm_fwd: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_fwd: n_groups");
@@ -3302,7 +3302,7 @@ static int coef_fallback(gad_dz_src& dz, void* stream) {
 }
 
 extern "C" int gad_gemm_dx(const gad_gemm_dx_args* a, void* stream) {
-    unsigned long long* ts = gad_take_timing_slot();
+    unsigned long long* ts = gad_take_timing_slot(stream);
     const int rows_hint = gad_take_grid_rows();
     GAD_REQUIRE(a && a->W, GAD_ERR_NULL, "gemm_dx: null pointer");
     GAD_REQUIRE(a->n_groups >= 1 && a->n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_dx: n_groups");
@@ -4394,7 +4394,7 @@ static bool dw_streamable(const gad_gemm_dw_args& a, int k_used) {
 }
 
 extern "C" int gad_gemm_dw(const gad_gemm_dw_args* a, void* stream) {
-    unsigned long long* ts = gad_take_timing_slot();
+    unsigned long long* ts = gad_take_timing_slot(stream);
     GAD_REQUIRE(a && a->gacc, GAD_ERR_NULL, "gemm_dw: null pointer");
     const gad_gemm_fwd_args& in = a->in;
     GAD_REQUIRE(in.n_groups >= 1 && in.n_groups <= GAD_MAX_GROUPS, GAD_ERR_SHAPE, "gemm_dw: n_groups");
@@ -4910,7 +4910,7 @@ extern "C" int gad_gemm_bwd(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* 
     const bool vec0 = dz_vectorizable(ax->dz, ax->dz_off, ax->n_out, ax->n_groups);
     const bool streamable = bwd_streamable(ax, aw);                    // (the SA1 shapes: the streaming kernel has precedence)
     if (!streamable && bwd_wideable(*ax, *aw, vec0)) {
-        unsigned long long* ts = gad_take_timing_slot();
+        unsigned long long* ts = gad_take_timing_slot(stream);
         (void)gad_take_grid_rows();
         if (ax->n_rows <= 0) return GAD_OK;
         const int N = ax->n_out[0], splits = bwd_wide_splits(*ax);
@@ -4941,7 +4941,7 @@ extern "C" int gad_gemm_bwd(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* 
         if (int e = gad_gemm_dw(&aw2, stream)) return e;
         return gad_gemm_dx(ax, stream);
     }
-    unsigned long long* ts = gad_take_timing_slot();
+    unsigned long long* ts = gad_take_timing_slot(stream);
     (void)gad_take_grid_rows();
     GAD_REQUIRE(aw->gacc && ax->W, GAD_ERR_NULL, "gemm_bwd: null pointer");
     if (ax->n_rows <= 0) return GAD_OK;

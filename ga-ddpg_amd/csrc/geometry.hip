@@ -21,7 +21,29 @@ unsigned long long* gad_take_timing_slot() {
     return p;
 }
 
+// wavefront issue priority per stream (gaddpg.h: gad_stream_priority): a small table, written before the steps start
+static void* g_prio_stream[8];
+static int g_prio_val[8];
+static int g_prio_n = 0;
+extern "C" int gad_stream_priority(void* stream, int prio) {
+    GAD_REQUIRE(prio >= 0 && prio <= 3, GAD_ERR_SHAPE, "stream_priority: priority %d outside 0..3", prio);
+    for (int i = 0; i < g_prio_n; ++i)
+        if (g_prio_stream[i] == stream) { g_prio_val[i] = prio; return GAD_OK; }
+    if (prio == 0) return GAD_OK;
+    GAD_REQUIRE(g_prio_n < 8, GAD_ERR_SHAPE, "stream_priority: more than 8 prioritised streams");
+    g_prio_stream[g_prio_n] = stream;
+    g_prio_val[g_prio_n++] = prio;
+    return GAD_OK;
+}
+unsigned long long* gad_take_timing_slot(void* stream) {
+    size_t v = reinterpret_cast<size_t>(gad_take_timing_slot());
+    for (int i = 0; i < g_prio_n; ++i)
+        if (g_prio_stream[i] == stream) v |= (size_t)g_prio_val[i];
+    return reinterpret_cast<unsigned long long*>(v);
+}
+
 extern "C" int gad_timing_slot(void* slot) {
+    GAD_REQUIRE((reinterpret_cast<size_t>(slot) & 7) == 0, GAD_ERR_SHAPE, "timing_slot: the slot must be 8-byte aligned");
     g_timing_slot = static_cast<unsigned long long*>(slot);
     return GAD_OK;
 }
@@ -51,7 +73,7 @@ void gad_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gad_last_error(void) { return g_err; }
-extern "C" int gad_abi_version(void) { return 9; }
+extern "C" int gad_abi_version(void) { return 10; }
 
 const char* g_gad_last_kernel = "";
 extern "C" const char* gad_last_kernel(void) { return g_gad_last_kernel; }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void segment_pool_kernel(const float* __restri
 
 extern "C" int gad_segment_pool(const float* z, int z_pitch, int C, const float* scale, const float* shift,
                                 const int32_t* grp_off, int G, float* out, int32_t* argmax, void* stream) {
-    unsigned long long* ts = gad_take_timing_slot();
+    unsigned long long* ts = gad_take_timing_slot(stream);
     GAD_REQUIRE(z && grp_off && out, GAD_ERR_NULL, "segment_pool: null pointer");
     GAD_REQUIRE((scale == nullptr) == (shift == nullptr), GAD_ERR_NULL, "segment_pool: scale and shift come together");
     GAD_REQUIRE(z_pitch % 4 == 0, GAD_ERR_SHAPE, "segment_pool: row pitch %d must be a multiple of 4", z_pitch);

@@ -534,6 +534,29 @@ def side_stream(device=None, which=0):
     return _SIDE[key]
 
 
+# Wavefront issue priority per lane (include/gaddpg.h: gad_stream_priority): "main:3,B:1" raises the GEMM-family launches of the
+# caller's stream (the TD-target / critic chain the step waits for) and of the actor lane above the weight-gradient lanes'
+# wavefronts they share SIMDs with.  s_setprio inside the kernels: no stream priority, the four-queue mapping is untouched.
+LANE_PRIO = _os.environ.get("GAD_LANE_PRIO", "")
+_PRIO_DONE = set()
+
+
+def apply_lane_priorities(main):
+    """once per caller's stream: hand the GAD_LANE_PRIO table to the library"""
+    if not LANE_PRIO or SERIAL:
+        return
+    dev = main.device.index
+    key = (dev, int(main.cuda_stream))
+    if key in _PRIO_DONE:
+        return
+    _PRIO_DONE.add(key)
+    from . import hip
+    for kv in LANE_PRIO.split(","):
+        name, pr = kv.split(":")
+        st = main if name == "main" else side_stream(dev, {"A": 1, "B": 2, "C": 3}[name])
+        hip.check(hip.lib().gad_stream_priority(hip.C.c_void_p(int(st.cuda_stream)), int(pr)), "gad_stream_priority")
+
+
 CONCURRENT_DW = _os.environ.get("GAD_CONCURRENT_DW", "1") == "1"      # fork dW GEMMs onto side streams (they feed nothing but the optimiser)
 FUSED_SA1_BWD = _os.environ.get("GAD_FUSED_SA1_BWD", "1") == "1"     # SA1 l3 / l2 backward: dX + dW in one kernel (gad_gemm_bwd)
 RECOMP_SA1 = _os.environ.get("GAD_RECOMP_SA1", "0") == "1"   # SA1 layer 2 recomputes layer 1's output from the gathered rows (gad_gemm_fwd mode 2); layer 1 stores nothing in a pass that is never

@@ -107,7 +107,7 @@ def lib():
 
 
 EXPORTS = (
-    "gad_abi_version", "gad_last_kernel", "gad_last_error", "gad_set_option", "gad_timing_slot", "gad_wall_clock_khz", "gad_grid_rows_hint", "gad_bn_running_update", "gad_replay_gather", "gad_zero_buffers", "gad_furthest_point_sampling", "gad_gather_points",
+    "gad_abi_version", "gad_last_kernel", "gad_last_error", "gad_set_option", "gad_timing_slot", "gad_stream_priority", "gad_wall_clock_khz", "gad_grid_rows_hint", "gad_bn_running_update", "gad_replay_gather", "gad_zero_buffers", "gad_furthest_point_sampling", "gad_gather_points",
     "gad_gather_points_grad", "gad_ball_query", "gad_group_points", "gad_group_points_grad",
     "gad_query_and_group", "gad_prep_points", "gad_rows_from_ball_query", "gad_rows_group_all",
     "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_pool_finalize", "gad_affine_act", "gad_transpose_batched",

@@ -605,6 +605,7 @@ class FusedRuntime(object):
 
         if OVERLAP_PASSES:
             s1, s2, sc = engine.side_stream(which=1), engine.side_stream(which=2), engine.side_stream(which=3)
+            engine.apply_lane_priorities(main)
             # the side streams share weights and activation scratch with the previous step: they start after it (ev[0] on the
             # main stream, which every stream of that step was joined into) and after their inputs on the prefetch stream
             self._ev[0].record(main)

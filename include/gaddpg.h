@@ -46,7 +46,7 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * and gad_dz_src (bn_*, gacc_*), GAD_STAT_REPLICAS 8 -> 4;
                                             * 8: split-bf16 weight mirrors (gad_split_weights; W_split* of gad_gemm_fwd_args,
                                             * W_split_t* of gad_gemm_dx_args), option "mfma_split" as a family mask;
-                                            * 9: gad_transpose_batched)                                               */
+                                            * 9: gad_transpose_batched; 10: gad_stream_priority)                      */
 /* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
  * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
  * with it instead of restating the routing rules.                                                  */
@@ -79,6 +79,13 @@ int gad_set_option(const char* name, int value);
  * tracing and regardless of what other streams do.  Wavefronts beyond GAD_TIMING_WAVES are not recorded.  NULL disarms. */
 #define GAD_TIMING_WAVES 16384
 int gad_timing_slot(void* slot);
+/* Wavefront issue priority of the launches a stream carries (ABI 10).  prio 0..3 (0 = the hardware default; 0 also removes the
+ * stream from the table, 8 entries): gad_gemm_fwd / _dx / _dw / _bwd / gad_segment_pool launches on `stream` raise their
+ * wavefronts with s_setprio at their first instruction, so that where they share a SIMD with the wavefronts of launches on
+ * other streams (the step's weight-gradient lanes, the next step's prefetch) the arbiter issues theirs first.  This is per
+ * wavefront, inside the CU -- unlike a HIP stream priority it does not change the queue mapping.  Numerics unaffected.
+ * Process-wide; call it before the steps start (not thread-safe against concurrent launches).                              */
+int gad_stream_priority(void* stream, int prio);
 int gad_wall_clock_khz(void);              /* rate of that clock (hipDeviceAttributeWallClockRate), 0 if unavailable    */
 
 /* Grid-size hint: the layers of SA1 / SA2 run over de-duplicated rows whose count lives on the device (n_rows_dev); the host

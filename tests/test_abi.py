@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), "libgaddpg.so does not export " + n
     assert set(names) == set(hip.EXPORTS), set(names) ^ set(hip.EXPORTS)
-    assert L.gad_abi_version() == 9
+    assert L.gad_abi_version() == 10
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -78,3 +78,11 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert L.gad_replay_gather(C.byref(g), null) < 0
     with pytest.raises(RuntimeError, match="gad_gemm_dx failed"):
         hip.check(L.gad_gemm_dx(C.byref(hip.GemmDxArgs()), null), "gad_gemm_dx")
+    # per-stream wavefront priority (ABI 10): a table entry, no launch -- range-checked, removable; the timing slot must be 8-byte
+    # aligned because the priority rides in the low bits of the pointer the kernels receive
+    st = C.c_void_p(0x1230)
+    assert L.gad_stream_priority(st, 7) < 0 and b"priority" in L.gad_last_error()
+    assert L.gad_stream_priority(st, 2) == 0 and L.gad_stream_priority(st, 0) == 0
+    assert L.gad_timing_slot(C.c_void_p(0x1004)) < 0 and b"aligned" in L.gad_last_error()
+    assert L.gad_timing_slot(null) == 0
+    assert L.gad_set_option(b"skinny_nw", 4) == 0 and L.gad_set_option(b"skinny_nw", 8) == 0
