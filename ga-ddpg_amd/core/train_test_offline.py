@@ -58,22 +58,44 @@ def device_replay_fits(memory, reserve=0.5):
     return need < reserve * free
 
 
+def _write_stamp(memory):
+    """changes whenever a transition was written since the stamp was taken (push / add_episode / load)"""
+    return (int(memory.cur_idx), bool(memory.is_full), int(memory.total_env_step))
+
+
+def device_mirror(memory):
+    """the HBM mirror of `memory`, built ONCE per memory object and kept on it (a caller that alternates
+    train_off_policy with buffer writes must neither re-allocate GBs per call nor train on a stale snapshot): a later call
+    re-uploads only when the buffer was written in between (everything up to upper_idx(): writes wrap around)."""
+    from .device_replay import DeviceReplay
+    ent = getattr(memory, "_gad_device_mirror", None)
+    stamp = _write_stamp(memory)
+    if ent is None or ent[0].cap != memory.point_state.shape[0]:
+        ent = [DeviceReplay(memory), stamp]
+        memory._gad_device_mirror = ent
+    elif ent[1] != stamp:
+        ent[0].refresh(0, memory.upper_idx())
+        ent[1] = stamp
+    return ent[0]
+
+
 def train_off_policy(agent, memory, config, model_output_dir=None, save_model=False, log=None, max_epochs=None,
-                     sample=None, run_ahead=False, device_replay="auto"):
+                     sample=None, run_ahead=False, device_replay="auto", rng=None):
     """The reference's train_off_policy() (:107-161) over an agent and a filled replay memory.
     config = cfg.RL_TRAIN (updates_per_step, batch_size, save_epoch, max_epoch).  `sample(batch_size)` overrides
     memory.sample (device-resident replay, prefetching samplers).  Returns the per-key loss history (deques, as the
     reference keeps them) and the number of epochs run.
     run_ahead: enqueue the `updates_per_step` updates of an epoch without waiting for each (update_parameters(sync=False));
-    their losses are read at the end of the epoch, the host samples / stages the next minibatch while the GPU works."""
+    their losses are read at the end of the epoch, the host samples / stages the next minibatch while the GPU works.
+    rng: a numpy Generator / RandomState for the minibatch indices of the mirrored path (default: the global np.random
+    stream, which is what the reference's memory.sample draws from)."""
     losses = get_loss_info_dict()
     if sample is None and device_replay and (device_replay is True or device_replay_fits(memory)) and hasattr(agent, "runtime"):
         # default feeding path (VERDICT r03 item 8): the buffer mirrored in HBM, indices drawn on the host with the
         # reference's arithmetic and random stream (np.random, as memory.sample uses), ONE gather launch per minibatch --
         # the only feeding path that keeps up with a 3 ms update step (bench.py: value_device_replay vs value_host_inclusive)
-        from .device_replay import DeviceReplay
-        dmem = DeviceReplay(memory)
-        sample = lambda batch_size: dmem.sample_lazy(batch_size)                 # noqa: E731
+        dmem = device_mirror(memory)
+        sample = lambda batch_size: dmem.sample_lazy(batch_size, rng=rng)        # noqa: E731
         if log is not None:
             log("replay buffer mirrored in HBM (%d transitions); device_replay=False keeps the host sampling path" % len(memory))
     sample = sample or memory.sample

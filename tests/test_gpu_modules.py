@@ -339,3 +339,31 @@ def test_checkpoints_have_the_reference_writers_structure(tmp_path, golden_dir):
     st = a2.policy_optim.state_dict()["state"]
     ref_st = objs["DDPG_actor_PandaYCBEnv_latest"]["opt"]["state"]
     assert set(st) == set(ref_st) and all(torch.equal(st[i]["exp_avg"].cpu(), ref_st[i]["exp_avg"]) for i in st)
+
+
+def test_device_mirror_is_built_once_and_follows_writes():
+    """train_off_policy's default feeding path keeps ONE HBM mirror per memory object (no re-allocation per call) and
+    re-uploads it when the buffer was written in between, so a caller alternating training and data collection never trains on a
+    stale snapshot; the rng hook draws the same indices as BaseMemory.sample with that generator."""
+    from ga_ddpg_amd.api import make_agent
+    from ga_ddpg_amd.core import train_test_offline as tto
+    from ga_ddpg_amd.core.replay_memory import BaseMemory
+    from ga_ddpg_amd.synth_data import fill_synthetic_buffer
+    _, cfg = make_agent("ddpg_td3_aux.yaml")
+    mem = BaseMemory(300, cfg, point_dtype=np.float32)
+    fill_synthetic_buffer(mem, 200, seed=9)
+    d1 = tto.device_mirror(mem)
+    ptr = d1.point_state.data_ptr()
+    assert tto.device_mirror(mem) is d1 and d1.point_state.data_ptr() == ptr
+    lo = mem.upper_idx()
+    fill_synthetic_buffer(mem, 240, seed=10)                  # the collector wrote: 240 (different) transitions now
+    assert mem.upper_idx() > lo
+    d2 = tto.device_mirror(mem)
+    assert d2 is d1 and d2.point_state.data_ptr() == ptr      # same allocation, refreshed
+    hi = mem.upper_idx()
+    np.testing.assert_array_equal(d2.point_state[:hi].cpu().numpy(), np.asarray(mem.point_state[:hi], dtype=np.float32))
+    np.testing.assert_array_equal(d2.timestep[:hi].cpu().numpy(), np.asarray(mem.timestep[:hi], dtype=np.float32))
+    a = d2.sample_lazy(16, rng=np.random.default_rng(4))
+    b = mem.draw_indices(16, np.random.default_rng(4))
+    np.testing.assert_array_equal(a["idx"].cpu().numpy(), b)
+    d2.release(a)
