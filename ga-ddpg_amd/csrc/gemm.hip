@@ -895,7 +895,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
             psgn[1] = pe.gamma[n0 + 64 + lane] < 0.f ? -1.f : 1.f;
         }
         // rows past the live count are clamped to the last live row (never stored, weight 0 in the statistics)
-        const int ra0 = min(row0 + ur, n_rows - 1), ra1 = min(row0 + ur + 32, n_rows - 1);
+        const int ra0 = min(row0 + ur, max(n_rows - 1, 0)), ra1 = min(row0 + ur + 32, max(n_rows - 1, 0));
         const int va0 = ((XM == 0 ? ra0 * x.zin_pitch : x.row_pt[ra0] * x.feat_c) + c4) * 4;
         const int va1 = ((XM == 0 ? ra1 * x.zin_pitch : x.row_pt[ra1] * x.feat_c) + c4) * 4;
         // two register sets: the global loads of a K-tile are issued TWO tiles before its LDS write (one tile of MFMAs is
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
             const int r = row0 + tid;
             wS[tid] = r < n_rows ? (row_w ? row_w[r] : 1.f) : 0.f;
             if (XM == 1) {                               // the row's recentred coordinates (rounded as the oracle rounds them)
-                const int rr = min(r, n_rows - 1);
+                const int rr = min(r, max(n_rows - 1, 0));
                 const float* p = x.src_xyz + (size_t)x.row_pt[rr] * 3;
                 float q0 = p[0], q1 = p[1], q2 = p[2];
                 if (x.ctr_xyz) {
@@ -1219,11 +1219,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fwd_stream_kernel(XSrc x, const i
     }
     int pt_nxt = 0;
     auto load_pt = [&](int sl) {          // point index of the lane's row in slab sl (gather input only)
-        const int r = min(sl * 32 + l31, n_rows - 1);
+        const int r = min(sl * 32 + l31, max(n_rows - 1, 0));
         return (GATHER && sl < n_slabs) ? x.row_pt[r] : 0;
     };
     auto load_slab = [&](int sl, int pt, XRaw (&dst)[NG]) {
-        const int r = min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1);      // clamped: ragged rows repeat the last row
+        const int r = min(sl < n_slabs ? sl * 32 + l31 : 0, max(n_rows - 1, 0));      // clamped: ragged rows repeat the last row
         if (GATHER) {
             // SA1's gathered rows [f (4) | x_j - c_i (3) | action (0 / 6)]: everything a row needs in FIVE loads (features,
             // point, centre as 12-byte loads, action as two), then each (k group, half) picks its four columns.  x_raw per
@@ -1563,7 +1563,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fwd_skinny_kernel(XSrc x, Groups
     const int n0 = blockIdx.x * 32, row0 = blockIdx.y * 32;
     if (n0 >= n_out) return;                                  // workgroup-uniform
     const float* Wg = W + gr.woff[g] + (size_t)min(n0 + l31, n_out - 1) * Kp + 4 * half;   // clamped: extra columns unused
-    const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are neither stored nor counted
+    const int r = min(row0 + l31, max(n_rows - 1, 0));                // clamped: extra rows are neither stored nor counted
     const int nj = Kp >> 3;
     const int per = (nj + NW - 1) / NW;
     const int j0 = wave * per, j1 = min(nj, j0 + per);        // this wavefront's k groups (wave-uniform)
@@ -1583,7 +1583,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_fwd_skinny_kernel(XSrc x, Groups
     const float* pw[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        pa[i] = x.zin + (size_t)min(row0 + rsub + 8 * i, n_rows - 1) * x.zin_pitch + zoff + 4 * chunk;
+        pa[i] = x.zin + (size_t)min(row0 + rsub + 8 * i, max(n_rows - 1, 0)) * x.zin_pitch + zoff + 4 * chunk;
         pw[i] = W + gr.woff[g] + (size_t)min(n0 + rsub + 8 * i, n_out - 1) * Kp + 4 * chunk;
     }
     auto staged = [&](int jb) { return jb + 4 <= j1 && 8 * (jb + 4) <= x.c_in; };       // wave-uniform
@@ -2101,7 +2101,7 @@ __global__ __launch_bounds__(512, 2) void gemm_dx_stream_kernel(DzSrc d, const i
     float sb[2] = {0.f, 0.f}, sg[2] = {0.f, 0.f};
     float4 rz[2][4], rg[2][4];
     int4 ra[2][4];
-    auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+    auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, max(n_rows - 1, 0)); };
     auto load_chunk = [&](int r, int grp, int c, int buf) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -2293,7 +2293,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_kernel(DzSrc d, const 
         constexpr int NU = NO / 8, RING = 8, AHEAD = RING - 1;
         float4 rz[RING], rg[RING];
         int4 ra[RING];
-        auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+        auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, max(n_rows - 1, 0)); };
         auto load_u = [&](int r, int grp, int uu, int buf) {
             const unsigned n = 8 * uu + 4 * half;
             rz[buf] = ldg4(d.z + ((unsigned)r * NO + n));
@@ -2553,7 +2553,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bwd_stream_split_kernel(DzSrc d, 
         static_assert(NU % RING == 0 && NU % RINGG == 0, "a slab's entries must fill the rings a whole number of times");
         float4 rz[RING], rg[RINGG];
         int4 ra[RINGG];
-        auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, n_rows - 1); };
+        auto row_of = [&](int sl) { return min(sl < n_slabs ? sl * 32 + l31 : 0, max(n_rows - 1, 0)); };
         auto load_z = [&](int r, int uu) {
             const unsigned n = 16 * (uu >> 1) + 8 * half + 4 * (uu & 1);
             rz[uu % RING] = ldg4(d.z + ((unsigned)r * NO + n));
@@ -2875,7 +2875,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
         for (int u = 0; u < 2; ++u) {
             const int r = row0 + ur + 32 * u;
             live[u] = r < n_rows;
-            const int rr = live[u] ? r : n_rows - 1;
+            const int rr = live[u] ? r : max(n_rows - 1, 0);
             wrow[u] = d.row_w ? d.row_w[rr] : 1.f;
             vz[u] = (rr * d.z_pitch + c4) * 4;
             vg[u] = ((GM == 1 ? d.row_grp[rr] : rr) * gpitch + c4) * 4;
@@ -2924,7 +2924,7 @@ __global__ __launch_bounds__(256, 2) void gemm_dx_wide_kernel(DzSrc d, const int
         };
         load_regs(0);
         __syncthreads();                                 // vP visible; the previous row tile's LDS reads are done
-        if (SC && tid < BM) ptS[tid] = e.row_pt[min(row0 + tid, n_rows - 1)];     // (read after the K loop's barriers)
+        if (SC && tid < BM) ptS[tid] = e.row_pt[min(row0 + tid, max(n_rows - 1, 0))];     // (read after the K loop's barriers)
         write_lds(0);
         if (nk > 1) load_regs(1);
         __syncthreads();
@@ -3149,7 +3149,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dx_skinny_kernel(DzSrc d, Groups
         vec[2 * VMAX + i] = P; vec[3 * VMAX + i] = Q; vec[4 * VMAX + i] = S;
     }
     __syncthreads();
-    const int r = min(row0 + l31, n_rows - 1);                // clamped: extra rows are not stored
+    const int r = min(row0 + l31, max(n_rows - 1, 0));                // clamped: extra rows are not stored
     const int k = min(k0 + l31, Kp - 1);
     const float* Wg = W + gr.woff[g] + k;
     const float wrow = d.row_w ? d.row_w[r] : 1.f;
@@ -3169,7 +3169,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dx_skinny_kernel(DzSrc d, Groups
     const float* pg[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const size_t rr = (size_t)min(row0 + rsub + 8 * i, n_rows - 1);
+        const size_t rr = (size_t)min(row0 + rsub + 8 * i, max(n_rows - 1, 0));
         pz[i] = d.z ? d.z + rr * d.z_pitch + doff + 4 * chunk : nullptr;
         pg[i] = d.G + rr * d.g_pitch + doff + 4 * chunk;
     }
@@ -3614,7 +3614,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_dw_skinny_kernel(DzSrc d, XSrc x
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 8 * (c0 + u) + 4 * half + i;
-                const int rr = min(r, n_rows - 1);
+                const int rr = min(r, max(n_rows - 1, 0));
                 rz[u][i] = d.z ? d.z[(size_t)rr * d.z_pitch + ch] : 0.f;
                 rg[u][i] = d.G[(size_t)rr * d.g_pitch + ch];
                 rw[u][i] = d.row_w ? d.row_w[rr] : 1.f;
@@ -4639,7 +4639,7 @@ __global__ __launch_bounds__(256, NIT >= 8 ? 1 : 2) void gemm_bwd_wide_kernel(Dz
         for (int u = 0; u < 4; ++u) {
             const int r = row0 + sr + 16 * u;
             const bool live = r < n_rows;
-            const int rr = live ? r : n_rows - 1;
+            const int rr = live ? r : max(n_rows - 1, 0);
             const float w = d.row_w ? d.row_w[rr] : 1.f;
             wrow[u] = live ? w : 0.f;
             vz[u] = (r * d.z_pitch + c4) * 4;             // (the true row: past the live rows the bounded descriptor reads 0)
@@ -4660,7 +4660,7 @@ __global__ __launch_bounds__(256, NIT >= 8 ? 1 : 2) void gemm_bwd_wide_kernel(Dz
         const int row0 = tile << 6;
         __syncthreads();                                  // vP visible; the previous tile's LDS reads (As, Ws, ptS, relS) are done
         if (L1 && tid < 64) {
-            const int r = min(row0 + tid, n_rows - 1);
+            const int r = min(row0 + tid, max(n_rows - 1, 0));
             const int p = x.row_pt[r];
             ptS[tid] = p;
             const float* q = x.src_xyz + (size_t)p * 3;

@@ -365,5 +365,6 @@ def test_device_mirror_is_built_once_and_follows_writes():
     np.testing.assert_array_equal(d2.timestep[:hi].cpu().numpy(), np.asarray(mem.timestep[:hi], dtype=np.float32))
     a = d2.sample_lazy(16, rng=np.random.default_rng(4))
     b = mem.draw_indices(16, np.random.default_rng(4))
+    a["ready_event"].synchronize()                            # the index upload rides a stream of its own
     np.testing.assert_array_equal(a["idx"].cpu().numpy(), b)
     d2.release(a)
