@@ -1694,11 +1694,13 @@ static bool fwd_skinny(const gad_gemm_fwd_args& a) {
 
 
 static int g_opt_fwd_stream = 1;
+static int g_opt_fwd_stream_wgs = 256;         // persistent workgroups of the streaming forward's layers 2 / 3 (A/B: fewer leave CUs to the sibling pass's small launches)
 static int g_opt_fwd_stream_l1_wgs = 256;      // persistent workgroups of the streaming forward's gathered first layer (A/B: 512 = two per CU)
 
 extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
+    if (!strcmp(name, "fwd_stream_wgs")) { g_opt_fwd_stream_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_stream_l1_wgs")) { g_opt_fwd_stream_l1_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_wide")) { g_opt_fwd_wide = value; return GAD_OK; }
     if (!strcmp(name, "dx_wide")) { g_opt_dx_wide = value; return GAD_OK; }
@@ -1830,7 +1832,7 @@ extern "C" int gad_gemm_fwd(const gad_gemm_fwd_args* a, void* stream) {
         const int slabs = gad_cdiv(rows, 32);
         // one 8-wavefront workgroup per CU; the gathered first layer (K <= 16: ~100 registers, latency-bound on its five dependent
         // loads per row) may run more (option "fwd_stream_l1_wgs")
-        const int gcap = a->mode == 1 ? g_opt_fwd_stream_l1_wgs : 256;
+        const int gcap = a->mode == 1 ? g_opt_fwd_stream_l1_wgs : g_opt_fwd_stream_wgs;
         int gx = gad_cdiv(slabs, 8); if (gx > gcap) gx = gcap;
 #define LAUNCH_STREAM(KJ, TN, XM, POOL, ...)                                                               \
         hipLaunchKernelGGL((gemm_fwd_stream_kernel<KJ, TN, XM, POOL, ##__VA_ARGS__>), dim3(gx), dim3(512), 0, st, x, a->n_rows_dev, rows, \
