@@ -1694,12 +1694,15 @@ static bool fwd_skinny(const gad_gemm_fwd_args& a) {
 
 
 static int g_opt_fwd_stream = 1;
+#define DW_STREAM_SPLITS 256
+static int g_opt_bwd_stream_wgs = DW_STREAM_SPLITS;   // persistent workgroups (= partial dW blocks) of the fused SA1 backward: A/B, <= DW_STREAM_SPLITS
 static int g_opt_fwd_stream_wgs = 256;         // persistent workgroups of the streaming forward's layers 2 / 3 (A/B: fewer leave CUs to the sibling pass's small launches)
 static int g_opt_fwd_stream_l1_wgs = 256;      // persistent workgroups of the streaming forward's gathered first layer (A/B: 512 = two per CU)
 
 extern "C" int gad_set_option(const char* name, int value) {
     GAD_REQUIRE(name, GAD_ERR_NULL, "set_option: null name");
     if (!strcmp(name, "fwd_stream")) { g_opt_fwd_stream = value; return GAD_OK; }
+    if (!strcmp(name, "bwd_stream_wgs")) { g_opt_bwd_stream_wgs = (value > 0 && value <= DW_STREAM_SPLITS) ? value : DW_STREAM_SPLITS; return GAD_OK; }
     if (!strcmp(name, "fwd_stream_wgs")) { g_opt_fwd_stream_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_stream_l1_wgs")) { g_opt_fwd_stream_l1_wgs = value > 0 ? value : 256; return GAD_OK; }
     if (!strcmp(name, "fwd_wide")) { g_opt_fwd_wide = value; return GAD_OK; }
@@ -4382,7 +4385,6 @@ static bool dw_gather_streamable(const gad_gemm_dw_args& a, int k_used) {
     return a.row_splits <= 0;
 }
 
-#define DW_STREAM_SPLITS 256
 static bool dw_streamable(const gad_gemm_dw_args& a, int k_used) {
     const gad_gemm_fwd_args& in = a.in;
     const gad_dz_src& d = a.dz;
@@ -4895,7 +4897,7 @@ extern "C" int gad_gemm_dw_reduce(const gad_gemm_dx_args* ax, const gad_gemm_dw_
         return GAD_OK;
     }
     if (streamable) {
-        const int wgs = DW_STREAM_SPLITS;
+        const int wgs = g_opt_bwd_stream_wgs;
         const int splits = ax->n_out[0] == 64 ? 2 * wgs : wgs;
         Groups gr = make_groups(1, aw->dz_off, in.w_off, in.zin_off, in.n_out);
         hipLaunchKernelGGL(dw_reduce_kernel, dim3(gad_cdiv((long long)in.n_out[0] * 64, 256), gad_cdiv(splits, DW_RED_CHUNK), 1), dim3(256), 0, st,
@@ -4955,7 +4957,7 @@ extern "C" int gad_gemm_bwd(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* 
     e.stat_stride = ax->stat_stride; e.store_masked = 1;
     e.dfeat = nullptr; e.feat_c = 0; e.row_pt = nullptr; e.row_grp = nullptr; e.daction = nullptr; e.act_c = 0; e.gps = 1;
     hipStream_t st = (hipStream_t)stream;
-    const int rows = ax->n_rows, wgs = DW_STREAM_SPLITS;
+    const int rows = ax->n_rows, wgs = g_opt_bwd_stream_wgs;
     const int splits = ax->n_out[0] == 64 ? 2 * wgs : wgs;            // partial dW blocks the kernel writes (see its header)
     GAD_REQUIRE((long long)splits * in.n_out[0] * 64 <= aw->partial_elems, GAD_ERR_SHAPE, "gemm_bwd: partial workspace too small");
     if (split_on(GAD_SPLIT_BWD_STREAM) && ax->W_split_t && ax->W_split_t_pitch == ax->n_out[0] && ax->W_split_t_plane >= 64 * ax->n_out[0]) {

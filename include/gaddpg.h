@@ -56,7 +56,8 @@ const char* gad_last_error(void);          /* thread-local description of the la
  * shallow SA1 forward layers to the streaming kernel instead of the tiled one; "dx_stream" [1]: the same for their dX; "fwd_skinny" / "dx_skinny" / "dw_skinny" [1]: route
  * the small-M (<= 1024 rows) forward / dX / dW layers to the split-K kernels; "skinny_nw" [8]: wavefronts per workgroup of
  * those kernels (8, or 4 = the small-footprint instantiation: A/B in profiles/r05_skinny_footprint.txt); "fwd_stream_wgs" [256] /
- * "fwd_stream_l1_wgs" [256]: persistent workgroups of the streaming forward (SA1 layers 2 / 3; the gathered layer 1).  Returns GAD_ERR_SHAPE for an
+ * "fwd_stream_l1_wgs" [256] / "bwd_stream_wgs" [256]: persistent workgroups of the streaming forward (SA1 layers 2 / 3; the gathered
+ * layer 1) and of the fused SA1 backward (= its partial dW blocks).  Returns GAD_ERR_SHAPE for an
  * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.
  * "mfma_split" [1 = GAD_SPLIT_ALL since round 5, when its accuracy gates were green on hardware: DESIGN.md]: the arithmetic of the
  * layer GEMMs' products.
