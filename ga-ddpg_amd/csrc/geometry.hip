@@ -73,7 +73,7 @@ void gad_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 extern "C" const char* gad_last_error(void) { return g_err; }
-extern "C" int gad_abi_version(void) { return 10; }
+extern "C" int gad_abi_version(void) { return 11; }
 
 const char* g_gad_last_kernel = "";
 extern "C" const char* gad_last_kernel(void) { return g_gad_last_kernel; }

@@ -459,6 +459,56 @@ extern "C" int gad_zero_buffers(void* p0, long long n0, void* p1, long long n1, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// one launch copies up to GAD_COPY_MAX_SEGS device buffers (gaddpg.h: gad_copy_buffers): a device-resident minibatch adopted
+// into the step's static input buffers used to be one runtime copy dispatch per key (23 copyBuffer dispatches per step)
+// ------------------------------------------------------------------------------------------------
+struct CopySegs { gad_copy_seg s[GAD_COPY_MAX_SEGS]; };
+
+__global__ __launch_bounds__(256) void copy_buffers_kernel(CopySegs z) {
+    const gad_copy_seg sg = z.s[blockIdx.y];
+    char* dst = static_cast<char*>(sg.dst);
+    const char* src = static_cast<const char*>(sg.src);
+    const long long bytes = sg.bytes;
+    if (!dst || !src || bytes <= 0) return;
+    const long long stride = (long long)gridDim.x * 256;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool al16 = ((reinterpret_cast<size_t>(dst) | reinterpret_cast<size_t>(src)) & 15) == 0;
+    const long long body = al16 ? bytes / 16 : 0;
+    if (sg.add == 0.f) {
+        const float4* s16 = reinterpret_cast<const float4*>(src);
+        float4* d16 = reinterpret_cast<float4*>(dst);
+        for (long long i = t; i < body; i += stride) d16[i] = s16[i];
+        for (long long i = body * 4 + t; i < bytes / 4; i += stride)
+            reinterpret_cast<float*>(dst)[i] = reinterpret_cast<const float*>(src)[i];
+    } else {
+        for (long long i = t; i < bytes / 4; i += stride)
+            reinterpret_cast<float*>(dst)[i] = reinterpret_cast<const float*>(src)[i] + sg.add;
+    }
+}
+
+extern "C" int gad_copy_buffers(const gad_copy_seg* host_segs, int n_segs, void* stream) {
+    GAD_REQUIRE(host_segs || n_segs == 0, GAD_ERR_NULL, "copy_buffers: NULL segment table");
+    GAD_REQUIRE(n_segs >= 0 && n_segs <= GAD_COPY_MAX_SEGS, GAD_ERR_SHAPE, "copy_buffers: %d segments (at most %d)", n_segs,
+                GAD_COPY_MAX_SEGS);
+    CopySegs z = {};
+    long long nmax = 0;
+    for (int i = 0; i < n_segs; ++i) {
+        const gad_copy_seg& g = host_segs[i];
+        GAD_REQUIRE(g.bytes >= 0 && g.bytes % 4 == 0, GAD_ERR_SHAPE, "copy_buffers: byte count of segment %d must be a non-negative multiple of 4", i);
+        GAD_REQUIRE(((reinterpret_cast<size_t>(g.dst) | reinterpret_cast<size_t>(g.src)) & 3) == 0, GAD_ERR_SHAPE,
+                    "copy_buffers: segment %d is not 4-byte aligned", i);
+        z.s[i] = g;
+        if (g.dst && g.src && g.bytes > nmax) nmax = g.bytes;
+    }
+    if (nmax == 0) return GAD_OK;
+    long long blocks = (nmax / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
+    hipLaunchKernelGGL(copy_buffers_kernel, dim3((unsigned)blocks, n_segs), dim3(256), 0, (hipStream_t)stream, z);
+    GAD_CHECK_LAUNCH("copy_buffers");
+    return GAD_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // split-bf16 mirrors of packed weight matrices (include/gaddpg.h: gad_split_weights).  One thread per (row n, column pair
 // k, k + 1): hi / mid / lo by round-to-nearest-even conversions of the exact residuals, forward mirror as packed pairs
 // (coalesced 4-byte stores), transposed mirror as 2-byte stores (the matrices are a few hundred KB: the launch is ~4 us).

@@ -573,35 +573,177 @@ DW_REDUCE_LATER = -2                     # include/gaddpg.h GAD_DW_REDUCE_LATER
 DW_LANES = 1              # number of dW side streams (2 measured no faster: the overlapped kernels already saturate the GPU) the layers alternate between (each with its own partial workspace)
 
 
-class Plan(object):
-    """A recorded sequence of C-ABI calls over static buffers.  Calls marked `side` run on the auxiliary stream
-    between a fork (side waits for everything recorded so far on the main stream) and the next join (main waits
-    for the side stream) -- used for the weight-gradient GEMMs, which are off the dX critical path."""
+USE_C_PLANS = _os.environ.get("GAD_PLAN_C", "1") == "1"     # replay plans through gad_plan_run (one foreign call per plan segment);
+                                                            # 0: the item-by-item Python walk (the same launches in the same order)
+_ROUTES = hip.ROUTES       # tag -> kernel family (gad_last_kernel), learnt by the Python walk; cleared when a library option changes
+
+
+class _Item(object):
+    """one entry of a Plan: kind in {"call", "wait", "record", "wait_event", "zero", "memcpy", "py"}; `on` = the logical stream
+    (0 = the stream that is current when the plan runs, else a side_stream `which`)"""
+    __slots__ = ("kind", "on", "name", "f", "argv", "words", "kinds", "on2", "event", "holder", "tensor", "tag", "cpos", "clones")
+
+    def __init__(self, kind, on=0):
+        self.kind, self.on = kind, on
+        self.name = self.f = self.argv = self.words = self.kinds = self.on2 = self.event = self.holder = self.tensor = self.tag = None
+        self.cpos = []         # [(compiled plan, item index)]: where this item sits in gad_plans (an item may be shared by plans)
+        self.clones = []       # copies made by Plan.extend(on=...): a patch of this item reaches them too
+
+
+class EventHolder(object):
+    """a hipEvent_t that both the host language (torch.cuda.Event) and a replayed plan can record / wait for: the torch event is
+    recorded once at construction, which makes torch create the raw handle the plan items carry"""
 
     def __init__(self):
-        self.calls = []
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream())
+        self.handle = int(self.event.cuda_event)
+        assert self.handle, "torch did not create the event"
+
+
+def _pack_words(argv):
+    """ctypes arguments -> (uint64 words, GAD_ARG_* kinds) of a gad_plan_add_call item"""
+    import ctypes as C
+    import struct
+    words, kinds = [], []
+    for x in argv:
+        if isinstance(x, C.c_void_p):
+            words.append(int(x.value or 0)); kinds.append(1)
+        elif isinstance(x, (C.Structure, C.Array)):
+            words.append(C.addressof(x)); kinds.append(1)
+        elif isinstance(x, C.c_float):
+            words.append(struct.unpack("<I", struct.pack("<f", x.value))[0]); kinds.append(2)
+        elif isinstance(x, C.c_double):
+            words.append(struct.unpack("<Q", struct.pack("<d", x.value))[0]); kinds.append(3)
+        elif isinstance(x, (C.c_longlong, C.c_ulonglong, C.c_size_t)):
+            words.append(int(x.value) & 0xFFFFFFFFFFFFFFFF); kinds.append(1)
+        elif isinstance(x, (C.c_int, C.c_uint)):
+            words.append(int(x.value) & 0xFFFFFFFFFFFFFFFF); kinds.append(0)
+        else:
+            raise TypeError("cannot pack %r into a plan item" % (x,))
+    return words, kinds
+
+
+def _float_word(v):
+    import struct
+    return struct.unpack("<I", struct.pack("<f", float(v)))[0]
+
+
+class _Compiled(object):
+    """a Plan lowered to gad_plans: the segments between host callbacks, each replayed by one gad_plan_run"""
+
+    def __init__(self, plan):
+        import ctypes as C
+        L = hip.lib()
+        self.handles = []          # one gad_plan per segment
+        self.steps = []            # [("c", handle index) | ("py", item)]
+        self.whichs = [0]          # dense lane -> logical stream
+        self.timed = []            # [(segment handle index, item index in it, tag)] of the tagged launches
+        lane_of = {0: 0}
+
+        def lane(w):
+            if w not in lane_of:
+                lane_of[w] = len(self.whichs)
+                self.whichs.append(w)
+            return lane_of[w]
+
+        cur = None
+        for it in plan.calls:
+            if it.kind == "py":
+                cur = None
+                self.steps.append(("py", it))
+                continue
+            if cur is None:
+                h = C.c_void_p()
+                hip.check(L.gad_plan_create(C.byref(h)), "gad_plan_create")
+                self.handles.append(h)
+                self.steps.append(("c", len(self.handles) - 1))
+                cur = h
+            if it.kind == "call":
+                if it.words is None:
+                    it.words, it.kinds = _pack_words(it.argv)
+                n = len(it.words)
+                rc = L.gad_plan_add_call(cur, it.name.encode(), (C.c_uint64 * n)(*it.words), (C.c_uint8 * n)(*it.kinds), n, lane(it.on))
+                if rc >= 0 and it.tag is not None and it.name in _TIMED_CALLS:
+                    self.timed.append((len(self.handles) - 1, rc, it.tag))
+            elif it.kind == "wait":
+                rc = L.gad_plan_add_wait(cur, lane(it.on), lane(it.on2))
+            elif it.kind == "record":
+                rc = L.gad_plan_add_record(cur, lane(it.on), C.c_void_p(it.holder.handle if it.holder is not None else 0))
+            elif it.kind == "wait_event":
+                rc = L.gad_plan_add_wait_event(cur, lane(it.on), C.c_void_p(it.holder.handle if it.holder is not None else 0))
+            elif it.kind == "zero":
+                t = it.tensor
+                rc = L.gad_plan_add_memset(cur, C.c_void_p(t.data_ptr()), C.c_longlong(t.numel() * t.element_size()), lane(it.on))
+            elif it.kind == "memcpy":
+                rc = L.gad_plan_add_memcpy(cur, C.c_void_p(it.words[0]), C.c_void_p(it.words[1]), C.c_longlong(it.words[2]), lane(it.on))
+            else:
+                raise RuntimeError("unknown plan item %r" % it.kind)
+            if rc < 0:
+                raise RuntimeError("plan item %s failed to compile (status %d): %s" % (it.name or it.kind, rc, L.gad_last_error().decode()))
+            it.cpos.append((cur, rc))
+        self.n_items = len(plan.calls)
+        self._tables = {}
+
+    def table(self, main_handle):
+        """lane -> hipStream_t table for a run whose current stream is main_handle"""
+        import ctypes as C
+        key = (int(main_handle or 0), SERIAL)
+        t = self._tables.get(key)
+        if t is None:
+            hs = [int(main_handle or 0)] + [int(side_stream(which=w).cuda_stream) for w in self.whichs[1:]]
+            t = self._tables[key] = (C.c_void_p * len(hs))(*hs)
+        return t
+
+    def __del__(self):
+        try:
+            L = hip.lib()
+            for h in self.handles:
+                L.gad_plan_destroy(h)
+        except Exception:
+            pass
+
+
+class Plan(object):
+    """A recorded sequence of C-ABI calls over static buffers, with the stream each one is enqueued on.  `on` = 0 names the
+    stream that is current when the plan runs, any other value a logical side stream (side_stream(which=on)).  Calls marked
+    `side=k` run on weight-gradient lane k (= logical stream 10 + k) between a fork (the lane waits for everything recorded so
+    far on the main stream) and the next join (main waits for the lane): the weight-gradient GEMMs are off the dX critical path.
+    run() replays the list through gad_plan_run (include/gaddpg.h section H: one foreign call per plan, or per segment between
+    host callbacks); the item-by-item Python walk remains for the serialised / timing-probe diagnostics."""
+
+    def __init__(self):
+        self.calls = []      # _Items
         self.keep = []       # keeps ctypes structs / tensors alive
-        self.tags = {}       # call index -> tag (layer name) for profiling
+        self._c = None
+
+    # ---- recording -------------------------------------------------------------------------------------------------
+    def _add(self, it):
+        self.calls.append(it)
+        self._c = None
+        return it
 
     def tag_last(self, tag):
-        self.tags[len(self.calls) - 1] = tag
+        self.calls[-1].tag = tag
 
-    def call(self, name, *a, side=False):
-        f = getattr(hip.lib(), name)
-        args = hip._args(*a)
+    def call(self, name, *a, side=False, on=None):
+        """-> the item (for patch()); arguments as hip.call takes them, plus ctypes structures / arrays (passed by address)"""
+        import ctypes as C
+        it = _Item("call", (10 + int(side)) if side else (on or 0))
+        it.name, it.f = name, getattr(hip.lib(), name)
+        it.argv = hip._args(*a)
         self.keep.append(a)
-        self.calls.append((name, f, args, None, side))
+        return self._add(it)
 
-    def call_struct(self, name, s, side=False):
-        f = getattr(hip.lib(), name)
-        self.keep.append(s)
-        self.calls.append((name, f, None, s, side))
+    def call_struct(self, name, s, side=False, on=None):
+        return self.call(name, s, side=side, on=on)
 
-    def zero(self, t):
-        self.keep.append(t)
-        self.calls.append(("zero", None, t, None, False))
+    def zero(self, t, on=0):
+        it = _Item("zero", on)
+        it.tensor = t
+        return self._add(it)
 
-    def zero_multi(self, tensors):
+    def zero_multi(self, tensors, on=0):
         """clear several buffers with ONE launch per six of them (gad_zero_buffers) instead of a fill kernel each"""
         import ctypes as C
         ts = [t for t in tensors if t is not None]
@@ -611,70 +753,200 @@ class Plan(object):
             for t in grp:
                 a += [t, C.c_longlong(t.numel() * t.element_size())]
             a += [None, C.c_longlong(0)] * (6 - len(grp))
-            self.call("gad_zero_buffers", *a)
+            self.call("gad_zero_buffers", *a, on=on)
 
-    def fn(self, f, side=False):
-        """host callback at this point of the plan; side=lane: called with that lane's stream current (whatever it
+    def memcpy(self, dst, src, nbytes, on=0):
+        """hipMemcpyAsync(dst, src, nbytes) on the lane's stream; dst / src: raw addresses (device, or pinned host); patchable
+        words 0 (dst) and 1 (src)"""
+        it = _Item("memcpy", on)
+        it.words = [int(dst), int(src), int(nbytes)]
+        return self._add(it)
+
+    def fn(self, f, side=False, on=None):
+        """host callback at this point of the plan; on a side lane: called with that lane's stream current (whatever it
         enqueues -- a collective -- is ordered after the lane's launches, not after the main stream's)"""
-        self.calls.append(("py", f, None, None, side))
+        it = _Item("py", (10 + int(side)) if side else (on or 0))
+        it.f = f
+        return self._add(it)
+
+    def wait(self, waiter, signal):
+        """logical stream `waiter` waits for everything enqueued so far on `signal` (plan-owned event)"""
+        it = _Item("wait", waiter)
+        it.on2 = signal
+        it.event = torch.cuda.Event()
+        return self._add(it)
 
     def fork(self, k=1):
-        self.calls.append(("fork", None, torch.cuda.Event(), None, k))
+        return self.wait(10 + k, 0)
 
     def join(self, k=1):
-        self.calls.append(("join", None, torch.cuda.Event(), None, k))
+        return self.wait(0, 10 + k)
 
-    def extend(self, other):
-        n = len(self.calls)
-        self.calls += other.calls
+    def record(self, holder, on=0):
+        """record the caller-owned event (EventHolder, or None = no-op until patched) on the lane's stream"""
+        it = _Item("record", on)
+        it.holder = holder
+        return self._add(it)
+
+    def wait_event(self, holder, on=0):
+        it = _Item("wait_event", on)
+        it.holder = holder
+        return self._add(it)
+
+    def extend(self, other, on=0):
+        """append another plan's items; on != 0: the other plan's main stream becomes logical stream `on` here"""
+        import copy
+        for it in other.calls:
+            if on and (it.on == 0 or (it.kind == "wait" and it.on2 == 0)):
+                src, it = it, copy.copy(it)
+                src.clones.append(it)
+                it.cpos, it.clones = [], []
+                if it.kind == "wait":
+                    it.event = torch.cuda.Event()
+                    it.on2 = on if it.on2 == 0 else it.on2
+                it.on = on if it.on == 0 else it.on
+            self.calls.append(it)
         self.keep += other.keep
-        for i, t in other.tags.items():
-            self.tags[n + i] = t
+        self.keep.append(other)
+        self._c = None
 
+    # ---- per-run edits -----------------------------------------------------------------------------------------------
+    @staticmethod
+    def patch(it, index, value):
+        """replace argument `index` of a call item (a Python float / int / hip.Ptr / tensor / None, converted like hip.call
+        does), or word `index` of a memcpy item (an address), or the event of a record / wait_event item (EventHolder | None)"""
+        import ctypes as C
+        if it.kind == "call":
+            new = hip._args(value)[0]
+            it.argv[index] = new
+            w, k = _pack_words([new])
+            if it.words is not None:
+                assert it.kinds[index] == k[0], "patch changes the argument's kind"
+                it.words[index] = w[0]
+            word = w[0]
+        elif it.kind == "memcpy":
+            it.words[index] = word = int(value)
+        else:
+            it.holder = value
+            word = value.handle if value is not None else 0
+        L = hip.lib()
+        for h, i in it.cpos:
+            hip.check(L.gad_plan_patch(h, i, index, C.c_uint64(word)), "gad_plan_patch")
+        for cl in it.clones:           # (argv / words lists are shared with the clones; their compiled words and holders are not)
+            if cl.kind not in ("call", "memcpy"):
+                cl.holder = it.holder
+            for h, i in cl.cpos:
+                hip.check(L.gad_plan_patch(h, i, index, C.c_uint64(word)), "gad_plan_patch")
+
+    # ---- replay -------------------------------------------------------------------------------------------------------
     def run(self):
+        timed = TIMING["enabled"]
+        if not USE_C_PLANS or (timed and any(it.tag is not None and it.name in _TIMED_CALLS and it.tag not in _ROUTES
+                                              for it in self.calls)):
+            return self.run_py()
+        import ctypes as C
+        c = self._c
+        if c is None or c.n_items != len(self.calls):
+            c = self._c = _Compiled(self)
+        L = hip.lib()
+        main = torch.cuda.current_stream()
+        table = c.table(main.cuda_stream)
+        if timed:
+            for hi, idx, tag in c.timed:
+                if TIMING["next"] < TIMING["slots"].shape[0] and _timing_wants(tag):
+                    k = TIMING["next"]
+                    TIMING["next"] = k + 1
+                    TIMING["tags"].append(tag)
+                    TIMING["routed"][tag] = _ROUTES[tag]
+                    hip.check(L.gad_plan_arm_timing(c.handles[hi], idx, C.c_void_p(TIMING["slots"].data_ptr() + 16 * TIMING_WAVES * k)),
+                              "gad_plan_arm_timing")
+        n = len(table)
+        for kind, x in c.steps:
+            if kind == "c":
+                rc = L.gad_plan_run(c.handles[x], table, n, 0, -1)
+                if rc != 0:
+                    hip.check(rc, "gad_plan_run")
+            elif x.on:
+                with torch.cuda.stream(side_stream(which=x.on)):
+                    x.f()
+            else:
+                x.f()
+
+    def run_py(self):
+        """the same launches, item by item from Python (diagnostics; also learns the kernel family of every tagged launch)"""
         import ctypes as C
         main = torch.cuda.current_stream()
         st = hip.stream()
-        sides = {}            # lane -> (torch stream, raw handle); dW lanes use side_stream(which = 10 + lane)
+        sides = {}            # logical stream -> (torch stream, raw handle)
         timed = TIMING["enabled"]
-        for i, (name, f, args, s, lane) in enumerate(self.calls):
-            if name == "fork":
-                if lane not in sides:
-                    so = side_stream(which=10 + lane)
-                    sides[lane] = (so, C.c_void_p(so.cuda_stream))
-                args.record(main)
-                sides[lane][0].wait_event(args)
+
+        def stream_of(w):
+            if w == 0:
+                return main, st
+            if w not in sides:
+                so = side_stream(which=w)
+                sides[w] = (so, C.c_void_p(so.cuda_stream))
+            return sides[w]
+
+        for it in self.calls:
+            kind = it.kind
+            if kind == "wait":
+                a, b = stream_of(it.on2)[0], stream_of(it.on)[0]
+                it.event.record(a)
+                if a.cuda_stream != b.cuda_stream:
+                    b.wait_event(it.event)
                 continue
-            if name == "join":
-                if lane in sides:
-                    args.record(sides[lane][0])
-                    main.wait_event(args)
-                continue
-            lane = int(lane)
-            took_slot = False
-            if timed and name in _TIMED_CALLS and i in self.tags and TIMING["next"] < TIMING["slots"].shape[0] and (
-                    TIMING["tag"] == "*" or self.tags[i] == TIMING["tag"] or
-                    (isinstance(TIMING["tag"], (set, frozenset, tuple, list)) and self.tags[i] in TIMING["tag"])):
-                k = TIMING["next"]
-                TIMING["next"] = k + 1
-                TIMING["tags"].append(self.tags[i])
-                hip.lib().gad_timing_slot(C.c_void_p(TIMING["slots"].data_ptr() + 16 * TIMING_WAVES * k))   # consumed by the call below
-                took_slot = True
-            q = sides[lane][1] if lane else st
-            if name == "zero":
-                args.zero_()
-            elif name == "py":
-                if lane:
-                    with torch.cuda.stream(sides[lane][0]):
-                        f()
+            so, q = stream_of(it.on)
+            if kind == "call":
+                took_slot = False
+                if timed and it.name in _TIMED_CALLS and it.tag is not None and TIMING["next"] < TIMING["slots"].shape[0] and \
+                        _timing_wants(it.tag):
+                    k = TIMING["next"]
+                    TIMING["next"] = k + 1
+                    TIMING["tags"].append(it.tag)
+                    hip.lib().gad_timing_slot(C.c_void_p(TIMING["slots"].data_ptr() + 16 * TIMING_WAVES * k))   # consumed by the call below
+                    took_slot = True
+                argv = [C.byref(x) if isinstance(x, (C.Structure, C.Array)) else x for x in it.argv]
+                hip.check(it.f(*(argv + [q])), it.name)
+                if it.tag is not None and it.name in _TIMED_CALLS:
+                    _ROUTES[it.tag] = hip.lib().gad_last_kernel().decode()      # kernel family the call routed to
+                    if took_slot:
+                        TIMING["routed"][it.tag] = _ROUTES[it.tag]
+            elif kind == "zero":
+                with torch.cuda.stream(so):
+                    it.tensor.zero_()
+            elif kind == "py":
+                if it.on:
+                    with torch.cuda.stream(so):
+                        it.f()
                 else:
-                    f()
-            elif s is not None:
-                hip.check(f(C.byref(s), q), name)
-            else:
-                hip.check(f(*(args + [q])), name)
-            if took_slot:
-                TIMING["routed"][self.tags[i]] = hip.lib().gad_last_kernel().decode()      # kernel family the call routed to
+                    it.f()
+            elif kind == "record":
+                if it.holder is not None:
+                    it.holder.event.record(so)
+            elif kind == "wait_event":
+                if it.holder is not None:
+                    so.wait_event(it.holder.event)
+            elif kind == "memcpy":
+                rt = _hip_runtime()
+                rc = rt.hipMemcpyAsync(C.c_void_p(it.words[0]), C.c_void_p(it.words[1]), C.c_size_t(it.words[2]), 4, q)
+                if rc != 0:
+                    raise RuntimeError("hipMemcpyAsync failed (%d)" % rc)
+
+
+_HIPRT = []
+
+
+def _hip_runtime():
+    if not _HIPRT:
+        import ctypes as C
+        _HIPRT.append(C.CDLL("libamdhip64.so"))
+    return _HIPRT[0]
+
+
+def _timing_wants(tag):
+    t = TIMING["tag"]
+    return t == "*" or tag == t or (isinstance(t, (set, frozenset, tuple, list)) and tag in t)
 
 
 def timing_routes():
@@ -924,9 +1196,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
             plan.call("gad_grid_rows_hint", hip.Ptr(geo.rows_hint.ctypes.data + 4 * stage))
         if fused_dw:                       # dX and dW in one pass on this stream (gad_gemm_bwd): SA1 l3 / l2, SA2, SA3
             aw = fused_dw.pop()
-            import ctypes as C
-            plan.keep.extend([a, aw])
-            plan.call("gad_gemm_bwd", C.byref(a), C.byref(aw))
+            plan.call("gad_gemm_bwd", a, aw)
             plan.tag_last("bwd.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
             if aw.row_splits == DW_REDUCE_LATER:
                 # the f64 sum of the kernel's partial dW blocks leaves the dX chain: forked onto the weight-gradient lane
@@ -935,7 +1205,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
                 dw_lanes.append(lane)
                 if lane:
                     plan.fork(lane)
-                plan.call("gad_gemm_dw_reduce", C.byref(a), C.byref(aw), side=lane)
+                plan.call("gad_gemm_dw_reduce", a, aw, side=lane)
             return
         plan.call_struct("gad_gemm_dx", a)
         plan.tag_last("dx.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))

@@ -76,6 +76,13 @@ class OptimJob(C.Structure):
                 ("counter_add", _i32)]
 
 
+class CopySeg(C.Structure):
+    _fields_ = [("dst", _vp), ("src", _vp), ("bytes", C.c_longlong), ("add", _f32), ("reserved_", _i32)]
+
+
+COPY_MAX_SEGS = 16
+
+
 class SplitLayer(C.Structure):
     _fields_ = [("w_off", _i32), ("n_out", _i32), ("Kp", _i32), ("Ks", _i32), ("fwd_off", C.c_int64), ("t_off", C.c_int64)]
 
@@ -99,6 +106,7 @@ def lib():
         L.gad_last_error.restype = C.c_char_p
         L.gad_abi_version.restype = C.c_int
         L.gad_last_kernel.restype = C.c_char_p
+        L.gad_plan_entry_name.restype = C.c_char_p
         _lib = L
         for k, v in os.environ.items():          # GAD_OPT_<name>=<int>: kernel-selection switches for A/B diagnostics
             if k.startswith("GAD_OPT_"):
@@ -114,7 +122,10 @@ EXPORTS = (
     "gad_pool_bwd_stats", "gad_bn_bwd_coef", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_bwd", "gad_gemm_dw_reduce", "gad_critic_loss",
     "gad_policy_outputs", "gad_policy_sample", "gad_actor_loss", "gad_actor_critic_loss", "gad_mask_counts", "gad_target_noise",
     "gad_grad_from_arena", "gad_grad_from_arena_sumsq", "gad_optim_jobs", "gad_sumsq", "gad_absmax_segments", "gad_adam_step", "gad_polyak",
-    "gad_pack_params", "gad_split_weights")
+    "gad_pack_params", "gad_split_weights", "gad_copy_buffers",
+    "gad_plan_create", "gad_plan_destroy", "gad_plan_size", "gad_plan_add_call", "gad_plan_add_wait", "gad_plan_add_record",
+    "gad_plan_add_wait_event", "gad_plan_add_memset", "gad_plan_add_memcpy", "gad_plan_patch", "gad_plan_arm_timing", "gad_plan_run",
+    "gad_plan_entry_count", "gad_plan_entry_name")
 
 
 class Ptr(int):
@@ -197,12 +208,14 @@ def get_option_default(name):
 
 
 _options = {}
+ROUTES = {}               # engine.Plan: tag -> kernel family of the tagged launches (valid for the current option values)
 
 
 def set_option(name, value):
     """kernel-selection switch for A/B diagnostics (include/gaddpg.h: gad_set_option)"""
     check(lib().gad_set_option(name.encode(), int(value)), "gad_set_option")
     _options[name] = int(value)
+    ROUTES.clear()
 
 
 def get_option(name):

@@ -214,7 +214,7 @@ class _StageRun(object):
             import ctypes as C
             aw, a = dw_args(l, dz, m), dx_args(dz, m, k_valid, **epi)
             plan.keep.extend([a, aw])
-            plan.call("gad_gemm_bwd", C.byref(a), C.byref(aw))
+            plan.call("gad_gemm_bwd", a, aw)
 
         def dx(dz, m, k_valid, **epi):
             plan.call_struct("gad_gemm_dx", dx_args(dz, m, k_valid, **epi))

@@ -46,7 +46,8 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * and gad_dz_src (bn_*, gacc_*), GAD_STAT_REPLICAS 8 -> 4;
                                             * 8: split-bf16 weight mirrors (gad_split_weights; W_split* of gad_gemm_fwd_args,
                                             * W_split_t* of gad_gemm_dx_args), option "mfma_split" as a family mask;
-                                            * 9: gad_transpose_batched; 10: gad_stream_priority)                      */
+                                            * 9: gad_transpose_batched; 10: gad_stream_priority;
+                                            * 11: step replay (section H: gad_plan_*), gad_copy_buffers)              */
 /* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
  * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
  * with it instead of restating the routing rules.                                                  */
@@ -578,6 +579,69 @@ int gad_replay_gather(const gad_replay_gather_args* host_args, void* stream);
  * targets of one backward pass. */
 int gad_zero_buffers(void* p0, long long n0, void* p1, long long n1, void* p2, long long n2, void* p3,
                      long long n3, void* p4, long long n4, void* p5, long long n5, void* stream);
+
+/* Copies up to GAD_COPY_MAX_SEGS device buffers in one launch (bytes: multiples of 4, 4-byte aligned; a segment with a NULL
+ * pointer or 0 bytes is skipped).  add != 0: the segment is float32 data and dst[i] = src[i] + add (the step's "remaining time
+ * minus one" vector of the TD target, reference core/ddpg.py:100-104, is formed while the time vector is copied).  Replaces the
+ * key-by-key tensor copies with which a device-resident minibatch was adopted into the step's static input buffers
+ * (reference core/agent.py:211-240 prepare_data: one .cuda() per key). */
+#define GAD_COPY_MAX_SEGS 16
+typedef struct {
+    void* dst;
+    const void* src;
+    long long bytes;
+    float add;
+    int32_t reserved_;
+} gad_copy_seg;
+int gad_copy_buffers(const gad_copy_seg* host_segs, int n_segs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * H. step replay (ABI 11)
+ *
+ * The update step of reference core/ddpg.py:146-185 / core/agent.py:211-259 is ~240 launches of the entry points above on four
+ * streams.  The reference's host walks its step from Python, one torch call after the other
+ * (core/train_test_offline.py:117-126: sample, update_parameters, read the losses -- every iteration); a host that does the
+ * same over this ABI pays one foreign call per launch.  A gad_plan is the recorded list -- launches with their argument words,
+ * device copies / clears, stream forks and joins -- replayed by ONE call: gad_plan_run walks it in C and enqueues every item on
+ * the stream of its lane.  Nothing is captured or re-ordered (this is not a HIP graph: measured slower on this part); the
+ * launches are exactly those the item-by-item host would have made, in the same order on every stream.
+ *
+ *   - lanes: small integers naming the streams of a run; gad_plan_run takes the table lane -> hipStream_t.
+ *   - argument words: one uint64 per argument of the entry point, the trailing `stream` excluded, with its kind
+ *     (GAD_ARG_*: I32 = int / int32_t, I64 = pointers and long long, F32 = float bits in the low half, F64 = double bits).
+ *     gad_plan_add_call checks count and kinds against the entry point's real signature and fails with GAD_ERR_SHAPE on a
+ *     mismatch.  Pointers to host argument blocks (gad_gemm_fwd_args, gad_optim_job[], ...) are stored as pointers: the
+ *     caller keeps the blocks alive and may edit them between runs.
+ *   - gad_plan_patch rewrites one word of an item (a scalar that changes from step to step, the pinned block of this
+ *     step's ring slot, an event handle); 0 in the event word of a record / wait-event item makes it a no-op.
+ *   - gad_plan_arm_timing: gad_timing_slot for ONE launch item of the next run (consumed by it).
+ *   - a plan is not thread-safe; two plans may run from two threads.  gad_plan_add_* return the item's index (>= 0).
+ * ------------------------------------------------------------------------------------------- */
+#define GAD_ARG_I32 0
+#define GAD_ARG_I64 1
+#define GAD_ARG_F32 2
+#define GAD_ARG_F64 3
+#define GAD_PLAN_MAX_LANES 16
+typedef struct gad_plan gad_plan;
+int gad_plan_create(gad_plan** out);
+int gad_plan_destroy(gad_plan* plan);
+int gad_plan_size(const gad_plan* plan);
+int gad_plan_add_call(gad_plan* plan, const char* entry, const uint64_t* words, const uint8_t* kinds, int n_words, int lane);
+/* `waiter_lane` waits for everything enqueued so far on `signal_lane` (plan-owned event: record + hipStreamWaitEvent) */
+int gad_plan_add_wait(gad_plan* plan, int waiter_lane, int signal_lane);
+/* caller-owned hipEvent_t (nullable, patchable word 0): record on / make wait the lane's stream */
+int gad_plan_add_record(gad_plan* plan, int lane, void* event);
+int gad_plan_add_wait_event(gad_plan* plan, int lane, void* event);
+int gad_plan_add_memset(gad_plan* plan, void* dst, long long bytes, int lane);                 /* hipMemsetAsync(dst, 0, bytes) */
+int gad_plan_add_memcpy(gad_plan* plan, void* dst, const void* src, long long bytes, int lane); /* hipMemcpyAsync, any direction;
+                                                                                                 * words: dst, src, bytes     */
+int gad_plan_patch(gad_plan* plan, int item, int word, uint64_t value);
+int gad_plan_arm_timing(gad_plan* plan, int item, void* slot);
+/* enqueue items [first, first + count) (count < 0: to the end); no host synchronisation.  On failure: the status of the item
+ * that failed, gad_last_error() names it. */
+int gad_plan_run(gad_plan* plan, void* const* streams, int n_streams, int first, int count);
+int gad_plan_entry_count(void);               /* the entry points a plan can replay (every one above that takes a stream) */
+const char* gad_plan_entry_name(int i);
 
 #ifdef __cplusplus
 }
