@@ -235,10 +235,11 @@ class Geometry(object):
         self.idx2 = torch.empty(B, M2, sa2.nsample, **i32)
         self.cnt2 = torch.empty(B, M2, **i32)
         self.rows = []
-        for G, cap in ((B * M1, B * M1 * sa1.nsample), (B * M2, B * M2 * sa2.nsample), (B, B * M2)):
+        self.rows_n = torch.zeros(4, **i32)        # live rows of SA1, SA2, SA3 side by side: one 8-byte D2H copy brings SA1 + SA2 to the host
+        for s_, (G, cap) in enumerate(((B * M1, B * M1 * sa1.nsample), (B * M2, B * M2 * sa2.nsample), (B, B * M2))):
             self.rows.append(dict(G=G, cap=cap, off=torch.zeros(G + 1, **i32), pt=torch.zeros(cap, **i32),
                                   grp=torch.zeros(cap, **i32), w=torch.zeros(cap, **f32),
-                                  n=torch.zeros(1, **i32)))
+                                  n=self.rows_n[s_:s_ + 1]))
         r3 = self.rows[2]
         hip.call("gad_rows_group_all", B, M2, r3["off"], r3["pt"], r3["grp"], r3["w"], r3["n"])
         self.counts = (float(B * M1 * sa1.nsample), float(B * M2 * sa2.nsample), float(B * M2))
@@ -246,24 +247,35 @@ class Geometry(object):
         # rows (gad_grid_rows_hint); the owner of the geometry keeps them current from the row counts of earlier minibatches
         self.rows_hint = np.zeros(2, dtype=np.int32)
 
-    def run(self, point_state):
-        """point_state (B,4,NP) f32 device tensor in the replay layout (gripper points first)."""
+    def _calls(self, point_state):
         B, N = self.B, self.N
         NP = point_state.shape[2]
         skip = NP - N
-        hip.call("gad_prep_points", point_state, B, point_state.shape[1], NP, skip, self.xyz, self.feat0)
-        hip.call("gad_furthest_point_sampling", self.xyz, B, N, self.M1, self.fps1, self.new_xyz1)
-        hip.call("gad_ball_query", self.new_xyz1, self.xyz, B, N, self.M1, float(self.sa1.radius),
-                 self.sa1.nsample, self.idx1, self.cnt1)
-        r = self.rows[0]
-        hip.call("gad_rows_from_ball_query", self.idx1, self.cnt1, B * self.M1, self.M1, N, self.sa1.nsample,
-                 r["off"], r["pt"], r["grp"], r["w"], r["n"])
-        hip.call("gad_furthest_point_sampling", self.new_xyz1, B, self.M1, self.M2, self.fps2, self.new_xyz2)
-        hip.call("gad_ball_query", self.new_xyz2, self.new_xyz1, B, self.M1, self.M2, float(self.sa2.radius),
-                 self.sa2.nsample, self.idx2, self.cnt2)
-        r = self.rows[1]
-        hip.call("gad_rows_from_ball_query", self.idx2, self.cnt2, B * self.M2, self.M2, self.M1,
-                 self.sa2.nsample, r["off"], r["pt"], r["grp"], r["w"], r["n"])
+        r0, r1 = self.rows[0], self.rows[1]
+        return [("gad_prep_points", point_state, B, point_state.shape[1], NP, skip, self.xyz, self.feat0),
+                ("gad_furthest_point_sampling", self.xyz, B, N, self.M1, self.fps1, self.new_xyz1),
+                ("gad_ball_query", self.new_xyz1, self.xyz, B, N, self.M1, float(self.sa1.radius), self.sa1.nsample, self.idx1,
+                 self.cnt1),
+                ("gad_rows_from_ball_query", self.idx1, self.cnt1, B * self.M1, self.M1, N, self.sa1.nsample, r0["off"], r0["pt"],
+                 r0["grp"], r0["w"], r0["n"]),
+                ("gad_furthest_point_sampling", self.new_xyz1, B, self.M1, self.M2, self.fps2, self.new_xyz2),
+                ("gad_ball_query", self.new_xyz2, self.new_xyz1, B, self.M1, self.M2, float(self.sa2.radius), self.sa2.nsample,
+                 self.idx2, self.cnt2),
+                ("gad_rows_from_ball_query", self.idx2, self.cnt2, B * self.M2, self.M2, self.M1, self.sa2.nsample, r1["off"],
+                 r1["pt"], r1["grp"], r1["w"], r1["n"])]
+
+    def run(self, point_state):
+        """point_state (B,4,NP) f32 device tensor in the replay layout (gripper points first)."""
+        for c in self._calls(point_state):
+            hip.call(*c)
+
+    def plan(self, point_state):
+        """the same seven launches as a Plan over a static input buffer (embedded into the step's replay list)"""
+        p = Plan()
+        for c in self._calls(point_state):
+            p.call(*c)
+        p.keep.append(point_state)
+        return p
 
 
 # ----------------------------------------------------------------------------------------------

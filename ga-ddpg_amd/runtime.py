@@ -26,6 +26,8 @@ import os as _os
 ROW_HINTS = _os.environ.get("GAD_ROW_HINTS", "1") == "1"     # grids of the SA1 / SA2 tile launches sized for the expected live rows
 EARLY_ZERO = _os.environ.get("GAD_EARLY_ZERO", "1") == "1"   # backward buffers cleared at the end of the forward plans; t2's running update on the value stream
 INPUT_SETS = int(_os.environ.get("GAD_INPUT_SETS", "2"))      # 1: uploads + geometry in front of every step (round-1 schedule)
+STEP_PLAN = _os.environ.get("GAD_STEP_PLAN", "1") == "1"      # the whole update step as ONE replayed launch list (FusedRuntime._step_plan);
+                                                              # 0: enqueued call by call from Python (_ddpg_enqueue: the same launches)
 
 
 def _dev_f32(x, dev):
@@ -238,6 +240,7 @@ class FusedRuntime(object):
         return st
 
     def _build_all_plans(self):
+        self._plans_gen = getattr(self, "_plans_gen", 0) + 1          # (invalidates the replayed step lists built over the old plans)
         for i in reversed(range(len(self._sets))):
             self._bind_set(i)
             self._build_plans()
@@ -300,14 +303,27 @@ class FusedRuntime(object):
 
     # ------------------------------------------------------------------ host -> device
     def load_device_batch(self, dbatch, keys=None):
-        """device-resident minibatch (dict of CUDA float32 tensors with the BATCH_KEYS layout):
-        device-to-device copies into the static buffers, no host traffic.  `keys`: only these (staged upload)."""
-        for k in (BATCH_KEYS if keys is None else keys):
-            if k in dbatch:
-                self.dbuf[k].copy_(dbatch[k], non_blocking=True)
-                if k == "time_batch":
-                    hip.call("gad_affine_act", self.dbuf["time_batch"], 1, self.B, 1, self._one, self._minus_one, 0,
-                             self.dbuf["time_m1"], 1)
+        """device-resident minibatch (dict of CUDA float32 tensors with the BATCH_KEYS layout): ONE launch copies every key into
+        the static buffers (gad_copy_buffers; "time minus one" formed on the way), no host traffic.  `keys`: only these
+        (staged upload)."""
+        import ctypes as C
+        ks = [k for k in (BATCH_KEYS if keys is None else keys) if k in dbatch]
+        segs = []
+        for k in ks:
+            src, dst = dbatch[k], self.dbuf[k]
+            if src.dtype != torch.float32 or not src.is_contiguous() or src.numel() != dst.numel() or src.device != dst.device:
+                dst.copy_(src, non_blocking=True)            # (a layout gad_copy_buffers does not take: torch converts)
+                src = dst
+            else:
+                segs.append((dst.data_ptr(), src.data_ptr(), 4 * dst.numel(), 0.0))
+            if k == "time_batch":
+                segs.append((self.dbuf["time_m1"].data_ptr(), src.data_ptr(), 4 * dst.numel(), -1.0))
+        for i in range(0, len(segs), hip.COPY_MAX_SEGS):
+            grp = segs[i:i + hip.COPY_MAX_SEGS]
+            arr = (hip.CopySeg * len(grp))()
+            for a, (dp_, sp_, nb, add) in zip(arr, grp):
+                a.dst, a.src, a.bytes, a.add = dp_, sp_, nb, add
+            hip.check(hip.lib().gad_copy_buffers(arr, len(grp), hip.stream()), "gad_copy_buffers")
 
     def upload(self, batch, keys=None):
         """minibatch -> the static device buffers.  `keys` restricts the call to some of BATCH_KEYS: ddpg_step uploads
@@ -356,17 +372,15 @@ class FusedRuntime(object):
             j.counter, j.counter_n = hip.ptr(counter), int(counter.numel())
         return j
 
-    def _optim_phase(self, which, policy_step):
-        """gad_optim_jobs for the critic phase ("c"), the actor phase ("a") or the end of the step ("end": what has to
-        wait for both phases -- max |critic.grad| as the reference logs it after the actor backward, the value encoder's
-        BatchNorm counters)"""
-        import ctypes as C
+    def _optim_jobs(self):
+        """the gad_optim_job arrays of the optimiser phases (cached; rebuilt when the gradient buffers move)"""
         ag = self.agent
         jobs = getattr(self, "_optim_jobs_cache", None)
         ar = self.dp is None          # data-parallel: the .grad buffers hold the converted, all-reduced gradients already
         if jobs is None or jobs["key"] != (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar):
             sc = self.scal
             arr = lambda js: (hip.OptimJob * len(js))(*js)
+            self._jobs_gen = getattr(self, "_jobs_gen", 0) + 1
             jobs = self._optim_jobs_cache = {
                 "key": (id(self.pol.flat.grad), id(self.enc.flat.grad), bool(ag.train_feature), ar),
                 # value encoder: arena -> grad + Adam; critic: Adam with the clip (its .grad is converted already) + target
@@ -387,10 +401,16 @@ class FusedRuntime(object):
             ce = self._optim_job(self.cr.flat, arena=False, clip=self.clip_sumsq, target=self.cr_t.flat, sel=self.critic_sel,
                                  absmax_p=engine._ptr(sc, 48), absmax_grad=engine._ptr(sc, 40), counter=self.venc.batches_tracked)
             jobs["c+end"] = arr([jobs["c"][0], ce])
+        return jobs
+
+    def _optim_select(self, which, policy_step):
+        """the job array of an optimiser phase with this step's scalars written into it (None: the phase has no launch of its own)"""
+        ag = self.agent
+        jobs = self._optim_jobs()
         fold = self.dp is None                # (data-parallel runs keep the separate launch: their phases end with exchanges)
         if which == "end":
             if fold:
-                return                        # (folded: see above)
+                return None                   # (folded: see above)
             js = jobs["end"]
             js[0].counter_add = 3 if policy_step else 2
         elif which == "c":
@@ -404,6 +424,16 @@ class FusedRuntime(object):
             js[1].counter_add = 2
             if len(js) == 3:
                 js[2].counter_add = 3
+        return js
+
+    def _optim_phase(self, which, policy_step):
+        """gad_optim_jobs for the critic phase ("c"), the actor phase ("a") or the end of the step ("end": what has to
+        wait for both phases -- max |critic.grad| as the reference logs it after the actor backward, the value encoder's
+        BatchNorm counters)"""
+        ag = self.agent
+        js = self._optim_select(which, policy_step)
+        if js is None:
+            return
         hip.check(hip.lib().gad_optim_jobs(js, len(js), hip.stream()), "gad_optim_jobs")
         if which == "c":                     # the encoders' split-bf16 weight mirrors follow their packed weights
             self.venc.flat.refresh_split()
@@ -508,8 +538,210 @@ class FusedRuntime(object):
         ag = self.agent
         policy_step = ag.update_step % ag.policy_update_gap == 0
         slot = self._begin_step(alternate=True)
-        self._ddpg_enqueue(batch, noise_u, policy_step)
+        if STEP_PLAN and OVERLAP_PASSES and self.fused_optim and self.has_critic:
+            self._ddpg_replay(batch, noise_u, policy_step)
+        else:
+            self._ddpg_enqueue(batch, noise_u, policy_step)
         return self._end_step(slot, sync)
+
+    # ------------------------------------------------------------------ the step as ONE replayed launch list
+    def _step_key(self):
+        ag = self.agent
+        self._optim_jobs()
+        return (self._jobs_gen, self._plans_gen, id(self.dp), id(self.allreduce), None if self.inv_n is None else self.inv_n.data_ptr(),
+                bool(ag.train_feature), float(ag.gamma), bool(ag.critic_aux), bool(ag.policy_aux), float(ag.clip_grad),
+                self.bucketed, ROW_HINTS, EARLY_ZERO)
+
+    def _step_plan(self, set_index, policy_step):
+        """The whole update step over input / geometry set `set_index` as one engine.Plan (what _ddpg_enqueue issues call by
+        call, in the same order on the same logical streams): replayed by gad_plan_run in one foreign call -- or a few, when a
+        data-parallel run has host callbacks (collectives) inside the step.  What changes from step to step is patched into
+        the list before the run (_ddpg_replay): the noise level, the mix ratio, the pinned ring slot of the Adam scalars and
+        of the result block; the optimiser scalars live in the job arrays the list points to."""
+        key = self._step_key()
+        cache = self.__dict__.setdefault("_step_plans", {})
+        if cache.get("key") != key:
+            cache.clear()
+            cache["key"] = key
+            cache["refs"] = (self.dp, self.allreduce, self.inv_n)      # (alive while their ids are part of the key)
+        ent = cache.get((set_index, policy_step))
+        if ent is not None:
+            return ent
+        bound = self._set
+        st = self._bind_set(set_index)
+        try:
+            ent = self._build_step_plan(st, policy_step)
+        finally:
+            self._bind_set(bound)
+        cache[(set_index, policy_step)] = ent
+        return ent
+
+    def _build_step_plan(self, st, policy_step):
+        ag, d, P = self.agent, self.dbuf, self.plans
+        B = self.B
+        EH = engine.EventHolder
+        if "ev_up_h" not in st:
+            st["ev_up_h"] = EH()
+            st["ev_up"] = st["ev_up_h"].event
+            st["geo_plan"] = self.geo.plan(d["point_state_batch"])
+            st["geo_next_plan"] = self.geo_next.plan(d["next_point_state_batch"])
+        M = Plan()
+        H = {}                                  # items patched per step
+        MAIN, S1, S2, SC, PRE, PRE2 = 0, 1, 2, 3, 20, 21
+        ev_in, ev_gn, ev_g, ev0, ev1, ev2, ev3, ev4, ev_run, ev_counts = (EH() for _ in range(10))
+        M.keep.append((ev_in, ev_gn, ev_g, ev0, ev1, ev2, ev3, ev4, ev_run, ev_counts, st["ev_up_h"]))
+        # ---- prefetch lanes: [geometry of the next state] and [geometry of the current state]; the uploads were enqueued on
+        # these streams by _ddpg_replay's prelude
+        M.record(ev_in, on=PRE)
+        M.extend(st["geo_next_plan"], on=PRE)
+        M.record(ev_gn, on=PRE)
+        if ROW_HINTS:
+            M.memcpy(st["rows_pin"].data_ptr() + 8, self.geo_next.rows_n.data_ptr(), 8, on=PRE)
+        M.wait_event(ev_in, on=PRE2)
+        M.record(st["ev_up_h"], on=PRE2)                    # every input of the step has left the caller's buffers
+        M.extend(st["geo_plan"], on=PRE2)
+        M.record(ev_g, on=PRE2)
+        if ROW_HINTS:
+            M.memcpy(st["rows_pin"].data_ptr(), self.geo.rows_n.data_ptr(), 8, on=PRE2)
+        # ---- critic phase (the comments of _ddpg_enqueue apply line by line)
+        M.record(ev0, on=MAIN)
+        M.wait_event(ev_gn, on=MAIN)
+        M.extend(P["t1"], on=MAIN)
+        M.wait_event(ev0, on=SC)
+        M.wait_event(ev_g, on=SC)
+        M.zero(self.scal, on=SC)
+        H["hyper"] = M.memcpy(self.hyper_all.data_ptr(), self._hyper_ring[0].data_ptr(), 4 * self.hyper_all.numel(), on=SC)
+        if self.dp is not None:
+            M.fn(lambda: self.dp.set_counts(self._cur_batch), on=SC)
+        M.record(ev_counts, on=SC)
+        M.wait_event(ev_counts, on=MAIN)
+        M.wait_event(ev0, on=S1)
+        M.wait_event(ev_g, on=S1)
+        M.extend(P["c_fwd"], on=S1)
+        M.record(ev2, on=MAIN)
+        H["noise"] = M.call("gad_target_noise", self.pi_t, self.noise_u, B, 0.0, 0, self.a_next, on=MAIN)
+        M.extend(P["t2"], on=MAIN)
+
+        def actor_tail(g_pi, on):
+            H["actor_loss"] = M.call("gad_actor_loss", self.hs_p.out, self.pi, d["expert_action_batch"], d["expert_flag_batch"],
+                                     d["return_batch"], d["goal_batch"], B, self.pol.n_heads, 0.0, int(bool(ag.policy_aux)),
+                                     self.action_scale, g_pi, self.inv_n_actor(), self.hs_p.g_out, engine._ptr(self.scal, 4), on=on)
+            M.extend(P["p_bwd"], on=on)
+            if self.allreduce is not None:
+                M.fn(lambda: self._reduce([self.pol.flat, self.enc.flat], "a"), on=on)
+            optim("a", on)
+
+        def optim(which, on):
+            js = self._optim_select(which, policy_step)
+            if js is None:
+                return
+            M.call("gad_optim_jobs", js, len(js), on=on)
+            fl = self.venc.flat if which == "c" else (self.enc.flat if (which == "a" and ag.train_feature) else None)
+            if fl is not None and fl.split is not None:
+                M.call("gad_split_weights", fl.packed, fl._split_layers, len(fl._split_layers), fl.split, on=on)
+
+        M.wait_event(ev2, on=S2)
+        M.wait_event(ev0, on=S2)
+        M.wait_event(ev_g, on=S2)
+        M.extend(P["p_fwd"], on=S2)
+        nh = self.pol.n_heads
+        M.call("gad_policy_outputs", self.hs_p.out, B, nh, self.action_scale, self.pi, self.aux_pred if nh == 13 else None, on=S2)
+        if not policy_step:
+            actor_tail(None, S2)
+        M.record(ev1, on=S1)
+        M.wait_event(ev1, on=MAIN)
+        M.record(ev4, on=MAIN)
+        M.wait_event(ev4, on=S1)
+        lane_run = S1 if EARLY_ZERO else MAIN
+        M.extend(P["t2_run"], on=lane_run)
+        M.record(ev_run, on=lane_run)
+        M.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"], d["perturb_flag_batch"],
+               d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)), self.inv_n_critic(), self.y,
+               self.critic_aux_norm, self.hs_c.g_out, engine._ptr(self.scal, 0), on=MAIN)
+        M.extend(P["c_bwd"], on=MAIN)
+        M.wait_event(ev_run, on=MAIN)
+        if self.allreduce is not None:
+            M.fn(lambda: self._reduce([self.cr.flat, self.venc.flat], "c"), on=MAIN)
+        if self.dp is not None:
+            M.call("gad_sumsq", self.cr.flat.grad, self.cr.flat.n, self.clip_sumsq, on=MAIN)
+        optim("c", MAIN)
+        # ---- actor phase
+        M.record(ev3, on=S2)
+        M.wait_event(ev3, on=MAIN)
+        if policy_step:
+            M.extend(P["v_fwd"], on=MAIN)
+            H["ac_loss"] = M.call("gad_actor_critic_loss", self.hs_cpi.out, d["expert_flag_batch"], d["return_batch"], B, 0.0,
+                                  self.inv_n_actor_critic(), self.hs_cpi.g_out, engine._ptr(self.scal, 8), on=MAIN)
+            M.extend(P["v_bwd"], on=MAIN)
+            actor_tail(self.slot_v.daction, MAIN)
+        optim("end", MAIN)
+        if self.dp is not None:
+            M.fn(lambda: self.dp.reduce_scalars(self.scal), on=MAIN)
+        H["download"] = M.memcpy(self._scal_ring[0].data_ptr(), self.scal.data_ptr(), 4 * self.scal.numel(), on=MAIN)
+        return dict(plan=M, items=H, last={})
+
+    def _ddpg_replay(self, batch, noise_u, policy_step):
+        """enqueue one update step through its replayed launch list (_step_plan).  Eager host work that remains: the stream
+        waits on events owned by other steps / producers, the uploads (or the one gather / copy launch of a device-resident
+        minibatch), the TD3 noise draw from torch's generator, this step's scalars."""
+        ag = self.agent
+        st = self._sets[self._set]
+        ent = self._step_plan(self._set, policy_step)
+        M, H, last = ent["plan"], ent["items"], ent["last"]
+        self._cur_batch = batch
+        main = torch.cuda.current_stream()
+        spre, spre2, sc = engine.side_stream(which=20), engine.side_stream(which=21), engine.side_stream(which=3)
+        engine.apply_lane_priorities(main)
+        ready = batch.get("ready_event") if batch is not None else None
+        if ready is None and batch is not None and ("replay_gather" in batch or (
+                torch.is_tensor(batch["point_state_batch"]) and batch["point_state_batch"].is_cuda)):
+            self._ev_pre.record(main)               # device tensors of unknown origin: after everything enqueued so far
+            ready = self._ev_pre
+        for s_ in ((spre,) if spre2 is spre else (spre, spre2)):
+            if st["ev_free"] is not None:
+                s_.wait_event(st["ev_free"])
+            if ready is not None:                   # (a producer's event says when its device tensors are complete)
+                s_.wait_event(ready)
+        whole = batch is not None and "replay_gather" in batch          # one gather launch fills every buffer
+        first = ("next_point_state_batch", "time_batch")
+        with torch.cuda.stream(spre):
+            self.upload(batch, None if whole else first)
+        if not whole:
+            with torch.cuda.stream(spre2):
+                self.upload(batch, tuple(k for k in BATCH_KEYS if k not in first))
+        if isinstance(batch, dict) and "uploaded_event" in batch:   # asked for by the producer (PrefetchSampler): it may
+            batch["uploaded_event"] = st["ev_up"]                   # reuse its staging buffers after this event
+        # the TD3 noise: torch's device generator (or the injected draw), ordered after the previous step's reader
+        self._ev[0].record(main)
+        sc.wait_event(self._ev[0])
+        normal_noise = getattr(ag, "noise_type", "uniform") != "uniform"     # core/utils.py:568-569
+        with torch.cuda.stream(sc):
+            if noise_u is None:
+                if normal_noise:
+                    self.noise_u.normal_()                              # torch.randn_like (core/utils.py:573)
+                else:
+                    self.noise_u.uniform_(0.0, 1.0)                     # torch.rand_like (core/utils.py:575)
+            else:
+                self.noise_u.copy_(torch.as_tensor(np.asarray(noise_u, dtype=np.float32)), non_blocking=True)
+        # this step's scalars
+        self._adam_host(self.venc.flat, ag.state_feat_val_encoder_optim)
+        self._adam_host(self.cr.flat, ag.critic_optim)
+        self._adam_host(self.pol.flat, ag.policy_optim)
+        if ag.train_feature:
+            self._adam_host(self.enc.flat, ag.state_feat_encoder_optim)
+        for which in ("c", "a", "end"):
+            self._optim_select(which, policy_step)
+        idx = sum(1 for m in ag.mix_milestones if ag.update_step > m)
+        level = float(ag.action_noise * ag.noise_ratio_list[min(len(ag.noise_ratio_list) - 1, idx)])
+        ratio = float(ag.mix_policy_ratio)
+        want = {("noise", 3): level, ("noise", 4): int(normal_noise), ("actor_loss", 8): 1.0 - ratio, ("ac_loss", 4): ratio,
+                ("hyper", 1): self._hyper_ring[self._slot].data_ptr(), ("download", 0): self.scal_host.data_ptr()}
+        for (name, index), v in want.items():
+            if name in H and last.get((name, index)) != v:
+                Plan.patch(H[name], index, v)
+                last[(name, index)] = v
+        M.run()
+        self._cur_batch = None
 
     def _ddpg_enqueue(self, batch, noise_u, policy_step):
         """enqueue one update step on the current stream + the side streams (no host synchronisation inside); ends with the
