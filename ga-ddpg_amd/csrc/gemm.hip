@@ -101,6 +101,50 @@ __device__ __forceinline__ void stage_affine(float* sv, float* tv, const XSrc& x
 #else
 #define GAD_PH_STAMP(t)
 #endif
+// diagnostic build (-DGAD_W_PHASES, tools/ubench_wphases.py): the wide-tile forward / dX kernels write, per workgroup, the wall
+// clock (100 MHz) at the end of each part of their first row tile -- prologue | first tile staged | K loop | stores + statistics |
+// column atomics -- into the upper half of the launch's timing slot (entries 8192 + workgroup)
+#ifdef GAD_W_PHASES
+#define GAD_WPH_DECL long long wph_[6] = {0, 0, 0, 0, 0, 0}; wph_[0] = (long long)wall_clock64()
+#define GAD_WPH(i) do { if (wph_[i] == 0) wph_[i] = (long long)wall_clock64(); } while (0)
+#define GAD_WPH_STORE(ts)                                                                                                     \
+    do {                                                                                                                      \
+        unsigned long long* q_ = reinterpret_cast<unsigned long long*>(reinterpret_cast<size_t>(ts) & ~(size_t)7);            \
+        const unsigned blk_ = blockIdx.x + gridDim.x * blockIdx.y;                                                            \
+        if (q_ && threadIdx.x == 0 && blk_ < 4096) {                                                                          \
+            auto c_ = [&](int i) { const long long d_ = wph_[i] ? wph_[i] - wph_[0] : 0; return (unsigned long long)(d_ > 65535 ? 65535 : d_); }; \
+            q_[2 * (8192 + blk_)] = (unsigned long long)wph_[0];                                                              \
+            q_[2 * (8192 + blk_) + 1] = c_(1) | (c_(2) << 16) | (c_(3) << 32) | (c_(4) << 48);                                \
+            q_[2 * (12288 + blk_)] = c_(5);                                                                                    \
+        }                                                                                                                     \
+    } while (0)
+// ... and, summed over the K-tiles of the first row tile, every wavefront's shader cycles in: fragments + MFMAs issued | next tile
+// staged + loads issued | barrier wait (entries 4096 + 8 * workgroup + wavefront: {mfma << 32 | stage, barrier})
+#define GAD_WKL_DECL long long wkl_[4] = {0, 0, 0, 0}; long long wkt_ = 0, wkp_ = 0
+#define GAD_WKL(i)                                                                   \
+    do {                                                                             \
+        wkt_ = (long long)__builtin_readcyclecounter();                              \
+        if (i > 0) wkl_[i] += wkt_ - wkp_;                                           \
+        wkp_ = wkt_;                                                                 \
+    } while (0)
+#define GAD_WKL_STORE(ts)                                                                                                     \
+    do {                                                                                                                      \
+        unsigned long long* q_ = reinterpret_cast<unsigned long long*>(reinterpret_cast<size_t>(ts) & ~(size_t)7);            \
+        const unsigned blk_ = blockIdx.x + gridDim.x * blockIdx.y;                                                            \
+        if (q_ && (threadIdx.x & 63) == 0 && blk_ < 512) {                                                                    \
+            const unsigned e_ = 4096 + 8 * blk_ + (threadIdx.x >> 6);                                                         \
+            q_[2 * e_] = ((unsigned long long)wkl_[1] << 32) | (unsigned long long)(wkl_[2] & 0xffffffffu);                   \
+            q_[2 * e_ + 1] = (unsigned long long)wkl_[3];                                                                     \
+        }                                                                                                                     \
+    } while (0)
+#else
+#define GAD_WPH_DECL
+#define GAD_WPH(i)
+#define GAD_WPH_STORE(ts)
+#define GAD_WKL_DECL
+#define GAD_WKL(i)
+#define GAD_WKL_STORE(ts)
+#endif
 struct XRaw { float4 a; float4 s; };     // a: the 16 raw bytes; s: special columns (tail tiles only)
 
 // number of leading "bulk" columns served by aligned 16-byte loads
@@ -826,6 +870,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
                                                                int stat_stride, PoolEpi pe, const uint16_t* __restrict__ wsp,
                                                                int wsp_pitch, int wsp_plane, unsigned long long* __restrict__ ts) {
     KTimer kt_(ts);
+    GAD_WPH_DECL;
+    GAD_WKL_DECL;
     constexpr int BM = 64, BN = 128, P = KT + 4, STAGE = SP ? spw::STAGE / 4 : (BM + BN) * P, VM = 512;
     static_assert(2 * STAGE >= 64 * 129, "the pooled epilogue's tile lives in the operand buffers");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE + 2 * VM + BM + 4 * BM];
@@ -954,15 +1000,21 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
                 *reinterpret_cast<float4*>(dxS + 4 * tid) = make_float4(q0, q1, q2, 0.f);
             }
         }
+        GAD_WPH(1);
         write_lds(0, S0);
         if (nk > 2) load_regs(2, S0);
         __syncthreads();
+        GAD_WPH(2);
         auto ktile = [&](int kt, auto nxtc) {             // MFMAs of tile kt; tile kt + 1 (register set nxtc) -> LDS; loads of kt + 3
             if (SP) {
+                GAD_WKL(0);
                 spw::ktile(smem_b + (kt & 1) * spw::STAGE, (wm * 32 + l31) * 64, (wn * 64 + l31) * 64, sp_fo, acc, an);
+                GAD_WKL(1);
                 if (kt + 1 < nk) write_lds(kt + 1, nxtc);
                 if (kt + 3 < nk) load_regs(kt + 3, nxtc);
+                GAD_WKL(2);
                 __syncthreads();
+                GAD_WKL(3);
                 return;
             }
             const float* As = smem + (kt & 1) * STAGE + (wm * 32 + l31) * P + 4 * half;
@@ -995,6 +1047,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
             ktile(kt, S1);
             if (kt + 1 < nk) ktile(kt + 1, S0);
         }
+        GAD_WPH(3);
         if (SP) {
 #pragma unroll
             for (int t = 0; t < 2; ++t)
@@ -1070,12 +1123,19 @@ __global__ __launch_bounds__(256, 2) void gemm_fwd_wide_kernel(XSrc x, const int
         }
         }
         // (the next row tile's first barrier orders these wS / zt reads before its writes)
+        GAD_WPH(4);
     }
     if (stat_sum) {
         const int rep = blockIdx.x % GAD_STAT_REPLICAS;
         block_column_atomics<2, 2, 2>(smem, csum, csq, lane, wm, wn, n0, n_out, stat_sum + (size_t)rep * stat_stride,
                                       stat_sq + (size_t)rep * stat_stride);
     }
+#ifdef GAD_W_PHASES
+    __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GAD_WPH(5);
+    GAD_WPH_STORE(ts);
+    GAD_WKL_STORE(ts);
+#endif
 }
 
 static int g_opt_fwd_wide = 1;

@@ -158,7 +158,7 @@ extern "C" int gad_plan_create(gad_plan** out) {
 extern "C" int gad_plan_destroy(gad_plan* p) {
     if (!p) return GAD_OK;
     for (auto& it : p->items)
-        if (it.kind == IT_WAIT && it.ev) hipEventDestroy(it.ev);
+        if (it.kind == IT_WAIT && it.ev) (void)hipEventDestroy(it.ev);
     delete p;
     return GAD_OK;
 }
