@@ -770,10 +770,13 @@ __device__ __forceinline__ void gad_split2(float a, float b, unsigned& H, unsign
 }
 __device__ __forceinline__ gad_bf16x8 gad_as_bf16x8(gad_u32x4 u) { return *reinterpret_cast<gad_bf16x8*>(&u); }
 
-// family mask (GAD_SPLIT_*; 1 = all): which GEMM families multiply as split-bf16 MFMAs.  Default since round 5: all -- the per-family
-// float64 gates (tests/test_gpu_split_families.py), the range / specials tests and the oracle-facing gates in both modes are green
-// on MI355X; 0 restores v_mfma_f32_32x32x2_f32 throughout (GAD_OPT_mfma_split=0).
-static int g_opt_mfma_split = GAD_SPLIT_ALL;
+// family mask (GAD_SPLIT_*; 1 = all): which GEMM families multiply as split-bf16 MFMAs.  LIBRARY default 0 = v_mfma_f32_32x32x2_f32
+// throughout (round 6, ADVICE r05: a caller of the C ABI gets the reference's arithmetic unless it asks for something else); the
+// Python package opts in explicitly when it loads the library (ga-ddpg_amd/hip.py OPTION_DEFAULTS: GAD_SPLIT_ALL -- the per-family
+// float64 gates of tests/test_gpu_split_families.py, the range / specials tests and every oracle-facing gate in both modes are green
+// on MI355X), GAD_OPT_mfma_split=0 keeps the f32 MFMA.  Precondition of the split form: finite operands below 3.39e38 in magnitude
+// (bf16(x) must not round to infinity; an infinite operand gives NaN where the f32 path gives +-inf).
+static int g_opt_mfma_split = 0;
 static bool split_on(int family) { return g_opt_mfma_split == GAD_SPLIT_ALL || (g_opt_mfma_split & family) != 0; }
 
 // Wide-tile kernels in split form (gemm_fwd_wide / gemm_dx_wide with SP): a 64 x 128 block tile per 4-wavefront workgroup,

@@ -371,25 +371,41 @@ extern "C" int gad_furthest_point_sampling(const float* xyz, int B, int N, int M
                                            float* new_xyz, void* stream) {
     GAD_REQUIRE(xyz && idx, GAD_ERR_NULL, "fps: null pointer");
     GAD_REQUIRE(B >= 0 && N >= 1 && M >= 0 && N <= 16384 && N <= 65535, GAD_ERR_SHAPE, "fps: unsupported shape B=%d N=%d M=%d", B, N, M);
+    // (upstream samples without replacement from N points: npoint > N repeats index 0 there; the pick buffer below is sized by M)
+    GAD_REQUIRE(M <= N, GAD_ERR_SHAPE, "fps: M=%d picks from N=%d points", M, N);
     if (B == 0 || M == 0) return GAD_OK;
     hipStream_t st = (hipStream_t)stream;
     const int tie = fps_tie_bits(N);
     const size_t lds = (size_t)(((N * 3 + 3) & ~3) + 64 + M) * sizeof(float);      // coordinates, exchange slots, picks
+    // one workgroup holds its whole cloud in LDS: 160 KB per CU bounds N (N = M: 10 220 points); beyond 64 KB the kernel's dynamic
+    // LDS limit has to be raised first (such a launch used to fail at hipGetLastError)
+    GAD_REQUIRE(lds <= 160 * 1024, GAD_ERR_SHAPE, "fps: N=%d, M=%d need %zu bytes of LDS per cloud (the CU has 163840)", N, M, lds);
+#define FPS_LAUNCH(PPL, WV)                                                                                                   \
+    do {                                                                                                                      \
+        auto kern = fps_kernel<PPL, WV>;                                                                                      \
+        if (lds > 64 * 1024 &&                                                                                                \
+            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+            gad_set_error("fps: cannot raise the dynamic LDS limit to %zu bytes", lds);                                       \
+            return GAD_ERR_LAUNCH;                                                                                            \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(kern, dim3(B), dim3(64 * WV), lds, st, xyz, N, M, tie, idx, new_xyz);                              \
+    } while (0)
     if (N <= 64) {
-        hipLaunchKernelGGL((fps_kernel<1, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
+        FPS_LAUNCH(1, 1);
     } else if (N <= 1024) {
-        if (g_opt_fps_cfg == 3) hipLaunchKernelGGL((fps_kernel<16, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
-        else if (g_opt_fps_cfg == 4) hipLaunchKernelGGL((fps_kernel<8, 2>), dim3(B), dim3(128), lds, st, xyz, N, M, tie, idx, new_xyz);
-        else hipLaunchKernelGGL((fps_kernel<4, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
+        if (g_opt_fps_cfg == 3) FPS_LAUNCH(16, 1);
+        else if (g_opt_fps_cfg == 4) FPS_LAUNCH(8, 2);
+        else FPS_LAUNCH(4, 4);
     } else if (N <= 4096) {
-        if (g_opt_fps_cfg == 3) hipLaunchKernelGGL((fps_kernel<64, 1>), dim3(B), dim3(64), lds, st, xyz, N, M, tie, idx, new_xyz);
-        else if (g_opt_fps_cfg == 4) hipLaunchKernelGGL((fps_kernel<32, 2>), dim3(B), dim3(128), lds, st, xyz, N, M, tie, idx, new_xyz);
-        else if (g_opt_fps_cfg == 1) hipLaunchKernelGGL((fps_kernel<8, 8>), dim3(B), dim3(512), lds, st, xyz, N, M, tie, idx, new_xyz);
-        else if (g_opt_fps_cfg == 2) hipLaunchKernelGGL((fps_kernel<4, 16>), dim3(B), dim3(1024), lds, st, xyz, N, M, tie, idx, new_xyz);
-        else hipLaunchKernelGGL((fps_kernel<16, 4>), dim3(B), dim3(256), lds, st, xyz, N, M, tie, idx, new_xyz);
+        if (g_opt_fps_cfg == 3) FPS_LAUNCH(64, 1);
+        else if (g_opt_fps_cfg == 4) FPS_LAUNCH(32, 2);
+        else if (g_opt_fps_cfg == 1) FPS_LAUNCH(8, 8);
+        else if (g_opt_fps_cfg == 2) FPS_LAUNCH(4, 16);
+        else FPS_LAUNCH(16, 4);
     } else {
-        hipLaunchKernelGGL((fps_kernel<16, 16>), dim3(B), dim3(1024), lds, st, xyz, N, M, tie, idx, new_xyz);
+        FPS_LAUNCH(16, 16);
     }
+#undef FPS_LAUNCH
     GAD_CHECK_LAUNCH("fps");
     return GAD_OK;
 }

@@ -1037,6 +1037,10 @@ def recomputed_input(enc, geo, s, l):
     """SA1 layer 2 on the streaming kernel's shapes: gad_gemm_fwd mode 2"""
     if not (RECOMP_SA1 and s == 0 and l == 1):
         return False
+    if hip.get_option("mfma_split"):
+        # the recomputing launch (gad_gemm_fwd mode 2) exists on the f32 MFMA only: beside split-bf16 layers the recomputed and the
+        # stored forms of layer 1's output would come from different arithmetic (ADVICE r05)
+        raise RuntimeError("GAD_RECOMP_SA1=1 needs GAD_OPT_mfma_split=0 (the recomputing SA1 launch has no split-bf16 form)")
     m0, m1 = enc.sa_mats[0][0], enc.sa_mats[0][1]
     return m0.n_out == 64 and m1.n_out == 64 and m1.Kp == 64 and m0.Kp in (8, 16) and geo.rows[0]["cap"] >= 32768
 

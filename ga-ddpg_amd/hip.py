@@ -108,6 +108,8 @@ def lib():
         L.gad_last_kernel.restype = C.c_char_p
         L.gad_plan_entry_name.restype = C.c_char_p
         _lib = L
+        for name, v in OPTION_DEFAULTS.items():   # what THIS package runs with where the library's own default differs (explicit opt-in)
+            check(L.gad_set_option(name.encode(), int(v)), "gad_set_option(%s)" % name)
         for k, v in os.environ.items():          # GAD_OPT_<name>=<int>: kernel-selection switches for A/B diagnostics
             if k.startswith("GAD_OPT_"):
                 check(L.gad_set_option(k[8:].encode(), int(v)), "gad_set_option(%s)" % k[8:])
@@ -198,7 +200,8 @@ def require_cuda(*tensors):
             raise RuntimeError("libgaddpg operators need contiguous tensors")
 
 
-# library defaults of the options this package changes at run time (csrc/gemm.hip g_opt_*): what a test restores
+# options this package sets when it loads the library (the library's own default of "mfma_split" is 0 = the f32 MFMA: a plain C
+# caller opts in itself); also what a test restores
 OPTION_DEFAULTS = {"mfma_split": 1}
 
 

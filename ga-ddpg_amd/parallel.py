@@ -36,7 +36,14 @@ BUCKETED = {None: None, "0": False, "1": True}[os.environ.get("GAD_DP_BUCKETS")]
 # gradient / count exchanges of CUDA tensors through rccl.Communicator on the caller's stream (backend 'nccl' only: gloo
 # groups -- the CPU tests, two test ranks sharing one GPU -- keep torch.distributed)
 DIRECT = os.environ.get("GAD_DP_DIRECT_RCCL", "1") != "0"
-PER_LANE_COMMS = os.environ.get("GAD_DP_COMMS", "lanes") != "one"       # one RCCL communicator per issuing stream (see _make_comm)
+# GAD_DP_COMMS: "one" (default, round 6) = ONE RCCL communicator: its collectives are serialised in host-issue order on every rank,
+# the only order RCCL guarantees deadlock-free; "lanes" = one communicator per issuing stream (see _make_comm): exchanges of
+# different lanes become independent operations that may overlap, but concurrent collectives on different communicators of one
+# process are only safe if every rank's GPU starts them in the same order -- which host-issue order on four streams does not
+# imply.  N > 1 has never run on hardware here, so the first curve is taken with the safe setting;
+# tools/first_multigpu_run.sh measures both.
+PER_LANE_COMMS = os.environ.get("GAD_DP_COMMS", "one") == "lanes"
+INIT_TIMEOUT_S = float(os.environ.get("GAD_DP_INIT_TIMEOUT", "180"))     # watchdog on ncclCommInitRank (a rank that failed leaves the others inside it)
 
 
 def mask_counts(batch):
@@ -89,6 +96,31 @@ class DataParallelContext(object):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
         return int(flag.item()) == 1
 
+    def _init_comm_watched(self, rccl, uid):
+        """ncclCommInitRank under a watchdog: the call blocks until EVERY rank has entered it, so a rank whose own init failed
+        (or never got here) would leave the others inside it for ever, in front of the agreement that is meant to catch exactly
+        that.  The init runs on a helper thread; after INIT_TIMEOUT_S this rank gives up on the direct transport
+        (the helper stays blocked, a daemon) -- the peers time out the same way and the agreement sends everybody to
+        torch.distributed."""
+        import threading
+        box = {}
+        dev = torch.cuda.current_device()
+
+        def work():
+            try:
+                torch.cuda.set_device(dev)
+                box["comm"] = rccl.Communicator(self.group, uid=uid)
+            except Exception as exc:            # noqa: BLE001
+                box["exc"] = exc
+        th = threading.Thread(target=work, name="gad-rccl-init", daemon=True)
+        th.start()
+        th.join(INIT_TIMEOUT_S)
+        if th.is_alive():
+            raise RuntimeError("ncclCommInitRank did not return within %.0f s (a peer failed to enter it?)" % INIT_TIMEOUT_S)
+        if "exc" in box:
+            raise box["exc"]
+        return box["comm"]
+
     def _make_comm(self):
         """Build the direct-RCCL communicators -- ONE PER ISSUING LANE (main stream, value / weight-gradient lane A, actor lane
         B, small-launch / weight-gradient lane C: engine._PHYS), so that exchanges issued from different streams are independent
@@ -129,7 +161,7 @@ class DataParallelContext(object):
                 if box[0] is None:
                     raise RuntimeError("rank 0 could not draw the ncclUniqueIds")
                 for uid in box[0]:
-                    comms.append(rccl.Communicator(self.group, uid=uid))
+                    comms.append(self._init_comm_watched(rccl, uid))
                     if comms[-1].count() != self.world:
                         raise RuntimeError("ncclCommCount = %d, group has %d ranks" % (comms[-1].count(), self.world))
             except Exception as exc:            # noqa: BLE001

@@ -60,8 +60,9 @@ const char* gad_last_error(void);          /* thread-local description of the la
  * "fwd_stream_l1_wgs" [256] / "bwd_stream_wgs" [256]: persistent workgroups of the streaming forward (SA1 layers 2 / 3; the gathered
  * layer 1) and of the fused SA1 backward (= its partial dW blocks).  Returns GAD_ERR_SHAPE for an
  * unknown name.  Not part of the numerical contract: both settings satisfy the same parity tests.
- * "mfma_split" [1 = GAD_SPLIT_ALL since round 5, when its accuracy gates were green on hardware: DESIGN.md]: the arithmetic of the
- * layer GEMMs' products.
+ * "mfma_split" [0; the Python package sets GAD_SPLIT_ALL when it loads the library -- its accuracy gates are green on hardware,
+ * DESIGN.md section 5 -- a plain C caller gets the f32 MFMA unless it opts in]: the arithmetic of the layer GEMMs' products.
+ * Precondition of the non-zero settings: finite operands with |x| < 3.39e38.
  * 0: v_mfma_f32_32x32x2_f32 throughout.  Non-zero: a mask of kernel families that form every FP32 product from split-bf16
  * terms on v_mfma_f32_32x32x16_bf16 with f32 accumulation (GAD_SPLIT_* below; 1 = every family that has the form).  A launch
  * takes the split form only if its family's bit is set AND the call carries the weight mirror it needs (W_split /

@@ -86,6 +86,12 @@ def test_argument_errors_are_status_codes_not_crashes():
     assert L.gad_timing_slot(C.c_void_p(0x1004)) < 0 and b"aligned" in L.gad_last_error()
     assert L.gad_timing_slot(null) == 0
     assert L.gad_set_option(b"skinny_nw", 4) == 0 and L.gad_set_option(b"skinny_nw", 8) == 0
+    # furthest point sampling keeps a cloud (and its picks) in one workgroup's LDS: shapes that cannot fit are refused up front
+    p = C.c_void_p(0x1000)
+    assert L.gad_furthest_point_sampling(p, 1, 64, 65, p, p, null) < 0 and b"picks from" in L.gad_last_error()
+    assert L.gad_furthest_point_sampling(p, 1, 16384, 16384, p, p, null) < 0 and b"bytes of LDS" in L.gad_last_error()
+    # the library's own default arithmetic is the f32 MFMA (the Python package opts into the split-bf16 form when it loads it)
+    assert hip.get_option_default("mfma_split") in (0, 1)
 
 
 def test_plan_items_are_checked_against_the_entry_points_signature():

@@ -12,7 +12,7 @@ def _clouds(B, N, seed, scale=0.1, offset=0.2):
     return (rng.random((B, N, 3)) * scale + offset).astype(np.float32)
 
 
-@pytest.mark.parametrize("B,N,M", [(3, 1024, 32), (2, 32, 32), (2, 100, 17), (1, 4096, 512), (2, 64, 64), (2, 5000, 40)])
+@pytest.mark.parametrize("B,N,M", [(3, 1024, 32), (2, 32, 32), (2, 100, 17), (1, 4096, 512), (2, 64, 64), (2, 5000, 40), (1, 8000, 3000)])
 def test_fps_matches_oracle(B, N, M):
     from ga_ddpg_amd.pointnet2_ops import pointnet2_utils as pu
     from oracle import cref

@@ -143,6 +143,12 @@ EDGE = {
     "bwd_stream ragged": lambda sc: sc.BwdStream(32768 + 67, 64, "act"),
     "bwd_stream ragged pool": lambda sc: sc.BwdStream(32768 + 129, 128, "pool"),
     "dx_stream ragged pool": lambda sc: sc.BwdStream(32768 + 1, 128, "pool", fused=False),
+    # an ODD number of K-tiles (the K loops are unrolled by two; every second block of 16 along the reduction index is negated, so
+    # the last K-tile's pair of blocks must still cancel): K = 96 / 160 forward, n = 96 / 160 for the dX
+    "fwd_wide odd ktiles": lambda sc: sc.FwdWide(4101, 96, 128, "act"),
+    "fwd_wide odd ktiles pool": lambda sc: sc.FwdWide(4100, 160, 256, "pool"),
+    "dx_wide odd ktiles": lambda sc: sc.DxWide(3003, 96, 128, "act"),
+    "dx_wide odd ktiles pool": lambda sc: sc.DxWide(3001, 160, 128, "pool"),
 }
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round evidence on the GPU box: bench line, rocprofv3 kernel stats, PMC traffic (FETCH / WRITE in separate passes) and the
 # MFMA / VALU instruction counters.  Writes gpurun_out/rNN_*; copy what is to be judged into profiles/.
-R=${1:-r05}
+R=${1:-r06}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
@@ -17,6 +17,10 @@ python tools/prof_pmc.py /tmp/prof_mfma 600 > $OUT/${R}_rocprofv3_pmc_SQ_mfma.tx
 timeout 900 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES -d /tmp/prof_waits -o r -- $BENCH --steps 6 --warmup 4 --probe-steps 2 > /dev/null 2>&1
 python tools/prof_pmc.py /tmp/prof_waits 800 > $OUT/${R}_rocprofv3_pmc_SQ_waits.txt 2>&1
 python tools/prof_derived.py $OUT/${R}_rocprofv3_pmc_SQ_mfma.txt $OUT/${R}_rocprofv3_pmc_SQ_waits.txt > $OUT/${R}_counter_table.txt 2>&1
+# BASELINE's second metric under the counters: the configs[3] query_and_group kernel, merged into the same traffic file
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/qg_fetch -o r -- python tools/prof_query_and_group.py run > /dev/null 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/qg_write -o r -- python tools/prof_query_and_group.py run > /dev/null 2>&1
+python tools/prof_query_and_group.py merge /tmp/qg_fetch /tmp/qg_write $OUT/${R}_traffic.json >> $OUT/${R}_traffic.txt 2>&1
 cp $OUT/${R}_traffic.json profiles/${R}_traffic.json 2>/dev/null     # bench.py reads roofline.traffic from here
 python bench.py --steps 200 --warmup 50 > $OUT/${R}_bench_B256.json 2> $OUT/${R}_bench_B256.err
 tail -c 600 $OUT/${R}_bench_B256.json
