@@ -45,14 +45,15 @@ class DDPG(Agent):
         sync=False: return as soon as the step is enqueued -- the result dict fills in on first read (PendingLog), the
         host goes on to sample / stage / enqueue the next step while this one runs (agent.flush() waits for all)."""
         self.mix_value_ratio, self.mix_policy_ratio = self.get_mix_ratio(self.update_step)
-        if test:
-            # reference core/agent.py:276-280 would run the SAME update with eval-mode BatchNorm; no driver of the
-            # reference calls it that way and the fused step only implements train-mode statistics: refuse loudly
-            raise NotImplementedError("update_parameters(test=True): eval-mode update is not implemented")
+        # test=True (reference core/agent.py:276-280): the SAME update with the online networks in eval mode -- BatchNorm on its
+        # running statistics in every pass, forward and backward (FusedRuntime.ddpg_step(test=True)); no driver of the reference
+        # calls it that way, tests/golden/ddpg_steps_test_mode_B32.npz pins it
         self.set_mode(test)
+        if self._dp is not None:
+            self._dp.step_hook()
         ps = batch_data["point_state_batch"]
         rt = self.runtime(ps.shape[0], ps.shape[2])
-        s = rt.ddpg_step(batch_data, noise_u=noise_u, sync=sync)
+        s = rt.ddpg_step(batch_data, noise_u=noise_u, sync=sync, test=bool(test))
         self.update_step += 1
         # tensors the reference leaves on the agent after a step
         self.pi, self.aux_pred = rt.pi, rt.aux_pred

@@ -1085,6 +1085,13 @@ def plan_encoder_forward(enc, slot, action=None, train=True, update_running=True
     plan = Plan()
     plan.zero(slot.stats)
     tot = slot.tot
+    if not train and slot.with_backward:
+        # eval-mode BatchNorm under a training step (update_parameters(test=True), reference core/agent.py:276-280): the backward
+        # pass normalises with the RUNNING statistics too -- the vectors it reads as the layers' mean / inverse deviation
+        def running_vectors():
+            slot.mean.copy_(enc.running_mean)
+            slot.istd.copy_(torch.rsqrt(enc.running_var + BN_EPS))
+        plan.fn(running_vectors)
 
     def deferred(s, l):
         """layer (s, l)'s BatchNorm is finalised in the prologue of its consumer (s, l + 1): the SA2 / SA3 layers, whose
@@ -1152,7 +1159,7 @@ def _bn_coef(plan, enc, slot, m, count, want_dw):
 
 
 def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_daction=False, dw_lane=1, zero_scatter=True,
-                          early_hook=None):
+                          early_hook=None, train=True):
     # zero_scatter=False: the caller has cleared slot.dF[0], slot.dF[1] (and slot.daction) at the head of its plan
     """Backward of plan_encoder_forward.  g_fc2 (B, 512) is dLoss/d(relu(bn(Zfc[1]))) WITH the ReLU mask applied, as
     produced by the consumer head's dX kernel (store_masked), whose epilogue must also have filled this slot's bstats
@@ -1168,6 +1175,12 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
     plan = Plan()
     B = slot.B
     tot = slot.tot
+    # train=False: the backward of EVAL-mode BatchNorm (y = scale * z + shift with constants from the running statistics):
+    # dZ = scale * dY, no batch-statistics terms.  The coefficient kernels form Q and S as (sums) / count, so an infinite count gives
+    # exactly that (P = scale, Q = S = 0) through the same launches; dgamma / dbeta are the same sums as in train mode, taken with the
+    # running mean / inverse deviation that plan_encoder_forward(train=False) put into slot.mean / slot.istd
+    INF = float("inf")
+    n_fc = float(B) if train else INF
 
     def prev_stats(pm, zprev):
         o = enc.bn_off[pm.bn_index]
@@ -1280,10 +1293,10 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
 
     # ---- FC head ----
     fc1, fc2 = enc.fc_mats
-    d = layer(3, 1, fc2, slot.Zfc[1], float(B), True, G=g_fc2)
+    d = layer(3, 1, fc2, slot.Zfc[1], n_fc, True, G=g_fc2)
     dx(dict(n_rows=B, layer=2), d, fc2, fc1.n_out, epilogue=0, gout=_ptr(slot.Gfc), gout_pitch=fc1.n_out,
        **prev_stats(fc1, slot.Zfc[0]))
-    d = layer(3, 0, fc1, slot.Zfc[0], float(B), True, G=slot.Gfc)
+    d = layer(3, 0, fc1, slot.Zfc[0], n_fc, True, G=slot.Gfc)
     dx(dict(n_rows=B, layer=1), d, fc1, slot.F[2].shape[1], epilogue=0, gout=_ptr(slot.dF[2]), gout_pitch=slot.F[2].shape[1])
     # ---- SA3 -> SA1 ----
     for s in (2, 1, 0):
@@ -1297,7 +1310,7 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         m1, m2, m3 = enc.sa_mats[s]
         gbuf = slot.G[s]
         o3 = enc.bn_off[m3.bn_index]
-        cnt = geo.counts[s]
+        cnt = geo.counts[s] if train else INF
         # dbeta / dgamma of the pooled layer; the pooled gradient is ReLU-masked in place for its consumers
         plan.call("gad_pool_bwd_stats", slot.dF[s], slot.argmax[s], r["G"], m3.n_out, slot.Z[s][2], m3.n_out,
                   _bn_vec(slot, enc, m3, "scale"), _bn_vec(slot, enc, m3, "shift"), _bn_vec(slot, enc, m3, "mean"),

@@ -43,7 +43,58 @@ DIRECT = os.environ.get("GAD_DP_DIRECT_RCCL", "1") != "0"
 # imply.  N > 1 has never run on hardware here, so the first curve is taken with the safe setting;
 # tools/first_multigpu_run.sh measures both.
 PER_LANE_COMMS = os.environ.get("GAD_DP_COMMS", "one") == "lanes"
+CORUN_EVERY = int(os.environ.get("GAD_DP_CORUN_EVERY", "2000"))      # steps between co-run self-checks of a multi-rank job (0: only at attach)
 INIT_TIMEOUT_S = float(os.environ.get("GAD_DP_INIT_TIMEOUT", "180"))     # watchdog on ncclCommInitRank (a rank that failed leaves the others inside it)
+
+
+class _SplitAggressor(object):
+    """back-to-back split-bf16 GEMM launches over private buffers (the SA2 wide-tile forward and the SA1 streaming forward at
+    their B = 256 shapes): what corun_check runs beside the exchanges.  Results are discarded."""
+
+    def __init__(self, dev):
+        from . import hip
+        from .engine import _fwd_args, _ptr
+        g = torch.Generator(device=dev)
+        g.manual_seed(7)
+        self.calls, self.keep = [], []
+        for rows, K, N in ((27240, 128, 128), (213034, 64, 64)):
+            zin = torch.randn(rows, K, device=dev, generator=g)
+            scale, shift = torch.rand(K, device=dev, generator=g) + 0.5, torch.randn(K, device=dev, generator=g) * 0.3
+            W = torch.randn(N, K, device=dev, generator=g) * 0.05
+            nrows = torch.tensor([rows], dtype=torch.int32, device=dev)
+            zout = torch.empty(rows, N, device=dev)
+            stats = torch.zeros(hip.STAT_REPLICAS * 2 * N, dtype=torch.float64, device=dev)
+            plane = N * K
+            mirror = torch.zeros(6 * plane, dtype=torch.int16, device=dev)
+            lay = (hip.SplitLayer * 1)()
+            lay[0].w_off, lay[0].n_out, lay[0].Kp, lay[0].Ks, lay[0].fwd_off, lay[0].t_off = 0, N, K, K, 0, 3 * plane
+            hip.call("gad_split_weights", W, lay, 1, mirror)
+            a = _fwd_args(n_rows_dev=_ptr(nrows), n_rows=rows, W=_ptr(W), Kp=K, n_out=[N], zout=_ptr(zout), zout_pitch=N,
+                          stat_sum=_ptr(stats, 0, 8), stat_sq=_ptr(stats, N, 8), stat_stride=2 * N, mode=0, zin=_ptr(zin), zin_pitch=K,
+                          c_in=K, scale=_ptr(scale), shift=_ptr(shift), relu=1, W_split=_ptr(mirror, 0, 2), W_split_pitch=K,
+                          W_split_plane=plane)
+            self.calls.append(a)
+            self.keep.append((zin, scale, shift, W, nrows, zout, stats, mirror, lay))
+        self.routes = []
+
+    def launch(self, n):
+        """n rounds of the launches on the CURRENT stream, with the split-bf16 form forced on for them"""
+        import ctypes as C
+        from . import hip
+        was = hip.get_option("mfma_split")
+        hip.set_option("mfma_split", 1)
+        try:
+            f, st = hip.lib().gad_gemm_fwd, hip.stream()
+            for _ in range(n):
+                for a in self.calls:
+                    hip.check(f(C.byref(a), st), "gad_gemm_fwd")
+                    if len(self.routes) < len(self.calls):
+                        self.routes.append(hip.lib().gad_last_kernel().decode())
+        finally:
+            hip.set_option("mfma_split", was)
+
+    def describe(self):
+        return ", ".join(self.routes)
 
 
 def mask_counts(batch):
@@ -104,11 +155,12 @@ class DataParallelContext(object):
         torch.distributed."""
         import threading
         box = {}
-        dev = torch.cuda.current_device()
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
 
         def work():
             try:
-                torch.cuda.set_device(dev)
+                if dev is not None:
+                    torch.cuda.set_device(dev)
                 box["comm"] = rccl.Communicator(self.group, uid=uid)
             except Exception as exc:            # noqa: BLE001
                 box["exc"] = exc
@@ -236,9 +288,12 @@ class DataParallelContext(object):
     def transport(self):
         """what carries this context's CUDA collectives, and how many ranks IT reports (bench.py: config.rccl_nranks)"""
         if self._comm is not None:
-            return {"transport": "rccl-direct", "rccl_nranks": self._comm.count(), "rccl_comms": len(self._comms)}
-        return {"transport": "torch.distributed/%s" % dist.get_backend(self.group), "rccl_nranks": dist.get_world_size(self.group)
-                if dist.get_backend(self.group) == "nccl" else None}
+            info = {"transport": "rccl-direct", "rccl_nranks": self._comm.count(), "rccl_comms": len(self._comms)}
+        else:
+            info = {"transport": "torch.distributed/%s" % dist.get_backend(self.group), "rccl_nranks": dist.get_world_size(self.group)
+                    if dist.get_backend(self.group) == "nccl" else None}
+        info.update(getattr(self, "_corun", None) or {"allreduce_corun_checked": False})
+        return info
 
     def replicas_agree(self, flats):
         """True iff every rank holds bit-identical parameters: the all-reduced MAX and MIN of a per-rank checksum (sum of
@@ -277,11 +332,103 @@ class DataParallelContext(object):
         self._inflight = {}
         if self._direct and self._comm is None:
             self._make_comm()                       # eagerly, outside any stream context; may fall back (self._direct False)
+        # the first exchanges of a multi-rank job run beside split-bf16 GEMMs and are compared with their closed form (corun_check);
+        # GAD_DP_CORUN_CHECK=0 skips, =1 forces it for a one-rank group too (tests)
+        want_check = os.environ.get("GAD_DP_CORUN_CHECK", "auto")
+        self._corun, self._steps_seen = None, 0
+        if torch.device(rt.dev).type == "cuda" and (want_check == "1" or (want_check == "auto" and self.world > 1)):
+            self.corun_check()
         bucketed = BUCKETED if BUCKETED is not None else (self._direct and self.world > 1)
         if bucketed and hasattr(rt, "enable_bucketed_reduce"):
             rt.enable_bucketed_reduce()
         elif hasattr(rt, "_build_all_plans"):
             rt._build_all_plans()                   # the backward plans end differently once an exchange follows them
+
+    # ------------------------------------------------------------------ co-run self-check
+    def corun_check(self, n_elems=None, rounds=2):
+        """Known-answer exchanges WHILE split-bf16 GEMM launches run on the other lanes.  Round 5 found that, beside wavefronts
+        issuing v_mfma_f32_32x32x16_bf16, a packed-f32 instruction consuming LDS-fresh registers can compute with stale lanes
+        (DESIGN.md section 5); libgaddpg is built without packed-f32 instructions, RCCL's reduction kernels and torch's
+        elementwise kernels are not -- and a corrupted ring-reduce leaves every rank with the SAME wrong sum, which the replicas'
+        bit-identity check cannot see.  Here, on every lane that carries exchanges, a gradient-bucket-sized buffer of small integers
+        (rank-dependent, exactly representable: any summation order gives the same bits) is all-reduced through the transport the
+        step uses while a second stream issues split wide-tile and streaming GEMM launches back to back, and compared bit for bit
+        with the closed-form sum; the torch kernels that share the step's lanes (the fill and the uniform draw of the TD3 noise)
+        are checked the same way against their results alone.  Collective: every rank must call it.  -> dict for the bench line
+        (allreduce_corun_checked, corun_mismatches, ...)."""
+        from . import engine
+        dev = torch.cuda.current_device()
+        rt = getattr(self, "rt", None)
+        if n_elems is None:
+            n_elems = int(rt.bucket_c.numel()) if (rt is not None and getattr(rt, "bucket_c", None) is not None) else (1 << 21)
+        agg = _SplitAggressor(torch.device("cuda", dev))
+        main = torch.cuda.current_stream(dev)
+        lanes = [main] + [engine.side_stream(dev, w) for w in (1, 2, 3)]
+        i = torch.arange(n_elems, device="cuda:%d" % dev, dtype=torch.float32)
+        base = torch.remainder(i, 251.0)
+        want = (base * float(self.world) + float(self.world * (self.world - 1) // 2)).clone()
+        bad, n_checks = 0, 0
+        torch.cuda.synchronize(dev)
+        for rnd in range(rounds):
+            for li, lane in enumerate(lanes):
+                other = lanes[(li + 1) % len(lanes)]
+                bufs = [(base + float(self.rank)).clone() for _ in range(3)]
+                torch.cuda.synchronize(dev)
+                with torch.cuda.stream(other):
+                    agg.launch(40)
+                with torch.cuda.stream(lane):
+                    for b in bufs:
+                        self._sum(b)
+                torch.cuda.synchronize(dev)
+                for b in bufs:
+                    n_checks += 1
+                    bad += int(not torch.equal(b, want))
+        # torch's own kernels that share the lanes: a fill and the generator's uniform draw, beside the same launches vs alone
+        gen = torch.Generator(device="cuda:%d" % dev)
+        gen.manual_seed(1234)
+        ref_u = torch.empty(256, 6, device="cuda:%d" % dev).uniform_(0.0, 1.0, generator=gen)
+        torch.cuda.synchronize(dev)
+        t_bad = 0
+        for rnd in range(rounds):
+            with torch.cuda.stream(lanes[1]):
+                agg.launch(40)
+            with torch.cuda.stream(lanes[3]):
+                for _ in range(8):
+                    gen.manual_seed(1234)
+                    u = torch.empty(256, 6, device="cuda:%d" % dev).uniform_(0.0, 1.0, generator=gen)
+                    z = torch.full((1 << 16,), 3.0, device="cuda:%d" % dev)
+                    z.zero_()
+                    t_bad += int(not torch.equal(u, ref_u)) + int(bool((z != 0).any().item()))
+            torch.cuda.synchronize(dev)
+        # every rank reports the job-wide verdict
+        v = torch.tensor([float(bad), float(t_bad)], dtype=torch.float64, device="cuda:%d" % dev if self._counts_is_cuda() else "cpu")
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        bad_all, t_bad_all = int(v[0].item()), int(v[1].item())
+        self._corun = {"allreduce_corun_checked": bad_all == 0 and t_bad_all == 0, "corun_exchanges_checked": n_checks,
+                       "corun_exchange_mismatches": bad_all, "corun_torch_kernel_mismatches": t_bad_all,
+                       "corun_elems": int(n_elems), "corun_aggressor": agg.describe()}
+        if bad_all or t_bad_all:
+            import sys
+            print("ga_ddpg_amd.parallel: rank %d: CO-RUN CHECK FAILED: %d of %d known-answer all-reduces and %d torch launches "
+                  "beside split-bf16 GEMMs differ from their closed form (job-wide)" % (self.rank, bad_all, n_checks * self.world, t_bad_all),
+                  file=sys.stderr, flush=True)
+        return dict(self._corun)
+
+    def step_hook(self):
+        """called by the agent before every update step of a data-parallel run: every GAD_DP_CORUN_EVERY steps (default 2000,
+        0 = never) the co-run check is repeated -- between two steps, with the GPU drained (a collective: every rank counts the
+        same steps)"""
+        self._steps_seen = getattr(self, "_steps_seen", 0) + 1
+        if CORUN_EVERY > 0 and self.world > 1 and self._steps_seen % CORUN_EVERY == 0 and getattr(self, "rt", None) is not None:
+            if hasattr(self.rt, "flush"):
+                self.rt.flush()
+            self.corun_check(rounds=1)
+
+    def _counts_is_cuda(self):
+        try:
+            return dist.get_backend(self.group) == "nccl"
+        except Exception:                       # noqa: BLE001
+            return False
 
     def reduce_early(self, tag, tensors):
         """start the exchange of a bucket whose gradients are complete, ordered after the launches enqueued so far on the

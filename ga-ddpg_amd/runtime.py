@@ -245,12 +245,23 @@ class FusedRuntime(object):
             self._bind_set(i)
             self._build_plans()
             self._sets[i]["plans"] = self.plans
+            self._sets[i].pop("plans_eval", None)
 
-    def _build_plans(self):
+    def _eval_plans(self):
+        """the plans of update_parameters(test=True) over the current input / geometry set (built on first use): every encoder pass
+        with eval-mode BatchNorm, the backward passes with its eval-mode derivative (engine.plan_encoder_backward train=False)"""
+        st = self._sets[self._set]
+        if st.get("plans_eval") is None:
+            keep = self.plans
+            self._build_plans(train=False)
+            st["plans_eval"], self.plans = self.plans, keep
+        return st["plans_eval"]
+
+    def _build_plans(self, train=True):
         d = self.dbuf
         enc, pol = self.enc, self.pol
         P = self.plans = {}
-        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None)
+        P["p_fwd"] = engine.plan_encoder_forward(enc, self.slot_p, action=None, train=train)
         P["p_fwd"].extend(heads.plan_policy_forward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
         # the backward pass's buffers are cleared at the END of the forward plan (the actor stream, long before the backward
         # starts) instead of at the head of the backward plan, one launch in front of its critical chain
@@ -259,21 +270,21 @@ class FusedRuntime(object):
         (P["p_fwd"] if EARLY_ZERO else bw).zero_multi(zp)
         bw.extend(heads.plan_policy_backward(pol, self.hs_p, enc, self.slot_p, d["time_batch"]))
         bw.extend(engine.plan_encoder_backward(enc, self.slot_p, self.hs_p.g_feat, action=None, want_dw=True, dw_lane=2,
-                                               zero_scatter=False, early_hook=self._early_hook(pol, enc, "a")))
+                                               zero_scatter=False, early_hook=self._early_hook(pol, enc, "a"), train=train))
         self._grad_tail(bw, pol, enc, "a", True)
         P["p_bwd"] = bw
         if not self.has_critic:
             return
         venc, cr = self.venc, self.cr
-        c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"])
+        c = engine.plan_encoder_forward(venc, self.slot_v, action=d["action_batch"], train=train)
         c.extend(heads.plan_critic_forward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
         zc = [cr.flat.gacc, venc.flat.gacc, self.slot_v.bstats, self.slot_v.dF[0], self.slot_v.dF[1], self.clip_sumsq]
         if EARLY_ZERO:
             c.zero_multi(zc)
-        t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None)
+        t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None, train=train)
         t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
         t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.pi_t, None)
-        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES)
+        t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES, train=train)
         P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
         P["c_fwd"], P["t1"], P["t2"] = c, t1, t2
@@ -282,11 +293,11 @@ class FusedRuntime(object):
             cb.zero_multi(zc)
         cb.extend(heads.plan_critic_backward(cr, self.hs_c, venc, self.slot_v, d["time_batch"]))
         cb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_c.g_feat, action=d["action_batch"], want_dw=True,
-                                               zero_scatter=False, early_hook=self._early_hook(cr, venc, "c")))
+                                               zero_scatter=False, early_hook=self._early_hook(cr, venc, "c"), train=train))
         self._grad_tail(cb, cr, venc, "c", True)
         P["c_bwd"] = cb
         # actor-critic term: Q(s, pi(s)) through the freshly updated critic, gradient back to pi
-        v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi)
+        v = engine.plan_encoder_forward(venc, self.slot_v, action=self.pi, train=train)
         v.extend(heads.plan_critic_forward(cr, self.hs_cpi, venc, self.slot_v, d["time_batch"]))
         P["v_fwd"] = v
         vb = Plan()
@@ -296,7 +307,7 @@ class FusedRuntime(object):
         # weight-gradient lane, behind the head's dW GEMMs, off the dX chain (v_bwd's closing join covers it)
         vb.call("gad_grad_from_arena", cr.flat.gacc, cr.flat.m2p, cr.flat.n, cr.flat.grad, 1, side=1 if heads.CONCURRENT_DW_HEADS() else 0)
         vb.extend(engine.plan_encoder_backward(venc, self.slot_v, self.hs_cpi.g_feat, action=self.pi, want_dw=False,
-                                               want_daction=True, zero_scatter=False))
+                                               want_daction=True, zero_scatter=False, train=train))
         if heads.CONCURRENT_DW_HEADS():
             vb.join(1)                   # (no encoder weight gradients in this pass: nothing else joins the head's lane)
         P["v_bwd"] = vb
@@ -408,22 +419,23 @@ class FusedRuntime(object):
         ag = self.agent
         jobs = self._optim_jobs()
         fold = self.dp is None                # (data-parallel runs keep the separate launch: their phases end with exchanges)
+        ev = getattr(self, "_eval", False)    # eval-mode BatchNorm (test=True): num_batches_tracked stays
         if which == "end":
             if fold:
                 return None                   # (folded: see above)
             js = jobs["end"]
-            js[0].counter_add = 3 if policy_step else 2
+            js[0].counter_add = 0 if ev else (3 if policy_step else 2)
         elif which == "c":
             js = jobs["c+end"] if (fold and not policy_step) else jobs["c"]
             js[1].hard_enable = int(ag.update_step % ag.target_update_interval == 0)
             js[1].tau = float(ag.tau)
-            js[1].counter_add = 2
+            js[1].counter_add = 0 if ev else 2
         else:
             js = jobs["a+end"] if (fold and policy_step) else jobs["a"]
             js[0].tau = float(ag.tau)
-            js[1].counter_add = 2
+            js[1].counter_add = 0 if ev else 2
             if len(js) == 3:
-                js[2].counter_add = 3
+                js[2].counter_add = 0 if ev else 3
         return js
 
     def _optim_phase(self, which, policy_step):
@@ -530,7 +542,7 @@ class FusedRuntime(object):
                 p.wait()
         torch.cuda.current_stream().synchronize()
 
-    def ddpg_step(self, batch, noise_u=None, sync=True):
+    def ddpg_step(self, batch, noise_u=None, sync=True, test=False):
         """one DDPG / TD3 update: eager multi-stream enqueue.
         sync=False: return a PendingStep right after the enqueue.  The host then prepares and enqueues the next step while
         this one runs (up to engine.HOST_RING - 1 steps ahead): the ~2 ms of launch calls, the uploads and the geometry of
@@ -538,7 +550,17 @@ class FusedRuntime(object):
         ag = self.agent
         policy_step = ag.update_step % ag.policy_update_gap == 0
         slot = self._begin_step(alternate=True)
-        if STEP_PLAN and OVERLAP_PASSES and self.fused_optim and self.has_critic:
+        self._eval = bool(test)
+        if test:
+            # test=True (reference core/agent.py:276-280): the same update with eval-mode BatchNorm in every pass -- its own plans,
+            # enqueued call by call (no shipped configuration trains this way: not a replayed list, not a fast path)
+            keep = self.plans
+            self.plans = self._eval_plans()
+            try:
+                self._ddpg_enqueue(batch, noise_u, policy_step)
+            finally:
+                self.plans, self._eval = keep, False
+        elif STEP_PLAN and OVERLAP_PASSES and self.fused_optim and self.has_critic:
             self._ddpg_replay(batch, noise_u, policy_step)
         else:
             self._ddpg_enqueue(batch, noise_u, policy_step)
@@ -893,7 +915,8 @@ class FusedRuntime(object):
             self._ev[4].record(main)
             s1.wait_event(self._ev[4])
             with torch.cuda.stream(s1 if EARLY_ZERO else main):
-                P["t2_run"].run()
+                if not getattr(self, "_eval", False):      # (eval-mode BatchNorm: the running statistics stay)
+                    P["t2_run"].run()
                 self._ev_run.record(s1 if EARLY_ZERO else main)
         hip.call("gad_critic_loss", self.hs_c.out, self.hs_ct.out, d["reward_batch"], d["mask_batch"],
                  d["perturb_flag_batch"], d["return_batch"], d["goal_batch"], B, float(ag.gamma), int(bool(ag.critic_aux)),
@@ -934,8 +957,9 @@ class FusedRuntime(object):
         # (measured and not kept: the bookkeeping below on the small-launch lane instead of the main stream: 287 vs 297
         # steps/s -- that lane also carries the next step's uploads and geometry)
         self._stats()
-        self.enc.bump_batches_tracked(2)
-        self.venc.bump_batches_tracked(3 if policy_step else 2)
+        if not getattr(self, "_eval", False):
+            self.enc.bump_batches_tracked(2)
+            self.venc.bump_batches_tracked(3 if policy_step else 2)
         self._download(sync=False)
 
     def bc_step(self, batch):

@@ -35,6 +35,21 @@ def fill_module_(module, prefix, seed):
     return module
 
 
+def fill_running_stats_(module, prefix, seed):
+    """Deterministic BatchNorm running statistics (mean in [-0.2, 0.2], variance in [0.5, 1.5]) for the fixtures that evaluate the
+    networks in eval mode (update_parameters(test=True)): with the default buffers (0 / 1) eval-mode BatchNorm is almost an
+    identity and would pin nothing."""
+    with torch.no_grad():
+        for name, b in module.named_buffers():
+            leaf = name.rsplit(".", 1)[-1]
+            r = _rng(prefix + "/" + name, seed)
+            if leaf == "running_mean":
+                b.copy_(torch.from_numpy(r.uniform(-0.2, 0.2, size=tuple(b.shape)).astype(np.float32)).to(b.device))
+            elif leaf == "running_var":
+                b.copy_(torch.from_numpy(r.uniform(0.5, 1.5, size=tuple(b.shape)).astype(np.float32)).to(b.device))
+    return module
+
+
 SAMPLES = 24
 
 

@@ -307,6 +307,61 @@ def gen_ddpg(B=32):
     return ret
 
 
+def gen_ddpg_test_mode(B=32):
+    """update_parameters(..., test=True) (core/ddpg.py:146-150, core/agent.py:261-280): the SAME update with every online network in
+    eval mode -- BatchNorm normalises with its running statistics in all five encoder passes, its backward has no batch-statistics
+    terms, running statistics and num_batches_tracked stay as they are.  No driver of the reference calls it that way; the fixture
+    pins the form all the same.  Runs: 'e' at update_step 1 (no actor-critic term), 'f' at update_step 2 (policy step), one step each,
+    from det-filled parameters AND det-filled running statistics."""
+    from oracle.detfill import fill_running_stats_
+    out = {}
+    orig_rand_like = torch.rand_like
+    rands = []
+    def rand_like(x, *a, **k):
+        r = orig_rand_like(x, *a, **k)
+        rands.append(_np(r).copy())
+        return r
+    torch.rand_like = rand_like
+    ret = None
+    for run, start, like in (("e", 1, "a"), ("f", 2, "b")):
+        agent, cfg = _make_agent("DDPG", "td3_critic_aux_policy_aux.yaml")
+        _fill_agent(agent, SEED)
+        for name, net in _nets_of(agent).items():
+            fill_running_stats_(net, name, SEED)
+        agent.update_step = start
+        feats, crit_snap = [], {}
+        _hooked(agent, feats, rands, crit_snap)
+        torch.manual_seed(SEED)
+        batch = make_batch("ddpg_td3_aux.yaml", B, 1200, DDPG_BATCH_SEED[like])
+        rands.clear()
+        p = "%s0/" % run
+        for k, v in batch.items():
+            if k not in ("state_pose_batch", "grasp_sample_batch", "image_state_batch", "next_image_state_batch"):
+                out[p + "batch/" + k] = np.asarray(v)
+        out[p + "update_step"] = np.int64(agent.update_step)
+        ret = agent.update_parameters(batch, agent.update_step, 0, test=True)
+        agent.step_scheduler(agent.update_step)
+        assert len(rands) == 1 and not agent.state_feature_extractor.training
+        out[p + "noise_u"] = rands[0]
+        for i, f in enumerate(feats):
+            out[p + "feat%d" % i] = f
+        for k, v in ret.items():
+            out[p + "ret/" + k] = np.float64(v)
+        for k in ("qf1", "qf2", "next_q_value", "critic_grasp_aux", "pi", "aux_pred"):
+            out[p + "t/" + k] = _np(getattr(agent, k))
+        if agent.update_step % 2 == 1:
+            out[p + "t/qf1_pi"] = _np(agent.qf1_pi)
+            out[p + "t/qf2_pi"] = _np(agent.qf2_pi)
+        for k, v in crit_snap.items():
+            out[p + "critic_phase/" + k] = v
+        _record_grads(agent, out, p + "end/", ["policy", "critic", "state_feature_extractor"])
+        _record_state(agent, out, p + "end/")
+        out[p + "lr"] = np.array([agent.get_lr()[k] for k in ("policy_lr", "feature_lr", "value_lr")])
+    torch.rand_like = orig_rand_like
+    np.savez_compressed(os.path.join(OUT, "ddpg_steps_test_mode_B%d.npz" % B), **out)
+    return ret
+
+
 def gen_ddpg_f64(B=32):
     """The reference's OWN update step evaluated in float64 on the a0 / b0 inputs of gen_ddpg (same det-filled weights,
     same batches, the recorded noise draw): the yardstick for gradient accuracy -- a float32 implementation is judged by
@@ -608,7 +663,7 @@ def main():
     torch.set_num_threads(8)
     gens = [("config", gen_config), ("losses", gen_losses), ("heads", gen_heads), ("replay", gen_replay),
             ("replay_io", gen_replay_io), ("offpath", gen_offpath), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg),
-            ("ddpg_f64", gen_ddpg_f64), ("checkpoint", gen_checkpoint)]
+            ("ddpg_f64", gen_ddpg_f64), ("ddpg_test_mode", gen_ddpg_test_mode), ("checkpoint", gen_checkpoint)]
     if sys.argv[1:] == ["seeds"]:
         print(find_ddpg_seeds())
         return

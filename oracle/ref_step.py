@@ -268,11 +268,13 @@ class OracleAgent(object):
         return t, m
 
     # -- DDPG ------------------------------------------------------------------------
-    def update_ddpg(self, batch, noise_u=None):
+    def update_ddpg(self, batch, noise_u=None, test=False):
+        """test=True (core/agent.py:261-280 set_mode): the same update with the online networks in eval mode -- BatchNorm on its
+        running statistics, forward and backward"""
         c = self.c
         ratio = self.mix_policy_ratio()
         for n in (self.state_feature_extractor, self.policy, self.critic):
-            n.train()
+            n.train(not test)
         t, m = self._load(batch)
         out = OrderedDict((k, 0.0) for k in LOSS_KEYS)
         pc, nxt, time = t["point_state_batch"], t["next_point_state_batch"], t["time_batch"]
@@ -380,8 +382,10 @@ class OracleAgent(object):
                    policy_param=_max_abs(self.policy.parameters()))
         return out
 
-    def update_parameters(self, batch, noise_u=None):
-        return self.update_ddpg(batch, noise_u) if self.has_critic else self.update_bc(batch)
+    def update_parameters(self, batch, noise_u=None, test=False):
+        if test and not self.has_critic:
+            raise NotImplementedError("oracle: test=True is restated for the DDPG step only")
+        return self.update_ddpg(batch, noise_u, test) if self.has_critic else self.update_bc(batch)
 
     def step_scheduler(self):
         if self.has_critic:                                           # core/agent.py:179-190

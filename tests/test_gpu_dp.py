@@ -135,7 +135,13 @@ def _worker_nccl1(rank, port, out_dir):
             dp = DataParallelContext()
             assert dp.comm is not None                 # backend nccl: the exchanges go through rccl.Communicator on the caller's stream
             agent._dp = dp
+            os.environ["GAD_DP_CORUN_CHECK"] = "1"     # (auto = only with more than one rank)
             dp.attach(rt)
+            # known-answer all-reduces of a gradient-bucket-sized buffer on every lane while split-bf16 GEMMs run on another lane,
+            # and torch's fill / uniform kernels beside the same launches: bit-equal to the closed form / to the launch alone
+            tr = dp.transport()
+            assert tr["allreduce_corun_checked"] is True and tr["corun_exchange_mismatches"] == 0 and tr["corun_torch_kernel_mismatches"] == 0, tr
+            assert tr["corun_exchanges_checked"] >= 12 and tr["corun_aggressor"].count("split") == 2, tr
             # default: one communicator for every lane (collectives serialised in host-issue order); GAD_DP_COMMS=lanes: one per
             # issuing lane (main, A, B, C) -- exchanges of different streams are independent RCCL operations
             want = 4 if par.PER_LANE_COMMS else 1

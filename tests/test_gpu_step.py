@@ -47,10 +47,10 @@ def _check_params_after_adam(g, prefix, named, lr_bound, nsteps=1):
     assert n > 0
 
 
-def _check_step(agent, nets, g, p, kind, s, tight):
+def _check_step(agent, nets, g, p, kind, s, tight, test=False):
     batch = golden_batch(g, p)
     if kind == "ddpg":
-        ret = agent.update_parameters(batch, agent.update_step, s, noise_u=g[p + "noise_u"])
+        ret = agent.update_parameters(batch, agent.update_step, s, test=test, noise_u=g[p + "noise_u"])
     else:
         ret = agent.update_parameters(batch, agent.update_step, s)
     agent.step_scheduler(agent.update_step)
@@ -128,6 +128,32 @@ def test_ddpg_steps_vs_reference_golden(golden_dir):
         agent.update_step = start
         for s in range(nsteps):
             _check_step(agent, nets, g, "%s%d/" % (run, s), "ddpg", s, tight=(s == 0))
+
+
+def test_ddpg_step_test_mode_vs_reference_golden(golden_dir):
+    """update_parameters(..., test=True) (reference core/agent.py:261-280: the update with every online network in eval mode):
+    eval-mode BatchNorm in all five encoder passes and its derivative in the three backward passes, against the reference's own run
+    (tests/golden/ddpg_steps_test_mode_B32.npz, oracle/make_golden.py gen_ddpg_test_mode) from det-filled parameters and running
+    statistics; a policy and a non-policy step; running statistics and batch counters must stay untouched."""
+    from oracle.detfill import fill_running_stats_
+    g = np.load(os.path.join(golden_dir, "ddpg_steps_test_mode_B32.npz"))
+    for run, start in (("e", 1), ("f", 2)):
+        agent, nets = _filled_agent("ddpg_td3_aux.yaml", SEED)
+        for name, net in nets.items():
+            fill_running_stats_(net, name, SEED)
+        before = {k: v.clone() for k, v in agent.state_feature_extractor.state_dict().items() if "running" in k or "num_batches" in k}
+        assert len(before) >= 60
+        agent.update_step = start
+        _check_step(agent, nets, g, "%s0/" % run, "ddpg", 0, tight=True, test=True)
+        assert not agent.state_feature_extractor.training and agent.test_mode
+        for k, v in agent.state_feature_extractor.state_dict().items():
+            if k in before:
+                assert torch.equal(v.cpu(), before[k].cpu()), "eval-mode step touched " + k
+        # ... and the next ordinary step trains again (mode switch, train-mode plans of the same runtime)
+        batch = golden_batch(g, "%s0/" % run)
+        ret = agent.update_parameters(batch, agent.update_step, 1, noise_u=g["%s0/noise_u" % run])
+        assert agent.state_feature_extractor.training and all(np.isfinite(v) for v in ret.values())
+        assert int(agent.state_feature_extractor.state_dict()["module.encoder.0.0.mlps.0.1.num_batches_tracked"]) == 2
 
 
 @pytest.mark.parametrize("run,start", [("a", 1), ("b", 2)])

@@ -88,9 +88,12 @@ def test_encoder_forward_backward(golden_dir):
     check_summaries(g, "state/", net.state_dict().items(), RT, 1e-6)
 
 
-def _check_step(a, g, p, kind):
+def _check_step(a, g, p, kind, test=False):
     batch = golden_batch(g, p)
-    ret = a.update_parameters(batch, noise_u=g[p + "noise_u"] if kind == "ddpg" else None)
+    if test:
+        ret = a.update_parameters(batch, noise_u=g[p + "noise_u"], test=True)
+    else:
+        ret = a.update_parameters(batch, noise_u=g[p + "noise_u"] if kind == "ddpg" else None)
     a.step_scheduler()
     for k, v in ret.items():
         assert_close(v, g[p + "ret/" + k], 1e-4, 1e-6, p + k)
@@ -126,6 +129,26 @@ def test_ddpg_steps(golden_dir):
             assert a.update_step == int(g["%s%d/update_step" % (run, s)])
             _check_step(a, g, "%s%d/" % (run, s), "ddpg")
     assert "b0/t/qf1_pi" in g.files and "a0/t/qf1_pi" not in g.files     # b0 is the policy-update step
+
+
+def test_ddpg_steps_test_mode(golden_dir):
+    """update_parameters(test=True) as the reference's own classes run it (eval-mode BatchNorm in every pass, forward and
+    backward; tests/golden/ddpg_steps_test_mode_B32.npz from oracle/make_golden.py): the oracle reproduces it, and the running
+    statistics / batch counters stay where they were"""
+    from oracle.detfill import fill_running_stats_
+    g = np.load(os.path.join(golden_dir, "ddpg_steps_test_mode_B32.npz"))
+    for run, start in (("e", 1), ("f", 2)):
+        a = _agent("ddpg_td3_aux.yaml", SEED)
+        for name, net in a.nets().items():
+            fill_running_stats_(net, name, SEED)
+        before = {k: v.clone() for k, v in a.state_feature_extractor.state_dict().items() if "running" in k or "num_batches" in k}
+        a.update_step = start
+        assert a.update_step == int(g["%s0/update_step" % run])
+        _check_step(a, g, "%s0/" % run, "ddpg", test=True)
+        for k, v in a.state_feature_extractor.state_dict().items():
+            if k in before:
+                assert torch.equal(v, before[k]), k
+    assert "f0/t/qf1_pi" in g.files and "e0/t/qf1_pi" not in g.files
 
 
 def test_bc_steps(golden_dir):
