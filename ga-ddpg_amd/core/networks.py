@@ -160,10 +160,9 @@ class GaussianPolicy(nn.Module):
             self.action_bias = torch.zeros(num_actions)
         else:
             self.action_scale = torch.FloatTensor((action_space.high - action_space.low) / 2.0)
+            # (asymmetric bounds: pi = tanh(mean) * scale + bias in every pass of the update step, gad_policy_outputs' action_bias;
+            # PandaTaskSpace6D is symmetric, tests/golden/ddpg_steps_asym_bounds_B32.npz pins the other case)
             self.action_bias = torch.FloatTensor((action_space.high + action_space.low) / 2.0)
-            if np.abs(np.asarray(self.action_bias)).max() != 0:
-                raise NotImplementedError("asymmetric action bounds (the fused update step assumes action_bias == 0, "
-                                          "which PandaTaskSpace6D satisfies)")
 
     def sample(self, state, eps=None):
         """-> (squashed mean, log_prob (B,1), action, extra_pred) as reference core/networks.py:353-371:

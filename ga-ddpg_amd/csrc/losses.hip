@@ -144,14 +144,17 @@ extern "C" int gad_critic_loss(const float* out9, const float* tgt_out9, const f
     return GAD_OK;
 }
 
-// pi = tanh(mean)*scale, aux = [normalize(extra[:4]), extra[4:]]
+// pi = tanh(mean)*scale + bias, aux = [normalize(extra[:4]), extra[4:]]
 __global__ __launch_bounds__(256) void policy_outputs_kernel(const float* __restrict__ pol13, int B, int pitch,
-                                                             const float* __restrict__ ascale,
+                                                             const float* __restrict__ ascale, const float* __restrict__ abias,
                                                              float* __restrict__ pi, float* __restrict__ aux) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B) return;
     const float* o = pol13 + (size_t)i * pitch;
-    for (int c = 0; c < 6; ++c) pi[(size_t)i * 6 + c] = tanhf(o[c]) * ascale[c];
+    for (int c = 0; c < 6; ++c) {
+        const float t = tanhf(o[c]) * ascale[c];
+        pi[(size_t)i * 6 + c] = abias ? t + abias[c] : t;        // (two roundings, as torch evaluates tanh(mean) * scale + bias)
+    }
     if (aux) {
         float q[4];
         unit_quat(o + 6, q);
@@ -160,14 +163,14 @@ __global__ __launch_bounds__(256) void policy_outputs_kernel(const float* __rest
     }
 }
 
-extern "C" int gad_policy_outputs(const float* pol13, int B, int pitch, const float* action_scale, float* pi,
-                                  float* aux_norm, void* stream) {
+extern "C" int gad_policy_outputs(const float* pol13, int B, int pitch, const float* action_scale, const float* action_bias,
+                                  float* pi, float* aux_norm, void* stream) {
     GAD_REQUIRE(pol13 && action_scale && pi, GAD_ERR_NULL, "policy_outputs: null pointer");
     GAD_REQUIRE(pitch >= 6 && (!aux_norm || pitch >= 13), GAD_ERR_SHAPE,
                 "policy_outputs: head pitch %d (6 mean columns, + 7 aux columns when aux_norm is requested)", pitch);
     if (B <= 0) return GAD_OK;
     hipLaunchKernelGGL(policy_outputs_kernel, dim3(gad_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, pol13, B, pitch,
-                       action_scale, pi, aux_norm);
+                       action_scale, action_bias, pi, aux_norm);
     GAD_CHECK_LAUNCH("policy_outputs");
     return GAD_OK;
 }

@@ -35,10 +35,17 @@ class _Scale(nn.Module):
 
 
 class PointnetSAModuleMSG(nn.Module):
+    """bn=True, use_xyz=True with point features (every module GA-DDPG builds, reference core/networks.py:66-81): the fused
+    de-duplicated-row path of libgaddpg.  The other forms upstream's constructor accepts -- bn=False (biased convolutions, no
+    BatchNorm), use_xyz=False (the recentred coordinates are not concatenated), features=None -- take upstream's own composition
+    (_PointnetSAModuleBase.forward) over this package's operators: furthest_point_sample -> gather_operation -> QueryAndGroup /
+    GroupAll (libgaddpg section A kernels, differentiable through their _grad counterparts) -> the shared MLP as torch modules ->
+    max-pool over the neighbourhood.  Same results as upstream's module; the padded (B, C, npoint, nsample) tensor is materialised,
+    as it is there (no shipped GA-DDPG configuration builds these forms)."""
+
     def __init__(self, npoint, radii, nsamples, mlps, bn=True, use_xyz=True):
         super().__init__()
-        if not bn or not use_xyz:
-            raise NotImplementedError("the fused set-abstraction path covers bn=True, use_xyz=True (every GA-DDPG module)")
+        self.bn, self.use_xyz = bool(bn), bool(use_xyz)
         self.npoint = npoint
         self.radii, self.nsamples = list(radii), list(nsamples)
         self.radius, self.nsample = radii[0], nsamples[0]
@@ -48,13 +55,30 @@ class PointnetSAModuleMSG(nn.Module):
             spec = list(spec)
             self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz)
                                  if npoint is not None else pointnet2_utils.GroupAll(use_xyz))
-            spec[0] += 3
+            if use_xyz:
+                spec[0] += 3
             self.mlps.append(build_shared_mlp(spec, bn))
         if len(self.radii) > 1:           # (plain attribute: kept out of _modules / state_dict)
             object.__setattr__(self, "_scales", [_Scale(self, i) for i in range(len(self.radii))])
 
+    def _generic_forward(self, xyz, features):
+        """upstream _PointnetSAModuleBase.forward over this package's operators (see the class docstring)"""
+        import torch
+        import torch.nn.functional as F
+        new_xyz = None
+        if self.npoint is not None:
+            idx = pointnet2_utils.furthest_point_sample(xyz, self.npoint)
+            new_xyz = pointnet2_utils.gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+        outs = []
+        for grouper, mlp in zip(self.groupers, self.mlps):
+            x = mlp(grouper(xyz, new_xyz, features))
+            outs.append(F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1))
+        return new_xyz, torch.cat(outs, dim=1)
+
     def forward(self, xyz, features):
         from ..sa_function import sa_module_forward
+        if not (self.bn and self.use_xyz) or features is None:
+            return self._generic_forward(xyz, features)
         if len(self.radii) == 1:
             return sa_module_forward(self, xyz, features)
         # multi-scale grouping (upstream PointnetSAModuleMSG.forward): every scale groups around the SAME centroids -- furthest

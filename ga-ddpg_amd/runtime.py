@@ -111,6 +111,9 @@ class FusedRuntime(object):
         self.pi = torch.zeros(B, 6, **f32)
         self.aux_pred = torch.zeros(B, 7, **f32) if self.pol.n_heads == 13 else self.hs_p.out[:, 6:]
         self.action_scale = _dev_f32(agent.policy.action_scale, dev)
+        # (high + low) / 2 of the action space (core/networks.py:329-337); None when the bounds are symmetric (PandaTaskSpace6D)
+        ab = _dev_f32(agent.policy.action_bias, dev).reshape(-1)
+        self.action_bias = (ab.expand(6).contiguous() if ab.numel() == 1 else ab) if bool((ab != 0).any().item()) else None
         # static batch buffers + pinned staging
         shapes = {"point_state_batch": (B, 4, NP), "next_point_state_batch": (B, 4, NP), "action_batch": (B, 6),
                   "expert_action_batch": (B, 6), "goal_batch": (B, 7)}
@@ -283,7 +286,7 @@ class FusedRuntime(object):
             c.zero_multi(zc)
         t1 = engine.plan_encoder_forward(enc, self.slot_t, action=None, train=train)
         t1.extend(heads.plan_policy_forward(self.pol_t, self.hs_pt, enc, self.slot_t, d["time_m1"]))
-        t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.pi_t, None)
+        t1.call("gad_policy_outputs", self.hs_pt.out, self.B, self.pol_t.n_heads, self.action_scale, self.action_bias, self.pi_t, None)
         t2 = engine.plan_encoder_forward(venc, self.slot_t, action=self.a_next, update_running=not OVERLAP_PASSES, train=train)
         P["t2_run"] = engine.plan_running_update(venc, self.slot_t)
         t2.extend(heads.plan_critic_forward(self.cr_t, self.hs_ct, venc, self.slot_t, d["time_m1"]))
@@ -667,7 +670,8 @@ class FusedRuntime(object):
         M.wait_event(ev_g, on=S2)
         M.extend(P["p_fwd"], on=S2)
         nh = self.pol.n_heads
-        M.call("gad_policy_outputs", self.hs_p.out, B, nh, self.action_scale, self.pi, self.aux_pred if nh == 13 else None, on=S2)
+        M.call("gad_policy_outputs", self.hs_p.out, B, nh, self.action_scale, self.action_bias, self.pi, self.aux_pred if nh == 13 else None,
+               on=S2)
         if not policy_step:
             actor_tail(None, S2)
         M.record(ev1, on=S1)
@@ -989,7 +993,7 @@ class FusedRuntime(object):
     def _policy_outputs(self):
         """pi = tanh(mean) * scale and the aux pose (unit quaternion + translation) when the head has one"""
         nh = self.pol.n_heads
-        hip.call("gad_policy_outputs", self.hs_p.out, self.B, nh, self.action_scale, self.pi,
+        hip.call("gad_policy_outputs", self.hs_p.out, self.B, nh, self.action_scale, self.action_bias, self.pi,
                  self.aux_pred if nh == 13 else None)
 
     # data-parallel hooks: device pointers to globally reduced 1/count pairs (None = local counts)
@@ -1181,11 +1185,13 @@ def policy_forward(module, state):
     B, dev = out.shape[0], out.device
     pi = torch.empty(B, 6, device=dev)
     scale = _dev_f32(module.action_scale, dev)
+    bias = _dev_f32(module.action_bias, dev).reshape(-1)
+    bias = bias.expand(6).contiguous() if bias.numel() == 1 else bias
     if net.extra_dim == 7:
         aux = torch.empty(B, 7, device=dev)
-        hip.call("gad_policy_outputs", out, B, net.n_heads, scale, pi, aux)
+        hip.call("gad_policy_outputs", out, B, net.n_heads, scale, bias, pi, aux)
     else:
-        hip.call("gad_policy_outputs", out, B, net.n_heads, scale, pi, None)
+        hip.call("gad_policy_outputs", out, B, net.n_heads, scale, bias, pi, None)
         aux = out[:, 6:6 + net.extra_dim].clone()
     return pi, aux
 

@@ -47,7 +47,8 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * 8: split-bf16 weight mirrors (gad_split_weights; W_split* of gad_gemm_fwd_args,
                                             * W_split_t* of gad_gemm_dx_args), option "mfma_split" as a family mask;
                                             * 9: gad_transpose_batched; 10: gad_stream_priority;
-                                            * 11: step replay (section H: gad_plan_*), gad_copy_buffers)              */
+                                            * 11: step replay (section H: gad_plan_*), gad_copy_buffers,
+                                            * action_bias in gad_policy_outputs)                                      */
 /* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
  * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
  * with it instead of restating the routing rules.                                                  */
@@ -436,14 +437,15 @@ int gad_critic_loss(const float* out9, const float* tgt_out9, const float* rewar
                     float* y, float* aux_norm, float* g_out9, float* scalars, void* stream);
 
 /* Actor phase (core/agent.py:127-139, core/ddpg.py:169-177, core/loss.py): outputs of the policy
- * head pol13 (B,13) = [mean6 raw, extra7 raw].  pi = tanh(mean)*scale.  bc_loss over expert rows
+ * head pol13 (B,13) = [mean6 raw, extra7 raw].  pi = tanh(mean)*scale + bias (core/networks.py:329-337, 359: action_bias =
+ * (high + low) / 2 of the action space; ABI 11: nullable `action_bias`, NULL = symmetric bounds).  bc_loss over expert rows
  * scaled by bc_scale, goal aux over return>0 rows, and (optional) the gradient of
  * -ratio*mean(min(q1_pi,q2_pi)) wrt pi arriving as g_pi_critic (B,6) (already scaled).
  *   g_pol13 receives dLoss/d(pol13); scalars[0]=bc_loss (scaled), [1]=policy_grasp_aux_loss.     */
 /* `pitch` = floats per row of the head output / gradient buffers: 6 + extra_pred_dim (13 with policy_aux, 7
  * without: reference core/agent.py:31-36); aux_norm / policy_aux need pitch >= 13.                */
-int gad_policy_outputs(const float* pol13, int B, int pitch, const float* action_scale, float* pi,
-                       float* aux_norm /*nullable*/, void* stream);
+int gad_policy_outputs(const float* pol13, int B, int pitch, const float* action_scale, const float* action_bias /*nullable*/,
+                       float* pi, float* aux_norm /*nullable*/, void* stream);
 int gad_actor_loss(const float* pol13, const float* pi, const float* expert_action,
                    const float* expert_flag, const float* ret, const float* goal, int B, int pitch,
                    float bc_scale, int policy_aux, const float* action_scale,

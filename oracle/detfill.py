@@ -50,6 +50,17 @@ def fill_running_stats_(module, prefix, seed):
     return module
 
 
+class AsymTaskSpace6D(object):
+    """an action space with ASYMMETRIC bounds (the reference's PandaTaskSpace6D is symmetric, core/utils.py:505-510): the fixtures
+    of GaussianPolicy's action_bias = (high + low) / 2 path (core/networks.py:329-337)"""
+
+    def __init__(self):
+        self.high = np.array([0.08, 0.05, 0.07, np.pi / 5, np.pi / 7, np.pi / 6])
+        self.low = np.array([-0.04, -0.06, -0.03, -np.pi / 8, -np.pi / 6, -np.pi / 9])
+        self.shape = [6]
+        self.bounds = np.vstack([self.low, self.high])
+
+
 SAMPLES = 24
 
 

@@ -173,14 +173,14 @@ def gen_config():
         json.dump(res, f, indent=1, sort_keys=True, default=lambda o: list(o))
 
 
-def _make_agent(kind, ref_yaml):
+def _make_agent(kind, ref_yaml, space=None):
     """Build the reference agent exactly as train_test_offline.py does (setup() :60-104, :347-349)."""
     import importlib
     cfg = _fresh_ref_cfg(ref_yaml)
     from core.utils import make_nets_opts_schedulers, PandaTaskSpace6D
     net_dict = make_nets_opts_schedulers(cfg.RL_MODEL_SPEC, cfg.RL_TRAIN)
     mod = importlib.import_module("core.ddpg" if kind == "DDPG" else "core.bc")
-    agent = getattr(mod, kind)(cfg.RL_TRAIN.feature_input_dim, PandaTaskSpace6D(), cfg.RL_TRAIN)
+    agent = getattr(mod, kind)(cfg.RL_TRAIN.feature_input_dim, space or PandaTaskSpace6D(), cfg.RL_TRAIN)
     agent.setup_feature_extractor(net_dict, False)
     return agent, cfg
 
@@ -359,6 +359,52 @@ def gen_ddpg_test_mode(B=32):
         out[p + "lr"] = np.array([agent.get_lr()[k] for k in ("policy_lr", "feature_lr", "value_lr")])
     torch.rand_like = orig_rand_like
     np.savez_compressed(os.path.join(OUT, "ddpg_steps_test_mode_B%d.npz" % B), **out)
+    return ret
+
+
+def gen_ddpg_asym_bounds(B=32):
+    """One policy step (update_step 2: target action, Q(s, pi(s)) and the BC loss all see pi = tanh(mean) * scale + bias) of the
+    reference's DDPG with an action space whose bounds are NOT symmetric (oracle.detfill.AsymTaskSpace6D; core/networks.py:329-337:
+    action_bias = (high + low) / 2 != 0) -- the reference's own PandaTaskSpace6D never exercises the bias."""
+    from oracle.detfill import AsymTaskSpace6D
+    out = {}
+    orig_rand_like = torch.rand_like
+    rands = []
+    def rand_like(x, *a, **k):
+        r = orig_rand_like(x, *a, **k)
+        rands.append(_np(r).copy())
+        return r
+    torch.rand_like = rand_like
+    agent, cfg = _make_agent("DDPG", "td3_critic_aux_policy_aux.yaml", space=AsymTaskSpace6D())
+    assert float(agent.policy.action_bias.abs().max()) > 0.01
+    _fill_agent(agent, SEED)
+    agent.update_step = 2
+    feats, crit_snap = [], {}
+    _hooked(agent, feats, rands, crit_snap)
+    torch.manual_seed(SEED)
+    batch = make_batch("ddpg_td3_aux.yaml", B, 1200, DDPG_BATCH_SEED["b"])
+    p = "g0/"
+    for k, v in batch.items():
+        if k not in ("state_pose_batch", "grasp_sample_batch", "image_state_batch", "next_image_state_batch"):
+            out[p + "batch/" + k] = np.asarray(v)
+    out[p + "update_step"] = np.int64(agent.update_step)
+    ret = agent.update_parameters(batch, agent.update_step, 0)
+    agent.step_scheduler(agent.update_step)
+    out[p + "noise_u"] = rands[0]
+    out[p + "action_bias"] = _np(agent.policy.action_bias)
+    for i, f in enumerate(feats):
+        out[p + "feat%d" % i] = f
+    for k, v in ret.items():
+        out[p + "ret/" + k] = np.float64(v)
+    for k in ("qf1", "qf2", "next_q_value", "critic_grasp_aux", "pi", "aux_pred", "qf1_pi", "qf2_pi"):
+        out[p + "t/" + k] = _np(getattr(agent, k))
+    for k, v in crit_snap.items():
+        out[p + "critic_phase/" + k] = v
+    _record_grads(agent, out, p + "end/", ["policy", "critic", "state_feature_extractor"])
+    _record_state(agent, out, p + "end/")
+    out[p + "lr"] = np.array([agent.get_lr()[k] for k in ("policy_lr", "feature_lr", "value_lr")])
+    torch.rand_like = orig_rand_like
+    np.savez_compressed(os.path.join(OUT, "ddpg_steps_asym_bounds_B%d.npz" % B), **out)
     return ret
 
 
@@ -663,7 +709,8 @@ def main():
     torch.set_num_threads(8)
     gens = [("config", gen_config), ("losses", gen_losses), ("heads", gen_heads), ("replay", gen_replay),
             ("replay_io", gen_replay_io), ("offpath", gen_offpath), ("encoder", gen_encoder), ("bc", gen_bc), ("ddpg", gen_ddpg),
-            ("ddpg_f64", gen_ddpg_f64), ("ddpg_test_mode", gen_ddpg_test_mode), ("checkpoint", gen_checkpoint)]
+            ("ddpg_f64", gen_ddpg_f64), ("ddpg_test_mode", gen_ddpg_test_mode), ("ddpg_asym_bounds", gen_ddpg_asym_bounds),
+            ("checkpoint", gen_checkpoint)]
     if sys.argv[1:] == ["seeds"]:
         print(find_ddpg_seeds())
         return

@@ -118,14 +118,20 @@ class PolicyNet(nn.Module):
         self.extra_pred_dim = extra_pred_dim
         self.apply(_xavier)
         self.register_buffer("action_scale", torch.tensor(ACTION_HIGH, dtype=torch.float32), persistent=False)
-        # (a buffer, so .double() converts it together with the weights)
+        self.register_buffer("action_bias", torch.zeros(num_actions, dtype=torch.float32), persistent=False)
+        # (buffers, so .double() converts them together with the weights)
+
+    def set_action_space(self, space):
+        """core/networks.py:329-337: scale = (high - low) / 2, bias = (high + low) / 2"""
+        self.action_scale.copy_(torch.as_tensor((space.high - space.low) / 2.0, dtype=self.action_scale.dtype))
+        self.action_bias.copy_(torch.as_tensor((space.high + space.low) / 2.0, dtype=self.action_bias.dtype))
 
     def forward(self, s):
         h = F.relu(self.linear2(F.relu(self.linear1(s))))
         aux = self.extra_pred(h)
         if self.extra_pred_dim == 7:
             aux = _unit_quat_head(aux)
-        pi = torch.tanh(self.mean(h)) * self.action_scale          # action_bias = 0 (symmetric bounds)
+        pi = torch.tanh(self.mean(h)) * self.action_scale + self.action_bias
         return pi, aux
 
     def sample(self, s, eps):
@@ -140,10 +146,10 @@ class PolicyNet(nn.Module):
         std = log_std.exp()
         x_t = mean + std * eps
         y_t = torch.tanh(x_t)
-        action = y_t * self.action_scale
+        action = y_t * self.action_scale + self.action_bias
         log_prob = -((x_t - mean) ** 2) / (2 * std ** 2) - log_std - np.log(np.sqrt(2 * np.pi))
         log_prob = log_prob - torch.log(self.action_scale * (1 - y_t.pow(2)) + 1e-6)
-        return (torch.tanh(mean) * self.action_scale, log_prob.sum(1, keepdim=True), action, extra, mean, log_std)
+        return (torch.tanh(mean) * self.action_scale + self.action_bias, log_prob.sum(1, keepdim=True), action, extra, mean, log_std)
 
 
 # ----------------------------------------------------------------------------- losses / pose math

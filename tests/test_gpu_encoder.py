@@ -223,7 +223,7 @@ def test_heads_forward_backward_vs_oracle():
     (bc + pa + (pi_o * gpc).sum()).backward()
     ascale = torch.tensor(np.asarray(pol.action_scale), dtype=torch.float32, device="cuda")
     pi = torch.empty(B, 6, device="cuda"); auxn = torch.empty(B, 7, device="cuda"); sp = torch.zeros(4, device="cuda")
-    hip.call("gad_policy_outputs", hs_p.out, B, 13, ascale, pi, auxn)
+    hip.call("gad_policy_outputs", hs_p.out, B, 13, ascale, None, pi, auxn)
     assert_close(pi.cpu().numpy(), pi_o.detach().numpy(), 1e-4, 1e-6, "pi")
     assert_close(auxn.cpu().numpy(), aux_o.detach().numpy(), 1e-4, 1e-5, "policy aux")
     hip.call("gad_actor_loss", hs_p.out, pi, dv(expert_act), dv(expert_flag), dv(ret), dv(goal), B, 13, 0.9, 1, ascale,

@@ -191,3 +191,41 @@ def test_multi_scale_module_matches_oracle():
         _, e_ref = ref(xyz, feats)
         _, e_gpu = mine(xyz.cuda(), feats.cuda())
     assert float((e_gpu.cpu() - e_ref).abs().max()) <= 1e-4 * float(e_ref.abs().max())
+
+
+@pytest.mark.parametrize("bn,use_xyz,with_feats,group_all", [(False, True, True, False), (True, False, True, False), (False, False, True, False),
+                                                             (True, True, False, False), (False, True, True, True)])
+def test_module_forms_outside_the_fused_path_match_upstream_semantics(bn, use_xyz, with_feats, group_all):
+    """PointnetSAModule(bn=False) / (use_xyz=False) / features=None (these constructors used to raise): upstream's
+    composition over this package's HIP operators, forward and backward, against the CPU restatement of upstream's module
+    (oracle/pointnet2_ops) from the same det-filled parameters."""
+    from ga_ddpg_amd.pointnet2_ops import pointnet2_modules as pm
+    from oracle.detfill import fill_module_
+    from oracle.pointnet2_ops import pointnet2_modules as om
+    B, N, C = 2, 256, 4
+    g = torch.Generator().manual_seed(7)
+    xyz = torch.rand(B, N, 3, generator=g)
+    feats = torch.randn(B, C, N, generator=g) if with_feats else None
+    kw = dict(mlp=[C if with_feats else 0, 16, 16, 32], bn=bn, use_xyz=use_xyz)
+    if not group_all:
+        kw.update(npoint=16, radius=0.25, nsample=8)
+    mine, ref = pm.PointnetSAModule(**kw), om.PointnetSAModule(**kw)
+    fill_module_(mine, "sa", 3)
+    fill_module_(ref, "sa", 3)
+    assert [k for k, _ in mine.state_dict().items()] == [k for k, _ in ref.state_dict().items()]
+    mine.cuda().train()
+    ref.train()
+    fr = feats.clone().requires_grad_(True) if with_feats else None
+    fm = feats.clone().cuda().requires_grad_(True) if with_feats else None
+    xr, outr = ref(xyz, fr)
+    xm, outm = mine(xyz.cuda(), fm)
+    probe = torch.randn(outr.shape, generator=g)
+    (outr * probe).sum().backward()
+    (outm * probe.cuda()).sum().backward()
+    if not group_all:
+        assert_close(xm.cpu().numpy(), xr.numpy(), 0, 0, "new_xyz")
+    assert_close(outm.detach().cpu().numpy(), outr.detach().numpy(), 1e-4, 1e-5, "pooled features")
+    if with_feats:
+        assert_close(fm.grad.cpu().numpy(), fr.grad.numpy(), 1e-3, 1e-5 * float(fr.grad.abs().max()), "d features")
+    for (n, pmine), (_, pref) in zip(mine.named_parameters(), ref.named_parameters()):
+        assert_close(pmine.grad.cpu().numpy(), pref.grad.numpy(), 1e-3, 2e-5 * float(pref.grad.abs().max()) + 1e-7, "grad " + n)

@@ -156,6 +156,29 @@ def test_ddpg_step_test_mode_vs_reference_golden(golden_dir):
         assert int(agent.state_feature_extractor.state_dict()["module.encoder.0.0.mlps.0.1.num_batches_tracked"]) == 2
 
 
+def test_ddpg_step_asymmetric_action_bounds_vs_reference_golden(golden_dir):
+    """GaussianPolicy over an action space with asymmetric bounds (reference core/networks.py:329-337: action_bias = (high + low) / 2):
+    pi = tanh(mean) * scale + bias reaches the TD target (target policy), Q(s, pi(s)) and the BC loss of a policy step; against the
+    reference's own run with the same space (oracle/make_golden.py gen_ddpg_asym_bounds)"""
+    from ga_ddpg_amd.api import make_agent
+    from oracle.detfill import AsymTaskSpace6D, fill_module_
+    g = np.load(os.path.join(golden_dir, "ddpg_steps_asym_bounds_B32.npz"))
+    agent, cfg = make_agent("ddpg_td3_aux.yaml", action_space=AsymTaskSpace6D())
+    nets = {"policy": agent.policy, "policy_target": agent.policy_target, "state_feature_extractor": agent.state_feature_extractor,
+            "critic": agent.critic, "critic_target": agent.critic_target}
+    for name, net in nets.items():
+        fill_module_(net, name, SEED)
+    assert_close(agent.policy.action_bias.cpu().numpy(), g["g0/action_bias"], 1e-7, 0, "action_bias")
+    agent.update_step = 2
+    _check_step(agent, nets, g, "g0/", "ddpg", 0, tight=True)
+    # the module-level forward (select_action's path) carries the bias too
+    feat = torch.randn(8, 513, device="cuda")
+    pi, _ = agent.policy.sample(feat)[0], None
+    mean = agent.policy.forward(feat)[0]
+    want = torch.tanh(mean) * agent.policy.action_scale.to(mean.device) + agent.policy.action_bias.to(mean.device)
+    assert_close(pi.cpu().numpy(), want.cpu().numpy(), 1e-6, 1e-7, "policy.sample squashed mean")
+
+
 @pytest.mark.parametrize("run,start", [("a", 1), ("b", 2)])
 def test_gradients_vs_reference_float64(golden_dir, run, start):
     """Gradient accuracy with a reference-held yardstick: tests/golden/ddpg_steps_B32_f64.npz is the REFERENCE's own

@@ -151,6 +151,19 @@ def test_ddpg_steps_test_mode(golden_dir):
     assert "f0/t/qf1_pi" in g.files and "e0/t/qf1_pi" not in g.files
 
 
+def test_ddpg_step_asymmetric_action_bounds(golden_dir):
+    """an action space with asymmetric bounds (action_bias = (high + low) / 2 != 0, core/networks.py:329-337): the reference's own
+    policy step (tests/golden/ddpg_steps_asym_bounds_B32.npz) reproduced by the oracle"""
+    from oracle.detfill import AsymTaskSpace6D
+    g = np.load(os.path.join(golden_dir, "ddpg_steps_asym_bounds_B32.npz"))
+    a = _agent("ddpg_td3_aux.yaml", SEED)
+    for pol in (a.policy, a.policy_target):
+        pol.set_action_space(AsymTaskSpace6D())
+    assert_close(a.policy.action_bias.numpy(), g["g0/action_bias"], 1e-7, 0, "action_bias")
+    a.update_step = 2
+    _check_step(a, g, "g0/", "ddpg")
+
+
 def test_bc_steps(golden_dir):
     g = np.load(os.path.join(golden_dir, "bc_steps_B32.npz"))
     a = _agent("bc_dagger_aux.yaml", SEED + 1)
