@@ -42,7 +42,10 @@ def _check_params_after_adam(g, prefix, named, lr_bound, nsteps=1):
         gv = g[prefix + name + "#vals"]
         err = np.abs(vals.astype(np.float64) - gv)
         assert err.max() <= 2.2 * lr_bound * nsteps + 1e-6, (name, err.max())
-        assert abs(stats[2] - g[ks][2]) <= 2e-3 * g[ks][2] + 1e-6, name
+        # (a handful of sign-like entries moves the norm of a SMALL tensor -- mean.bias has six entries -- by up to ~lr: absolute slack
+        # that vanishes with the tensor's size)
+        small = 2.2 * lr_bound * nsteps * min(1.0, 8.0 / np.sqrt(max(t.numel(), 1)))
+        assert abs(stats[2] - g[ks][2]) <= 2e-3 * g[ks][2] + 1e-6 + small, name
         n += 1
     assert n > 0
 
