@@ -708,6 +708,9 @@ class _Compiled(object):
         return t
 
     def __del__(self):
+        import sys
+        if sys is None or sys.is_finalizing():      # interpreter exit: the HIP runtime may be gone already, the process frees everything
+            return
         try:
             L = hip.lib()
             for h in self.handles:

@@ -312,7 +312,10 @@ class _SAFunction(torch.autograd.Function):
             g_feat = torch.empty(B, net.c_feat, N, dtype=torch.float32, device=g_out.device)
             _transpose(run.dfeat, g_feat, B, N, net.c_feat, net.c_pad, N * net.c_pad, N, net.c_feat * N)
         grads = []
-        gcopy = run.grad.clone()                              # ONE copy of the call's parameter gradients; views of it go out
+        # ONE copy of the call's parameter gradients; VIEWS of it go out.  Autograd may adopt such a view as p.grad (set_to_none /
+        # first accumulation): the parameters' .grad tensors of one call then share one storage (disjoint slices: in-place optimizers
+        # are unaffected; the flat buffer lives as long as any of them).  One clone per parameter would cost nine launches per call.
+        gcopy = run.grad.clone()
         for p, o in zip(net.flat.params, net.flat.offsets[:-1]):
             o = int(o)
             grads.append(gcopy[o:o + p.numel()].view(p.shape) if p.requires_grad else None)
