@@ -436,6 +436,17 @@ def main():
         step(args.warmup + args.steps + i, sync=True)
     fence()
     rate_sync = n_sync / (time.perf_counter() - t1)
+    # ... and the same synchronous loop with the NEXT minibatch handed to agent.prefetch() before each update (what
+    # core.train_test_offline.train_off_policy does by default: it samples one minibatch ahead): upload + geometry of step N + 1
+    # run beside step N, the loop still reads every step's losses before it enqueues the next
+    fence()
+    t1 = time.perf_counter()
+    base = args.warmup + args.steps + n_sync
+    for i in range(n_sync):
+        agent.prefetch(ring[(base + i + 1) % len(ring)])
+        step(base + i, sync=True)
+    fence()
+    rate_sync_prefetch = n_sync / (time.perf_counter() - t1)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -501,7 +512,7 @@ def main():
                       "batch_per_gpu": B, "global_batch": B * world, "points": 1024,
                       "parallelism": "dp%d" % world, "iterations_per_s": steps_per_s, "mfma_split": split_mode,
                       "enqueue": "run-ahead (update_parameters(sync=False), all steps complete at the closing fence)",
-                      "iterations_per_s_sync_each_step": rate_sync,
+                      "iterations_per_s_sync_each_step": rate_sync, "iterations_per_s_sync_prefetch_next": rate_sync_prefetch,
                       "value_definition": "B=%d minibatch gradient steps per second summed over ranks (= iterations/s x n_gpus)" % B, "inputs": "HBM-resident ring of %d pre-sampled minibatches" % args.ring},
            "losses": {k: out[k] for k in ("critic_loss", "bc_loss", "actor_critic_loss")},
            "roofline": roof}

@@ -98,6 +98,14 @@ class Agent(object):
                 self._dp.attach(self._rt)
         return self._rt
 
+    def prefetch(self, batch_data):
+        """Stage the NEXT update's minibatch while the current one runs (its upload and the furthest-point-sampling / ball-query
+        geometry of both cloud sets, on the prefetch lanes): the following update_parameters(batch_data) -- the same object -- starts
+        from there.  A hint: results never depend on it; device-resident minibatches only.  -> True if something was staged."""
+        if self._rt is None or batch_data is None:
+            return False
+        return bool(self._rt.prefetch_inputs(batch_data))
+
     def get_lr(self):
         return {"policy_lr": self.policy_optim.param_groups[0]["lr"],
                 "feature_lr": self.state_feature_extractor_optim.param_groups[0]["lr"],

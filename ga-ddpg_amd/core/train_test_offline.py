@@ -100,13 +100,27 @@ def train_off_policy(agent, memory, config, model_output_dir=None, save_model=Fa
             log("replay buffer mirrored in HBM (%d transitions); device_replay=False keeps the host sampling path" % len(memory))
     sample = sample or memory.sample
     epochs = 0
+    # The loop below is the reference's: sample, update, read the losses -- every iteration.  What keeps the GPU busy across that
+    # host synchronisation: the NEXT minibatch is drawn one iteration early (same draws in the same order: nothing else consumes
+    # the sampler's random stream in between) and handed to agent.prefetch(), which stages its upload + geometry beside the
+    # running update (device-resident minibatches; a no-op otherwise).
+    lookahead = (not run_ahead) and hasattr(agent, "prefetch")
+    ahead = None
+
+    def is_last(epoch, i):
+        return i == config.updates_per_step - 1 and (agent.update_step + 1 >= config.max_epoch or
+                                                      (max_epochs is not None and epoch >= max_epochs))
     for epoch in itertools.count(1):
         start_time = time.time()
         lrs = agent.get_lr()
         data_time, network_time = 0.0, 0.0
         pending = []
         for i in range(config.updates_per_step):
-            batch_data = sample(batch_size=config.batch_size)
+            batch_data = ahead if ahead is not None else sample(batch_size=config.batch_size)
+            ahead = None
+            if lookahead and not is_last(epoch, i):
+                ahead = sample(batch_size=config.batch_size)
+                agent.prefetch(ahead)
             data_time += time.time() - start_time
             start_time = time.time()
             if run_ahead and "sync" in agent.update_parameters.__code__.co_varnames:

@@ -554,6 +554,9 @@ class FusedRuntime(object):
         policy_step = ag.update_step % ag.policy_update_gap == 0
         slot = self._begin_step(alternate=True)
         self._eval = bool(test)
+        replay = (not test) and STEP_PLAN and OVERLAP_PASSES and self.fused_optim and self.has_critic
+        if not replay:
+            self._sets[self._set]["prefetched"] = None        # (the call-by-call path stages its inputs itself)
         if test:
             # test=True (reference core/agent.py:276-280): the same update with eval-mode BatchNorm in every pass -- its own plans,
             # enqueued call by call (no shipped configuration trains this way: not a replayed list, not a fast path)
@@ -563,7 +566,7 @@ class FusedRuntime(object):
                 self._ddpg_enqueue(batch, noise_u, policy_step)
             finally:
                 self.plans, self._eval = keep, False
-        elif STEP_PLAN and OVERLAP_PASSES and self.fused_optim and self.has_critic:
+        elif replay:
             self._ddpg_replay(batch, noise_u, policy_step)
         else:
             self._ddpg_enqueue(batch, noise_u, policy_step)
@@ -610,24 +613,34 @@ class FusedRuntime(object):
             st["ev_up"] = st["ev_up_h"].event
             st["geo_plan"] = self.geo.plan(d["point_state_batch"])
             st["geo_next_plan"] = self.geo_next.plan(d["next_point_state_batch"])
-        M = Plan()
         H = {}                                  # items patched per step
         MAIN, S1, S2, SC, PRE, PRE2 = 0, 1, 2, 3, 20, 21
-        ev_in, ev_gn, ev_g, ev0, ev1, ev2, ev3, ev4, ev_run, ev_counts = (EH() for _ in range(10))
-        M.keep.append((ev_in, ev_gn, ev_g, ev0, ev1, ev2, ev3, ev4, ev_run, ev_counts, st["ev_up_h"]))
         # ---- prefetch lanes: [geometry of the next state] and [geometry of the current state]; the uploads were enqueued on
-        # these streams by _ddpg_replay's prelude
-        M.record(ev_in, on=PRE)
-        M.extend(st["geo_next_plan"], on=PRE)
-        M.record(ev_gn, on=PRE)
-        if ROW_HINTS:
-            M.memcpy(st["rows_pin"].data_ptr() + 8, self.geo_next.rows_n.data_ptr(), 8, on=PRE)
-        M.wait_event(ev_in, on=PRE2)
-        M.record(st["ev_up_h"], on=PRE2)                    # every input of the step has left the caller's buffers
-        M.extend(st["geo_plan"], on=PRE2)
-        M.record(ev_g, on=PRE2)
-        if ROW_HINTS:
-            M.memcpy(st["rows_pin"].data_ptr(), self.geo.rows_n.data_ptr(), 8, on=PRE2)
+        # these streams by the prelude (_stage_inputs).  This part is a list of its own, ONE per input set (both kinds of step
+        # start from its events): prefetch_inputs() replays it for the NEXT step's minibatch while the current step runs
+        cache = self.__dict__["_step_plans"]
+        pre = cache.get(("pre", self._set))
+        if pre is None:
+            ev_in, ev_gn, ev_g = EH(), EH(), EH()
+            M = Plan()
+            M.keep.append((ev_in, ev_gn, ev_g, st["ev_up_h"]))
+            M.record(ev_in, on=PRE)
+            M.extend(st["geo_next_plan"], on=PRE)
+            M.record(ev_gn, on=PRE)
+            if ROW_HINTS:
+                M.memcpy(st["rows_pin"].data_ptr() + 8, self.geo_next.rows_n.data_ptr(), 8, on=PRE)
+            M.wait_event(ev_in, on=PRE2)
+            M.record(st["ev_up_h"], on=PRE2)                    # every input of the step has left the caller's buffers
+            M.extend(st["geo_plan"], on=PRE2)
+            M.record(ev_g, on=PRE2)
+            if ROW_HINTS:
+                M.memcpy(st["rows_pin"].data_ptr(), self.geo.rows_n.data_ptr(), 8, on=PRE2)
+            pre = cache[("pre", self._set)] = dict(plan=M, ev_gn=ev_gn, ev_g=ev_g)
+        Mpre, ev_gn, ev_g = pre["plan"], pre["ev_gn"], pre["ev_g"]
+        M = Mstep = Plan()
+        ev0, ev1, ev2, ev3, ev4, ev_run, ev_counts = (EH() for _ in range(7))
+        M.keep.append((ev0, ev1, ev2, ev3, ev4, ev_run, ev_counts, pre))
+        M = Mstep
         # ---- critic phase (the comments of _ddpg_enqueue apply line by line)
         M.record(ev0, on=MAIN)
         M.wait_event(ev_gn, on=MAIN)
@@ -704,20 +717,14 @@ class FusedRuntime(object):
         if self.dp is not None:
             M.fn(lambda: self.dp.reduce_scalars(self.scal), on=MAIN)
         H["download"] = M.memcpy(self._scal_ring[0].data_ptr(), self.scal.data_ptr(), 4 * self.scal.numel(), on=MAIN)
-        return dict(plan=M, items=H, last={})
+        return dict(plan=M, pre=Mpre, items=H, last={})
 
-    def _ddpg_replay(self, batch, noise_u, policy_step):
-        """enqueue one update step through its replayed launch list (_step_plan).  Eager host work that remains: the stream
-        waits on events owned by other steps / producers, the uploads (or the one gather / copy launch of a device-resident
-        minibatch), the TD3 noise draw from torch's generator, this step's scalars."""
-        ag = self.agent
-        st = self._sets[self._set]
-        ent = self._step_plan(self._set, policy_step)
-        M, H, last = ent["plan"], ent["items"], ent["last"]
-        self._cur_batch = batch
+    def _stage_inputs(self, batch, st, pre):
+        """the inputs of a step into set `st` + its prefetch list `pre` (geometry of both cloud sets): stream waits on events
+        owned by other steps / producers, the uploads (or the one gather / copy launch of a device-resident minibatch), then
+        the replayed prefetch-lane launches.  The set must be the bound one (self.dbuf / self.geo*)."""
         main = torch.cuda.current_stream()
-        spre, spre2, sc = engine.side_stream(which=20), engine.side_stream(which=21), engine.side_stream(which=3)
-        engine.apply_lane_priorities(main)
+        spre, spre2 = engine.side_stream(which=20), engine.side_stream(which=21)
         ready = batch.get("ready_event") if batch is not None else None
         if ready is None and batch is not None and ("replay_gather" in batch or (
                 torch.is_tensor(batch["point_state_batch"]) and batch["point_state_batch"].is_cuda)):
@@ -737,6 +744,47 @@ class FusedRuntime(object):
                 self.upload(batch, tuple(k for k in BATCH_KEYS if k not in first))
         if isinstance(batch, dict) and "uploaded_event" in batch:   # asked for by the producer (PrefetchSampler): it may
             batch["uploaded_event"] = st["ev_up"]                   # reuse its staging buffers after this event
+        pre.run()
+
+    def prefetch_inputs(self, batch):
+        """Stage the NEXT step's minibatch now: its upload (one gather / copy launch) and the geometry of both cloud sets go onto
+        the prefetch lanes, into the input set the current step is not using, and run beside whatever is in flight.  The next
+        ddpg_step(batch) -- the SAME batch object -- then starts from there.  This is what lets the reference-shaped loop
+        (sample, update, read the losses, every iteration: core/train_test_offline.py:117-126) keep the GPU busy across its
+        host synchronisation: core.train_test_offline.train_off_policy samples one minibatch ahead and calls this.
+        Device-resident minibatches only (DeviceReplay.sample_lazy, CUDA tensors); -> False when nothing was staged."""
+        if not (STEP_PLAN and OVERLAP_PASSES and self.fused_optim and self.has_critic) or engine.SERIAL or batch is None:
+            return False
+        dev_batch = "replay_gather" in batch or (torch.is_tensor(batch.get("point_state_batch")) and batch["point_state_batch"].is_cuda)
+        if not dev_batch or len(self._sets) < 2 or self._sets[(self._set + 1) % len(self._sets)].get("prefetched") is not None:
+            return False
+        bound = self._set
+        nxt = (self._set + 1) % len(self._sets)
+        ent = self._step_plan(nxt, True)                     # (the prefetch list is the same for both step kinds)
+        st = self._bind_set(nxt)
+        try:
+            self._stage_inputs(batch, st, ent["pre"])
+            st["prefetched"] = batch
+        finally:
+            self._bind_set(bound)
+        return True
+
+    def _ddpg_replay(self, batch, noise_u, policy_step):
+        """enqueue one update step through its replayed launch list (_step_plan).  Eager host work that remains: the staging of
+        the inputs (unless prefetch_inputs did it), the TD3 noise draw from torch's generator, this step's scalars."""
+        ag = self.agent
+        st = self._sets[self._set]
+        ent = self._step_plan(self._set, policy_step)
+        M, H, last = ent["plan"], ent["items"], ent["last"]
+        self._cur_batch = batch
+        main = torch.cuda.current_stream()
+        sc = engine.side_stream(which=3)
+        engine.apply_lane_priorities(main)
+        staged, st["prefetched"] = st.get("prefetched"), None
+        if staged is None or staged is not batch:
+            self._stage_inputs(batch, st, ent["pre"])
+        elif isinstance(batch, dict) and "uploaded_event" in batch:
+            batch["uploaded_event"] = st["ev_up"]
         # the TD3 noise: torch's device generator (or the injected draw), ordered after the previous step's reader
         self._ev[0].record(main)
         sc.wait_event(self._ev[0])

@@ -316,8 +316,13 @@ def test_run_ahead_steps_equal_synchronous_steps(source):
                 for g in opt.param_groups:
                     g["lr"] = lr
         logs = []
-        for b, u in zip(batches, noise):
-            out = agent.update_parameters(b, agent.update_step, 0, noise_u=u, sync=(mode == "sync"))
+        for i, (b, u) in enumerate(zip(batches, noise)):
+            if mode == "prefetch" and i + 1 < len(batches):
+                # the reference-shaped loop with the NEXT minibatch staged ahead (Agent.prefetch -> FusedRuntime.prefetch_inputs):
+                # before the first step there is no runtime yet (False), host batches are never staged ahead (False)
+                staged = agent.prefetch(batches[i + 1])
+                assert staged == (source == "device" and i >= 1), (i, staged)
+            out = agent.update_parameters(b, agent.update_step, 0, noise_u=u, sync=(mode != "ahead"))
             agent.step_scheduler(agent.update_step)
             logs.append(out)
         if mode == "ahead":
@@ -342,4 +347,9 @@ def test_run_ahead_steps_equal_synchronous_steps(source):
     for s in range(len(batches)):
         for k in la[s]:
             assert_close(lb[s][k], la[s][k], 2e-4, 1e-6, "lr=0 step %d %s" % (s, k))
+    # (c) synchronous steps with the next minibatch's inputs + geometry staged one step ahead: the same numbers, step by step
+    (lc, _) = run("prefetch", 0.0)
+    for s in range(len(batches)):
+        for k in la[s]:
+            assert_close(lc[s][k], la[s][k], 2e-4, 1e-6, "lr=0 prefetched step %d %s" % (s, k))
     assert abs(la[2]["critic_loss"] - la[3]["critic_loss"]) > 1e-3            # the batches do differ
