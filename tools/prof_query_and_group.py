@@ -26,6 +26,7 @@ def main():
     res = json.load(open(out)) if os.path.exists(out) else {}
     res["query_and_group"] = {"kernel": k, "launches": f[k][0], "fetch_kb": round(f[k][1], 1), "write_kb": round(w[k][1], 1),
                               "bytes_per_launch": round((2 * f[k][1] + w[k][1]) * 1024.0, 0), "avg_us_under_pmc": round(f[k][2], 2),
+                              "bytes_per_launch_fetch_as_counted": round((f[k][1] + w[k][1]) * 1024.0, 0),
                               "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of tools/prof_query_and_group.py run "
                                      "(configs[3]: B=128, N=4096, npoint 512, nsample 64, C=4); FETCH_SIZE doubled (gfx950)"}
     json.dump(res, open(out, "w"), indent=1)
