@@ -104,7 +104,7 @@ def train_off_policy(agent, memory, config, model_output_dir=None, save_model=Fa
     # host synchronisation: the NEXT minibatch is drawn one iteration early (same draws in the same order: nothing else consumes
     # the sampler's random stream in between) and handed to agent.prefetch(), which stages its upload + geometry beside the
     # running update (device-resident minibatches; a no-op otherwise).
-    lookahead = (not run_ahead) and hasattr(agent, "prefetch")
+    lookahead = (not run_ahead) and hasattr(agent, "prefetch") and os.environ.get("GAD_TRAIN_LOOKAHEAD", "1") == "1"
     ahead = None
 
     def is_last(epoch, i):
