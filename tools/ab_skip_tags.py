@@ -53,20 +53,23 @@ def main():
             for st in rt._sets:
                 if any(st["plans"].get(k) is self for k in plans):
                     return
-        calls = self.calls
         tagp = tuple(x for x in pre if ":" not in x and x not in ("optim", "geometry"))
         names = tuple(x.split(":", 1)[1] for x in pre if x.startswith("name:"))            # every call of that entry point
         untag = tuple(x.split(":", 1)[1] for x in pre if x.startswith("untagged:"))        # its untagged calls (the heads' GEMMs)
-        keep = [c for i, c in enumerate(calls) if not ((tagp and i in self.tags and self.tags[i].startswith(tagp)) or
-                                                       c[0] in names or (c[0] in untag and i not in self.tags))]
-        tags = self.tags
-        self.calls, self.tags = keep, {}
-        try:
-            return plain_run(self)
-        finally:
-            self.calls, self.tags = calls, tags
+        key = (id(self), pre)
+        filt = filtered.get(key)
+        if filt is None or filt.n_src != len(self.calls):
+            filt = engine.Plan()                    # the same items minus the skipped launches (compiled and replayed like any plan)
+            filt.calls = [it for it in self.calls if not (it.kind == "call" and (
+                (tagp and it.tag is not None and it.tag.startswith(tagp)) or it.name in names or (it.name in untag and it.tag is None)))]
+            filt.keep = [self]
+            filt.n_src = len(self.calls)
+            filtered[key] = filt
+        return plain_run(filt)
+    filtered = {}
     engine.Plan.run = run
     from ga_ddpg_amd import runtime as rtm
+    rtm.STEP_PLAN = False       # the step enqueued phase by phase (each plan still replayed in C): whole phases can be skipped from here
     plain_optim = rtm.FusedRuntime._optim_phase
 
     def optim(self, which, policy_step):                       # token "optim": the fused optimiser launches (gad_optim_jobs)
