@@ -765,7 +765,7 @@ class FusedRuntime(object):
         if not (STEP_PLAN and OVERLAP_PASSES and self.fused_optim and self.has_critic) or engine.SERIAL or batch is None:
             return False
         dev_batch = "replay_gather" in batch or (torch.is_tensor(batch.get("point_state_batch")) and batch["point_state_batch"].is_cuda)
-        if not dev_batch or len(self._sets) < 2 or self._sets[(self._set + 1) % len(self._sets)].get("prefetched") is not None:
+        if not dev_batch or len(self._sets) < 2:
             return False
         # DEFERRED to the end of the next ddpg_step's enqueue: the prefetch lanes share a hardware queue with the value pass and the
         # critic's weight-gradient lane (engine._PHYS), so launches enqueued NOW would sit in front of that step's value pass
@@ -774,6 +774,8 @@ class FusedRuntime(object):
         return True
 
     def _prefetch_now(self, batch):
+        if self._sets[(self._set + 1) % len(self._sets)].get("prefetched") is not None:
+            return False
         bound = self._set
         nxt = (self._set + 1) % len(self._sets)
         ent = self._step_plan(nxt, True)                     # (the prefetch list is the same for both step kinds)
