@@ -223,7 +223,7 @@ ROUTE_SYMBOL = {"gemm_fwd(stream)": "gemm_fwd_stream_kernel", "gemm_fwd(wide)": 
                 "gemm_dw(skinny)": "gemm_dw_skinny_kernel", "gemm_dw": "gemm_dw_kernel", "gemm_bwd(stream)": "gemm_bwd_stream_kernel", "gemm_bwd(wide)": "gemm_bwd_wide_kernel",
                 # split-bf16 forms (library option "mfma_split"): same layers, products on v_mfma_f32_32x32x16_bf16
                 "gemm_fwd(stream split)": "gemm_fwd_stream_kernel<split>", "gemm_fwd(wide split)": "gemm_fwd_wide_kernel<split>",
-                "gemm_dx(wide split)": "gemm_dx_wide_kernel<split>", "gemm_dw(wide split)": "gemm_dw_wide_split_kernel", "gemm_dw(wide split group)": "gemm_dw_wide_split_group_kernel",
+                "gemm_dx(wide split)": "gemm_dx_wide_kernel<split>", "gemm_dw(wide split)": "gemm_dw_wide_split_kernel",
                 "gemm_bwd(stream split)": "gemm_bwd_stream_split_kernel", "gemm_dx(stream split)": "gemm_bwd_stream_split_kernel<dX only>"}
 ROUTES = {}                 # tag -> routed kernel family, filled from engine.timing_routes() after each probe
 
@@ -235,24 +235,18 @@ def tag_info(tag, rows, B):
     kind, stage = parts[0], parts[1]
     if kind == "pool" or tag not in ROUTES:
         return None
-    if len(parts) > 2 and parts[2] == "g":          # grouped weight gradients of a stage (gad_gemm_dw_group): its three layers together
-        infos = [tag_info_layer(kind, stage, l, rows, B, ROUTES[tag]) for l in (1, 2, 3)]
-        return (infos[0][0], infos[0][1]) + tuple(sum(i[j] for i in infos) for j in (2, 3, 4))
     layer = int(parts[2][1:]) if len(parts) > 2 else 0
     if stage.startswith("fc"):                      # fwd.fc1 / fwd.fc2 carry the layer in the stage name
         layer, stage = (int(stage[2:]) if len(stage) > 2 else layer), "fc"
     if layer == 0:
         return None
-    return tag_info_layer(kind, stage, layer, rows, B, ROUTES[tag])
-
-
-def tag_info_layer(kind, stage, layer, rows, B, route):
     k, n = SA_DIMS[stage][layer - 1]
     if k is None:
         k = 13.0                                    # SA1 layer 1: 3 + 4 (policy encoder) or 3 + 10 (value encoder) inputs
     r = float(rows[stage])
     flops = 2.0 * r * k * n
     dense = 2.0 * B * DENSE_ROWS[stage] * k * n
+    route = ROUTES[tag]
     sym = ROUTE_SYMBOL.get(route, route)
     stream = "stream" in route
     if kind == "fwd":

@@ -1147,7 +1147,6 @@ static int g_opt_bwd_fused = 1;
 static int g_opt_fwd_bn_prologue = 1;           // 0: routes with a BatchNorm-finalising prologue launch gad_bn_finalize instead (A/B)
 static int g_opt_bwd_wide = 0;                  // fused wide backward: 0 off (default: slower in the step), 1 SA2 and SA3 shapes, 2 only layers with >= 16384 rows (SA2)
 static int g_opt_bwd_wide_slab = 4;             // most partial-dW elements (millions) a fused launch may write: bounds its workgroups per k block
-static int g_opt_dw_group = 1;             // gad_gemm_dw_group: 1 = one grouped launch + one grouped reduce where every job takes the split wide-tile form; 0 = job by job (A/B)
 static int g_opt_dw_wide_wgs = 256;        // workgroups a wide-tile dW launch aims for (its partial slab = this x 128 x 128 floats)
 // the wide-tile kernel covers: ACT input, one group, K = the channel count itself (a multiple of 32, no bias / extra
 // column), outputs a multiple of 128
@@ -1778,7 +1777,6 @@ extern "C" int gad_set_option(const char* name, int value) {
     if (!strcmp(name, "bwd_wide_slab")) { g_opt_bwd_wide_slab = value > 0 ? value : 4; return GAD_OK; }
     if (!strcmp(name, "mfma_split")) { g_opt_mfma_split = value; return GAD_OK; }
     if (!strcmp(name, "dw_wide_wgs")) { g_opt_dw_wide_wgs = value > 0 ? value : 256; return GAD_OK; }
-    if (!strcmp(name, "dw_group")) { g_opt_dw_group = value; return GAD_OK; }
     if (!strcmp(name, "skinny_nw")) { g_opt_skinny_nw = value == 4 ? 4 : SK_NW; return GAD_OK; }
     if (!strcmp(name, "fwd_skinny")) { g_opt_fwd_skinny = value; return GAD_OK; }
     if (!strcmp(name, "dx_skinny")) { g_opt_dx_skinny = value; return GAD_OK; }
@@ -4217,29 +4215,29 @@ __global__ __launch_bounds__(256, 2) void gemm_dw_wide_kernel(DzSrc d, XSrc x, c
 // K-tile carry NEGATED dZ and accumulate into the second accumulator set (the bf16 MFMA's truncation bias cancels in the
 // difference).  One workgroup per CU (eight accumulators per wavefront), LDS double-buffered, one barrier per K-tile.
 // ------------------------------------------------------------------------------------------------
-namespace dws { constexpr int BT = 128, OPL = BT * 64, STAGE = 6 * OPL, VM = 512; }   // bytes: one operand plane, one stage (A planes | B planes)
-// the workgroup's work: output tile `tile` of the layer (tile / tiles_k = its 128-channel block of dZ, tile % tiles_k = of the input),
-// row chunk `split` of `nsplits`; smem_b: 2 * dws::STAGE bytes, vP: 5 * dws::VM floats (P | Q | S of the dZ channels, scale | shift
-// of the input channels).  One body for the single-layer launch and for the grouped launch of a whole stage (gad_gemm_dw_group).
 template <int XM, int GM>
-__device__ __forceinline__ void dw_wide_split_body(const DzSrc& d, const XSrc& x, int n_rows, int Kp, int n_out, int tiles_k,
-                                                   float* __restrict__ partial, int tile, int split, int nsplits,
-                                                   unsigned char* smem_b, float* vP) {
-    using namespace dws;
+__global__ __launch_bounds__(256, 1) void gemm_dw_wide_split_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
+                                                                    int n_rows_static, int Kp, int n_out, int tiles_k,
+                                                                    float* __restrict__ partial, unsigned long long* __restrict__ ts) {
+    KTimer kt_(ts);
+    constexpr int BT = 128, OPL = BT * 64, STAGE = 6 * OPL, VM = 512;      // bytes: one operand plane, one stage (A planes | B planes)
+    __shared__ __attribute__((aligned(16))) unsigned char smem_b[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float vP[5 * VM];               // P | Q | S of the dZ channels, scale | shift of the input channels
     float* sv = vP + 3 * VM;
     float* tv = sv + VM;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, half = lane >> 5;
-    const int n0 = (tile / tiles_k) * BT, k0 = (tile % tiles_k) * BT;
-    int chunk = gad_cdiv_dev(n_rows, nsplits);
+    const int n0 = (blockIdx.x / tiles_k) * BT, k0 = (blockIdx.x % tiles_k) * BT;
+    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
+    int chunk = gad_cdiv_dev(n_rows, (int)gridDim.y);
     chunk = (chunk + KT - 1) / KT * KT;                  // == dw_reduce_kernel's split geometry
-    const int r_begin = split * chunk, r_end = min(r_begin + chunk, n_rows);
+    const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, n_rows);
     if (r_begin >= r_end) return;                        // the reducer skips the same splits
     for (int i = tid; i < BT; i += 256) {
         float Pc, Qc, Sc;
-        dz_coef(d, n0 + i, Pc, Qc, Sc, split == 0 && k0 == 0);
+        dz_coef(d, n0 + i, Pc, Qc, Sc, blockIdx.y == 0 && k0 == 0);
         vP[i] = Pc; vP[VM + i] = Qc; vP[2 * VM + i] = Sc;
         if (XM == 0) { sv[i] = x.scale[k0 + i]; tv[i] = x.shift[k0 + i]; }
     }
@@ -4395,7 +4393,7 @@ __device__ __forceinline__ void dw_wide_split_body(const DzSrc& d, const XSrc& x
         if (rb0 + 2 * KT < r_end) load_regs(rb0 + 2 * KT);
         __syncthreads();
     }
-    float* pout = partial + (size_t)split * n_out * Kp;
+    float* pout = partial + (size_t)blockIdx.y * n_out * Kp;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -4419,80 +4417,6 @@ __device__ __forceinline__ void dw_wide_split_body(const DzSrc& d, const XSrc& x
             pout[(size_t)(n0 + i / 3) * Kp + x.feat_c + i % 3] = sum;
         }
     }
-}
-
-
-template <int XM, int GM>
-__global__ __launch_bounds__(256, 1) void gemm_dw_wide_split_kernel(DzSrc d, XSrc x, const int32_t* __restrict__ n_rows_dev,
-                                                                    int n_rows_static, int Kp, int n_out, int tiles_k,
-                                                                    float* __restrict__ partial, unsigned long long* __restrict__ ts) {
-    KTimer kt_(ts);
-    __shared__ __attribute__((aligned(16))) unsigned char smem_b[2 * dws::STAGE];
-    __shared__ __attribute__((aligned(16))) float vP[5 * dws::VM];
-    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    dw_wide_split_body<XM, GM>(d, x, n_rows, Kp, n_out, tiles_k, partial, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y, smem_b, vP);
-}
-
-// ------------------------------------------------------------------------------------------------
-// The weight gradients of a WHOLE STAGE in one launch (gaddpg.h: gad_gemm_dw_group).  The three layers of
-// SA2 / SA3 share their rows; launched one by one (12 launches + 12 reduces per step) each spreads its 1 - 8 output tiles over
-// ~256 workgroups, i.e. cuts the rows into up to 256 chunks of 4 K-tiles whose 64 KB partial tiles are written and read back:
-// the slab traffic is 1.7x the operands and a workgroup is mostly prologue + epilogue.  Grouped, the stage's 4 (SA2) / 16 (SA3)
-// tiles share the ~256 workgroups: 64 / 16 row chunks of 14 - 16 K-tiles, a third / an eighth of the slab, one launch + one reduce.
-// ------------------------------------------------------------------------------------------------
-struct DwGroupJob {
-    DzSrc d; XSrc x;
-    int Kp, n_out, tiles_k, tiles, variant, wg_begin;      // variant: 0 = <0, 0> dense gradient, 1 = <0, 1> pooled gradient, 2 = <1, 0> gathered input
-    float* partial;
-};
-struct DwGroup { int n, splits; DwGroupJob j[GAD_DW_GROUP_MAX]; };
-static_assert(sizeof(DwGroup) <= 3584, "the job table travels as a kernel argument");
-
-__global__ __launch_bounds__(256, 1) void gemm_dw_wide_split_group_kernel(DwGroup g, const int32_t* __restrict__ n_rows_dev,
-                                                                          int n_rows_static, unsigned long long* __restrict__ ts) {
-    KTimer kt_(ts);
-    __shared__ __attribute__((aligned(16))) unsigned char smem_b[2 * dws::STAGE];
-    __shared__ __attribute__((aligned(16))) float vP[5 * dws::VM];
-    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    const int bx = (int)blockIdx.x;
-    int ji = 0;
-#pragma unroll
-    for (int i = 1; i < GAD_DW_GROUP_MAX; ++i)
-        if (i < g.n && bx >= g.j[i].wg_begin) ji = i;
-    // (workgroup-uniform: the job's fields are scalar loads from the kernel-argument segment)
-#define GAD_DWG_RUN(I)                                                                                                         \
-    if (ji == I) {                                                                                                             \
-        const DwGroupJob& jb = g.j[I];                                                                                         \
-        const int local = bx - jb.wg_begin, tile = local % jb.tiles, split = local / jb.tiles;                                 \
-        if (jb.variant == 0) dw_wide_split_body<0, 0>(jb.d, jb.x, n_rows, jb.Kp, jb.n_out, jb.tiles_k, jb.partial, tile, split, g.splits, smem_b, vP); \
-        else if (jb.variant == 1) dw_wide_split_body<0, 1>(jb.d, jb.x, n_rows, jb.Kp, jb.n_out, jb.tiles_k, jb.partial, tile, split, g.splits, smem_b, vP); \
-        else dw_wide_split_body<1, 0>(jb.d, jb.x, n_rows, jb.Kp, jb.n_out, jb.tiles_k, jb.partial, tile, split, g.splits, smem_b, vP); \
-        return;                                                                                                                \
-    }
-    GAD_DWG_RUN(0) GAD_DWG_RUN(1) GAD_DWG_RUN(2) GAD_DWG_RUN(3)
-#undef GAD_DWG_RUN
-}
-
-struct DwRedJob { const float* partial; double* gacc; int n_out, Kp, k_used, pad_; };
-struct DwRedGroup { int n, splits; DwRedJob j[GAD_DW_GROUP_MAX]; };
-
-__global__ __launch_bounds__(256) void dw_reduce_group_kernel(DwRedGroup g, const int32_t* __restrict__ n_rows_dev, int n_rows_static) {
-    const DwRedJob jb = g.j[blockIdx.z];
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)jb.n_out * jb.Kp) return;
-    if ((int)(e % jb.Kp) >= jb.k_used) return;
-    const int n_rows = n_rows_dev ? min(*n_rows_dev, n_rows_static) : n_rows_static;
-    int chunk = (n_rows + g.splits - 1) / g.splits;
-    chunk = (chunk + KT - 1) / KT * KT;                  // == dw_wide_split_body's split geometry
-    const int active = chunk > 0 ? (n_rows + chunk - 1) / chunk : 0;
-    const int s0 = blockIdx.y * DW_RED_CHUNK, s1 = min(s0 + DW_RED_CHUNK, active);
-    if (s0 >= s1) return;
-    const float* p = jb.partial + e;
-    const size_t stride = (size_t)jb.n_out * jb.Kp;
-    double s = 0.0;
-#pragma unroll 4
-    for (int sidx = s0; sidx < s1; ++sidx) s += (double)p[(size_t)sidx * stride];
-    atomic_add_f64(jb.gacc + e, s);
 }
 
 // the wide-tile dW covers: ACT input with BatchNorm + ReLU in front, one group, 128-multiples on both sides, no bias / extra column
@@ -5018,82 +4942,6 @@ static bool bwd_streamable(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* a
 
 // the reduce launch of a fused backward call whose aw->row_splits was GAD_DW_REDUCE_LATER (include/gaddpg.h): sums the partial
 // dW blocks that call left in aw->partial into the arena.  A layer gad_gemm_bwd does not fuse has reduced already: no-op.
-extern "C" int gad_gemm_dw_group(const gad_gemm_dw_args* const* host_jobs, int n_jobs, void* stream) {
-    GAD_REQUIRE(host_jobs || n_jobs == 0, GAD_ERR_NULL, "gemm_dw_group: NULL job table");
-    GAD_REQUIRE(n_jobs >= 0 && n_jobs <= GAD_DW_GROUP_MAX, GAD_ERR_SHAPE, "gemm_dw_group: %d jobs (at most %d)", n_jobs, GAD_DW_GROUP_MAX);
-    for (int i = 0; i < n_jobs; ++i) GAD_REQUIRE(host_jobs[i] && host_jobs[i]->gacc, GAD_ERR_NULL, "gemm_dw_group: job %d: null pointer", i);
-    if (n_jobs == 0) return GAD_OK;
-    // the grouped form: every job on the split wide-tile route, over the SAME rows, the partial tiles carved from job 0's workspace
-    bool grouped = g_opt_dw_group && n_jobs > 1 && split_on(GAD_SPLIT_DW_WIDE);
-    int k_used[GAD_DW_GROUP_MAX], tiles[GAD_DW_GROUP_MAX], total_tiles = 0;
-    const gad_gemm_dw_args& a0 = *host_jobs[0];
-    for (int i = 0; i < n_jobs && grouped; ++i) {
-        const gad_gemm_dw_args& a = *host_jobs[i];
-        const gad_gemm_fwd_args& in = a.in;
-        if (in.n_groups != 1 || in.Kp % 8 != 0 || in.n_rows <= 0 || in.n_rows_dev != a0.in.n_rows_dev || in.n_rows != a0.in.n_rows) { grouped = false; break; }
-        if (a.dz.gmode == 0 ? a.dz.G == nullptr : !(a.dz.argmax && a.dz.dout && a.dz.row_grp)) { grouped = false; break; }
-        int ku = in.mode == 0 ? in.c_in + (in.extra ? 1 : 0) : in.feat_c + 3 + in.act_c;
-        if (in.ones_col >= ku) ku = in.ones_col + 1;
-        if (ku > in.Kp) ku = in.Kp;
-        k_used[i] = ku;
-        const bool vec = dz_vectorizable(a.dz, a.dz_off, in.n_out, in.n_groups);
-        if (!dw_wideable(a, ku, vec)) { grouped = false; break; }
-        tiles[i] = (in.n_out[0] / 128) * ((in.mode == 1 ? in.feat_c : in.Kp) / 128);
-        total_tiles += tiles[i];
-    }
-    int splits = 1;
-    if (grouped) {
-        splits = gad_cdiv(g_opt_dw_wide_wgs, total_tiles);
-        const int by_rows = gad_cdiv(a0.in.n_rows, 4 * KT);
-        if (splits > by_rows) splits = by_rows;
-        if (splits < 1) splits = 1;
-        long long need = 0;
-        for (int i = 0; i < n_jobs; ++i) need += (long long)splits * host_jobs[i]->in.n_out[0] * host_jobs[i]->in.Kp;
-        if (!a0.partial || need > a0.partial_elems) grouped = false;
-    }
-    if (!grouped) {                                      // (the same results, launch by launch)
-        for (int i = 0; i < n_jobs; ++i)
-            if (int e = gad_gemm_dw(host_jobs[i], stream)) return e;
-        return GAD_OK;
-    }
-    unsigned long long* ts = gad_take_timing_slot(stream);
-    for (int i = 0; i < n_jobs; ++i)
-        if (int e = check_input(host_jobs[i]->in, "gemm_dw_group")) return e;
-    DwGroup g;
-    DwRedGroup rg;
-    g.n = rg.n = n_jobs;
-    g.splits = rg.splits = splits;
-    float* part = a0.partial;
-    int wg = 0, emax = 0;
-    for (int i = 0; i < n_jobs; ++i) {
-        const gad_gemm_dw_args& a = *host_jobs[i];
-        const gad_gemm_fwd_args& in = a.in;
-        DwGroupJob& j = g.j[i];
-        j.d = make_dzsrc(a.dz);
-        j.x = make_xsrc(in);
-        j.Kp = in.Kp; j.n_out = in.n_out[0];
-        j.tiles_k = (in.mode == 1 ? in.feat_c : in.Kp) / 128;
-        j.tiles = tiles[i];
-        j.variant = in.mode == 1 ? 2 : (a.dz.gmode == 0 ? 0 : 1);
-        j.wg_begin = wg;
-        j.partial = part;
-        wg += tiles[i] * splits;
-        rg.j[i].partial = part;
-        rg.j[i].gacc = a.gacc + in.w_off[0];
-        rg.j[i].n_out = in.n_out[0]; rg.j[i].Kp = in.Kp; rg.j[i].k_used = k_used[i]; rg.j[i].pad_ = 0;
-        part += (size_t)splits * in.n_out[0] * in.Kp;
-        if (in.n_out[0] * in.Kp > emax) emax = in.n_out[0] * in.Kp;
-    }
-    for (int i = n_jobs; i < GAD_DW_GROUP_MAX; ++i) { g.j[i] = g.j[0]; g.j[i].wg_begin = wg; rg.j[i] = rg.j[0]; }
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_dw_wide_split_group_kernel, dim3(wg), dim3(256), 0, st, g, a0.in.n_rows_dev, a0.in.n_rows, ts);
-    GAD_CHECK_LAUNCH("gemm_dw(wide split group)");
-    hipLaunchKernelGGL(dw_reduce_group_kernel, dim3(gad_cdiv(emax, 256), gad_cdiv(splits, DW_RED_CHUNK), n_jobs), dim3(256), 0, st, rg,
-                       a0.in.n_rows_dev, a0.in.n_rows);
-    GAD_CHECK_LAUNCH("dw_reduce(group)");
-    return GAD_OK;
-}
-
 extern "C" int gad_gemm_dw_reduce(const gad_gemm_dx_args* ax, const gad_gemm_dw_args* aw, void* stream) {
     GAD_REQUIRE(ax && aw, GAD_ERR_NULL, "gemm_dw_reduce: null pointer");
     const gad_gemm_fwd_args& in = aw->in;

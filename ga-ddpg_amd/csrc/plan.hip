@@ -102,7 +102,6 @@ const std::vector<reg_entry>& registry() {
         GAD_PLAN_ENTRY(gad_bn_bwd_coef)
         GAD_PLAN_ENTRY(gad_gemm_dx)
         GAD_PLAN_ENTRY(gad_gemm_dw)
-        GAD_PLAN_ENTRY(gad_gemm_dw_group)
         GAD_PLAN_ENTRY(gad_gemm_bwd)
         GAD_PLAN_ENTRY(gad_gemm_dw_reduce)
         GAD_PLAN_ENTRY(gad_critic_loss)

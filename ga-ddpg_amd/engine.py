@@ -413,7 +413,7 @@ def _dz(**kw):
 # wavefront start -> last wavefront end on the device wall clock -- what a profiler reports as the dispatch duration;
 # HIP events around a 25 us launch inside a five-stream step read 8 - 20 us high: event packets, queue waits)
 TIMING = {"enabled": False, "tag": None, "slots": None, "next": 0, "tags": [], "routed": {}}
-_TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_dw_group", "gad_gemm_bwd", "gad_segment_pool")      # (entry points that take a timing slot)
+_TIMED_CALLS = ("gad_gemm_fwd", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_bwd", "gad_segment_pool")      # (entry points that take a timing slot)
 
 
 TIMING_WAVES = 16384          # include/gaddpg.h GAD_TIMING_WAVES
@@ -582,8 +582,6 @@ FUSED_WIDE_BWD = _os.environ.get("GAD_FUSED_WIDE_BWD", "0") == "1"   # SA2 / SA3
                                                                      # the step follows the length of its dX chain, and dW on its own lane is nearly free
 WIDE_SLAB_ELEMS = 9 * 1024 * 1024        # floats per fused wide layer's partial-dW workspace (library option bwd_wide_slab <= 8)
 DW_REDUCE_LATER = -2                     # include/gaddpg.h GAD_DW_REDUCE_LATER
-GROUP_DW = _os.environ.get("GAD_GROUP_DW", "1") == "1"   # SA2 / SA3: the three weight-gradient GEMMs of a stage as ONE grouped launch + ONE reduce
-                                                         # (gad_gemm_dw_group), forked once the stage's dX chain has produced the last gradient they read
 DW_LANES = 1              # number of dW side streams (2 measured no faster: the overlapped kernels already saturate the GPU) the layers alternate between (each with its own partial workspace)
 
 
@@ -1245,22 +1243,6 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         plan.tag_last("dx.%s.l%d" % (rows_kw.get("name", "fc"), rows_kw.get("layer", 0)))
 
     dw_lanes = []
-    group_dw = []
-
-    def flush_group(s):
-        """the stage's weight-gradient jobs (layers 3, 2, 1) as one gad_gemm_dw_group call on the weight-gradient lane"""
-        if not group_dw:
-            return
-        import ctypes as C
-        jobs = [a for a, _ in group_dw]
-        lane = group_dw[0][1]
-        arr = (C.c_void_p * len(jobs))(*[C.addressof(a) for a in jobs])
-        plan.keep.append((jobs, arr))
-        if lane:
-            plan.fork(lane)
-        plan.call("gad_gemm_dw_group", arr, len(jobs), side=lane)
-        plan.tag_last("dw.sa%d.g" % (s + 1))
-        del group_dw[:]
     fused_dw = []
     deferred_dw = []
     has_dx_now = [True]                # (set by layer(): a layer without a dX launch cannot take the fused call)
@@ -1291,9 +1273,6 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
         ws = dw_workspace(enc.flat.device, lane=lane)
         a.partial, a.partial_elems = _ptr(ws), ws.numel()
         tag = "dw.%s.l%d" % ("sa%d" % (s + 1) if s < 3 else "fc", l + 1)
-        if GROUP_DW and s in (1, 2) and not DEFER_DW:
-            group_dw.append((a, lane))            # launched by flush_group() once layer 1's job exists
-            return
         if DEFER_DW and lane:                 # A/B: every weight-gradient GEMM of the pass behind its dX chain (one fork at the end)
             deferred_dw.append((a, lane, tag))
             return
@@ -1348,7 +1327,6 @@ def plan_encoder_backward(enc, slot, g_fc2, action=None, want_dw=True, want_dact
            **prev_stats(m1, slot.Z[s][0]))
         has_dx = s > 0 or (want_daction and action is not None)
         d = layer(s, 0, m1, slot.Z[s][0], cnt, has_dx, G=gbuf[1], row_w=_ptr(r["w"]))
-        flush_group(s)                                   # (layer 1's job reads gbuf[1]: the dX of layer 2 is enqueued above)
         if s > 0:
             fc = slot.F[s - 1].shape[1]
             if zero_scatter:

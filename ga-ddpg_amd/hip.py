@@ -121,7 +121,7 @@ EXPORTS = (
     "gad_gather_points_grad", "gad_ball_query", "gad_group_points", "gad_group_points_grad",
     "gad_query_and_group", "gad_prep_points", "gad_rows_from_ball_query", "gad_rows_group_all",
     "gad_gemm_fwd", "gad_bn_finalize", "gad_bn_eval_affine", "gad_segment_pool", "gad_pool_finalize", "gad_affine_act", "gad_transpose_batched",
-    "gad_pool_bwd_stats", "gad_bn_bwd_coef", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_dw_group", "gad_gemm_bwd", "gad_gemm_dw_reduce", "gad_critic_loss",
+    "gad_pool_bwd_stats", "gad_bn_bwd_coef", "gad_gemm_dx", "gad_gemm_dw", "gad_gemm_bwd", "gad_gemm_dw_reduce", "gad_critic_loss",
     "gad_policy_outputs", "gad_policy_sample", "gad_actor_loss", "gad_actor_critic_loss", "gad_mask_counts", "gad_target_noise",
     "gad_grad_from_arena", "gad_grad_from_arena_sumsq", "gad_optim_jobs", "gad_sumsq", "gad_absmax_segments", "gad_adam_step", "gad_polyak",
     "gad_pack_params", "gad_split_weights", "gad_copy_buffers",

@@ -48,7 +48,7 @@ int gad_abi_version(void);                 /* bumped on any signature change or 
                                             * W_split_t* of gad_gemm_dx_args), option "mfma_split" as a family mask;
                                             * 9: gad_transpose_batched; 10: gad_stream_priority;
                                             * 11: step replay (section H: gad_plan_*), gad_copy_buffers,
-                                            * action_bias in gad_policy_outputs, gad_gemm_dw_group)                   */
+                                            * action_bias in gad_policy_outputs)                                      */
 /* diagnostics: which kernel family the last gad_gemm_fwd / _dx / _dw / _bwd call routed to ("gemm_fwd(stream)",
  * "gemm_dx(wide)", "gemm_bwd(stream)", "gemm_dw" = generic tile kernel, ...); bench.py labels its per-kernel table
  * with it instead of restating the routing rules.                                                  */
@@ -403,16 +403,6 @@ typedef struct {
 } gad_gemm_dw_args;
 
 int gad_gemm_dw(const gad_gemm_dw_args* host_args, void* stream);
-
-/* The weight gradients of SEVERAL layers over the same rows in one call (round 6): the three layers of a set-abstraction stage
- * (reference core/networks.py:66-81: one SharedMLP per stage, its three convolutions share the grouped rows).  Same results and
- * contract as gad_gemm_dw(jobs[i]) for i = 0 .. n_jobs - 1 on `stream`.  Where every job takes the split wide-tile form (option
- * "mfma_split", >= 2048 rows, 128-multiples: the SA2 / SA3 layers) and the jobs share n_rows / n_rows_dev, ONE launch computes all
- * their output tiles -- the row chunks are cut for the stage, not per layer: a third to an eighth of the partial-tile traffic -- and
- * ONE launch reduces them (partial tiles carved from jobs[0]->partial, which must hold sum(splits x n_out x Kp) floats); any other
- * job list runs job by job.  Option "dw_group" [1]: 0 = always job by job (A/B).  host_jobs: a HOST array of pointers. */
-#define GAD_DW_GROUP_MAX 4
-int gad_gemm_dw_group(const gad_gemm_dw_args* const* host_jobs, int n_jobs, void* stream);
 
 /* dX and dW of ONE layer in one call: `dx` and `dw` describe the same layer (same gradient source; dw->in = the layer
  * dx writes the gradient of).  The SA1 layers of the update step (>= 32768 rows, 64 input channels, 64 / 128 outputs,

@@ -201,53 +201,3 @@ def test_row_tensor_of_exactly_two_gib(kind):
     case = TWO_GIB[kind](sc)
     bad = check_case(case, "two_gib." + kind)
     assert not bad, "\n".join(bad)
-
-
-@pytest.mark.parametrize("stage", ["sa2", "sa3", "ragged"])
-def test_grouped_stage_weight_gradients_match_float64_and_the_single_launches(stage):
-    """gad_gemm_dw_group: the three weight-gradient GEMMs of a stage (pooled layer 3, dense layer 2, gathered layer 1) over the same
-    rows as ONE grouped launch + ONE grouped reduce.  Against float64 with the single launches' bound (<= 1.25x the f32-MFMA path's
-    error), and against the job-by-job form (option dw_group = 0), which must agree to the f32 partial sums' rounding."""
-    import ctypes as C
-    from ga_ddpg_amd import hip
-    from tests import split_cases as sc
-    rows, n2, n3 = {"sa2": (27240, 128, 256), "sa3": (8192, 256, 512), "ragged": (4099, 128, 256)}[stage]
-    cases = [sc.DwWide(rows, n3, n2, "pool", seed=5), sc.DwWide(rows, n2, n2, "act", seed=6), sc.DwWide(rows, n2, n2 if n2 >= 128 else 128, "gather", seed=7)]
-    nrows = cases[0].dx.nrows
-    cap = min(c.dx.cap for c in cases)
-
-    def run(group, split):
-        hip.set_option("mfma_split", hip.SPLIT_DW_WIDE if split else 0)
-        hip.set_option("dw_group", group)
-        try:
-            jobs = []
-            for c in cases:
-                c.gacc.zero_()
-                a = c.args()
-                a.inp.n_rows_dev, a.inp.n_rows = _ptr_of(nrows), cap           # one row set for the stage
-                a.partial, a.partial_elems = _ptr_of(cases[0].ws), cases[0].ws.numel()
-                jobs.append(a)
-            arr = (C.c_void_p * 3)(*[C.addressof(a) for a in jobs])
-            hip.check(hip.lib().gad_gemm_dw_group(arr, 3, hip.stream()), "gad_gemm_dw_group")
-            routed = hip.lib().gad_last_kernel().decode()
-            torch.cuda.synchronize()
-            return [c.gacc.view(c.N, c.Kp)[:, :c.K + (3 if c.mode == "gather" else 0)].clone() for c in cases], routed
-        finally:
-            hip.set_option("mfma_split", hip.get_option_default("mfma_split"))
-            hip.set_option("dw_group", 1)
-    grouped, r1 = run(1, True)
-    single, r0 = run(0, True)
-    f32, _ = run(0, False)
-    assert "group" in r1 and "group" not in r0, (r1, r0)
-    for c, g, s1, s32 in zip(cases, grouped, single, f32):
-        ref = c.ref()
-        eg, es, e32 = (sc.errors(x, ref["dW"]) for x in (g, s1, s32))
-        floor = 4e-9 * float(ref["dW#abs"].max())
-        assert eg[0] <= 1.25 * e32[0] + floor and eg[1] <= 1.25 * e32[1] + floor, (c.mode, eg, e32)
-        assert abs(eg[2]) <= max(2.0 * abs(e32[2]), floor), (c.mode, eg, e32)
-        assert float((g - s1).abs().max()) <= 4.0 * max(eg[0], es[0]) + floor, c.mode
-
-
-def _ptr_of(t):
-    from ga_ddpg_amd.engine import _ptr
-    return _ptr(t)
